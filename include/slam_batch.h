@@ -1,0 +1,158 @@
+/* slam_batch.h — C ABI of the MI355X batched EKF/UKF-SLAM predict–update engine (libslam_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of kevin-robb/live_ekf_slam: `Filter::update()` of the EKF / UKF
+ * subclasses plus the simulator's range-bearing generator.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference repo root).  Plain pointers and sizes only; no
+ * C++/torch types.  All functions return SLAM_OK (0) or a negative slam_status_code; slam_last_error() gives text.
+ *
+ * Threading: one caller thread per handle (the reference is single-threaded: localization_node.cpp:197).
+ * Kernels are enqueued on one HIP stream per handle (slam_set_stream); slam_get_ and slam_sync synchronise.
+ *
+ * The batch: B independent filter instances that share the landmark map and the command sequence and differ
+ * only in their noise streams (Monte-Carlo seeds).  Instance b of this handle has GLOBAL index
+ * instance_offset + b (slam_set_instance_offset), which keys its counter-based RNG stream, so results do not
+ * depend on how a batch is sharded over GPUs.
+ */
+#ifndef SLAM_BATCH_H
+#define SLAM_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* FilterChoice (ekf_ws/src/localization_pkg/include/localization_pkg/filter.h:44-51) */
+enum slam_filter_kind { SLAM_EKF_SLAM = 1, SLAM_UKF_LOC = 2, SLAM_UKF_SLAM = 3 };
+
+/* storage type of x and P in HBM (arithmetic is always fp64, as in the reference's Eigen MatrixXd) */
+enum slam_dtype { SLAM_F64 = 0, SLAM_F32 = 1 };
+
+enum slam_status_code {
+    SLAM_OK = 0,
+    SLAM_ERR_ARG = -1,          /* bad argument / bad handle                                                  */
+    SLAM_ERR_HIP = -2,          /* a HIP runtime call failed (text in slam_last_error)                          */
+    SLAM_ERR_UNSUPPORTED = -3,  /* configuration not supported by this build (e.g. L_max above the kernel limit) */
+    SLAM_ERR_STATE = -4,        /* call order violated (step before init, sim step before set_map, ...)        */
+    SLAM_ERR_IO = -5            /* config file unreadable / malformed                                          */
+};
+
+/* per-instance status bits returned by slam_status(); an instance with any FAIL bit set is frozen, mirroring the
+ * reference where the corresponding condition throws and kills the node (filter.h:5 eigen_assert -> exception). */
+enum slam_instance_flags {
+    SLAM_INST_OK = 0,
+    SLAM_INST_NONFINITE = 1,     /* x or P became non-finite                                                    */
+    SLAM_INST_S_SINGULAR = 2,    /* zero pivot while inverting the 2x2 innovation covariance (ekf.cpp:135)      */
+    SLAM_INST_INDEX_OOR = 4,     /* landmark index outside x_t (ekf.cpp:115 under the duplicate/unknown-id quirk) */
+    SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max; that detection was dropped               */
+    SLAM_INST_SQRT_FAILED = 16   /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
+};
+
+/* Flat mirror of the YAML keys the hot path reads (ekf_ws/src/base_pkg/config/params.yaml; key names kept).
+ * Filter side: Filter::readCommonParams (filter.h:105-121).  Simulator side: get_cmd (sim_node.py:209-250). */
+typedef struct slam_config {
+    /* process_noise.mean.{v_d,v_th} (float in filter.h:84-85), process_noise.cov.{V_00,V_11} */
+    float v_d, v_th;
+    double V_00, V_11;
+    /* sensing_noise.mean.{w_r,w_b} (float, filter.h:88-89), sensing_noise.cov.{W_00,W_11} */
+    float w_r, w_b;
+    double W_00, W_11;
+    /* constraints.measurements */
+    int landmark_id_is_known;
+    float min_landmark_separation;
+    /* constraints.commands / constraints.vision — used by the measurement generator only */
+    double d_max, th_max;
+    double range_max, fov_min, fov_max;
+    /* init_pose (params.yaml:19-22) — the simulator's start pose = the filter's init pose */
+    double init_x, init_y, init_yaw;
+    /* Quirk switches.  Default 1 = behave exactly like the reference.
+     * replicate_vw_quirk: filter.h:116-117 store W_00,W_11 into V and leave W = I2.                       */
+    int replicate_vw_quirk;
+    /* UKF only: resolve unqualified cos/sin on a float argument to the float overload (1) or to double (0);
+     * see SURVEY.md Appendix B precision note. */
+    int ukf_float_trig;
+    int reserved[6];
+} slam_config;
+
+typedef struct slam_handle slam_handle;
+
+/* ---- configuration ------------------------------------------------------------------------------------- */
+/* Fill *cfg with the values committed in the reference's params.yaml (lines 25-52). */
+int slam_config_default(slam_config* cfg);
+/* Minimal `key: value` reader for a params.yaml-shaped file; replaces YAML::LoadFile + readCommonParams
+ * (localization_node.cpp:29-30, filter.h:105-121).  Unknown keys are ignored, missing keys keep defaults. */
+int slam_config_load(slam_config* cfg, const char* yaml_path);
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+/* Replaces the filter factory `std::make_unique<EKF|UKF>()` + `filter->readParams(config)`
+ * (localization_node.cpp:33-47).  batch = number of instances on THIS device, L_max = landmark capacity. */
+int slam_create(const slam_config* cfg, int filter_kind, int batch, int L_max, int dtype, int device,
+                slam_handle** out);
+int slam_destroy(slam_handle* h);
+/* Use an existing HIP stream (hipStream_t passed as void*) instead of the handle's own. */
+int slam_set_stream(slam_handle* h, void* hip_stream);
+int slam_set_instance_offset(slam_handle* h, int64_t first_global_instance);
+int slam_set_seed(slam_handle* h, uint64_t seed);
+/* Change the simulated sensor limits at run time (constraints.vision.*; sim_node.py:238-243). */
+int slam_set_vision(slam_handle* h, double range_max, double fov_min, double fov_max);
+
+/* ---- Filter::init (ekf.cpp:29-34, ukf.cpp:31-45; called from initCallback localization_node.cpp:90-106) -- */
+/* Same start pose for every instance (all seeds share the scenario).  Also resets truth pose, timestep,
+ * M, status and the error accumulators. */
+int slam_init(slam_handle* h, float x_0, float y_0, float yaw_0);
+
+/* True landmark map [L][2] (x,y), id = row index.  Needed by slam_step_sim (sim_node.py:231-236) and by
+ * UKF_LOC (`filter->map`, localization_node.cpp:152-156). Host pointer. */
+int slam_set_map(slam_handle* h, const double* map_xy, int L);
+
+/* ---- Filter::update (ekf.cpp:37-179, ukf.cpp:161-195; called from iterate localization_node.cpp:131) ------ */
+/* One timestep for all instances.  cmd = {fwd, ang} (Command.msg:3-5), shared by the batch.
+ * meas: [batch][k_stride][3] float32 {id, range, bearing} (Float32MultiArray layout of sim_node.py:245-249,
+ * padded to k_stride detections per instance); meas_count: [batch].  HOST pointers (copied to the device
+ * asynchronously, mirroring `lm_meas = lmMeasMsg->data`, ekf.cpp:64). */
+int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* meas_count, int k_stride);
+/* Same, with DEVICE pointers (no copy). */
+int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_meas_count,
+                  int k_stride);
+/* One timestep where the device-side generator (a port of get_cmd, sim_node.py:209-250) advances each
+ * instance's true pose with its own noise stream and produces its measurements, then the filter consumes
+ * them in the same kernel.  Also accumulates the position error of plotting_node.py:209-212. */
+int slam_step_sim(slam_handle* h, const float cmd[2]);
+/* T consecutive slam_step_sim calls; cmds = [T][2] float32 host array (precomputed trajectory,
+ * sim_node.py:142-152). */
+int slam_run_sim(slam_handle* h, const float* cmds, int T);
+/* UKF only: the two public halves of UKF::update (filter.h:187-188). */
+int slam_predict(slam_handle* h, const float cmd[2]);
+int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_meas_count, int k_stride);
+
+/* ---- state export: getStateVector / publishState payload (ekf.cpp:181-220, ukf.cpp:47-104) ---------------- */
+/* Sizes: x needs n_max doubles, P needs n_max*n_max doubles, ids needs L_max ints, where
+ * n_max = 3+2*L_max (EKF) or 4+2*L_max (UKF).  On return *M landmarks are valid, n = 3|4 + 2*M, and P holds the
+ * n x n matrix ROW-MAJOR with leading dimension n (EKFState.msg:12-13 order).  Any pointer may be NULL. */
+int slam_get_state(slam_handle* h, int instance, double* x, double* P, int32_t* M, int32_t* ids,
+                   int32_t* timestep);
+/* Vehicle pose estimate (x, y, yaw) of every instance: [batch][3] (EKFState x_v,y_v,yaw_v). */
+int slam_get_poses(slam_handle* h, double* poses);
+int slam_get_landmark_counts(slam_handle* h, int32_t* M);            /* [batch] */
+int slam_get_truth(slam_handle* h, double* truth_poses);             /* [batch][3], sim_node.py x_v */
+/* Measurements the generator produced in the last slam_step_sim: meas [batch][k_stride][3], count [batch]. */
+int slam_get_last_meas(slam_handle* h, float* meas, int32_t* meas_count, int k_stride);
+/* compute_average_error (plotting_node.py:195-218): mean over steps so far of the Euclidean position error of
+ * the estimate at timestep t against the true pose of step t, per instance: [batch]. */
+int slam_error_stats(slam_handle* h, double* per_instance_avg_err);
+int slam_status(slam_handle* h, int32_t* per_instance_flags);       /* [batch] slam_instance_flags */
+
+/* ---- misc ------------------------------------------------------------------------------------------------ */
+int slam_sync(slam_handle* h);
+int slam_batch(const slam_handle* h);
+int slam_state_dim_max(const slam_handle* h);
+/* Algorithmic HBM bytes of the last step summed over instances: sum_b 2*(n_b^2+n_b)*sizeof(storage)
+ * (SURVEY.md §8d).  Computed on the device from the per-instance M; synchronises. */
+int slam_algorithmic_bytes(slam_handle* h, double* bytes);
+const char* slam_last_error(void);
+const char* slam_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_BATCH_H */

@@ -1,0 +1,153 @@
+"""ctypes binding of oracle/libslam_oracle.so — the CPU checker.  TEST INFRASTRUCTURE ONLY.
+
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from live_ekf_slam_amd.config import SlamConfig, default_config  # noqa: F401  (struct layout is shared)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MATH_LIBM, MATH_DET = 0, 1
+MODE_FAST, MODE_DENSE = 0, 1
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+def build(force=False):
+    so = os.path.join(HERE, "libslam_oracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.orc_version.restype = C.c_char_p
+        L.orc_ekf_create.restype = C.c_void_p
+        L.orc_ekf_create.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int]
+        L.orc_ekf_destroy.argtypes = [C.c_void_p]
+        L.orc_ekf_init.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_ekf_update.argtypes = [C.c_void_p, C.c_float, C.c_float, _fp, C.c_int]
+        L.orc_ekf_get.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip]
+        L.orc_ekf_set.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _ip, C.c_int]
+        L.orc_sim_create.restype = C.c_void_p
+        L.orc_sim_create.argtypes = [C.POINTER(SlamConfig), _dp, C.c_int, C.c_int]
+        L.orc_sim_destroy.argtypes = [C.c_void_p]
+        L.orc_sim_reset.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.orc_sim_step_draws.argtypes = [C.c_void_p, C.c_float, C.c_float, _dp, _dp, _fp, _dp, _ip]
+        L.orc_sim_step_philox.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _fp, _ip]
+        L.orc_average_error.restype = C.c_double
+        L.orc_average_error.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int]
+        L.orc_run_ekf_batch.restype = C.c_double
+        L.orc_run_ekf_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int,
+                                        C.c_uint64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp, _ip, _dp,
+                                        C.POINTER(C.c_int64)]
+        L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+        L.orc_noise_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
+        for name in ("orc_det_sincos", "orc_libm_sincos"):
+            getattr(L, name).argtypes = [_dp, _dp, _dp, C.c_int]
+        for name in ("orc_det_atan2", "orc_libm_atan2"):
+            getattr(L, name).argtypes = [_dp, _dp, _dp, C.c_int]
+        L.orc_libm_remainder2pi.argtypes = [_dp, _dp, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+class OracleEKF:
+    """One reference-equivalent EKF-SLAM filter instance (ekf.cpp)."""
+
+    def __init__(self, cfg=None, L_max=50, math=MATH_DET, mode=MODE_FAST):
+        self.cfg = cfg or default_config()
+        self.L_max = L_max
+        self.h = lib().orc_ekf_create(C.byref(self.cfg), L_max, math, mode)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ekf_destroy(self.h)
+            self.h = None
+
+    def init(self, x0=0.0, y0=0.0, yaw0=0.0):
+        lib().orc_ekf_init(self.h, x0, y0, yaw0)
+
+    def update(self, fwd, ang, meas):
+        """meas: array-like [k][3] float32 (id, r, b)."""
+        m = np.ascontiguousarray(np.asarray(meas, dtype=np.float32).reshape(-1, 3))
+        return lib().orc_ekf_update(self.h, float(np.float32(fwd)), float(np.float32(ang)), _f(m), m.shape[0])
+
+    def state(self):
+        nmax = 3 + 2 * self.L_max
+        x = np.zeros(nmax); P = np.zeros(nmax * nmax); ids = np.zeros(self.L_max, dtype=np.int32)
+        M = C.c_int(0); ts = C.c_int(0)
+        lib().orc_ekf_get(self.h, _d(x), _d(P), C.byref(M), _i(ids), C.byref(ts))
+        n = 3 + 2 * M.value
+        return dict(x=x[:n].copy(), P=P[:n * n].reshape(n, n).copy(), M=M.value, ids=ids[:M.value].copy(), timestep=ts.value)
+
+    def set_state(self, x, P, ids, timestep=0):
+        x = np.ascontiguousarray(x, dtype=np.float64); P = np.ascontiguousarray(P, dtype=np.float64)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lib().orc_ekf_set(self.h, _d(x), _d(P), len(ids), _i(ids), timestep)
+
+
+class OracleSim:
+    """The reference's measurement generator get_cmd (sim_node.py:209-250)."""
+
+    def __init__(self, map_xy, cfg=None, math=MATH_DET):
+        self.cfg = cfg or default_config()
+        self.map = np.ascontiguousarray(map_xy, dtype=np.float64)
+        self.L = self.map.shape[0]
+        self.h = lib().orc_sim_create(C.byref(self.cfg), _d(self.map), self.L, math)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_sim_destroy(self.h)
+            self.h = None
+
+    def step_draws(self, fwd, ang, draws):
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        truth = np.zeros(3); meas = np.zeros((self.L, 3), dtype=np.float32); meas64 = np.zeros((self.L, 3))
+        k = C.c_int(0)
+        used = lib().orc_sim_step_draws(self.h, float(np.float32(fwd)), float(np.float32(ang)), _d(draws), _d(truth), _f(meas), _d(meas64), C.byref(k))
+        return truth, meas[:k.value], meas64[:k.value], used
+
+    def step_philox(self, fwd, ang, seed, inst, t):
+        truth = np.zeros(3); meas = np.zeros((self.L, 3), dtype=np.float32); k = C.c_int(0)
+        lib().orc_sim_step_philox(self.h, float(np.float32(fwd)), float(np.float32(ang)), seed, inst, t, _d(truth), _f(meas), C.byref(k))
+        return truth, meas[:k.value]
+
+
+def average_error(est_x, est_y, true_x, true_y, math=MATH_LIBM):
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (est_x, est_y, true_x, true_y)]
+    return lib().orc_average_error(_d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), len(a[0]), math)
+
+
+def run_ekf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, mode=MODE_FAST, nthreads=1, want_P=True):
+    """Lockstep sim + EKF for instances inst0..inst0+B-1 over all commands. Returns dict of numpy outputs."""
+    cfg = cfg or default_config()
+    map_xy = np.ascontiguousarray(map_xy, dtype=np.float64); cmds = np.ascontiguousarray(cmds, dtype=np.float32)
+    L, T, nmax = map_xy.shape[0], cmds.shape[0], 3 + 2 * L_max
+    x = np.zeros((B, nmax)); P = np.zeros((B, nmax * nmax)) if want_P else None
+    M = np.zeros(B, dtype=np.int32); ids = np.zeros((B, L_max), dtype=np.int32)
+    err = np.zeros(B); flags = np.zeros(B, dtype=np.int32); truth = np.zeros((B, 3)); ktot = C.c_int64(0)
+    secs = lib().orc_run_ekf_batch(C.byref(cfg), L_max, math, mode, _d(map_xy), L, _f(cmds), T, seed, inst0, B, nthreads,
+                                   _d(x), _d(P) if want_P else None, _i(M), _i(ids), _d(err), _i(flags), _d(truth), C.byref(ktot))
+    return dict(x=x, P=P, M=M, ids=ids, avg_err=err, flags=flags, truth=truth, seconds=secs, k_total=ktot.value)

@@ -1,0 +1,589 @@
+// slam_oracle.cpp — CPU ORACLE for the EKF-SLAM predict–update path.  TEST INFRASTRUCTURE, NOT PRODUCT.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The product
+// (live_ekf_slam_amd/, include/) never includes, links or calls anything in oracle/.
+//
+// PARITY STATUS: "parity unpinned" against the real reference binary.  The reference C++ cannot be built in
+// this image (filter.h:8-40 needs ROS, Eigen, yaml-cpp, GTSAM, SE-Sync — none installed, no network) and it
+// ships no tests / golden vectors for the filter.  This file is therefore a statement-by-statement
+// restatement of
+//     ekf_ws/src/localization_pkg/src/ekf.cpp:4-21,29-34,37-179      (EKF ctor/init/update)
+//     ekf_ws/src/localization_pkg/include/localization_pkg/filter.h:105-121 (readCommonParams, incl. V/W quirk)
+//     ekf_ws/src/base_pkg/src/sim_node.py:209-250                     (get_cmd measurement generator)
+//     ekf_ws/src/base_pkg/src/plotting_node.py:195-218                (compute_average_error)
+// including every `float` truncation, pinned by (1) the known-answer vectors of SURVEY.md Appendix E,
+// (2) two independent evaluation modes that must agree (MODE_FAST: structure-exploiting O(n^2);
+// MODE_DENSE: literal dense matrix products F*P*F^T, (K*H)*P, Y*p_temp*Y^T exactly as the reference asks
+// Eigen for), and (3) for the Python generator, bit-exact agreement with fixtures produced by importing the
+// reference simulator (tests/golden/make_golden.py).
+//
+// Evaluation order (what "identical results" means): plain IEEE-754 fp64 +,-,*,/ with NO fused multiply-add
+// (compiled -ffp-contract=off; the reference's catkin flags are just -std=c++17, i.e. SSE2 without FMA),
+// matrix-product sums accumulated in ascending inner index, exact-zero terms dropped in MODE_FAST.
+// Math policy: MATH_LIBM uses glibc sin/cos/atan2/pow like the reference; MATH_DET uses the shared
+// deterministic functions of live_ekf_slam_amd/csrc/slam_math.h (what the GPU evaluates) so GPU-vs-oracle
+// comparisons can be bit-exact.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
+
+#include "../include/slam_batch.h"
+#include "../live_ekf_slam_amd/csrc/slam_math.h"
+#include "../live_ekf_slam_amd/csrc/slam_rng.h"
+
+namespace {
+
+enum { MATH_LIBM = 0, MATH_DET = 1 };
+enum { MODE_FAST = 0, MODE_DENSE = 1 };
+
+struct LibmMath {
+    static void sincos(double x, double* s, double* c) { *s = ::sin(x); *c = ::cos(x); }
+    static double atan2(double y, double x) { return ::atan2(y, x); }
+    static double sq(double x) { return ::pow(x, 2.0); }        // std::pow(v,2) ekf.cpp:115 ; v**2 sim_node.py:34
+    static double root(double x) { return ::pow(x, 0.5); }      // (...)**(1/2) sim_node.py:34
+};
+struct DetMath {
+    static void sincos(double x, double* s, double* c) { slam::det_sincos(x, s, c); }
+    static double atan2(double y, double x) { return slam::det_atan2(y, x); }
+    static double sq(double x) { return x * x; }
+    static double root(double x) { return ::sqrt(x); }
+};
+
+// effective filter noise matrices after Filter::readCommonParams (filter.h:105-121)
+struct FilterNoise {
+    double V00, V11, W00, W11;
+};
+FilterNoise effective_noise(const slam_config& c) {
+    FilterNoise f;
+    if (c.replicate_vw_quirk) {  // filter.h:116-117 write W_00/W_11 into V; W stays identity (filter.h:113)
+        f.V00 = c.W_00; f.V11 = c.W_11; f.W00 = 1.0; f.W11 = 1.0;
+    } else {
+        f.V00 = c.V_00; f.V11 = c.V_11; f.W00 = c.W_00; f.W11 = c.W_11;
+    }
+    return f;
+}
+
+// ---- small dense helpers for MODE_DENSE (row-major, k ascending, every term incl. zeros) -----------------
+// C[m x n] = A[m x k] * B[k x n]
+void matmul(const double* A, const double* B, double* C, int m, int k, int n) {
+    for (int i = 0; i < m; ++i) {
+        double* c = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) c[j] = 0.0;
+        for (int p = 0; p < k; ++p) {
+            const double a = A[(size_t)i * k + p];
+            const double* b = B + (size_t)p * n;
+            for (int j = 0; j < n; ++j) c[j] = c[j] + a * b[j];
+        }
+    }
+}
+// C[m x n] = A[m x k] * B^T, B is [n x k]
+void matmul_bt(const double* A, const double* B, double* C, int m, int k, int n) {
+    std::vector<double> Bt((size_t)k * n);
+    for (int j = 0; j < n; ++j)
+        for (int p = 0; p < k; ++p) Bt[(size_t)p * n + j] = B[(size_t)j * k + p];
+    matmul(A, Bt.data(), C, m, k, n);
+}
+
+// MatrixXd::inverse() on a dynamic 2x2 = PartialPivLU + solve against the identity (ekf.cpp:135).
+// Returns false when a pivot is exactly zero (Eigen would then produce inf/nan; so do we).
+bool inv2x2_lu(const double S[4], double Si[4]) {
+    int p0 = 0, p1 = 1;
+    if (fabs(S[2]) > fabs(S[0])) { p0 = 1; p1 = 0; }
+    const double a00 = S[2 * p0 + 0], a01 = S[2 * p0 + 1];
+    const double a10 = S[2 * p1 + 0], a11 = S[2 * p1 + 1];
+    const double l = a10 / a00;
+    const double u11 = a11 - l * a01;
+    bool ok = (a00 != 0.0) && (u11 != 0.0);
+    for (int j = 0; j < 2; ++j) {  // column j of the inverse: solve A x = e_j with rows permuted
+        const double r0 = (p0 == j) ? 1.0 : 0.0, r1 = (p1 == j) ? 1.0 : 0.0;
+        const double y1 = r1 - l * r0;
+        const double x1 = y1 / u11;
+        const double x0 = (r0 - a01 * x1) / a00;
+        Si[0 + j] = x0;
+        Si[2 + j] = x1;
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// EKF-SLAM (ekf.cpp)
+// ------------------------------------------------------------------------------------------------------------
+struct Ekf {
+    slam_config cfg;
+    FilterNoise nz;
+    int L_max, math, mode;
+    int timestep = 0, M = 0, flags = 0;
+    bool frozen = false;
+    std::vector<double> x_t, x_pred, P_t, P_pred;  // P row-major n x n
+    std::vector<int> ids;
+    // scratch
+    std::vector<double> HP, PHt, K, tmpA, tmpB, tmpC;
+
+    int n() const { return 3 + 2 * M; }
+
+    Ekf(const slam_config& c, int Lm, int mth, int md) : cfg(c), nz(effective_noise(c)), L_max(Lm), math(mth), mode(md) {
+        reset_ctor();
+    }
+    void reset_ctor() {  // EKF::EKF ekf.cpp:4-21
+        timestep = 0; M = 0; flags = 0; frozen = false; ids.clear();
+        x_t.assign(3, 0.0); x_pred.assign(3, 0.0);
+        P_t.assign(9, 0.0);
+        P_t[0] = 0.01 * 0.01; P_t[4] = 0.01 * 0.01; P_t[8] = 0.005 * 0.005;
+        P_pred = P_t;
+    }
+    void init(float x0, float y0, float yaw0) {  // ekf.cpp:29-34
+        reset_ctor();
+        x_t[0] = x0; x_t[1] = y0; x_t[2] = yaw0;
+    }
+
+    template <class MP> int update_t(float fwd, float ang, const float* meas, int k);
+    template <class MP> void predict_fast(float d_d, float d_th);
+    template <class MP> void predict_dense(float d_d, float d_th);
+    void landmark_update_apply_fast(int ii, const double H0[5], const double H1[5], double nu0, double nu1);
+    void landmark_update_apply_dense(int ii, const double H0[5], const double H1[5], double nu0, double nu1);
+    void insert_fast(double rd, double sphi, double cphi);
+    void insert_dense(double rd, double sphi, double cphi);
+
+    int update(float fwd, float ang, const float* meas, int k) {
+        return math == MATH_DET ? update_t<DetMath>(fwd, ang, meas, k) : update_t<LibmMath>(fwd, ang, meas, k);
+    }
+};
+
+template <class MP>
+void Ekf::predict_fast(float d_d, float d_th) {
+    const int nn = n();
+    const double th = x_t[2];
+    double s, c;
+    MP::sincos(th, &s, &c);
+    const double a = (double)(-1 * d_d) * s;  // F_x(0,2) ekf.cpp:48
+    const double b = (double)d_d * c;         // F_x(1,2) ekf.cpp:49
+    x_pred = x_t;                             // ekf.cpp:56
+    const float dd = d_d + cfg.v_d;           // float add, ekf.cpp:57
+    x_pred[0] = x_t[0] + (double)dd * c;
+    x_pred[1] = x_t[1] + (double)dd * s;
+    x_pred[2] = remainder((th + (double)d_th) + (double)cfg.v_th, slam::kTwoPi);  // ekf.cpp:59
+    // P_pred = F_x P_t F_x^T + F_v V F_v^T  (ekf.cpp:61), closed form:
+    P_pred = P_t;
+    double* P = P_pred.data();
+    // rows 0,1 of F_x*P
+    for (int cc = 0; cc < nn; ++cc) {
+        const double p2 = P_t[(size_t)2 * nn + cc];
+        P[cc] = P_t[cc] + a * p2;
+        P[(size_t)nn + cc] = P_t[(size_t)nn + cc] + b * p2;
+    }
+    // cols 0,1 of (F_x*P)*F_x^T
+    for (int r = 0; r < nn; ++r) {
+        const double a2 = P[(size_t)r * nn + 2];
+        P[(size_t)r * nn + 0] = P[(size_t)r * nn + 0] + a2 * a;
+        P[(size_t)r * nn + 1] = P[(size_t)r * nn + 1] + a2 * b;
+    }
+    // + F_v V F_v^T
+    const double cv = c * nz.V00, sv = s * nz.V00;
+    P[0] = P[0] + cv * c;
+    P[1] = P[1] + cv * s;
+    P[(size_t)nn] = P[(size_t)nn] + sv * c;
+    P[(size_t)nn + 1] = P[(size_t)nn + 1] + sv * s;
+    P[(size_t)2 * nn + 2] = P[(size_t)2 * nn + 2] + nz.V11;
+}
+
+template <class MP>
+void Ekf::predict_dense(float d_d, float d_th) {
+    const int nn = n();
+    const double th = x_t[2];
+    double s, c;
+    MP::sincos(th, &s, &c);
+    std::vector<double> F((size_t)nn * nn, 0.0), Fv((size_t)nn * 2, 0.0), V(4, 0.0);
+    for (int i = 0; i < nn; ++i) F[(size_t)i * nn + i] = 1.0;
+    F[2] = (double)(-1 * d_d) * s;
+    F[(size_t)nn + 2] = (double)d_d * c;
+    Fv[0] = c; Fv[2] = s; Fv[5] = 1.0;
+    V[0] = nz.V00; V[3] = nz.V11;
+    x_pred = x_t;
+    const float dd = d_d + cfg.v_d;
+    x_pred[0] = x_t[0] + (double)dd * c;
+    x_pred[1] = x_t[1] + (double)dd * s;
+    x_pred[2] = remainder((th + (double)d_th) + (double)cfg.v_th, slam::kTwoPi);
+    tmpA.resize((size_t)nn * nn); tmpB.resize((size_t)nn * nn);
+    matmul(F.data(), P_t.data(), tmpA.data(), nn, nn, nn);
+    matmul_bt(tmpA.data(), F.data(), tmpB.data(), nn, nn, nn);
+    std::vector<double> FvV((size_t)nn * 2), Q((size_t)nn * nn);
+    matmul(Fv.data(), V.data(), FvV.data(), nn, 2, 2);
+    matmul_bt(FvV.data(), Fv.data(), Q.data(), nn, 2, nn);
+    P_pred.resize((size_t)nn * nn);
+    for (size_t i = 0; i < (size_t)nn * nn; ++i) P_pred[i] = tmpB[i] + Q[i];
+}
+
+// H has non-zeros in columns {0,1,2,ii,ii+1}: H0 = row 0 values, H1 = row 1 values at those five columns
+void Ekf::landmark_update_apply_fast(int ii, const double H0[5], const double H1[5], double nu0, double nu1) {
+    const int nn = n();
+    double* P = P_pred.data();
+    HP.resize((size_t)2 * nn); PHt.resize((size_t)2 * nn); K.resize((size_t)2 * nn);
+    const int col[5] = {0, 1, 2, ii, ii + 1};
+    for (int c = 0; c < nn; ++c) {  // H * P (rows of P), H0[2] == 0 is skipped
+        const double p0 = P[c], p1 = P[(size_t)nn + c], p2 = P[(size_t)2 * nn + c];
+        const double pi = P[(size_t)ii * nn + c], pj = P[(size_t)(ii + 1) * nn + c];
+        HP[c] = ((H0[0] * p0 + H0[1] * p1) + H0[3] * pi) + H0[4] * pj;
+        HP[(size_t)nn + c] = (((H1[0] * p0 + H1[1] * p1) + H1[2] * p2) + H1[3] * pi) + H1[4] * pj;
+    }
+    for (int r = 0; r < nn; ++r) {  // P * H^T (columns of P)
+        const double* pr = P + (size_t)r * nn;
+        PHt[(size_t)2 * r] = ((pr[0] * H0[0] + pr[1] * H0[1]) + pr[ii] * H0[3]) + pr[ii + 1] * H0[4];
+        PHt[(size_t)2 * r + 1] = (((pr[0] * H1[0] + pr[1] * H1[1]) + pr[2] * H1[2]) + pr[ii] * H1[3]) + pr[ii + 1] * H1[4];
+    }
+    double S[4], Si[4];
+    {  // S = (H P) H^T + H_w W H_w^T   ekf.cpp:133
+        const double* h0 = HP.data();
+        const double* h1 = HP.data() + nn;
+        S[0] = ((h0[col[0]] * H0[0] + h0[col[1]] * H0[1]) + h0[col[3]] * H0[3]) + h0[col[4]] * H0[4];
+        S[1] = (((h0[col[0]] * H1[0] + h0[col[1]] * H1[1]) + h0[col[2]] * H1[2]) + h0[col[3]] * H1[3]) + h0[col[4]] * H1[4];
+        S[2] = ((h1[col[0]] * H0[0] + h1[col[1]] * H0[1]) + h1[col[3]] * H0[3]) + h1[col[4]] * H0[4];
+        S[3] = (((h1[col[0]] * H1[0] + h1[col[1]] * H1[1]) + h1[col[2]] * H1[2]) + h1[col[3]] * H1[3]) + h1[col[4]] * H1[4];
+        S[0] = S[0] + nz.W00;
+        S[3] = S[3] + nz.W11;
+    }
+    if (!inv2x2_lu(S, Si)) flags |= SLAM_INST_S_SINGULAR;
+    for (int r = 0; r < nn; ++r) {  // K = (P H^T) S^-1   ekf.cpp:135
+        const double a = PHt[(size_t)2 * r], b = PHt[(size_t)2 * r + 1];
+        K[(size_t)2 * r] = a * Si[0] + b * Si[2];
+        K[(size_t)2 * r + 1] = a * Si[1] + b * Si[3];
+    }
+    for (int r = 0; r < nn; ++r)  // x_pred += K nu   ekf.cpp:138
+        x_pred[r] = x_pred[r] + (K[(size_t)2 * r] * nu0 + K[(size_t)2 * r + 1] * nu1);
+    x_pred[2] = remainder(x_pred[2], slam::kTwoPi);  // ekf.cpp:139
+    for (int r = 0; r < nn; ++r) {  // P_pred -= K (H P)   ekf.cpp:140 (re-associated rank-2 form)
+        const double k0 = K[(size_t)2 * r], k1 = K[(size_t)2 * r + 1];
+        double* pr = P + (size_t)r * nn;
+        for (int c = 0; c < nn; ++c) pr[c] = pr[c] - (k0 * HP[c] + k1 * HP[(size_t)nn + c]);
+    }
+}
+
+void Ekf::landmark_update_apply_dense(int ii, const double H0[5], const double H1[5], double nu0, double nu1) {
+    const int nn = n();
+    std::vector<double> H((size_t)2 * nn, 0.0);
+    const int col[5] = {0, 1, 2, ii, ii + 1};
+    for (int j = 0; j < 5; ++j) { H[col[j]] = H0[j]; H[(size_t)nn + col[j]] = H1[j]; }
+    std::vector<double> HPd((size_t)2 * nn), Sd(4), PHtd((size_t)nn * 2), Kd((size_t)nn * 2), KH((size_t)nn * nn), KHP((size_t)nn * nn);
+    matmul(H.data(), P_pred.data(), HPd.data(), 2, nn, nn);
+    matmul_bt(HPd.data(), H.data(), Sd.data(), 2, nn, 2);
+    double S[4] = {Sd[0] + nz.W00, Sd[1] + 0.0, Sd[2] + 0.0, Sd[3] + nz.W11}, Si[4];
+    if (!inv2x2_lu(S, Si)) flags |= SLAM_INST_S_SINGULAR;
+    matmul_bt(P_pred.data(), H.data(), PHtd.data(), nn, nn, 2);
+    matmul(PHtd.data(), Si, Kd.data(), nn, 2, 2);
+    for (int r = 0; r < nn; ++r) x_pred[r] = x_pred[r] + (Kd[(size_t)2 * r] * nu0 + Kd[(size_t)2 * r + 1] * nu1);
+    x_pred[2] = remainder(x_pred[2], slam::kTwoPi);
+    matmul(Kd.data(), H.data(), KH.data(), nn, 2, nn);              // (K*H)
+    matmul(KH.data(), P_pred.data(), KHP.data(), nn, nn, nn);       // (K*H)*P_pred : the reference's n^3 product
+    for (size_t i = 0; i < (size_t)nn * nn; ++i) P_pred[i] = P_pred[i] - KHP[i];
+}
+
+// landmark insertion, ekf.cpp:141-173, closed form of Y * blkdiag(P, W) * Y^T.  M, x_pred, ids already grown.
+void Ekf::insert_fast(double rd, double sphi, double cphi) {
+    const int nn = n(), no = nn - 2;
+    const double g02 = -rd * sphi, g12 = rd * cphi;  // G_x(0,2), G_x(1,2); also G_z(0,1), G_z(1,1)
+    std::vector<double> Pn((size_t)nn * nn, 0.0);
+    const double* P = P_pred.data();
+    for (int r = 0; r < no; ++r)
+        for (int c = 0; c < no; ++c) Pn[(size_t)r * nn + c] = P[(size_t)r * no + c];
+    std::vector<double> R((size_t)2 * no);
+    for (int c = 0; c < no; ++c) {  // new rows: G_x * P[0:3, :]
+        R[c] = P[c] + g02 * P[(size_t)2 * no + c];
+        R[(size_t)no + c] = P[(size_t)no + c] + g12 * P[(size_t)2 * no + c];
+        Pn[(size_t)no * nn + c] = R[c];
+        Pn[(size_t)(no + 1) * nn + c] = R[(size_t)no + c];
+    }
+    for (int r = 0; r < no; ++r) {  // new cols: P[:, 0:3] * G_x^T
+        Pn[(size_t)r * nn + no] = P[(size_t)r * no + 0] + P[(size_t)r * no + 2] * g02;
+        Pn[(size_t)r * nn + no + 1] = P[(size_t)r * no + 1] + P[(size_t)r * no + 2] * g12;
+    }
+    // corner: (G_x P_vv) G_x^T + (G_z W) G_z^T
+    const double gz[2][2] = {{cphi, g02}, {sphi, g12}};
+    for (int a = 0; a < 2; ++a) {
+        const double gw0 = gz[a][0] * nz.W00, gw1 = gz[a][1] * nz.W11;
+        const double ra0 = R[(size_t)a * no + 0], ra1 = R[(size_t)a * no + 1], ra2 = R[(size_t)a * no + 2];
+        Pn[(size_t)(no + a) * nn + no] = ((ra0 + ra2 * g02) + gw0 * gz[0][0]) + gw1 * gz[0][1];
+        Pn[(size_t)(no + a) * nn + no + 1] = ((ra1 + ra2 * g12) + gw0 * gz[1][0]) + gw1 * gz[1][1];
+    }
+    P_pred.swap(Pn);
+}
+
+void Ekf::insert_dense(double rd, double sphi, double cphi) {
+    const int nn = n(), no = nn - 2;
+    std::vector<double> Y((size_t)nn * nn, 0.0), pt((size_t)nn * nn, 0.0), t1((size_t)nn * nn), t2((size_t)nn * nn);
+    for (int i = 0; i < nn; ++i) Y[(size_t)i * nn + i] = 1.0;
+    Y[(size_t)no * nn + no] = cphi;       Y[(size_t)no * nn + no + 1] = -rd * sphi;
+    Y[(size_t)(no + 1) * nn + no] = sphi; Y[(size_t)(no + 1) * nn + no + 1] = rd * cphi;
+    Y[(size_t)no * nn + 0] = 1; Y[(size_t)no * nn + 1] = 0; Y[(size_t)no * nn + 2] = -rd * sphi;
+    Y[(size_t)(no + 1) * nn + 0] = 0; Y[(size_t)(no + 1) * nn + 1] = 1; Y[(size_t)(no + 1) * nn + 2] = rd * cphi;
+    for (int r = 0; r < no; ++r)
+        for (int c = 0; c < no; ++c) pt[(size_t)r * nn + c] = P_pred[(size_t)r * no + c];
+    pt[(size_t)no * nn + no] = nz.W00;
+    pt[(size_t)(no + 1) * nn + no + 1] = nz.W11;
+    matmul(Y.data(), pt.data(), t1.data(), nn, nn, nn);
+    matmul_bt(t1.data(), Y.data(), t2.data(), nn, nn, nn);
+    P_pred.swap(t2);
+}
+
+template <class MP>
+int Ekf::update_t(float fwd, float ang, const float* meas, int k) {
+    if (frozen) return flags;
+    timestep += 1;                                   // ekf.cpp:39
+    const float d_d = fwd, d_th = ang;               // ekf.cpp:43-44
+    if (mode == MODE_DENSE) predict_dense<MP>(d_d, d_th); else predict_fast<MP>(d_d, d_th);
+    if (k < 1) {                                     // ekf.cpp:67-71
+        x_t = x_pred; P_t = P_pred;
+        return flags;
+    }
+    for (int l = 0; l < k; ++l) {                    // ekf.cpp:73
+        const float r = meas[3 * l + 1], b = meas[3 * l + 2];
+        int i = -1, id;
+        if (!cfg.landmark_id_is_known) {             // ekf.cpp:82-98
+            id = M;
+            double s, c;
+            MP::sincos(x_pred[2] + (double)b, &s, &c);
+            const float x_det = (float)(x_pred[0] + (double)r * c);
+            const float y_det = (float)(x_pred[1] + (double)r * s);
+            for (int j = 0; j < M; ++j) {
+                const float xd = (float)fabs((double)x_det - x_pred[3 + 2 * j]);
+                const float yd = (float)fabs((double)y_det - x_pred[3 + 2 * j + 1]);
+                if (xd < cfg.min_landmark_separation && yd < cfg.min_landmark_separation) { i = j; id = j; break; }
+            }
+        } else {                                     // ekf.cpp:99-108
+            id = (int)meas[3 * l];
+            for (int j = 0; j < M; ++j)
+                if (ids[j] == id) { i = j; break; }
+        }
+        if (i != -1) {                               // ekf.cpp:110-140 landmark update
+            const int ii = 2 * i + 3;
+            if (ii + 1 >= (int)x_t.size()) {         // x_t(i) out of range -> eigen_assert throws (filter.h:5)
+                flags |= SLAM_INST_INDEX_OOR; frozen = true;
+                return flags;
+            }
+            const double dx = x_t[ii] - x_pred[0], dy = x_t[ii + 1] - x_pred[1];
+            const float dist = (float)::sqrt(MP::sq(dx) + MP::sq(dy));      // ekf.cpp:115 (float)
+            const double dd = (double)dist, d2 = (double)(dist * dist);     // dist*dist is a float product
+            const double H0[5] = {-dx / dd, -dy / dd, 0.0, dx / dd, dy / dd};
+            const double H1[5] = {dy / d2, -dx / d2, -1.0, -dy / d2, dx / d2};
+            const float angf = (float)remainder(MP::atan2(dy, dx) - x_pred[2], slam::kTwoPi);  // ekf.cpp:129
+            const float nu0 = r - dist - cfg.w_r;    // float arithmetic ekf.cpp:130-131
+            const float nu1 = b - angf - cfg.w_b;
+            if (mode == MODE_DENSE) landmark_update_apply_dense(ii, H0, H1, (double)nu0, (double)nu1);
+            else landmark_update_apply_fast(ii, H0, H1, (double)nu0, (double)nu1);
+        } else {                                     // ekf.cpp:141-173 landmark insertion
+            if (M >= L_max) { flags |= SLAM_INST_CAPACITY; continue; }
+            M += 1;
+            const int nn = n();
+            const double phi = x_pred[2] + (double)b;
+            double s, c;
+            MP::sincos(phi, &s, &c);
+            x_pred.resize(nn);
+            x_pred[nn - 2] = x_pred[0] + (double)r * c;
+            x_pred[nn - 1] = x_pred[1] + (double)r * s;
+            ids.push_back(id);
+            if (mode == MODE_DENSE) insert_dense((double)r, s, c); else insert_fast((double)r, s, c);
+        }
+    }
+    x_t = x_pred; P_t = P_pred;                      // ekf.cpp:176-177
+    bool fin = true;
+    for (double v : x_t) fin = fin && std::isfinite(v);
+    for (double v : P_t) fin = fin && std::isfinite(v);
+    if (!fin) flags |= SLAM_INST_NONFINITE;
+    return flags;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// measurement generator: get_cmd, sim_node.py:209-250
+// ------------------------------------------------------------------------------------------------------------
+struct Sim {
+    slam_config cfg;
+    std::vector<double> map;  // [L][2]
+    int L, math;
+    double xv[3];
+
+    template <class MP, class Draw>
+    int step_t(float fwd, float ang, Draw&& draw, float* meas, double* meas64, int* k_out) {
+        // sim_node.py:216-217 : msg.fwd + 2*V_00*random() - V_00
+        double d = ((double)fwd + (2 * cfg.V_00) * draw(0, 0)) - cfg.V_00;
+        double hdg = ((double)ang + (2 * cfg.V_11) * draw(0, 1)) - cfg.V_11;
+        d = std::max(0.0, std::min(d, cfg.d_max));                      // :219
+        hdg = std::max(-cfg.th_max, std::min(hdg, cfg.th_max));         // :220
+        double s, c;
+        MP::sincos(xv[2], &s, &c);
+        const double nx = xv[0] + d * c, ny = xv[1] + d * s, nt = xv[2] + hdg;  // :222 (yaw NOT wrapped)
+        xv[0] = nx; xv[1] = ny; xv[2] = nt;
+        int k = 0;
+        std::vector<double> vis;  // id, r, beta
+        for (int id = 0; id < L; ++id) {                                // :231-243
+            const double dx = map[2 * id] - xv[0], dy = map[2 * id + 1] - xv[1];
+            const double r = MP::root(MP::sq(dx) + MP::sq(dy));         // norm() sim_node.py:31-34
+            const double gb = MP::atan2(dy, dx);
+            const double beta = remainder(gb - xv[2], slam::kTwoPi);
+            if (r > cfg.range_max) continue;
+            if (beta > cfg.fov_min && beta < cfg.fov_max) { vis.push_back(id); vis.push_back(r); vis.push_back(beta); ++k; }
+        }
+        for (int v = 0; v < k; ++v) {                                   // :245-249
+            const double rn = (vis[3 * v + 1] + (2 * cfg.W_00) * draw(1 + v, 0)) - cfg.W_00;
+            const double bn = (vis[3 * v + 2] + (2 * cfg.W_11) * draw(1 + v, 1)) - cfg.W_11;
+            if (meas) { meas[3 * v] = (float)vis[3 * v]; meas[3 * v + 1] = (float)rn; meas[3 * v + 2] = (float)bn; }  // float32 wire
+            if (meas64) { meas64[3 * v] = vis[3 * v]; meas64[3 * v + 1] = rn; meas64[3 * v + 2] = bn; }
+        }
+        *k_out = k;
+        return k;
+    }
+};
+
+// position error of one step: plotting_node.py:209-212 (pure function of the lists it is given)
+template <class MP>
+double step_pos_error(double est_x, double est_y, double true_x, double true_y) {
+    return ::sqrt(MP::sq(est_x - true_x) + MP::sq(est_y - true_y));
+}
+// what the plotter receives: EKFState.x_v / y_v are float32 on the wire (EKFState.msg:5-6, ekf.cpp:198-199),
+// the truth is a float64 geometry_msgs/Vector3 (sim_node.py:225).
+inline double wire_f32(double v) { return (double)(float)v; }
+
+}  // namespace
+
+// ================================================================================================================
+// C ABI (ctypes) — test/bench checker only
+// ================================================================================================================
+extern "C" {
+
+const char* orc_version() { return "slam_oracle r1 (parity unpinned vs reference binary; see header)"; }
+
+// ---- math probes ----------------------------------------------------------------------------------------------
+void orc_det_sincos(const double* x, double* s, double* c, int n) { for (int i = 0; i < n; ++i) slam::det_sincos(x[i], &s[i], &c[i]); }
+void orc_det_atan2(const double* y, const double* x, double* out, int n) { for (int i = 0; i < n; ++i) out[i] = slam::det_atan2(y[i], x[i]); }
+void orc_libm_sincos(const double* x, double* s, double* c, int n) { for (int i = 0; i < n; ++i) { s[i] = sin(x[i]); c[i] = cos(x[i]); } }
+void orc_libm_atan2(const double* y, const double* x, double* out, int n) { for (int i = 0; i < n; ++i) out[i] = atan2(y[i], x[i]); }
+void orc_libm_remainder2pi(const double* x, double* out, int n) { for (int i = 0; i < n; ++i) out[i] = remainder(x[i], slam::kTwoPi); }
+void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    slam::Philox4 r = slam::philox4x32_10(c0, c1, c2, c3, k0, k1);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+void orc_noise_pair(uint64_t seed, uint64_t inst, uint32_t t, uint32_t p, double out[2]) { slam::noise_pair(seed, inst, t, p, &out[0], &out[1]); }
+
+// ---- EKF ------------------------------------------------------------------------------------------------------
+void* orc_ekf_create(const slam_config* cfg, int L_max, int math, int mode) { return new Ekf(*cfg, L_max, math, mode); }
+void orc_ekf_destroy(void* h) { delete (Ekf*)h; }
+void orc_ekf_init(void* h, float x0, float y0, float yaw0) { ((Ekf*)h)->init(x0, y0, yaw0); }
+int orc_ekf_update(void* h, float fwd, float ang, const float* meas, int k) { return ((Ekf*)h)->update(fwd, ang, meas, k); }
+// x: n doubles; P: n*n row-major; ids: M ints
+void orc_ekf_get(void* h, double* x, double* P, int* M, int* ids, int* timestep) {
+    Ekf* e = (Ekf*)h;
+    const int n = e->n();
+    if (x) memcpy(x, e->x_t.data(), sizeof(double) * n);
+    if (P) memcpy(P, e->P_t.data(), sizeof(double) * n * n);
+    if (M) *M = e->M;
+    if (ids) memcpy(ids, e->ids.data(), sizeof(int) * e->M);
+    if (timestep) *timestep = e->timestep;
+}
+void orc_ekf_set(void* h, const double* x, const double* P, int M, const int* ids, int timestep) {
+    Ekf* e = (Ekf*)h;
+    e->M = M;
+    const int n = e->n();
+    e->x_t.assign(x, x + n); e->x_pred = e->x_t;
+    e->P_t.assign(P, P + (size_t)n * n); e->P_pred = e->P_t;
+    e->ids.assign(ids, ids + M);
+    e->timestep = timestep; e->flags = 0; e->frozen = false;
+}
+
+// ---- simulator ------------------------------------------------------------------------------------------------
+void* orc_sim_create(const slam_config* cfg, const double* map_xy, int L, int math) {
+    Sim* s = new Sim();
+    s->cfg = *cfg; s->L = L; s->math = math;
+    s->map.assign(map_xy, map_xy + 2 * L);
+    s->xv[0] = cfg->init_x; s->xv[1] = cfg->init_y; s->xv[2] = cfg->init_yaw;
+    return s;
+}
+void orc_sim_destroy(void* h) { delete (Sim*)h; }
+void orc_sim_reset(void* h, double x, double y, double yaw) { Sim* s = (Sim*)h; s->xv[0] = x; s->xv[1] = y; s->xv[2] = yaw; }
+// draws are consumed in the reference's order: d, hdg, then (r, beta) per visible landmark. Returns #draws used.
+int orc_sim_step_draws(void* h, float fwd, float ang, const double* draws, double truth[3], float* meas, double* meas64, int* k) {
+    Sim* s = (Sim*)h;
+    auto draw = [&](int pair, int which) { return draws[2 * pair + which]; };
+    if (s->math == MATH_DET) s->step_t<DetMath>(fwd, ang, draw, meas, meas64, k);
+    else s->step_t<LibmMath>(fwd, ang, draw, meas, meas64, k);
+    truth[0] = s->xv[0]; truth[1] = s->xv[1]; truth[2] = s->xv[2];
+    return 2 + 2 * (*k);
+}
+void orc_sim_step_philox(void* h, float fwd, float ang, uint64_t seed, uint64_t inst, uint32_t t, double truth[3], float* meas, int* k) {
+    Sim* s = (Sim*)h;
+    auto draw = [&](int pair, int which) {
+        double u0, u1;
+        slam::noise_pair(seed, inst, t, (uint32_t)pair, &u0, &u1);
+        return which ? u1 : u0;
+    };
+    if (s->math == MATH_DET) s->step_t<DetMath>(fwd, ang, draw, meas, nullptr, k);
+    else s->step_t<LibmMath>(fwd, ang, draw, meas, nullptr, k);
+    truth[0] = s->xv[0]; truth[1] = s->xv[1]; truth[2] = s->xv[2];
+}
+
+// compute_average_error, plotting_node.py:195-218 (timestamps = 1..T, estimate t pairs with truth[t-1])
+double orc_average_error(const double* est_x, const double* est_y, const double* true_x, const double* true_y, int T, int math) {
+    double sum = 0.0;
+    for (int i = 0; i < T; ++i)
+        sum = sum + (math == MATH_DET ? step_pos_error<DetMath>(est_x[i], est_y[i], true_x[i], true_y[i])
+                                      : step_pos_error<LibmMath>(est_x[i], est_y[i], true_x[i], true_y[i]));
+    return sum / T;
+}
+
+// ---- batch runner: B instances (global ids inst0..inst0+B-1), T lockstep sim+filter steps, `nthreads` threads. ---
+// Step t (1-based) uses cmds[t-1] and RNG step index t0 + t - 1.  Outputs may be NULL.
+//   x_out [B][n_max], P_out [B][n_max*n_max] (each instance's n x n block packed row-major at the start),
+//   M_out [B], ids_out [B][L_max], avg_err [B], flags [B], truth_out [B][3], k_total (sum of detections).
+// Returns elapsed seconds of the stepping loop.
+double orc_run_ekf_batch(const slam_config* cfg, int L_max, int math, int mode, const double* map_xy, int L,
+                         const float* cmds, int T, uint64_t seed, int64_t inst0, int B, int nthreads,
+                         double* x_out, double* P_out, int* M_out, int* ids_out, double* avg_err, int* flags,
+                         double* truth_out, int64_t* k_total) {
+    const int n_max = 3 + 2 * L_max;
+    std::atomic<int> next(0);
+    std::atomic<long long> ktot(0);
+    auto worker = [&]() {
+        std::vector<float> meas((size_t)3 * std::max(L, 1));
+        for (;;) {
+            const int b = next.fetch_add(1);
+            if (b >= B) break;
+            Ekf ekf(*cfg, L_max, math, mode);
+            ekf.init((float)cfg->init_x, (float)cfg->init_y, (float)cfg->init_yaw);
+            Sim sim;
+            sim.cfg = *cfg; sim.L = L; sim.math = math; sim.map.assign(map_xy, map_xy + 2 * L);
+            sim.xv[0] = cfg->init_x; sim.xv[1] = cfg->init_y; sim.xv[2] = cfg->init_yaw;
+            double errsum = 0.0;
+            long long kk = 0;
+            for (int t = 0; t < T; ++t) {
+                int k = 0;
+                double truth[3];
+                orc_sim_step_philox(&sim, cmds[2 * t], cmds[2 * t + 1], seed, (uint64_t)(inst0 + b), (uint32_t)t, truth, meas.data(), &k);
+                kk += k;
+                ekf.update(cmds[2 * t], cmds[2 * t + 1], meas.data(), k);
+                errsum = errsum + (math == MATH_DET ? step_pos_error<DetMath>(wire_f32(ekf.x_t[0]), wire_f32(ekf.x_t[1]), truth[0], truth[1])
+                                                    : step_pos_error<LibmMath>(wire_f32(ekf.x_t[0]), wire_f32(ekf.x_t[1]), truth[0], truth[1]));
+            }
+            ktot += kk;
+            const int n = ekf.n();
+            if (x_out) memcpy(x_out + (size_t)b * n_max, ekf.x_t.data(), sizeof(double) * n);
+            if (P_out) memcpy(P_out + (size_t)b * n_max * n_max, ekf.P_t.data(), sizeof(double) * n * n);
+            if (M_out) M_out[b] = ekf.M;
+            if (ids_out) memcpy(ids_out + (size_t)b * L_max, ekf.ids.data(), sizeof(int) * ekf.M);
+            if (avg_err) avg_err[b] = T > 0 ? errsum / T : 0.0;
+            if (flags) flags[b] = ekf.flags;
+            if (truth_out) { truth_out[3 * b] = sim.xv[0]; truth_out[3 * b + 1] = sim.xv[1]; truth_out[3 * b + 2] = sim.xv[2]; }
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int i = 1; i < nthreads; ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    const auto t1 = std::chrono::steady_clock::now();
+    if (k_total) *k_total = ktot.load();
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"
