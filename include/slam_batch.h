@@ -149,6 +149,10 @@ int slam_state_dim_max(const slam_handle* h);
 /* Algorithmic HBM bytes of the last step summed over instances: sum_b 2*(n_b^2+n_b)*sizeof(storage)
  * (SURVEY.md §8d).  Computed on the device from the per-instance M; synchronises. */
 int slam_algorithmic_bytes(slam_handle* h, double* bytes);
+/* Diagnostics: evaluate the device's elementary functions on host arrays a[n], b[n]; out[8*n] =
+ * {sin a, cos a, atan2(a,b), remainder(a,2pi), sqrt|a|, a/b, (double)(float)a, u53 noise} per element.
+ * Used by the parity tests to prove the device math is bit-identical to the host's. */
+int slam_math_probe(const double* a, const double* b, double* out, int n, int device);
 const char* slam_last_error(void);
 const char* slam_version(void);
 

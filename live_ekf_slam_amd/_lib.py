@@ -1,0 +1,77 @@
+"""ctypes loader for the in-tree HIP extension libslam_hip.so (C ABI: include/slam_batch.h).
+
+There is no CPU fallback: if the library is missing or a HIP call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+from .config import SlamConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libslam_hip.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_H = C.c_void_p
+
+
+class SlamError(RuntimeError):
+    """Raised for any non-zero return of the C ABI (the reference signals errors by C++ exceptions)."""
+
+
+# name -> (restype, argtypes); every symbol include/slam_batch.h declares
+SIGNATURES = {
+    "slam_config_default": (C.c_int, [C.POINTER(SlamConfig)]),
+    "slam_config_load": (C.c_int, [C.POINTER(SlamConfig), C.c_char_p]),
+    "slam_create": (C.c_int, [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "slam_destroy": (C.c_int, [_H]),
+    "slam_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "slam_set_instance_offset": (C.c_int, [_H, C.c_int64]),
+    "slam_set_seed": (C.c_int, [_H, C.c_uint64]),
+    "slam_set_vision": (C.c_int, [_H, C.c_double, C.c_double, C.c_double]),
+    "slam_init": (C.c_int, [_H, C.c_float, C.c_float, C.c_float]),
+    "slam_set_map": (C.c_int, [_H, _dp, C.c_int]),
+    "slam_step": (C.c_int, [_H, _fp, _fp, _ip, C.c_int]),
+    "slam_step_dev": (C.c_int, [_H, _fp, C.c_void_p, C.c_void_p, C.c_int]),
+    "slam_step_sim": (C.c_int, [_H, _fp]),
+    "slam_run_sim": (C.c_int, [_H, _fp, C.c_int]),
+    "slam_predict": (C.c_int, [_H, _fp]),
+    "slam_update_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),
+    "slam_get_state": (C.c_int, [_H, C.c_int, _dp, _dp, _ip, _ip, _ip]),
+    "slam_get_poses": (C.c_int, [_H, _dp]),
+    "slam_get_landmark_counts": (C.c_int, [_H, _ip]),
+    "slam_get_truth": (C.c_int, [_H, _dp]),
+    "slam_get_last_meas": (C.c_int, [_H, _fp, _ip, C.c_int]),
+    "slam_error_stats": (C.c_int, [_H, _dp]),
+    "slam_status": (C.c_int, [_H, _ip]),
+    "slam_sync": (C.c_int, [_H]),
+    "slam_batch": (C.c_int, [_H]),
+    "slam_state_dim_max": (C.c_int, [_H]),
+    "slam_algorithmic_bytes": (C.c_int, [_H, _dp]),
+    "slam_math_probe": (C.c_int, [_dp, _dp, _dp, C.c_int, C.c_int]),
+    "slam_last_error": (C.c_char_p, []),
+    "slam_version": (C.c_char_p, []),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlamError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -m live_ekf_slam_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SlamError(f"libslam_hip error {rc}: {lib().slam_last_error().decode()}")

@@ -1,0 +1,56 @@
+"""Build recipe for the HIP extension (libslam_hip.so), in-tree, gfx950 only.
+
+`python -m live_ekf_slam_amd.build` or build_extension() from __graft_entry__.build().
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the parity contract (bit-identical to the
+CPU oracle) relies on unfused IEEE mul/add on both sides.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libslam_hip.so")
+SOURCES = ["ekf_inst_103_2.hip", "ekf_inst_103_4.hip", "ekf_inst_43_1.hip", "ekf_kernel.hip", "slam_capi.cpp"]
+HEADERS = ["ekf_kernel.h", "ekf_kernel_impl.h", "slam_math.h", "slam_rng.h", "../../include/slam_batch.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
+         "-Wno-unused-function", "-x", "hip"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_extension(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs, procs = [], []
+    for src in SOURCES:  # one hipcc per translation unit, all in parallel (the kernel variants dominate)
+        obj = os.path.join(CSRC, src + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = []
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if verbose or pr.returncode != 0:
+            sys.stderr.write(out)
+        if pr.returncode != 0:
+            failed.append(src)
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_extension(force="--force" in sys.argv, verbose="-v" in sys.argv))

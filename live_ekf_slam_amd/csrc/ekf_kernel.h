@@ -1,0 +1,68 @@
+// ekf_kernel.h — parameter block and launcher of the fused EKF-SLAM step kernel (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slam {
+
+// One launch = one timestep of EKF::update (ekf.cpp:37-179) for every instance of the batch, optionally
+// preceded (SIM mode) by the measurement generator get_cmd (sim_node.py:209-250) for the same instance.
+struct EkfStepParams {
+    // ---- filter state in HBM ----
+    double* P;          // [B][pstride]  packed row-major n x n, leading dimension n = 3+2*M[b]
+    double* x;          // [B][xstride]  x_t
+    int32_t* M;         // [B]
+    int32_t* ids;       // [B][L_max]    lm_IDs
+    int32_t* flags;     // [B]           slam_instance_flags
+    int32_t* timestep;  // [B]
+    // ---- simulator state (SIM mode) ----
+    double* truth;      // [B][3] true pose x_v (sim_node.py:222)
+    double* err_sum;    // [B]   running sum of position errors (plotting_node.py:209-212)
+    const double* map;  // [L][2]
+    int32_t L;
+    // ---- measurements ----
+    const float* meas_in;         // EXT mode: [B][k_stride_in][3]
+    const int32_t* meas_count_in; // EXT mode: [B]
+    int32_t k_stride_in;
+    float* meas_out;              // SIM mode, optional dump: [B][k_stride_out][3]
+    int32_t* meas_count_out;      // SIM mode, optional: [B]
+    int32_t k_stride_out;
+    // ---- command (Command.msg) ----
+    float fwd, ang;
+    // ---- filter config after readCommonParams (filter.h:105-121), effective V / W ----
+    float v_d, v_th, w_r, w_b;
+    double V00, V11, W00, W11;
+    int32_t id_known;
+    float min_sep;
+    // ---- simulator config (raw YAML values, used as half-widths: sim_node.py:216-217,247-248) ----
+    double sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max;
+    uint64_t seed;
+    int64_t inst0;
+    uint32_t step;  // RNG step index t (0-based)
+    // ---- geometry ----
+    int32_t B, L_max, pstride, xstride;
+    int32_t sim;  // 1 = SIM mode, 0 = EXT mode
+};
+
+// Largest landmark capacity the register-resident kernel supports (n = 3+2L <= 103).
+static constexpr int kEkfMaxLandmarks = 50;
+
+// waves_per_filter: 0 = let the library pick; 1, 2 or 4 otherwise.
+hipError_t launch_ekf_step(const EkfStepParams& p, int waves_per_filter, hipStream_t stream);
+
+// sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)
+hipError_t launch_algorithmic_bytes(const int32_t* M, int B, double* out, hipStream_t stream);
+
+// fill x/P/M/... for Filter::init (ekf.cpp:4-21,29-34)
+struct EkfInitParams {
+    double* P; double* x; int32_t* M; int32_t* flags; int32_t* timestep; double* truth; double* err_sum;
+    int32_t B, pstride, xstride;
+    float x0, y0, yaw0;
+    double tx, ty, tyaw;
+};
+hipError_t launch_ekf_init(const EkfInitParams& p, hipStream_t stream);
+
+// device math self-test: out[0..n) = det_sincos/atan2/remainder/sqrt/div results for bit-exactness checks
+hipError_t launch_math_probe(const double* a, const double* b, double* out, int n, hipStream_t stream);
+
+}  // namespace slam

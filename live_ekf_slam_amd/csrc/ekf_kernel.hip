@@ -1,0 +1,84 @@
+// ekf_kernel.hip — variant dispatch of the fused EKF-SLAM step kernel + small auxiliary kernels.
+// The kernel template lives in ekf_kernel_impl.h; each (NMAX, W) variant is instantiated in its own
+// translation unit (ekf_inst_*.hip) so they compile in parallel.
+#include "ekf_kernel.h"
+
+#include "../../include/slam_batch.h"
+#include "slam_math.h"
+#include "slam_rng.h"
+
+namespace slam {
+
+template <int NMAX, int W>
+hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream);
+extern template hipError_t launch_variant<43, 1>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 2>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4>(const EkfStepParams&, hipStream_t);
+
+// L_max <= 20 (n <= 43): one wavefront per filter, 15 register pairs per lane.
+// L_max <= 50 (n <= 103): two (default) or four wavefronts per filter, 42 / 21 register pairs per lane.
+hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, hipStream_t stream) {
+    const int nmax = 3 + 2 * p.L_max;
+    if (nmax <= 43 && (wpf == 0 || wpf == 1)) return launch_variant<43, 1>(p, stream);
+    if (nmax <= 103) {
+        if (wpf == 4) return launch_variant<103, 4>(p, stream);
+        return launch_variant<103, 2>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void alg_bytes_kernel(const int32_t* M, int B, double* out) {
+    double acc = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        const double n = 3.0 + 2.0 * M[i];
+        acc += 2.0 * (n * n + n) * 8.0;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+hipError_t launch_algorithmic_bytes(const int32_t* M, int B, double* out, hipStream_t stream) {
+    hipLaunchKernelGGL(alg_bytes_kernel, dim3(64), dim3(256), 0, stream, M, B, out);
+    return hipGetLastError();
+}
+
+__global__ void ekf_init_kernel(const EkfInitParams p) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    double* P = p.P + (size_t)b * p.pstride;
+    double* x = p.x + (size_t)b * p.xstride;
+    for (int i = 0; i < 9; ++i) P[i] = 0.0;
+    P[0] = 0.01 * 0.01; P[4] = 0.01 * 0.01; P[8] = 0.005 * 0.005;   // ekf.cpp:11-14
+    x[0] = p.x0; x[1] = p.y0; x[2] = p.yaw0;                         // ekf.cpp:31 (float arguments)
+    p.M[b] = 0; p.flags[b] = 0; p.timestep[b] = 0;
+    p.truth[3 * (size_t)b] = p.tx; p.truth[3 * (size_t)b + 1] = p.ty; p.truth[3 * (size_t)b + 2] = p.tyaw;
+    p.err_sum[b] = 0.0;
+}
+hipError_t launch_ekf_init(const EkfInitParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(ekf_init_kernel, dim3((p.B + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// out layout per i: [sin, cos, atan2(a,b), remainder(a,2pi), sqrt(|a|), a/b, (double)(float)a, u53-noise]
+__global__ void math_probe_kernel(const double* a, const double* b, double* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    det_sincos(a[i], &s, &c);
+    out[8 * (size_t)i + 0] = s;
+    out[8 * (size_t)i + 1] = c;
+    out[8 * (size_t)i + 2] = det_atan2(a[i], b[i]);
+    out[8 * (size_t)i + 3] = remainder(a[i], kTwoPi);
+    out[8 * (size_t)i + 4] = sqrt(fabs(a[i]));
+    out[8 * (size_t)i + 5] = a[i] / b[i];
+    out[8 * (size_t)i + 6] = (double)(float)a[i];
+    double u0, u1;
+    noise_pair(12345ull, (uint64_t)i, 7u, 3u, &u0, &u1);
+    out[8 * (size_t)i + 7] = u0 + u1;
+}
+hipError_t launch_math_probe(const double* a, const double* b, double* out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, b, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace slam

@@ -1,0 +1,427 @@
+// slam_capi.cpp — C ABI (include/slam_batch.h) over the HIP kernels.  Host-side only: owns device memory,
+// the stream, the step counter and the config; every compute entry point enqueues one fused kernel.
+// There is NO CPU fallback: without a HIP device every compute call fails with SLAM_ERR_HIP.
+#include "../../include/slam_batch.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ekf_kernel.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(SLAM_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct slam_handle {
+    slam_config cfg;
+    int kind, B, L_max, dtype, device;
+    int n_max, pstride, xstride;
+    int waves_per_filter = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool inited = false;
+    uint64_t seed = 2025;
+    int64_t inst0 = 0;
+    uint32_t step = 0;
+    double range_max, fov_min, fov_max;
+    // device buffers
+    double* dP = nullptr; double* dx = nullptr; int32_t* dM = nullptr; int32_t* dids = nullptr;
+    int32_t* dflags = nullptr; int32_t* dts = nullptr; double* dtruth = nullptr; double* derr = nullptr;
+    double* dmap = nullptr; int L = 0;
+    float* dmeas = nullptr; int32_t* dcount = nullptr; int k_stride = 0;   // staging / last-measurement dump
+    double* dscalar = nullptr;
+    bool dump_meas = false;
+};
+
+namespace {
+
+void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
+    memset(&p, 0, sizeof(p));
+    p.P = h->dP; p.x = h->dx; p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
+    p.truth = h->dtruth; p.err_sum = h->derr; p.map = h->dmap; p.L = h->L;
+    p.fwd = cmd[0]; p.ang = cmd[1];
+    const slam_config& c = h->cfg;
+    p.v_d = c.v_d; p.v_th = c.v_th; p.w_r = c.w_r; p.w_b = c.w_b;
+    if (c.replicate_vw_quirk) {  // filter.h:116-117: W_00/W_11 land in V, W stays I2
+        p.V00 = c.W_00; p.V11 = c.W_11; p.W00 = 1.0; p.W11 = 1.0;
+    } else {
+        p.V00 = c.V_00; p.V11 = c.V_11; p.W00 = c.W_00; p.W11 = c.W_11;
+    }
+    p.id_known = c.landmark_id_is_known;
+    p.min_sep = c.min_landmark_separation;
+    p.sV00 = c.V_00; p.sV11 = c.V_11; p.sW00 = c.W_00; p.sW11 = c.W_11;
+    p.d_max = c.d_max; p.th_max = c.th_max;
+    p.range_max = h->range_max; p.fov_min = h->fov_min; p.fov_max = h->fov_max;
+    p.seed = h->seed; p.inst0 = h->inst0; p.step = h->step;
+    p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
+}
+
+int ensure_meas_buffers(slam_handle* h, int k_stride) {
+    if (h->dmeas && h->k_stride >= k_stride) return SLAM_OK;
+    if (h->dmeas) { hipFree(h->dmeas); hipFree(h->dcount); h->dmeas = nullptr; h->dcount = nullptr; }
+    HIP_TRY(hipMalloc(&h->dmeas, sizeof(float) * 3 * (size_t)k_stride * h->B));
+    HIP_TRY(hipMalloc(&h->dcount, sizeof(int32_t) * (size_t)h->B));
+    HIP_TRY(hipMemsetAsync(h->dcount, 0, sizeof(int32_t) * (size_t)h->B, h->stream));
+    h->k_stride = k_stride;
+    return SLAM_OK;
+}
+
+bool parse_scalar(const char* line, const char* key, double* out) {
+    // matches "<spaces>key: value [# comment]"
+    const char* p = line;
+    while (*p == ' ' || *p == '\t') ++p;
+    const size_t kl = strlen(key);
+    if (strncmp(p, key, kl) != 0 || p[kl] != ':') return false;
+    p += kl + 1;
+    while (*p == ' ' || *p == '\t') ++p;
+    if (strncmp(p, "true", 4) == 0) { *out = 1.0; return true; }
+    if (strncmp(p, "false", 5) == 0) { *out = 0.0; return true; }
+    char* end = nullptr;
+    const double v = strtod(p, &end);
+    if (end == p) return false;
+    *out = v;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* slam_last_error(void) { return g_err; }
+const char* slam_version(void) { return "live_ekf_slam_amd 0.1 (gfx950)"; }
+
+int slam_config_default(slam_config* c) {
+    if (!c) return fail(SLAM_ERR_ARG, "cfg is NULL");
+    memset(c, 0, sizeof(*c));
+    c->v_d = 0.0f; c->v_th = 0.0f; c->V_00 = 0.01; c->V_11 = 0.001;      // params.yaml:39-45
+    c->w_r = 0.0f; c->w_b = 0.0f; c->W_00 = 0.01; c->W_11 = 0.01;        // params.yaml:46-52
+    c->landmark_id_is_known = 1; c->min_landmark_separation = 0.1f;        // params.yaml:35-36
+    c->d_max = 0.1; c->th_max = 0.0546;                                    // params.yaml:27-28
+    c->range_max = 3.0; c->fov_min = -1.57; c->fov_max = 1.57;             // params.yaml:30-32
+    c->init_x = 0.0; c->init_y = 0.0; c->init_yaw = 0.0;                   // params.yaml:19-22
+    c->replicate_vw_quirk = 1;
+    c->ukf_float_trig = 1;
+    return SLAM_OK;
+}
+
+// The reference reads one YAML file with nested maps; the keys the hot path needs are unique leaf names
+// except min_landmark_separation (constraints.measurements vs map), disambiguated by section tracking.
+int slam_config_load(slam_config* c, const char* path) {
+    if (!c || !path) return fail(SLAM_ERR_ARG, "NULL argument");
+    FILE* f = fopen(path, "r");
+    if (!f) return fail(SLAM_ERR_IO, "cannot open %s", path);
+    char line[1024];
+    std::string section;
+    double v;
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] != ' ' && line[0] != '#' && line[0] != '\n') {  // top-level key
+            char key[128];
+            if (sscanf(line, "%127[^:]:", key) == 1) section = key;
+        }
+        if (parse_scalar(line, "v_d", &v)) c->v_d = (float)v;
+        else if (parse_scalar(line, "v_th", &v)) c->v_th = (float)v;
+        else if (parse_scalar(line, "V_00", &v)) c->V_00 = v;
+        else if (parse_scalar(line, "V_11", &v)) c->V_11 = v;
+        else if (parse_scalar(line, "w_r", &v)) c->w_r = (float)v;
+        else if (parse_scalar(line, "w_b", &v)) c->w_b = (float)v;
+        else if (parse_scalar(line, "W_00", &v)) c->W_00 = v;
+        else if (parse_scalar(line, "W_11", &v)) c->W_11 = v;
+        else if (parse_scalar(line, "landmark_id_is_known", &v)) c->landmark_id_is_known = (int)v;
+        else if (parse_scalar(line, "min_landmark_separation", &v)) { if (section == "constraints") c->min_landmark_separation = (float)v; }
+        else if (parse_scalar(line, "d_max", &v)) c->d_max = v;
+        else if (parse_scalar(line, "th_max", &v)) c->th_max = v;
+        else if (parse_scalar(line, "range_max", &v)) c->range_max = v;
+        else if (parse_scalar(line, "fov_min", &v)) c->fov_min = v;
+        else if (parse_scalar(line, "fov_max", &v)) c->fov_max = v;
+        else if (section == "init_pose" && parse_scalar(line, "x", &v)) c->init_x = v;
+        else if (section == "init_pose" && parse_scalar(line, "y", &v)) c->init_y = v;
+        else if (section == "init_pose" && parse_scalar(line, "yaw", &v)) c->init_yaw = v;
+    }
+    fclose(f);
+    return SLAM_OK;
+}
+
+int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtype, int device, slam_handle** out) {
+    if (!cfg || !out) return fail(SLAM_ERR_ARG, "NULL argument");
+    if (batch <= 0 || L_max <= 0) return fail(SLAM_ERR_ARG, "batch and L_max must be positive");
+    if (kind != SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "filter kind %d not available in this build (EKF_SLAM only)", kind);
+    if (dtype != SLAM_F64) return fail(SLAM_ERR_UNSUPPORTED, "only fp64 state storage is implemented");
+    if (L_max > slam::kEkfMaxLandmarks)
+        return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the register-resident kernel limit %d", L_max, slam::kEkfMaxLandmarks);
+    HIP_TRY(hipSetDevice(device));
+    slam_handle* h = new slam_handle();
+    h->cfg = *cfg; h->kind = kind; h->B = batch; h->L_max = L_max; h->dtype = dtype; h->device = device;
+    h->n_max = 3 + 2 * L_max;
+    h->pstride = round_up(h->n_max * h->n_max + 1, 32);   // 256-byte aligned per-filter slab
+    h->xstride = round_up(h->n_max + 1, 2);
+    h->range_max = cfg->range_max; h->fov_min = cfg->fov_min; h->fov_max = cfg->fov_max;
+    const char* env = getenv("SLAM_WAVES_PER_FILTER");
+    if (env) h->waves_per_filter = atoi(env);
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
+    h->own_stream = true;
+    const size_t B = (size_t)batch;
+    hipError_t errs[] = {
+        hipMalloc(&h->dP, sizeof(double) * B * h->pstride),
+        hipMalloc(&h->dx, sizeof(double) * B * h->xstride),
+        hipMalloc(&h->dM, sizeof(int32_t) * B),
+        hipMalloc(&h->dids, sizeof(int32_t) * B * L_max),
+        hipMalloc(&h->dflags, sizeof(int32_t) * B),
+        hipMalloc(&h->dts, sizeof(int32_t) * B),
+        hipMalloc(&h->dtruth, sizeof(double) * B * 3),
+        hipMalloc(&h->derr, sizeof(double) * B),
+        hipMalloc(&h->dscalar, sizeof(double) * 4),
+    };
+    for (hipError_t ee : errs)
+        if (ee != hipSuccess) {
+            slam_destroy(h);
+            return fail(SLAM_ERR_HIP, "hipMalloc -> %s", hipGetErrorString(ee));
+        }
+    HIP_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * B * h->pstride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dx, 0, sizeof(double) * B * h->xstride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dids, 0, sizeof(int32_t) * B * L_max, h->stream));
+    *out = h;
+    return SLAM_OK;
+}
+
+int slam_destroy(slam_handle* h) {
+    if (!h) return SLAM_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->dP, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar};
+    for (void* q : bufs)
+        if (q) hipFree(q);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return SLAM_OK;
+}
+
+int slam_set_stream(slam_handle* h, void* s) {
+    if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)s;
+    h->own_stream = false;
+    return SLAM_OK;
+}
+int slam_set_instance_offset(slam_handle* h, int64_t v) { if (!h) return fail(SLAM_ERR_ARG, "NULL handle"); h->inst0 = v; return SLAM_OK; }
+int slam_set_seed(slam_handle* h, uint64_t s) { if (!h) return fail(SLAM_ERR_ARG, "NULL handle"); h->seed = s; return SLAM_OK; }
+int slam_set_vision(slam_handle* h, double range_max, double fov_min, double fov_max) {
+    if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    h->range_max = range_max; h->fov_min = fov_min; h->fov_max = fov_max;
+    return SLAM_OK;
+}
+
+int slam_init(slam_handle* h, float x0, float y0, float yaw0) {
+    if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    slam::EkfInitParams p;
+    p.P = h->dP; p.x = h->dx; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
+    p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride;
+    p.x0 = x0; p.y0 = y0; p.yaw0 = yaw0;
+    // the simulator starts from the un-rounded YAML pose (sim_node.py:361); the filter gets float args
+    p.tx = h->cfg.init_x; p.ty = h->cfg.init_y; p.tyaw = h->cfg.init_yaw;
+    HIP_TRY(slam::launch_ekf_init(p, h->stream));
+    h->step = 0;
+    h->inited = true;
+    return SLAM_OK;
+}
+
+int slam_set_map(slam_handle* h, const double* map_xy, int L) {
+    if (!h || !map_xy || L <= 0) return fail(SLAM_ERR_ARG, "bad map");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->dmap) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(h->dmap); h->dmap = nullptr; }
+    HIP_TRY(hipMalloc(&h->dmap, sizeof(double) * 2 * (size_t)L));
+    HIP_TRY(hipMemcpyAsync(h->dmap, map_xy, sizeof(double) * 2 * (size_t)L, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->L = L;
+    return SLAM_OK;
+}
+
+int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_count, int k_stride) {
+    if (!h || !cmd || !d_meas || !d_count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    HIP_TRY(hipSetDevice(h->device));
+    slam::EkfStepParams p;
+    fill_params(h, p, cmd);
+    p.sim = 0;
+    p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
+    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+    h->step += 1;
+    return SLAM_OK;
+}
+
+int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* count, int k_stride) {
+    if (!h || !cmd || !meas || !count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_meas_buffers(h, k_stride);
+    if (rc) return rc;
+    // pack to the staging stride
+    HIP_TRY(hipMemcpy2DAsync(h->dmeas, sizeof(float) * 3 * h->k_stride, meas, sizeof(float) * 3 * k_stride,
+                             sizeof(float) * 3 * k_stride, h->B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->dcount, count, sizeof(int32_t) * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+    // host buffers may be reused by the caller right after return (ekf.cpp:64 copies the message)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    slam::EkfStepParams p;
+    fill_params(h, p, cmd);
+    p.sim = 0;
+    p.meas_in = h->dmeas; p.meas_count_in = h->dcount; p.k_stride_in = h->k_stride;
+    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+    h->step += 1;
+    return SLAM_OK;
+}
+
+int slam_step_sim(slam_handle* h, const float cmd[2]) {
+    if (!h || !cmd) return fail(SLAM_ERR_ARG, "bad argument");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
+    HIP_TRY(hipSetDevice(h->device));
+    slam::EkfStepParams p;
+    fill_params(h, p, cmd);
+    p.sim = 1;
+    if (h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
+    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+    h->step += 1;
+    return SLAM_OK;
+}
+
+int slam_run_sim(slam_handle* h, const float* cmds, int T) {
+    if (!h || !cmds || T < 0) return fail(SLAM_ERR_ARG, "bad argument");
+    for (int t = 0; t < T; ++t) {
+        int rc = slam_step_sim(h, cmds + 2 * (size_t)t);
+        if (rc) return rc;
+    }
+    return SLAM_OK;
+}
+
+int slam_predict(slam_handle*, const float*) { return fail(SLAM_ERR_UNSUPPORTED, "predictionStage/updateStage split exists only for the UKF (filter.h:187-188)"); }
+int slam_update_dev(slam_handle*, const float*, const int32_t*, int) { return fail(SLAM_ERR_UNSUPPORTED, "predictionStage/updateStage split exists only for the UKF (filter.h:187-188)"); }
+
+int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, int32_t* ids, int32_t* ts) {
+    if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int32_t m = 0;
+    HIP_TRY(hipMemcpy(&m, h->dM + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int n = 3 + 2 * m;
+    if (M) *M = m;
+    if (x) HIP_TRY(hipMemcpy(x, h->dx + (size_t)inst * h->xstride, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (P) HIP_TRY(hipMemcpy(P, h->dP + (size_t)inst * h->pstride, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+    if (ids && m > 0) HIP_TRY(hipMemcpy(ids, h->dids + (size_t)inst * h->L_max, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    if (ts) HIP_TRY(hipMemcpy(ts, h->dts + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+int slam_get_poses(slam_handle* h, double* poses) {
+    if (!h || !poses) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy2D(poses, sizeof(double) * 3, h->dx, sizeof(double) * h->xstride, sizeof(double) * 3, h->B, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+static int copy_out(slam_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!h || !dst) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+int slam_get_landmark_counts(slam_handle* h, int32_t* M) { return copy_out(h, M, h ? h->dM : nullptr, h ? sizeof(int32_t) * (size_t)h->B : 0); }
+int slam_get_truth(slam_handle* h, double* t) { return copy_out(h, t, h ? h->dtruth : nullptr, h ? sizeof(double) * 3 * (size_t)h->B : 0); }
+int slam_status(slam_handle* h, int32_t* f) { return copy_out(h, f, h ? h->dflags : nullptr, h ? sizeof(int32_t) * (size_t)h->B : 0); }
+
+int slam_get_last_meas(slam_handle* h, float* meas, int32_t* count, int k_stride) {
+    if (!h || !meas || !count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->dump_meas || h->k_stride < k_stride) {
+        // enable the dump for subsequent slam_step_sim calls; nothing recorded yet for past steps
+        int rc = ensure_meas_buffers(h, k_stride);
+        if (rc) return rc;
+        if (!h->dump_meas) {
+            h->dump_meas = true;
+            memset(count, 0, sizeof(int32_t) * (size_t)h->B);
+            return SLAM_OK;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy2D(meas, sizeof(float) * 3 * k_stride, h->dmeas, sizeof(float) * 3 * h->k_stride,
+                        sizeof(float) * 3 * k_stride, h->B, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(count, h->dcount, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+int slam_error_stats(slam_handle* h, double* avg) {
+    if (!h || !avg) return fail(SLAM_ERR_ARG, "bad argument");
+    std::vector<int32_t> ts(h->B);
+    int rc = copy_out(h, avg, h->derr, sizeof(double) * (size_t)h->B);
+    if (rc) return rc;
+    rc = copy_out(h, ts.data(), h->dts, sizeof(int32_t) * (size_t)h->B);
+    if (rc) return rc;
+    for (int i = 0; i < h->B; ++i) avg[i] = ts[i] > 0 ? avg[i] / ts[i] : 0.0;  // sum(errors) / num_iters
+    return SLAM_OK;
+}
+
+int slam_sync(slam_handle* h) {
+    if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+int slam_batch(const slam_handle* h) { return h ? h->B : 0; }
+int slam_state_dim_max(const slam_handle* h) { return h ? h->n_max : 0; }
+
+int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
+    if (!h || !bytes) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(h->dscalar, 0, sizeof(double), h->stream));
+    HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->dscalar, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(bytes, h->dscalar, sizeof(double), hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+// device math probe for the bit-exactness tests (a, b, out are HOST arrays; out has 8*n doubles)
+int slam_math_probe(const double* a, const double* b, double* out, int n, int device) {
+    if (!a || !b || !out || n <= 0) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    double *da, *db, *dout;
+    HIP_TRY(hipMalloc(&da, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&db, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&dout, sizeof(double) * 8 * (size_t)n));
+    HIP_TRY(hipMemcpy(da, a, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(slam::launch_math_probe(da, db, dout, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return SLAM_OK;
+}
+
+}  // extern "C"
