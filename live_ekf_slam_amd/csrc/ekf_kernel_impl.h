@@ -289,6 +289,20 @@ __global__ __launch_bounds__(64 * W, (ekf_waves_per_simd(NMAX, W))) void ekf_ste
         });
     }
 
+    // x_pred of the vehicle (ekf.cpp:56-59); needed before the first group because unknown-id association
+    // (ekf.cpp:82-98) projects detections with the PREDICTED pose.  The covariance part of the prediction runs
+    // on the thin rows/cols of the first group.
+    if (tid == 0) {
+        const float d_d = p.fwd, d_th = p.ang;
+        const double th = s_xt[2];
+        double s, c;
+        det_sincos(th, &s, &c);
+        const float dd = d_d + p.v_d;
+        s_xp[0] = s_xt[0] + (double)dd * c;
+        s_xp[1] = s_xt[1] + (double)dd * s;
+        s_xp[2] = remainder((th + (double)d_th) + (double)p.v_th, kTwoPi);
+    }
+
     // ------------------------------------------------------------------------------------------------------
     // groups of <= KG detections
     // ------------------------------------------------------------------------------------------------------
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(64 * W, (ekf_waves_per_simd(NMAX, W))) void ekf_ste
 
         // ---- prediction stage on the thin copies (first group only), ekf.cpp:41-61 ----
         if (first) {
-            const float d_d = p.fwd, d_th = p.ang;
+            const float d_d = p.fwd;
             const double th = s_xt[2];
             double s, c;
             det_sincos(th, &s, &c);
@@ -380,11 +394,6 @@ __global__ __launch_bounds__(64 * W, (ekf_waves_per_simd(NMAX, W))) void ekf_ste
             #pragma unroll 1
             for (int i = tid; i < LDP; i += TPB) { s_r2[i] = s_R[2 * LDP + i]; s_c2[i] = s_C[2 * LDP + i]; }
             __syncthreads();
-            if (tid == 0) {
-                s_xp[0] = s_xt[0] + (double)dd * c;
-                s_xp[1] = s_xt[1] + (double)dd * s;
-                s_xp[2] = remainder((th + (double)d_th) + (double)p.v_th, kTwoPi);
-            }
             const double p22 = s_r2[2];
             const double cv = c * p.V00, sv = s * p.V00;
             auto predicted = [&](double t, int r, int cc) -> double {

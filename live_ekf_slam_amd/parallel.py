@@ -1,0 +1,51 @@
+"""Multi-GPU sharding of the instance batch.
+
+Instances are independent given the shared map + command sequence, so the batch shards embarrassingly: rank r of
+G owns the contiguous global instances [r*per_rank, (r+1)*per_rank) and keys its noise streams with GLOBAL
+instance ids (slam_set_instance_offset), so results are identical for any G.  There is no per-step exchange; the
+only collective is the end-of-run gather of per-instance error statistics (plotting_node.py:195-218 metric),
+over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""
+import numpy as np
+
+
+def shard_range(global_batch, rank, world):
+    """Contiguous block partition; the first (global_batch % world) ranks get one extra instance."""
+    base, extra = divmod(int(global_batch), int(world))
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def gather_error_stats(local_err, dist=None, device=None):
+    """All-gather per-instance average errors (ragged shards allowed). Returns the global float64 vector on every
+    rank.  `dist` is torch.distributed (initialised) or None for a single process."""
+    local_err = np.ascontiguousarray(local_err, dtype=np.float64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_err
+    import torch
+    world = dist.get_world_size()
+    dev = device if device is not None else "cpu"
+    n = torch.tensor([local_err.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    pad = max(sizes)
+    buf = torch.zeros(pad, dtype=torch.float64, device=dev)
+    buf[:local_err.shape[0]] = torch.from_numpy(local_err).to(dev)
+    out = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return np.concatenate([o[:s].cpu().numpy() for o, s in zip(out, sizes)])
+
+
+def reduce_summary(local_err, dist=None, device=None):
+    """{sum, sum of squares, count} all-reduced -> (mean, std, count) of the per-instance average error."""
+    local_err = np.asarray(local_err, dtype=np.float64)
+    acc = np.array([local_err.sum(), (local_err ** 2).sum(), float(local_err.size)])
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+        t = torch.from_numpy(acc).to(device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        acc = t.cpu().numpy()
+    mean = acc[0] / acc[2]
+    var = max(acc[1] / acc[2] - mean * mean, 0.0)
+    return mean, var ** 0.5, int(acc[2])

@@ -49,7 +49,7 @@ def lib():
         L.orc_run_ekf_batch.restype = C.c_double
         L.orc_run_ekf_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int,
                                         C.c_uint64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp, _ip, _dp,
-                                        C.POINTER(C.c_int64)]
+                                        C.POINTER(C.c_int64), _dp]
         L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
         L.orc_noise_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
         for name in ("orc_det_sincos", "orc_libm_sincos"):
@@ -140,7 +140,7 @@ def average_error(est_x, est_y, true_x, true_y, math=MATH_LIBM):
     return lib().orc_average_error(_d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), len(a[0]), math)
 
 
-def run_ekf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, mode=MODE_FAST, nthreads=1, want_P=True):
+def run_ekf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, mode=MODE_FAST, nthreads=1, want_P=True, vision=None):
     """Lockstep sim + EKF for instances inst0..inst0+B-1 over all commands. Returns dict of numpy outputs."""
     cfg = cfg or default_config()
     map_xy = np.ascontiguousarray(map_xy, dtype=np.float64); cmds = np.ascontiguousarray(cmds, dtype=np.float32)
@@ -148,6 +148,9 @@ def run_ekf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MAT
     x = np.zeros((B, nmax)); P = np.zeros((B, nmax * nmax)) if want_P else None
     M = np.zeros(B, dtype=np.int32); ids = np.zeros((B, L_max), dtype=np.int32)
     err = np.zeros(B); flags = np.zeros(B, dtype=np.int32); truth = np.zeros((B, 3)); ktot = C.c_int64(0)
+    if vision is not None:
+        vision = np.ascontiguousarray(vision, dtype=np.float64).reshape(T, 3)
     secs = lib().orc_run_ekf_batch(C.byref(cfg), L_max, math, mode, _d(map_xy), L, _f(cmds), T, seed, inst0, B, nthreads,
-                                   _d(x), _d(P) if want_P else None, _i(M), _i(ids), _d(err), _i(flags), _d(truth), C.byref(ktot))
+                                   _d(x), _d(P) if want_P else None, _i(M), _i(ids), _d(err), _i(flags), _d(truth), C.byref(ktot),
+                                   _d(vision) if vision is not None else None)
     return dict(x=x, P=P, M=M, ids=ids, avg_err=err, flags=flags, truth=truth, seconds=secs, k_total=ktot.value)

@@ -332,6 +332,8 @@ void Ekf::insert_dense(double rd, double sphi, double cphi) {
 template <class MP>
 int Ekf::update_t(float fwd, float ang, const float* meas, int k) {
     if (frozen) return flags;
+    const int M_before = M;                          // for the freeze roll-back below
+    const std::vector<int> ids_before = ids;
     timestep += 1;                                   // ekf.cpp:39
     const float d_d = fwd, d_th = ang;               // ekf.cpp:43-44
     if (mode == MODE_DENSE) predict_dense<MP>(d_d, d_th); else predict_fast<MP>(d_d, d_th);
@@ -361,7 +363,9 @@ int Ekf::update_t(float fwd, float ang, const float* meas, int k) {
         if (i != -1) {                               // ekf.cpp:110-140 landmark update
             const int ii = 2 * i + 3;
             if (ii + 1 >= (int)x_t.size()) {         // x_t(i) out of range -> eigen_assert throws (filter.h:5)
+                // The reference node dies here.  The batch engine freezes the instance in its pre-step state.
                 flags |= SLAM_INST_INDEX_OOR; frozen = true;
+                M = M_before; ids = ids_before; timestep -= 1; x_pred = x_t; P_pred = P_t;
                 return flags;
             }
             const double dx = x_t[ii] - x_pred[0], dy = x_t[ii + 1] - x_pred[1];
@@ -536,11 +540,12 @@ double orc_average_error(const double* est_x, const double* est_y, const double*
 // Step t (1-based) uses cmds[t-1] and RNG step index t0 + t - 1.  Outputs may be NULL.
 //   x_out [B][n_max], P_out [B][n_max*n_max] (each instance's n x n block packed row-major at the start),
 //   M_out [B], ids_out [B][L_max], avg_err [B], flags [B], truth_out [B][3], k_total (sum of detections).
+// vision (optional) overrides the sensor limits per step (slam_set_vision on the product side).
 // Returns elapsed seconds of the stepping loop.
 double orc_run_ekf_batch(const slam_config* cfg, int L_max, int math, int mode, const double* map_xy, int L,
                          const float* cmds, int T, uint64_t seed, int64_t inst0, int B, int nthreads,
                          double* x_out, double* P_out, int* M_out, int* ids_out, double* avg_err, int* flags,
-                         double* truth_out, int64_t* k_total) {
+                         double* truth_out, int64_t* k_total, const double* vision /* [T][3] range_max,fov_min,fov_max or NULL */) {
     const int n_max = 3 + 2 * L_max;
     std::atomic<int> next(0);
     std::atomic<long long> ktot(0);
@@ -559,9 +564,11 @@ double orc_run_ekf_batch(const slam_config* cfg, int L_max, int math, int mode, 
             for (int t = 0; t < T; ++t) {
                 int k = 0;
                 double truth[3];
+                if (vision) { sim.cfg.range_max = vision[3 * t]; sim.cfg.fov_min = vision[3 * t + 1]; sim.cfg.fov_max = vision[3 * t + 2]; }
                 orc_sim_step_philox(&sim, cmds[2 * t], cmds[2 * t + 1], seed, (uint64_t)(inst0 + b), (uint32_t)t, truth, meas.data(), &k);
                 kk += k;
-                ekf.update(cmds[2 * t], cmds[2 * t + 1], meas.data(), k);
+                const int fl = ekf.update(cmds[2 * t], cmds[2 * t + 1], meas.data(), k);
+                if (fl & SLAM_INST_INDEX_OOR) break;   // frozen: no further truth / error / timestep updates
                 errsum = errsum + (math == MATH_DET ? step_pos_error<DetMath>(wire_f32(ekf.x_t[0]), wire_f32(ekf.x_t[1]), truth[0], truth[1])
                                                     : step_pos_error<LibmMath>(wire_f32(ekf.x_t[0]), wire_f32(ekf.x_t[1]), truth[0], truth[1]));
             }
@@ -571,7 +578,7 @@ double orc_run_ekf_batch(const slam_config* cfg, int L_max, int math, int mode, 
             if (P_out) memcpy(P_out + (size_t)b * n_max * n_max, ekf.P_t.data(), sizeof(double) * n * n);
             if (M_out) M_out[b] = ekf.M;
             if (ids_out) memcpy(ids_out + (size_t)b * L_max, ekf.ids.data(), sizeof(int) * ekf.M);
-            if (avg_err) avg_err[b] = T > 0 ? errsum / T : 0.0;
+            if (avg_err) avg_err[b] = ekf.timestep > 0 ? errsum / ekf.timestep : 0.0;
             if (flags) flags[b] = ekf.flags;
             if (truth_out) { truth_out[3 * b] = sim.xv[0]; truth_out[3 * b + 1] = sim.xv[1]; truth_out[3 * b + 2] = sim.xv[2]; }
         }

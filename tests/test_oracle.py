@@ -1,0 +1,223 @@
+"""CPU tests of the oracle itself: it must reproduce every known-answer vector and fixture available for the path
+ before it is trusted as the GPU checker."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+# ---- RNG / math building blocks -------------------------------------------------------------------------------
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors for philox4x32-10
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    out = (C.c_uint32 * 4)()
+    for ctr, key, exp in kats:
+        oracle.lib().orc_philox(*ctr, *key, out)
+        assert tuple(out) == exp
+
+
+def test_u53_matches_cpython_recipe(oracle):
+    out = (C.c_double * 2)()
+    w = (C.c_uint32 * 4)()
+    oracle.lib().orc_noise_pair(2025, 7, 3, 1, out)
+    oracle.lib().orc_philox(3, 1, 7, 0, 2025, 0, w)
+    # CPython random(): (a>>5, b>>6) -> (a*67108864+b)/9007199254740992
+    assert out[0] == ((w[0] >> 5) * 67108864.0 + (w[1] >> 6)) / 9007199254740992.0
+    assert out[1] == ((w[2] >> 5) * 67108864.0 + (w[3] >> 6)) / 9007199254740992.0
+    assert 0.0 <= out[0] < 1.0 and 0.0 <= out[1] < 1.0
+
+
+def _ulps(a, b):
+    return np.abs(a - b) / np.spacing(np.maximum(np.abs(b), 1e-300))
+
+
+def test_deterministic_math_within_one_ulp_of_libm(oracle):
+    """The shared sincos/atan2 (what the GPU evaluates) stay within 1 ulp of glibc (what the reference calls)."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-10, 10, 400000), rng.uniform(-400, 400, 100000), rng.uniform(-1e-3, 1e-3, 20000),
+                        np.array([0.0, np.pi / 4, -np.pi / 4, np.pi / 2, np.pi, -np.pi, 2 * np.pi, 1e-300])])
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    s, c, s2, c2 = (np.zeros_like(x) for _ in range(4))
+    oracle.lib().orc_det_sincos(dp(x), dp(s), dp(c), len(x))
+    oracle.lib().orc_libm_sincos(dp(x), dp(s2), dp(c2), len(x))
+    assert _ulps(s, s2).max() <= 1.0 and _ulps(c, c2).max() <= 1.0
+    y, xx = rng.uniform(-10, 10, 400000), rng.uniform(-10, 10, 400000)
+    y[:4] = [0.0, 0.0, 1.0, -1.0]; xx[:4] = [1.0, -1.0, 0.0, 0.0]
+    a, a2 = np.zeros_like(y), np.zeros_like(y)
+    oracle.lib().orc_det_atan2(dp(y), dp(xx), dp(a), len(y))
+    oracle.lib().orc_libm_atan2(dp(y), dp(xx), dp(a2), len(y))
+    assert _ulps(a, a2).max() <= 1.0
+    assert np.array_equal(a[:4], a2[:4])  # axis cases exact
+
+
+# ---- EKF known-answer vectors ------------------------------------------------------------
+KAT_T1_X = [0.10000000149011612, 0.0, 0.01999999955296516]
+KAT_T1_P = [[1.01e-2, 0, 0], [0, 1.0025000000745058e-04, 2.5000000372529031e-06], [0, 2.5000000372529031e-06, 1.0025000000000001e-02]]
+KAT_T2_X = [0.19998000364748603, 0.0019998666544391, 0.03999999910593033, 1.915397367294481, 1.0302718484269628]
+KAT_T2_P0 = [2.0096040628136677e-02, 1.9793720140862426e-04, -2.0048663210751974e-05, 2.0116656106788287e-02, 1.6354537641898961e-04]
+KAT_T3_X = [0.2998623521168726, 0.00599729269191174, 0.03002472023749497, 1.9209894079837309, 1.0280203880251169]
+KAT_T3_DIAG = [3.0039657908003996e-02, 6.2161421557307365e-04, 2.9977441960757054e-02, 9.3473006225623279e-01, 1.5916809183321421]
+
+
+@pytest.mark.parametrize("math", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ekf_known_answer_vectors(oracle, math, mode):
+    """3-step KAT: predict only / landmark insertion / landmark update; tolerance 1e-12 relative (App. E)."""
+    e = oracle.OracleEKF(L_max=5, math=math, mode=mode)
+    e.init(0, 0, 0)
+    e.update(0.1, 0.02, [])
+    s = e.state()
+    np.testing.assert_allclose(s["x"], KAT_T1_X, rtol=1e-15, atol=0)
+    np.testing.assert_allclose(s["P"], KAT_T1_P, rtol=1e-14, atol=0)
+    e.update(0.1, 0.02, [[3, 2.0, 0.5]])
+    s = e.state()
+    assert s["M"] == 1 and list(s["ids"]) == [3]
+    np.testing.assert_allclose(s["x"], KAT_T2_X, rtol=1e-12)
+    np.testing.assert_allclose(s["P"][0], KAT_T2_P0, rtol=1e-12)
+    for (i, j), v in {(3, 3): 1.8343180219109152, (3, 4): -1.3591287810142156, (4, 4): 3.2695715100422982,
+                      (2, 2): 2.0025000000000001e-02, (2, 3): -2.0611195098205540e-02, (2, 4): 3.5356032228695967e-02}.items():
+        assert s["P"][i, j] == pytest.approx(v, rel=1e-12)
+    e.update(0.1, -0.01, [[3, 1.92, 0.53]])
+    s = e.state()
+    np.testing.assert_allclose(s["x"], KAT_T3_X, rtol=1e-12)
+    np.testing.assert_allclose(np.diag(s["P"]), KAT_T3_DIAG, rtol=1e-12)
+    assert s["P"][3, 4] == pytest.approx(-6.7032799116251951e-01, rel=1e-12)
+    assert s["timestep"] == 3
+
+
+def test_t1_closed_form(oracle):
+    """Analytic check of the first predict: P00 = 1e-4 + V00, P11 = 1e-4 + d^2*2.5e-5, P12 = d*2.5e-5 (V/W quirk on)."""
+    e = oracle.OracleEKF(L_max=2)
+    e.init(0, 0, 0)
+    e.update(0.1, 0.0, [])
+    P = e.state()["P"]
+    d = float(np.float32(0.1))
+    assert P[0, 0] == pytest.approx(1e-4 + 0.01, rel=1e-15)
+    assert P[1, 1] == pytest.approx(1e-4 + d * d * 2.5e-5, rel=1e-14)
+    assert P[1, 2] == pytest.approx(d * 2.5e-5, rel=1e-14) and P[2, 1] == P[1, 2]
+    assert P[2, 2] == pytest.approx(2.5e-5 + 0.01, rel=1e-15)
+
+
+def test_vw_quirk_switch(oracle):
+    cfg = oracle.default_config(); cfg.replicate_vw_quirk = 0
+    e = oracle.OracleEKF(cfg=cfg, L_max=2); e.init(0, 0, 0); e.update(0.1, 0.0, [])
+    P = e.state()["P"]
+    assert P[0, 0] == pytest.approx(1e-4 + 0.01, rel=1e-15)     # V_00 = 0.01 either way
+    assert P[2, 2] == pytest.approx(2.5e-5 + 0.001, rel=1e-15)  # V_11 = 0.001 without the quirk (0.01 with it)
+
+
+# ---- trajectories on the golden measurement streams ------------------------------------------------------------
+def _run(oracle, g, L_max, math, mode, T=None):
+    e = oracle.OracleEKF(L_max=L_max, math=math, mode=mode)
+    e.init(0, 0, 0)
+    Ms = []
+    for t in range(T or int(g["T"])):
+        k = int(g["meas_count"][t])
+        e.update(g["cmds"][t, 0], g["cmds"][t, 1], g["meas"][t, :k])
+        Ms.append(e.state()["M"] if t % 50 == 0 else Ms[-1] if Ms else 0)
+    return e.state(), Ms
+
+
+def test_fast_dense_libm_det_agree_on_trajectory(oracle):
+    """Structure-exploiting vs literal dense products, libm vs deterministic math: same trajectory to ~1e-11."""
+    g = load_golden("sim_seed2_L50_T1000.npz")
+    base, _ = _run(oracle, g, 50, 1, 0, T=400)
+    for math, mode in [(0, 0), (0, 1), (1, 1)]:
+        s, _ = _run(oracle, g, 50, math, mode, T=400)
+        assert s["M"] == base["M"] and np.array_equal(s["ids"], base["ids"])
+        assert np.abs(s["x"] - base["x"]).max() < 1e-10
+        assert np.abs(s["P"] - base["P"]).max() < 1e-10
+
+
+def test_invariants_on_trajectory(oracle):
+    """P symmetric to rounding, PSD, M monotone, yaw wrapped, estimate near truth."""
+    g = load_golden("sim_seed0_L20_T1000.npz")
+    s, Ms = _run(oracle, g, 20, 1, 0)
+    P = s["P"]
+    assert np.abs(P - P.T).max() < 1e-9
+    assert np.linalg.eigvalsh((P + P.T) / 2).min() > -1e-12
+    assert all(a <= b for a, b in zip(Ms, Ms[1:])) and s["M"] <= 20
+    assert -np.pi <= s["x"][2] <= np.pi
+    assert np.hypot(*(s["x"][:2] - g["truth"][-1][:2])) < 1.0   # reference EKF errors are 0.15-0.5 m
+    assert s["timestep"] == 1000
+
+
+def test_duplicate_new_id_freezes_instance(oracle):
+    """A repeated NEW id in one message indexes x_t out of range in the reference (exception); we freeze."""
+    e = oracle.OracleEKF(L_max=5); e.init(0, 0, 0)
+    e.update(0.1, 0.0, [])
+    before = e.state()
+    fl = e.update(0.1, 0.0, [[7, 1.0, 0.1], [7, 1.0, 0.1]])
+    assert fl & 4
+    after = e.state()
+    assert after["M"] == before["M"] and np.array_equal(after["x"], before["x"]) and after["timestep"] == before["timestep"]
+    assert e.update(0.1, 0.0, []) & 4 and e.state()["timestep"] == before["timestep"]
+
+
+def test_capacity_drop(oracle):
+    e = oracle.OracleEKF(L_max=1); e.init(0, 0, 0)
+    fl = e.update(0.1, 0.0, [[1, 1.0, 0.1], [2, 1.5, -0.2]])
+    assert fl & 8 and e.state()["M"] == 1 and list(e.state()["ids"]) == [1]
+
+
+def test_unknown_id_association(oracle):
+    cfg = oracle.default_config(); cfg.landmark_id_is_known = 0
+    e = oracle.OracleEKF(cfg=cfg, L_max=5); e.init(0, 0, 0)
+    e.update(0.1, 0.0, [[99, 2.0, 0.3]])
+    assert e.state()["M"] == 1 and list(e.state()["ids"]) == [0]   # id = M at insertion (ekf.cpp:85)
+    e.update(0.0, 0.0, [[55, 2.0, 0.3]])                            # same place -> associated, not inserted
+    assert e.state()["M"] == 1
+    e.update(0.0, 0.0, [[55, 2.5, -0.8]])                           # elsewhere -> new landmark
+    assert e.state()["M"] == 2
+
+
+# ---- measurement generator vs the reference simulator -----------------------------------------------------------
+def test_sim_matches_reference_fixtures_bit_exact(oracle, golden_files):
+    """get_cmd restatement (libm policy) == imported reference simulator, draw for draw, on every fixture."""
+    for f in golden_files:
+        g = np.load(f)
+        sim = oracle.OracleSim(g["map"], math=oracle.MATH_LIBM)
+        for t in range(int(g["T"])):
+            k = int(g["meas_count"][t])
+            truth, meas, meas64, used = sim.step_draws(g["cmds"][t, 0], g["cmds"][t, 1], np.nan_to_num(g["draws_step"][t]))
+            assert len(meas) == k and used == 2 + 2 * k
+            assert np.array_equal(truth, g["truth"][t])
+            assert np.array_equal(meas, g["meas"][t, :k])
+            assert np.array_equal(meas64, g["meas64"][t, :k])
+
+
+def test_sim_deterministic_math_close_to_reference(oracle, golden_files):
+    """With the GPU's math policy the truth differs by a few ulp at most and the float32 wire values not at all."""
+    g = np.load(golden_files[-1])
+    sim = oracle.OracleSim(g["map"], math=oracle.MATH_DET)
+    for t in range(int(g["T"])):
+        k = int(g["meas_count"][t])
+        truth, meas, _, _ = sim.step_draws(g["cmds"][t, 0], g["cmds"][t, 1], np.nan_to_num(g["draws_step"][t]))
+        assert len(meas) == k
+        assert np.abs(truth - g["truth"][t]).max() < 1e-13
+        assert np.array_equal(meas, g["meas"][t, :k])
+
+
+def test_average_error_matches_reference(oracle):
+    g = load_golden("avg_err_case.npz")
+    assert oracle.average_error(g["est_x"], g["est_y"], g["true_x"], g["true_y"], oracle.MATH_LIBM) == float(g["avg_err"])
+    assert oracle.average_error(g["est_x"], g["est_y"], g["true_x"], g["true_y"], oracle.MATH_DET) == pytest.approx(float(g["avg_err"]), rel=1e-14)
+
+
+# ---- batch runner ------------------------------------------------------------------------------------------------
+def test_batch_runner_sharding_invariance_and_statistics(oracle):
+    from live_ekf_slam_amd.scenario import make_scenario
+    lm, cmds = make_scenario(1234, 20, 300)
+    full = oracle.run_ekf_batch(lm, cmds, 48, 20, seed=5, inst0=0, nthreads=4)
+    a = oracle.run_ekf_batch(lm, cmds, 24, 20, seed=5, inst0=0, nthreads=2)
+    b = oracle.run_ekf_batch(lm, cmds, 24, 20, seed=5, inst0=24, nthreads=2)
+    for key in ("x", "P", "M", "ids", "avg_err", "truth"):
+        assert np.array_equal(full[key], np.concatenate([a[key], b[key]]))
+    assert np.all(full["flags"] == 0)
+    assert len({tuple(r) for r in np.round(full["truth"], 9)}) == 48   # every instance has its own noise stream
+    assert 0.02 < full["avg_err"].mean() < 1.0                          # EKF error scale of BASELINE.md

@@ -1,0 +1,32 @@
+"""Host-side scenario generators vs fixtures captured from the reference simulator (sim_node.py:63-206)."""
+import numpy as np
+
+from live_ekf_slam_amd.scenario import generate_landmarks, make_scenario
+import random
+
+
+def test_random_map_and_tsp_trajectory_match_reference(golden_files):
+    for f in golden_files:
+        g = np.load(f)
+        lm, cmds = make_scenario(int(g["seed"]), int(g["L"]), int(g["T"]))
+        assert np.array_equal(lm, g["map"])
+        assert cmds.dtype == np.float32 and np.array_equal(cmds, g["cmds"])
+
+
+def test_draw_consumption_matches_reference(golden_files):
+    g = np.load(golden_files[0])
+    rng = random.Random(int(g["seed"]))
+    generate_landmarks("random", int(g["L"]), rng)
+    # after the map, the next draws must be the planner's (2 per landmark)
+    nxt = [rng.random() for _ in range(2 * int(g["L"]))]
+    assert np.array_equal(np.array(nxt), g["draws_traj"])
+
+
+def test_command_constraints_and_grid_map():
+    lm, cmds = make_scenario(3, 30, 500)
+    assert np.all(cmds[:, 0] >= 0) and np.all(cmds[:, 0] <= np.float32(0.1))
+    assert np.all(np.abs(cmds[:, 1]) <= np.float32(0.0546))
+    d = np.linalg.norm(lm[:, None] - lm[None], axis=-1) + np.eye(30)
+    assert d.min() >= 0.05 and np.abs(lm).max() <= 10.0
+    grid = generate_landmarks("grid", 0, random.Random(0))
+    assert grid.shape == (25, 2) and grid[0].tolist() == [-8.0, -8.0] and grid[-1].tolist() == [8.0, 8.0]
