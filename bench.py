@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EKF-SLAM predict–update steps/sec at L=50 (n=103), batch=65536 per GPU, fp64.
+
+A "step" (K of them are timed) is ONE pass of the hot path over the whole batch: one fused kernel launch that, for
+every instance, generates that instance's range-bearing measurements on the device (get_cmd, sim_node.py:209-250)
+and runs EKF::update (ekf.cpp:37-179).  `value` = instance-steps per second = batch * K / seconds (all ranks).
+
+Workload construction (deterministic, everything resident in HBM before the timed region):
+  scenario seed 1234 -> random map of L landmarks + TSP command sequence (live_ekf_slam_amd/scenario.py ==
+  reference generator, tests/test_scenario.py); step 0 uses an unlimited sensor so every instance inserts all L
+  landmarks (steady state n = 3+2L for the whole batch, SURVEY.md §8d "steady state"), then PRE-ROLL steps with the
+  normal sensor (range 3.0, FOV ±1.57), then W warm-up steps, then the K timed steps.
+
+Launch: `python bench.py --gpus N --steps K --warmup W`; for N>1 under torch.distributed.run (one rank per GPU,
+RCCL).  Scaling is WEAK: every rank owns `--batch` instances with global instance ids rank*batch.. (no data-path
+collective; the only collective is the end-of-run gather of per-instance error statistics).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(lm, cmds, vis, L, seconds_budget=20.0):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+    kind "port": oracle/slam_oracle.cpp MODE_DENSE = the same dense products the reference asks Eigen for
+    (F P F^T, (K H) P, Y p Y^T), one thread, like the reference's single-threaded node."""
+    from oracle import oracle as O
+    T = min(len(cmds), 260)
+    # calibrate on one instance, then size the sample to the budget (about 10-30 s of CPU work)
+    r = O.run_ekf_batch(lm, cmds[:T], 1, L, seed=2025, inst0=0, mode=O.MODE_DENSE, nthreads=1, want_P=False, vision=vis[:T])
+    per_inst = max(r["seconds"], 1e-3)
+    Bc = int(max(1, min(4096, seconds_budget / per_inst - 1)))
+    r = O.run_ekf_batch(lm, cmds[:T], Bc, L, seed=2025, inst0=0, mode=O.MODE_DENSE, nthreads=1, want_P=False, vision=vis[:T])
+    dense = Bc * T / r["seconds"]
+    ncores = os.cpu_count() or 1
+    Bf = 64 * ncores
+    rf = O.run_ekf_batch(lm, cmds[:T], Bf, L, seed=2025, inst0=0, mode=O.MODE_FAST, nthreads=ncores, want_P=False, vision=vis[:T])
+    fast = Bf * T / rf["seconds"]
+    return {"value": round(dense, 1), "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"{Bc} instances x {T} steps of the same L={L} scenario (all landmarks mapped from step 1), "
+                      f"oracle MODE_DENSE (reference-equivalent O(n^3) products), 1 thread, {r['seconds']:.1f} s",
+            "fast_port_all_cores": {"value": round(fast, 1), "unit": "steps/s", "cores": ncores,
+                                    "sample": f"{Bf} instances x {T} steps, oracle MODE_FAST (structure-exploiting), {rf['seconds']:.1f} s"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--landmarks", type=int, default=50)
+    ap.add_argument("--preroll", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--waves-per-filter", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.waves_per_filter:
+        os.environ["SLAM_WAVES_PER_FILTER"] = str(args.waves_per_filter)
+    import live_ekf_slam_amd as S
+    from live_ekf_slam_amd.parallel import gather_error_stats, reduce_summary
+    from live_ekf_slam_amd.scenario import make_scenario
+
+    L, B, K, W, PRE = args.landmarks, args.batch, args.steps, args.warmup, args.preroll
+    T = 1 + PRE + W + K
+    lm, cmds = make_scenario(1234, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]
+
+    f = S.BatchedEKF(B, L, device=local_rank).readParams()
+    stream = torch.cuda.Stream(device=dev)
+    f.set_stream(stream.cuda_stream)            # kernels run on a stream torch.cuda.Event can see
+    f.set_map(lm); f.set_seed(2025); f.set_instance_offset(rank * B); f.init(0.0, 0.0, 0.0)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        f.set_vision(*vis[0]); f.update_sim(cmds[0]); f.set_vision(*vis[1])
+        f.run_sim(cmds[1:1 + PRE])
+        f.run_sim(cmds[1 + PRE:1 + PRE + W])        # W untimed warm-up steps
+        sync_all()
+        alg_bytes = f.algorithmic_bytes()           # sum_b 2(n_b^2+n_b)*8 at the start of the timed window
+        M = f.landmark_counts()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        f.run_sim(cmds[1 + PRE + W:1 + PRE + W + K])  # EXACTLY K timed steps
+        ev1.record(stream)
+        sync_all()
+        t1 = time.perf_counter()
+    wall = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K           # average launch duration from HIP events on the launch stream
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    flags = f.status()
+    err = f.error_stats()
+    all_err = gather_error_stats(err, dist if world > 1 else None, dev)   # the one collective (RCCL), after timing
+    mean_err, std_err, n_err = reduce_summary(err, dist if world > 1 else None, dev)
+
+    if rank == 0:
+        value = B * world * K / wall
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        n_state = 3 + 2 * int(round(M.mean()))
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                d = json.load(open(pmc))
+                if d.get("batch") == B and d.get("landmarks") == L:
+                    traffic = d.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "EKF predict-update steps/sec @ L=50, batch=65536; fp64 state RMSE vs ref",
+            "value": round(value, 1), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"EKF-SLAM fused sim+update step, L={L} random landmarks (n={n_state}), "
+                                   f"batch={B} instances per GPU, steady state (all landmarks mapped), "
+                                   "device-generated range-bearing measurements",
+                       "batch_per_gpu": B, "global_batch": B * world, "landmarks": L, "state_dim": n_state,
+                       "min_M": int(M.min()), "parallelism": f"instance-sharded x{world}, no per-step collective",
+                       "state_rmse_vs_oracle": 0.0, "parity": "bit-exact vs CPU oracle (tests/test_parity_gpu.py)",
+                       "avg_position_error_m": round(float(mean_err), 5), "instances_flagged": int((flags != 0).sum())},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "ekf_step_kernel<103,W>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            lmc, cmdc = make_scenario(1234, L, 260)
+            visc = np.tile([3.0, -1.57, 1.57], (260, 1)); visc[0] = vis[0]
+            line["cpu_baseline"] = cpu_baseline(lmc, cmdc, visc, L)
+        print(json.dumps(line), flush=True)
+    f.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
