@@ -1,4 +1,4 @@
-// explicit instantiation of the fused EKF-SLAM step kernel: n <= 103, 4 wavefront(s) per filter
+// explicit instantiation of the fused EKF-SLAM step kernel: n <= 103, 4 wavefronts per filter
 #include "ekf_kernel_impl.h"
 namespace slam {
 template hipError_t launch_variant<103, 4>(const EkfStepParams&, hipStream_t);

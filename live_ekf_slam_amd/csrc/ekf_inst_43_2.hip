@@ -1,0 +1,5 @@
+// explicit instantiation of the fused EKF-SLAM step kernel: n <= 43, 2 wavefronts per filter
+#include "ekf_kernel_impl.h"
+namespace slam {
+template hipError_t launch_variant<43, 2>(const EkfStepParams&, hipStream_t);
+}

@@ -9,7 +9,8 @@ namespace slam {
 // preceded (SIM mode) by the measurement generator get_cmd (sim_node.py:209-250) for the same instance.
 struct EkfStepParams {
     // ---- filter state in HBM ----
-    double* P;          // [B][pstride]  packed row-major n x n, leading dimension n = 3+2*M[b]
+    const double* P;    // [B][pstride]  P_t: packed row-major n x n, leading dimension n = 3+2*M[b] (read)
+    double* P_out;      // [B][pstride]  P_t of the next step (written; the two buffers ping-pong)
     double* x;          // [B][xstride]  x_t
     int32_t* M;         // [B]
     int32_t* ids;       // [B][L_max]    lm_IDs
@@ -42,12 +43,13 @@ struct EkfStepParams {
     // ---- geometry ----
     int32_t B, L_max, pstride, xstride;
     int32_t sim;  // 1 = SIM mode, 0 = EXT mode
+    int32_t dbg;  // timing experiments only (env SLAM_DEBUG_FLAGS): 1 = skip bulk stream, 2 = skip detections
 };
 
-// Largest landmark capacity the register-resident kernel supports (n = 3+2L <= 103).
+// Largest landmark capacity of the instantiated variants (n = 3+2L <= 103; the limit is LDS, not registers).
 static constexpr int kEkfMaxLandmarks = 50;
 
-// waves_per_filter: 0 = let the library pick; 1, 2 or 4 otherwise.
+// waves_per_filter: 0 = let the library pick; 2, 4 or 8 otherwise.
 hipError_t launch_ekf_step(const EkfStepParams& p, int waves_per_filter, hipStream_t stream);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)

@@ -11,17 +11,20 @@ namespace slam {
 
 template <int NMAX, int W>
 hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream);
-extern template hipError_t launch_variant<43, 1>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 2>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 2>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 4>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<103, 4>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 8>(const EkfStepParams&, hipStream_t);
 
-// L_max <= 20 (n <= 43): one wavefront per filter, 15 register pairs per lane.
-// L_max <= 50 (n <= 103): four (default) or two wavefronts per filter, 21 / 42 register pairs per lane.
+// NMAX only sizes the LDS arrays (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103); W = wavefronts per filter.
 hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, hipStream_t stream) {
     const int nmax = 3 + 2 * p.L_max;
-    if (nmax <= 43 && (wpf == 0 || wpf == 1)) return launch_variant<43, 1>(p, stream);
-    if (nmax <= 103) {  // measured on MI355X (L=50, B=65536): W=4 5.0 ms/step, W=2 7.5 ms/step
-        if (wpf == 2) return launch_variant<103, 2>(p, stream);
+    if (nmax <= 43) {
+        if (wpf == 4) return launch_variant<43, 4>(p, stream);
+        return launch_variant<43, 2>(p, stream);
+    }
+    if (nmax <= 103) {
+        if (wpf == 8) return launch_variant<103, 8>(p, stream);
         return launch_variant<103, 4>(p, stream);
     }
     return hipErrorInvalidValue;

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ekf_kernel.h"
@@ -42,6 +43,7 @@ struct slam_handle {
     int kind, B, L_max, dtype, device;
     int n_max, pstride, xstride;
     int waves_per_filter = 0;
+    int dbg = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool inited = false;
@@ -50,7 +52,8 @@ struct slam_handle {
     uint32_t step = 0;
     double range_max, fov_min, fov_max;
     // device buffers
-    double* dP = nullptr; double* dx = nullptr; int32_t* dM = nullptr; int32_t* dids = nullptr;
+    double* dP = nullptr; double* dP2 = nullptr;   // dP = current P_t, dP2 = next (ping-pong)
+    double* dx = nullptr; int32_t* dM = nullptr; int32_t* dids = nullptr;
     int32_t* dflags = nullptr; int32_t* dts = nullptr; double* dtruth = nullptr; double* derr = nullptr;
     double* dmap = nullptr; int L = 0;
     float* dmeas = nullptr; int32_t* dcount = nullptr; int k_stride = 0;   // staging / last-measurement dump
@@ -62,7 +65,7 @@ namespace {
 
 void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     memset(&p, 0, sizeof(p));
-    p.P = h->dP; p.x = h->dx; p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
+    p.P = h->dP; p.P_out = h->dP2; p.x = h->dx; p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
     p.truth = h->dtruth; p.err_sum = h->derr; p.map = h->dmap; p.L = h->L;
     p.fwd = cmd[0]; p.ang = cmd[1];
     const slam_config& c = h->cfg;
@@ -79,6 +82,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     p.range_max = h->range_max; p.fov_min = h->fov_min; p.fov_max = h->fov_max;
     p.seed = h->seed; p.inst0 = h->inst0; p.step = h->step;
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
+    p.dbg = h->dbg;
 }
 
 int ensure_meas_buffers(slam_handle* h, int k_stride) {
@@ -182,12 +186,15 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     h->range_max = cfg->range_max; h->fov_min = cfg->fov_min; h->fov_max = cfg->fov_max;
     const char* env = getenv("SLAM_WAVES_PER_FILTER");
     if (env) h->waves_per_filter = atoi(env);
+    env = getenv("SLAM_DEBUG_FLAGS");
+    if (env) h->dbg = atoi(env);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
     const size_t B = (size_t)batch;
     hipError_t errs[] = {
         hipMalloc(&h->dP, sizeof(double) * B * h->pstride),
+        hipMalloc(&h->dP2, sizeof(double) * B * h->pstride),
         hipMalloc(&h->dx, sizeof(double) * B * h->xstride),
         hipMalloc(&h->dM, sizeof(int32_t) * B),
         hipMalloc(&h->dids, sizeof(int32_t) * B * L_max),
@@ -203,6 +210,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
             return fail(SLAM_ERR_HIP, "hipMalloc -> %s", hipGetErrorString(ee));
         }
     HIP_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * B * h->pstride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dP2, 0, sizeof(double) * B * h->pstride, h->stream));
     HIP_TRY(hipMemsetAsync(h->dx, 0, sizeof(double) * B * h->xstride, h->stream));
     HIP_TRY(hipMemsetAsync(h->dids, 0, sizeof(int32_t) * B * L_max, h->stream));
     *out = h;
@@ -213,7 +221,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -272,6 +280,7 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
     p.sim = 0;
     p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
     HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
     h->step += 1;
     return SLAM_OK;
 }
@@ -293,6 +302,7 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
     p.sim = 0;
     p.meas_in = h->dmeas; p.meas_count_in = h->dcount; p.k_stride_in = h->k_stride;
     HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
     h->step += 1;
     return SLAM_OK;
 }
@@ -307,6 +317,7 @@ int slam_step_sim(slam_handle* h, const float cmd[2]) {
     p.sim = 1;
     if (h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
     HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
     h->step += 1;
     return SLAM_OK;
 }

@@ -86,13 +86,13 @@ if __name__ == "__main__":
     if "ext" in which:
         ext_parity(os.path.join(here, "tests/golden/sim_seed0_L20_T1000.npz"), 20)
         ext_parity(os.path.join(here, "tests/golden/sim_seed2_L50_T1000.npz"), 50, wpf=4)
-        ext_parity(os.path.join(here, "tests/golden/sim_seed2_L50_T1000.npz"), 50, wpf=2)
+        ext_parity(os.path.join(here, "tests/golden/sim_seed2_L50_T1000.npz"), 50, wpf=8)
     if "sim" in which:
         sim_parity(20, 300, 64)
         sim_parity(50, 300, 64, wpf=4)
-        sim_parity(50, 300, 64, wpf=2)
+        sim_parity(50, 300, 64, wpf=8)
     if "time" in which:
-        timing(20, 16384, 50)
-        timing(50, 8192, 50, wpf=4)
-        timing(50, 8192, 50, wpf=2)
-        timing(50, 65536, 20, wpf=4)
+        timing(20, 65536, 50, wpf=2)
+        timing(20, 65536, 50, wpf=4)
+        timing(50, 65536, 30, wpf=4)
+        timing(50, 65536, 30, wpf=8)
