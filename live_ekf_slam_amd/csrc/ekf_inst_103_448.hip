@@ -1,0 +1,6 @@
+// explicit instantiation of the fused EKF-SLAM step kernel: n <= 103, 4 wavefronts per filter,
+// 4 detections per group, 8 register pairs in flight per lane
+#include "ekf_kernel_impl.h"
+namespace slam {
+template hipError_t launch_variant<103, 4, 4, 8>(const EkfStepParams&, hipStream_t);
+}

@@ -43,7 +43,8 @@ struct EkfStepParams {
     // ---- geometry ----
     int32_t B, L_max, pstride, xstride;
     int32_t sim;  // 1 = SIM mode, 0 = EXT mode
-    int32_t dbg;  // timing experiments only (env SLAM_DEBUG_FLAGS): 1 = skip bulk stream, 2 = skip detections
+    unsigned long long* prof;  // optional [B][16] per-block phase cycles of the last launch (dbg & 4), NULL otherwise
+    int32_t dbg;  // timing experiments only (env SLAM_DEBUG_FLAGS): 1 = skip bulk stream, 2 = skip detections, 4 = phase timers
 };
 
 // Largest landmark capacity of the instantiated variants (n = 3+2L <= 103; the limit is LDS, not registers).

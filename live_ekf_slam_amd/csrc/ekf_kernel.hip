@@ -9,23 +9,48 @@
 
 namespace slam {
 
-template <int NMAX, int W>
+template <int NMAX, int W, int KG, int UNR>
 hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream);
-extern template hipError_t launch_variant<43, 2>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 4>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 8>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 4, 4>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 3, 4>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 2, 3, 8>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 2, 4, 8>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 8, 4, 2>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 4, 8>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 2, 4>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 2, 4, 4>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 4, 4, 4>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 1, 4, 8>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 2, 4, 8>(const EkfStepParams&, hipStream_t);
 
-// NMAX only sizes the LDS arrays (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103); W = wavefronts per filter.
+// NMAX only sizes the LDS arrays (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103).  `wpf` selects a tuning
+// variant: 0 = default, W (wavefronts per filter) or the 3-digit code W*100 + KG*10 + UNR.
 hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, hipStream_t stream) {
     const int nmax = 3 + 2 * p.L_max;
     if (nmax <= 43) {
-        if (wpf == 4) return launch_variant<43, 4>(p, stream);
-        return launch_variant<43, 2>(p, stream);
+        switch (wpf) {
+            case 244: return launch_variant<43, 2, 4, 4>(p, stream);
+            case 444: return launch_variant<43, 4, 4, 4>(p, stream);
+            case 148: return launch_variant<43, 1, 4, 8>(p, stream);
+            case 248: return launch_variant<43, 2, 4, 8>(p, stream);
+            case 4: return launch_variant<43, 4, 4, 4>(p, stream);
+            case 1: return launch_variant<43, 1, 4, 8>(p, stream);
+            default: return launch_variant<43, 2, 4, 4>(p, stream);
+        }
     }
     if (nmax <= 103) {
-        if (wpf == 8) return launch_variant<103, 8>(p, stream);
-        return launch_variant<103, 4>(p, stream);
+        switch (wpf) {
+            case 444: return launch_variant<103, 4, 4, 4>(p, stream);
+            case 434: return launch_variant<103, 4, 3, 4>(p, stream);
+            case 238: return launch_variant<103, 2, 3, 8>(p, stream);
+            case 248: return launch_variant<103, 2, 4, 8>(p, stream);
+            case 842: return launch_variant<103, 8, 4, 2>(p, stream);
+            case 448: return launch_variant<103, 4, 4, 8>(p, stream);
+            case 424: return launch_variant<103, 4, 2, 4>(p, stream);
+            case 8: return launch_variant<103, 8, 4, 2>(p, stream);
+            case 2: return launch_variant<103, 2, 4, 8>(p, stream);
+            default: return launch_variant<103, 4, 4, 4>(p, stream);
+        }
     }
     return hipErrorInvalidValue;
 }

@@ -30,15 +30,15 @@
 
 namespace slam {
 
-template <int NMAX, int W>
+template <int NMAX, int W, int KG_, int UNR_>
 struct EkfGeom {
     static constexpr int TPB = 64 * W;
     static constexpr int LDP = (NMAX + 2) & ~1;          // LDS row length (> NMAX, even)
     static constexpr int LMAX = (NMAX - 3) / 2;
     static constexpr int KCAP = LMAX > 0 ? LMAX : 1;     // detections held per step
-    static constexpr int KG = 4;                         // detections per group
+    static constexpr int KG = KG_;                       // detections per group
     static constexpr int TS = 3 + 2 * KG;                // thin rows / cols held in LDS
-    static constexpr int UNR = 4;                        // register pairs in flight per lane in the bulk stream
+    static constexpr int UNR = UNR_;                     // register pairs in flight per lane in the bulk stream
 };
 
 // PartialPivLU inverse of a 2x2 (MatrixXd::inverse(), ekf.cpp:135); same sequence as the oracle's inv2x2_lu.
@@ -66,13 +66,23 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
     return ok;
 }
 
+// phase timers (debug only): thread 0 stores the shader-clock delta since the previous stamp to prof[block][i]
+#define SLAM_STAMP(i)                                                                    \
+    do {                                                                                 \
+        if (prof_on && tid == 0) {                                                       \
+            const unsigned long long now_ = __builtin_readcyclecounter();                \
+            p.prof[(size_t)blockIdx.x * 16 + (i)] = now_ - tprev;                         \
+            tprev = now_;                                                                \
+        }                                                                                \
+    } while (0)
+
 __device__ __forceinline__ unsigned hi_abs(double v) {
     return (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu;
 }
 
-template <int NMAX, int W>
-__global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p) {
-    using G = EkfGeom<NMAX, W>;
+template <int NMAX, int W, int KG_, int UNR_>
+__global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(const EkfStepParams p) {
+    using G = EkfGeom<NMAX, W, KG_, UNR_>;
     constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, TS = G::TS, UNR = G::UNR;
 
     __shared__ double s_xt[LDP];          // x_t  (posterior of the previous step; landmark positions for H)
@@ -81,7 +91,6 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
     __shared__ double s_C[TS * LDP];      // thin cols   C[s][r] = P[r][T_s]
     __shared__ double2 s_K[KG * LDP];     // per update of the group: K[r][0..1]
     __shared__ double2 s_HP[KG * LDP];    // per update of the group: (H P)[0..1][c]
-    __shared__ double s_r2[LDP], s_c2[LDP];  // row 2 / col 2 of P_t (predict operands)
     __shared__ double s_sc[16];           // scalars computed by the leader lane (H entries, nu, S^-1, G_x ...)
     __shared__ float s_meas[3 * KCAP];
     __shared__ int s_ids[LMAX > 0 ? LMAX : 1];
@@ -90,16 +99,38 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
     __shared__ signed char s_slot[LDP];   // state index -> thin slot or -1
     __shared__ int s_misc[8];             // k, n_insert, freeze, capacity, l1, nT, singular-S
 
+    // row 2 / col 2 of P_t (predict operands) live in the K buffer, which is idle until the first update
+    double* const s_r2 = reinterpret_cast<double*>(s_K);
+    double* const s_c2 = s_r2 + LDP;
+    static_assert(KG >= 1, "need one K slot for the predict operands");
+
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    int flags = p.flags[b];
-    const int M_old = p.M[b];
-    const int n_old = 3 + 2 * M_old;
+    const bool prof_on = (p.dbg & 4) && p.prof != nullptr;
+    unsigned long long tprev = prof_on ? __builtin_readcyclecounter() : 0ull;
+    // ---- prologue: every load that does not depend on another load is issued up front (one HBM round trip) ----
     const double* __restrict__ Pin = p.P + (size_t)b * p.pstride;
     double* __restrict__ Pout = p.P_out + (size_t)b * p.pstride;
     double* __restrict__ xb = p.x + (size_t)b * p.xstride;
+    int flags = p.flags[b];
+    const int M_old = p.M[b];
+    double xpre[(LDP + TPB - 1) / TPB];
+#pragma unroll
+    for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
+        const int i = tid + TPB * u;
+        xpre[u] = (i < p.xstride && i < LDP) ? xb[i] : 0.0;   // beyond n_old the slab holds stale values: masked below
+    }
+    const int idpre = (tid < p.L_max) ? p.ids[(size_t)b * p.L_max + tid] : 0;
+    double tx = 0.0, ty = 0.0, tth = 0.0, lmx = 0.0, lmy = 0.0;
+    if (p.sim && tid < 64) {
+        tx = p.truth[3 * (size_t)b];
+        ty = p.truth[3 * (size_t)b + 1];
+        tth = p.truth[3 * (size_t)b + 2];
+        if (tid < p.L) { lmx = p.map[2 * tid]; lmy = p.map[2 * tid + 1]; }
+    }
+    const int n_old = 3 + 2 * M_old;
 
     if (flags & SLAM_INST_INDEX_OOR) {
         // frozen instance (the reference node died here, filter.h:5): carry the state into the other buffer
@@ -108,25 +139,26 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
         return;
     }
 
-    for (int i = tid; i < LDP; i += TPB) {
-        const double v = i < n_old ? xb[i] : 0.0;
-        s_xt[i] = v;
-        s_xp[i] = v;
+#pragma unroll
+    for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
+        const int i = tid + TPB * u;
+        if (i < LDP) {
+            const double v = i < n_old ? xpre[u] : 0.0;
+            s_xt[i] = v;
+            s_xp[i] = v;
+        }
     }
-    for (int i = tid; i < M_old; i += TPB) s_ids[i] = p.ids[(size_t)b * p.L_max + i];
+    if (tid < M_old) s_ids[tid] = idpre;
     if (tid < 8) s_misc[tid] = 0;
 
     // ------------------------------------------------------------------------------------------------------
     // measurements: generate (sim_node.py:209-250) or fetch
     // ------------------------------------------------------------------------------------------------------
-    double tx = 0.0, ty = 0.0;
     __syncthreads();
+    SLAM_STAMP(0);   // initial loads
     if (p.sim) {
         if (tid < 64) {  // one wavefront advances the truth and scans the map in ascending id (sim_node.py:209-243)
             const uint64_t inst = (uint64_t)(p.inst0 + b);
-            tx = p.truth[3 * (size_t)b];
-            ty = p.truth[3 * (size_t)b + 1];
-            double tth = p.truth[3 * (size_t)b + 2];
             double u0, u1;
             noise_pair(p.seed, inst, p.step, 0u, &u0, &u1);
             double d = ((double)p.fwd + (2 * p.sV00) * u0) - p.sV00;        // sim_node.py:216
@@ -147,7 +179,8 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
                 bool vis = false;
                 double r = 0.0, beta = 0.0;
                 if (id < p.L) {
-                    const double dx = p.map[2 * id] - tx, dy = p.map[2 * id + 1] - ty;
+                    if (base > 0) { lmx = p.map[2 * id]; lmy = p.map[2 * id + 1]; }   // ids 0..63 were prefetched
+                    const double dx = lmx - tx, dy = lmy - ty;
                     r = sqrt(dx * dx + dy * dy);
                     const double gb = det_atan2(dy, dx);
                     beta = remainder(gb - tth, kTwoPi);
@@ -182,6 +215,7 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
         if (tid == 0) s_misc[0] = kk;
     }
     __syncthreads();
+    SLAM_STAMP(1);   // measurement generation / fetch
     const int k = s_misc[0];
     if (p.sim && p.meas_out != nullptr) {
         for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB)
@@ -195,18 +229,24 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
     int n_ins = 0;  // insertions this step (exact for known ids, upper bound k otherwise)
     if (p.id_known) {
         if (tid < 64) {
+            // lanes scan lm_IDs in parallel for each detection (first match wins, ekf.cpp:102-107); lane l then
+            // keeps the result of detection l
             int idx = -1;
             bool isnew = false, dup = false;
-            if (lane < k) {
-                const int id = (int)s_meas[3 * lane];
+            const int myid = lane < k ? (int)s_meas[3 * lane] : -1;
 #pragma unroll 1
-                for (int j = 0; j < M_old; ++j)
-                    if (idx < 0 && s_ids[j] == id) idx = j;
-                if (idx < 0) {
-                    isnew = true;
+            for (int l = 0; l < k; ++l) {
+                const int id = (int)s_meas[3 * l];
+                int found = -1;
 #pragma unroll 1
-                    for (int l2 = 0; l2 < lane; ++l2) dup = dup || ((int)s_meas[3 * l2] == id);
+                for (int j0 = 0; j0 < M_old && found < 0; j0 += 64) {
+                    const int j = j0 + lane;
+                    const unsigned long long m = __ballot(j < M_old && s_ids[j] == id);
+                    if (m != 0ull) found = j0 + (__ffsll((long long)m) - 1);
                 }
+                // among the NEW ids: has an earlier detection of this message the same id?
+                const unsigned long long e = __ballot(lane < l && myid == id);
+                if (lane == l) { idx = found; isnew = found < 0; dup = isnew && e != 0ull; }
             }
             // a repeated NEW id would be found among the ids pushed this step and index x_t out of range
             // (ekf.cpp:115 -> eigen_assert -> exception, filter.h:5): the reference dies, we freeze.
@@ -235,6 +275,7 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
         return;
     }
     if (s_misc[3]) flags |= SLAM_INST_CAPACITY;
+    SLAM_STAMP(2);   // association
     int nf = n_old + 2 * n_ins;           // leading dimension of the matrix written this step
     nf = nf < NMAX ? nf : NMAX;
 
@@ -321,6 +362,7 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
         }
         __syncthreads();
         const int l1 = s_misc[4], nT = s_misc[5];
+        SLAM_STAMP(3);   // x_pred + group formation
         if (s_misc[2]) {
             // unknown-id quirk: the reference throws.  Freeze in the pre-step state.
             const int nn = n_old * n_old;
@@ -330,21 +372,32 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
         }
         if (s_misc[3]) flags |= SLAM_INST_CAPACITY;
 
-        // ---- thin gather: HBM -> LDS.  Rows are contiguous, columns are strided 8-byte loads. ----
-#pragma unroll 1
-        for (int i = tid; i < nT * LDP; i += TPB) {
-            const int sl = i / LDP, j = i - sl * LDP;
-            const int t_s = s_T[sl];
-            double rv = 0.0, cv = 0.0;
-            if (j < nsrc && t_s < nsrc) {
-                rv = src[(size_t)t_s * lds + j];   // P[t_s][j]
-                cv = src[(size_t)j * lds + t_s];   // P[j][t_s]
+        // ---- thin gather: HBM -> LDS.  Rows are contiguous, columns are strided 8-byte loads.  All loads of a
+        //      lane are issued before the first LDS store so their latencies overlap. ----
+        {
+            constexpr int GI = (TS * LDP + TPB - 1) / TPB;
+            double rv[GI], cv[GI];
+#pragma unroll
+            for (int u = 0; u < GI; ++u) {
+                const int i = tid + TPB * u;
+                rv[u] = 0.0; cv[u] = 0.0;
+                if (i < nT * LDP) {
+                    const int sl = i / LDP, j = i - sl * LDP;
+                    const int t_s = s_T[sl];
+                    if (j < nsrc && t_s < nsrc) {
+                        rv[u] = src[(size_t)t_s * lds + j];   // P[t_s][j]
+                        cv[u] = src[(size_t)j * lds + t_s];   // P[j][t_s]
+                    }
+                }
             }
-            s_R[i] = rv;
-            s_C[i] = cv;
+#pragma unroll
+            for (int u = 0; u < GI; ++u) {
+                const int i = tid + TPB * u;
+                if (i < nT * LDP) { s_R[i] = rv[u]; s_C[i] = cv[u]; }
+            }
         }
         __syncthreads();
-
+        SLAM_STAMP(4);   // thin gather
         // ---- prediction stage on the thin copies (first group only), ekf.cpp:41-61 ----
         if (first) {
             if (tid == 0) {  // leader: the scalars of F_x, F_v V F_v^T
@@ -399,6 +452,7 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
             __syncthreads();
         }
 
+        SLAM_STAMP(5);   // predict
         // ---- detections of the group in message order ----
         int nu = 0;  // updates recorded for the bulk pass
 #pragma unroll 1
@@ -554,6 +608,7 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
             }
         }
 
+        SLAM_STAMP(6);   // detections
         // ---- BULK: stream P once.  dst pair q = (elements 2q, 2q+1 of the nf-leading-dimension layout). ----
         {
             const int nn2 = nf * nf;
@@ -620,6 +675,7 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
         first = false;
     }
     __syncthreads();
+    SLAM_STAMP(7);   // bulk stream
 
     // ------------------------------------------------------------------------------------------------------
     // x_t = x_pred (ekf.cpp:176) and bookkeeping.  P_t = P_pred was written by the bulk stream.
@@ -661,6 +717,7 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
         p.M[b] = M;
         p.flags[b] = flags;
         p.timestep[b] = p.timestep[b] + 1;
+        SLAM_STAMP(8);   // epilogue
         if (p.sim) {  // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
             const double ex = (double)(float)s_xp[0] - tx, ey = (double)(float)s_xp[1] - ty;
             p.err_sum[b] = p.err_sum[b] + sqrt(ex * ex + ey * ey);
@@ -668,9 +725,9 @@ __global__ __launch_bounds__(64 * W) void ekf_step_kernel(const EkfStepParams p)
     }
 }
 
-template <int NMAX, int W>
+template <int NMAX, int W, int KG_, int UNR_>
 hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((ekf_step_kernel<NMAX, W>), dim3(p.B), dim3(64 * W), 0, stream, p);
+    hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_>), dim3(p.B), dim3(64 * W), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -58,6 +58,7 @@ struct slam_handle {
     double* dmap = nullptr; int L = 0;
     float* dmeas = nullptr; int32_t* dcount = nullptr; int k_stride = 0;   // staging / last-measurement dump
     double* dscalar = nullptr;
+    unsigned long long* dprof = nullptr;
     bool dump_meas = false;
 };
 
@@ -83,6 +84,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     p.seed = h->seed; p.inst0 = h->inst0; p.step = h->step;
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
     p.dbg = h->dbg;
+    p.prof = (h->dbg & 4) ? h->dprof : nullptr;
 }
 
 int ensure_meas_buffers(slam_handle* h, int k_stride) {
@@ -203,6 +205,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMalloc(&h->dtruth, sizeof(double) * B * 3),
         hipMalloc(&h->derr, sizeof(double) * B),
         hipMalloc(&h->dscalar, sizeof(double) * 4),
+        hipMalloc(&h->dprof, sizeof(unsigned long long) * 16 * B),
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -213,6 +216,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     HIP_TRY(hipMemsetAsync(h->dP2, 0, sizeof(double) * B * h->pstride, h->stream));
     HIP_TRY(hipMemsetAsync(h->dx, 0, sizeof(double) * B * h->xstride, h->stream));
     HIP_TRY(hipMemsetAsync(h->dids, 0, sizeof(int32_t) * B * L_max, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * 16 * B, h->stream));
     *out = h;
     return SLAM_OK;
 }
@@ -221,7 +225,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -415,6 +419,20 @@ int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
     HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->dscalar, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(bytes, h->dscalar, sizeof(double), hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+// debug only (not declared in slam_batch.h): per-block phase cycles of the LAST launch, summed over blocks
+// (SLAM_DEBUG_FLAGS & 4)
+int slam_debug_read_prof(slam_handle* h, unsigned long long out[16]) {
+    if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> buf((size_t)16 * h->B);
+    HIP_TRY(hipMemcpy(buf.data(), h->dprof, sizeof(unsigned long long) * buf.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (int b = 0; b < h->B; ++b)
+        for (int i = 0; i < 16; ++i) out[i] += buf[(size_t)16 * b + i];
     return SLAM_OK;
 }
 
