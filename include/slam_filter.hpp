@@ -1,0 +1,151 @@
+// slam_filter.hpp — ROS-free C++ mirror of the reference's `Filter` interface over the C ABI (slam_batch.h).
+//
+// Reference: ekf_ws/src/localization_pkg/include/localization_pkg/filter.h:54-77 (abstract class Filter),
+// :148-174 (class EKF); caller ekf_ws/src/localization_pkg/src/localization_node.cpp:33-47 (factory),
+// :90-106 (initCallback -> init), :108-140 (iterate -> update, publishState).
+// Same method names, argument meaning and error convention (std::runtime_error) as the reference, so the node
+// harness can hold a `std::unique_ptr<Filter>` to a BatchedEKF exactly as it holds an EKF today.  The message
+// types are shims with the fields the hot path reads (ROS is not available in the build image); on a ROS box
+// they are replaced by base_pkg::Command / std_msgs::Float32MultiArray via the two typedefs below
+// (INTEGRATION.md §2).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "slam_batch.h"
+
+namespace slam_amd {
+
+#ifndef SLAM_AMD_USE_ROS_MSGS
+struct Command {            // base_pkg/Command.msg:3-5
+    float fwd = 0.f, ang = 0.f;
+    using ConstPtr = std::shared_ptr<const Command>;
+};
+struct Float32MultiArray {  // std_msgs/Float32MultiArray: data = [id, range, bearing] * k (sim_node.py:245-249)
+    std::vector<float> data;
+    using ConstPtr = std::shared_ptr<const Float32MultiArray>;
+};
+#endif
+
+enum class FilterChoice { NOT_SET = 0, EKF_SLAM, UKF_LOC, UKF_SLAM, POSE_GRAPH_SLAM, NAIVE_COMMAND_PROPAGATION };  // filter.h:44-51
+
+// EKFState.msg payload as EKF::publishState fills it (ekf.cpp:192-220)
+struct EKFState {
+    int32_t timestep = 0;
+    float x_v = 0, y_v = 0, yaw_v = 0;
+    int32_t M = 0;
+    std::vector<float> landmarks;  // [id, x, y] * M   (ekf.cpp:203-208)
+    std::vector<float> P;          // row-major (3+2M)^2 (ekf.cpp:211-217)
+};
+
+inline void check(int rc) {
+    if (rc != SLAM_OK) throw std::runtime_error(std::string("slam_batch: ") + slam_last_error());
+}
+
+class Filter {  // filter.h:54-77
+public:
+    FilterChoice type = FilterChoice::NOT_SET;
+    bool isInit = false;
+    std::vector<int> lm_IDs;  // of instance 0 (filter.h:70)
+    virtual ~Filter() = default;
+    virtual void readParams(const slam_config& config) = 0;                     // filter.h:59 (YAML::Node there)
+    virtual void init(float x_0, float y_0, float yaw_0) = 0;                   // filter.h:60
+    virtual void update(Command::ConstPtr cmdMsg, Float32MultiArray::ConstPtr lmMeasMsg) = 0;  // filter.h:61
+    virtual void publishState() = 0;                                            // filter.h:66
+    virtual std::vector<double> getStateVector() { throw std::runtime_error("getStateVector is not defined for this filter."); }  // filter.h:76
+};
+
+// Batch of B EKF-SLAM instances behind the single-instance interface.  update(cmd, meas) applies the SAME message
+// to every instance (a drop-in for one filter when B == 1); updateBatch / updateSim are the batched entry points.
+class BatchedEKF : public Filter {
+public:
+    BatchedEKF(int batch, int L_max, int device = 0) : batch_(batch), L_max_(L_max), device_(device) {
+        type = FilterChoice::EKF_SLAM;
+        check(slam_config_default(&cfg_));
+    }
+    ~BatchedEKF() override { if (h_) slam_destroy(h_); }
+    BatchedEKF(const BatchedEKF&) = delete;
+    BatchedEKF& operator=(const BatchedEKF&) = delete;
+
+    void readParams(const slam_config& config) override {
+        cfg_ = config;
+        if (h_) { slam_destroy(h_); h_ = nullptr; }
+        check(slam_create(&cfg_, SLAM_EKF_SLAM, batch_, L_max_, SLAM_F64, device_, &h_));
+    }
+    void readParamsFile(const std::string& params_yaml) {  // localization_node.cpp:29-30
+        slam_config c;
+        check(slam_config_default(&c));
+        check(slam_config_load(&c, params_yaml.c_str()));
+        readParams(c);
+    }
+    void init(float x_0, float y_0, float yaw_0) override {
+        need();
+        check(slam_init(h_, x_0, y_0, yaw_0));
+        isInit = true;
+    }
+    void update(Command::ConstPtr cmdMsg, Float32MultiArray::ConstPtr lmMeasMsg) override {
+        need();
+        const int k = (int)(lmMeasMsg->data.size() / 3);   // ekf.cpp:65
+        const int ks = k > 0 ? k : 1;
+        std::vector<float> meas((size_t)batch_ * ks * 3, 0.f);
+        std::vector<int32_t> cnt(batch_, k);
+        for (int b = 0; b < batch_; ++b)
+            for (int i = 0; i < 3 * k; ++i) meas[(size_t)b * ks * 3 + i] = lmMeasMsg->data[i];
+        const float cmd[2] = {cmdMsg->fwd, cmdMsg->ang};
+        check(slam_step(h_, cmd, meas.data(), cnt.data(), ks));
+    }
+    void updateBatch(const Command& cmd, const float* meas, const int32_t* meas_count, int k_stride) {
+        need();
+        const float c[2] = {cmd.fwd, cmd.ang};
+        check(slam_step(h_, c, meas, meas_count, k_stride));
+    }
+    void setMap(const std::vector<double>& map_xy) { need(); check(slam_set_map(h_, map_xy.data(), (int)(map_xy.size() / 2))); }
+    void setSeed(uint64_t seed) { need(); check(slam_set_seed(h_, seed)); }
+    void updateSim(const Command& cmd) {  // device-side get_cmd (sim_node.py:209-250) + update
+        need();
+        const float c[2] = {cmd.fwd, cmd.ang};
+        check(slam_step_sim(h_, c));
+    }
+    std::vector<double> getStateVector() override { return getStateVector(0); }   // ekf.cpp:181-184
+    std::vector<double> getStateVector(int instance) {
+        need();
+        std::vector<double> x(slam_state_dim_max(h_));
+        int32_t M = 0;
+        std::vector<int32_t> ids(L_max_);
+        check(slam_get_state(h_, instance, x.data(), nullptr, &M, ids.data(), nullptr));
+        x.resize(3 + 2 * M);
+        if (instance == 0) lm_IDs.assign(ids.begin(), ids.begin() + M);
+        return x;
+    }
+    // EKF::publishState (ekf.cpp:192-220): build the message payload; `last_state` is what would be published.
+    void publishState() override { last_state = stateMsg(0); }
+    EKFState stateMsg(int instance) {
+        need();
+        const int nmax = slam_state_dim_max(h_);
+        std::vector<double> x(nmax), P((size_t)nmax * nmax);
+        std::vector<int32_t> ids(L_max_);
+        EKFState s;
+        check(slam_get_state(h_, instance, x.data(), P.data(), &s.M, ids.data(), &s.timestep));
+        const int n = 3 + 2 * s.M;
+        s.x_v = (float)x[0]; s.y_v = (float)x[1]; s.yaw_v = (float)x[2];
+        for (int i = 0; i < s.M; ++i) { s.landmarks.push_back((float)ids[i]); s.landmarks.push_back((float)x[3 + 2 * i]); s.landmarks.push_back((float)x[4 + 2 * i]); }
+        s.P.resize((size_t)n * n);
+        for (size_t i = 0; i < (size_t)n * n; ++i) s.P[i] = (float)P[i];
+        return s;
+    }
+    std::vector<double> errorStats() { need(); std::vector<double> e(batch_); check(slam_error_stats(h_, e.data())); return e; }
+    slam_handle* handle() { return h_; }
+    EKFState last_state;
+
+private:
+    void need() const { if (!h_) throw std::runtime_error("readParams() has not been called"); }
+    slam_config cfg_{};
+    slam_handle* h_ = nullptr;
+    int batch_, L_max_, device_;
+};
+
+}  // namespace slam_amd

@@ -49,7 +49,19 @@ def build_extension(force=False, verbose=False):
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    build_driver()
     return LIB
+
+
+DRIVER = os.path.join(HERE, "filter_driver")
+
+
+def build_driver():
+    """C++ host example over include/slam_filter.hpp (the reference's Filter interface), plain g++, links the .so."""
+    src = os.path.join(CSRC, "host", "filter_driver.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", DRIVER, "-L" + HERE, "-lslam_hip",
+                           "-Wl,-rpath,$ORIGIN"])
+    return DRIVER
 
 
 if __name__ == "__main__":

@@ -1,0 +1,21 @@
+"""The C++ host example over include/slam_filter.hpp (the reference's Filter interface) runs on the GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_filter_driver_runs():
+    exe = os.path.join(ROOT, "live_ekf_slam_amd", "filter_driver")
+    assert os.path.exists(exe), "build the extension first (__graft_entry__.build())"
+    out = subprocess.run([exe, "512", "20", "120"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"mean_avg_err=([0-9.]+) M0=(\d+) timestep=(\d+) P_len=(\d+)", out.stdout)
+    assert m, out.stdout
+    err, M0, ts, plen = float(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))
+    assert ts == 121 and plen == (3 + 2 * M0) ** 2 and 0.0 < err < 1.0
