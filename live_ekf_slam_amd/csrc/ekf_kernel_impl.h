@@ -76,6 +76,18 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
         }                                                                                \
     } while (0)
 
+// The P stream is touched once per step: mark it non-temporal so it does not evict the thin-gather sectors (which
+// the stream re-reads a few microseconds later) or other workgroups' lines from L2.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load(const double2* ptr) {
+    const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(ptr));
+    return make_double2(t.x, t.y);
+}
+__device__ __forceinline__ void nt_store(double2* ptr, double x, double y) {
+    dbl2_t t; t.x = x; t.y = y;
+    __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t*>(ptr));
+}
+
 __device__ __forceinline__ unsigned hi_abs(double v) {
     return (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu;
 }
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     v[u] = make_double2(0.0, 0.0);
                     if (q < npair) {
                         if (same_layout) {
-                            v[u] = src2[q];
+                            v[u] = (p.dbg & 8) ? src2[q] : nt_load(src2 + q);
                         } else {  // re-lay-out from leading dimension lds to nf (steps that grow the state)
                             int c1 = c + 1, r1 = r;
                             if (c1 == nf) { c1 = 0; r1 = r + 1; }
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         const unsigned h0a = hi_abs(vx), h1a = hi_abs(vy);
                         hiacc = hiacc > h0a ? hiacc : h0a;
                         hiacc = hiacc > h1a ? hiacc : h1a;
-                        dst2[q] = make_double2(vx, vy);
+                        if (p.dbg & 8) dst2[q] = make_double2(vx, vy); else nt_store(dst2 + q, vx, vy);
                     }
                 }
             }

@@ -11,10 +11,12 @@ lm, cmds = make_scenario(1234, L, 200)
 f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.init(0, 0, 0)
 f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
 f.run_sim(cmds[1:40]); f.sync()
-t0 = time.time(); f.run_sim(cmds[40:40 + steps]); f.sync(); dt = time.time() - t0
+dt = 1e9
+for rep in range(3):
+    t0 = time.time(); f.run_sim(cmds[40:40 + steps]); f.sync(); dt = min(dt, time.time() - t0)
 print(f"L={L} dbg={os.environ.get('SLAM_DEBUG_FLAGS','0')} wpf={os.environ.get('SLAM_WAVES_PER_FILTER','-')}: {dt / steps * 1e3:.3f} ms/step", flush=True)
 '''
-for L in (50, 20):
-    for dbg in ("0", "1", "2", "3"):
+for L in (50,):
+    for dbg in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("0", "1", "2", "3")):
         env = dict(os.environ, SLAM_DEBUG_FLAGS=dbg)
         subprocess.run([sys.executable, "-c", code, str(L)], env=env)
