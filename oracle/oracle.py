@@ -50,6 +50,16 @@ def lib():
         L.orc_run_ekf_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int,
                                         C.c_uint64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp, _ip, _dp,
                                         C.POINTER(C.c_int64), _dp]
+        L.orc_ukf_create.restype = C.c_void_p
+        L.orc_ukf_create.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int]
+        L.orc_ukf_destroy.argtypes = [C.c_void_p]
+        L.orc_ukf_init.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_ukf_update.argtypes = [C.c_void_p, C.c_float, C.c_float, _fp, C.c_int]
+        L.orc_ukf_get.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip]
+        L.orc_ukf_sqrt_probe.argtypes = [_dp, C.c_int, C.c_double, _dp]
+        L.orc_run_ukf_batch.restype = C.c_double
+        L.orc_run_ukf_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int, C.c_uint64,
+                                        C.c_int64, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp, _ip, _dp, _dp]
         L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
         L.orc_noise_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
         for name in ("orc_det_sincos", "orc_libm_sincos"):
@@ -154,3 +164,55 @@ def run_ekf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MAT
                                    _d(x), _d(P) if want_P else None, _i(M), _i(ids), _d(err), _i(flags), _d(truth), C.byref(ktot),
                                    _d(vision) if vision is not None else None)
     return dict(x=x, P=P, M=M, ids=ids, avg_err=err, flags=flags, truth=truth, seconds=secs, k_total=ktot.value)
+
+
+class OracleUKF:
+    """One reference-equivalent UKF-SLAM filter instance (ukf.cpp)."""
+
+    def __init__(self, cfg=None, L_max=20, math=MATH_DET):
+        self.cfg = cfg or default_config()
+        self.L_max = L_max
+        self.h = lib().orc_ukf_create(C.byref(self.cfg), L_max, math)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ukf_destroy(self.h)
+            self.h = None
+
+    def init(self, x0=0.0, y0=0.0, yaw0=0.0):
+        lib().orc_ukf_init(self.h, x0, y0, yaw0)
+
+    def update(self, fwd, ang, meas):
+        m = np.ascontiguousarray(np.asarray(meas, dtype=np.float32).reshape(-1, 3))
+        return lib().orc_ukf_update(self.h, float(np.float32(fwd)), float(np.float32(ang)), _f(m), m.shape[0])
+
+    def state(self):
+        nmax = 4 + 2 * self.L_max
+        x = np.zeros(nmax); P = np.zeros(nmax * nmax); ids = np.zeros(self.L_max, dtype=np.int32)
+        M = C.c_int(0); ts = C.c_int(0); sw = C.c_int(0)
+        lib().orc_ukf_get(self.h, _d(x), _d(P), C.byref(M), _i(ids), C.byref(ts), C.byref(sw))
+        n = 4 + 2 * M.value
+        return dict(x=x[:n].copy(), P=P[:n * n].reshape(n, n).copy(), M=M.value, ids=ids[:M.value].copy(),
+                    timestep=ts.value, sweeps=sw.value)
+
+
+def ukf_sqrt_probe(P, scale):
+    P = np.ascontiguousarray(P, dtype=np.float64); n = P.shape[0]
+    out = np.zeros((n, n))
+    sweeps = lib().orc_ukf_sqrt_probe(_d(P), n, float(scale), _d(out))
+    return out, sweeps
+
+
+def run_ukf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, nthreads=1, want_P=True, vision=None):
+    cfg = cfg or default_config()
+    map_xy = np.ascontiguousarray(map_xy, dtype=np.float64); cmds = np.ascontiguousarray(cmds, dtype=np.float32)
+    L, T, nmax = map_xy.shape[0], cmds.shape[0], 4 + 2 * L_max
+    x = np.zeros((B, nmax)); P = np.zeros((B, nmax * nmax)) if want_P else None
+    M = np.zeros(B, dtype=np.int32); ids = np.zeros((B, L_max), dtype=np.int32)
+    err = np.zeros(B); flags = np.zeros(B, dtype=np.int32); truth = np.zeros((B, 3))
+    if vision is not None:
+        vision = np.ascontiguousarray(vision, dtype=np.float64).reshape(T, 3)
+    secs = lib().orc_run_ukf_batch(C.byref(cfg), L_max, math, _d(map_xy), L, _f(cmds), T, seed, inst0, B, nthreads,
+                                   _d(x), _d(P) if want_P else None, _i(M), _i(ids), _d(err), _i(flags), _d(truth),
+                                   _d(vision) if vision is not None else None)
+    return dict(x=x, P=P, M=M, ids=ids, avg_err=err, flags=flags, truth=truth, seconds=secs)

@@ -1,0 +1,414 @@
+// slam_oracle_ukf.cpp — CPU ORACLE for the UKF-SLAM predict–update path.  TEST INFRASTRUCTURE, NOT PRODUCT.
+//
+// Restates ekf_ws/src/localization_pkg/src/ukf.cpp:3-45 (ctor/init), :106-123 (nearestSPD), :125-159 (motion /
+// sensing models), :161-372 (update, predictionStage, updateStage, landmarkUpdate, landmarkInsertion) and
+// filter.h:207 (W_0 = 0.2f), statement by statement, with the reference's float truncations and its quirks
+// (signed process noise Q, z_est(1) never accumulated, sensingModel yaw taken from x_t,
+// sigma points not redrawn between landmark updates, plain weighted mean of (cos, sin), updates before insertions).
+//
+// PARITY STATUS: "parity unpinned" against the reference binary (unbuildable here, see slam_oracle.cpp).  Pinned by
+// the UKF known-answer table of SURVEY.md Appendix E (1e-6 absolute) and by an independent numpy transliteration
+// that uses LAPACK's eigh for the matrix square root (tests/test_oracle_ukf.py).
+//
+// Two places where the reference delegates to Eigen routines whose rounding cannot be reproduced:
+//  * SelfAdjointEigenSolver + MatrixFunctions .sqrt() (ukf.cpp:116-122,208).  Mathematically sqtP = Qv sqrt(D+) Qv^T
+//    is unique; here it is computed with a cyclic Jacobi eigen-iteration in PARALLEL (round-robin) ORDER on the
+//    exactly-symmetric matrix, the same schedule the GPU kernel runs, so GPU == oracle bit for bit.
+//  * unqualified cos/sin on a float argument (ukf.cpp:39-42,129-133,183-186,358-359): float overload
+//    (cfg.ukf_float_trig = 1, default) or double function (0); SURVEY.md Appendix B.
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+#include "oracle_common.h"
+
+namespace {
+using namespace orc;
+
+// ---- symmetric eigen-decomposition: cyclic Jacobi, round-robin parallel ordering -------------------------------
+// A: n x n row-major, exactly symmetric on entry and kept so (only pair-blocks i >= j are computed, then mirrored).
+// V: n x n, columns = eigenvectors.  n is even (n = 4 + 2M).  Returns the number of sweeps, or -1 if not converged.
+// All rotations of a round read the matrix as it was at the start of the round (disjoint index pairs).
+int jacobi_round_robin(double* A, double* V, int n, int max_sweeps) {
+    const int m = n / 2;
+    std::vector<int> pp(m), qq(m);
+    std::vector<double> cs(m), sn(m), tn(m);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        // convergence test on the current matrix: max |off-diagonal| against max |diagonal|
+        double off = 0.0, dmax = 0.0;
+        for (int i = 0; i < n; ++i) {
+            dmax = std::max(dmax, fabs(A[(size_t)i * n + i]));
+            for (int j = 0; j < i; ++j) off = std::max(off, fabs(A[(size_t)i * n + j]));
+        }
+        if (!(off > 1e-15 * dmax)) return sweep;
+        for (int t = 0; t < n - 1; ++t) {
+            // round-robin pairing: position 0 is fixed, positions 1..n-1 rotate
+            auto at = [&](int k) { return k == 0 ? 0 : 1 + ((k - 1 + t) % (n - 1)); };
+            for (int k = 0; k < m; ++k) {
+                const int a = at(k), b = at(n - 1 - k);
+                pp[k] = std::min(a, b); qq[k] = std::max(a, b);
+                const double app = A[(size_t)pp[k] * n + pp[k]], aqq = A[(size_t)qq[k] * n + qq[k]], apq = A[(size_t)qq[k] * n + pp[k]];
+                double c = 1.0, s = 0.0, tt = 0.0;
+                if (apq != 0.0) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + tt * tt);
+                    s = tt * c;
+                }
+                cs[k] = c; sn[k] = s; tn[k] = tt;
+            }
+            // pair-blocks (i, j), i >= j:  B' = R_i^T B R_j  with R = [[c, s], [-s, c]]
+            for (int i = 0; i < m; ++i) {
+                const int pi = pp[i], qi = qq[i];
+                const double ci = cs[i], si = sn[i];
+                for (int j = 0; j < i; ++j) {
+                    const int pj = pp[j], qj = qq[j];
+                    const double cj = cs[j], sj = sn[j];
+                    const double b00 = A[(size_t)pi * n + pj], b01 = A[(size_t)pi * n + qj];
+                    const double b10 = A[(size_t)qi * n + pj], b11 = A[(size_t)qi * n + qj];
+                    const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
+                    const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
+                    const double r00 = t00 * cj - t01 * sj, r01 = t00 * sj + t01 * cj;
+                    const double r10 = t10 * cj - t11 * sj, r11 = t10 * sj + t11 * cj;
+                    A[(size_t)pi * n + pj] = r00; A[(size_t)pj * n + pi] = r00;
+                    A[(size_t)pi * n + qj] = r01; A[(size_t)qj * n + pi] = r01;
+                    A[(size_t)qi * n + pj] = r10; A[(size_t)pj * n + qi] = r10;
+                    A[(size_t)qi * n + qj] = r11; A[(size_t)qj * n + qi] = r11;
+                }
+            }
+            for (int i = 0; i < m; ++i) {  // diagonal blocks
+                const int p = pp[i], q = qq[i];
+                const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q], apq = A[(size_t)q * n + p];
+                A[(size_t)p * n + p] = app - tn[i] * apq;
+                A[(size_t)q * n + q] = aqq + tn[i] * apq;
+                if (apq != 0.0) { A[(size_t)q * n + p] = 0.0; A[(size_t)p * n + q] = 0.0; }
+            }
+            for (int i = 0; i < m; ++i) {  // V <- V J
+                const int p = pp[i], q = qq[i];
+                const double c = cs[i], s = sn[i];
+                for (int k = 0; k < n; ++k) {
+                    const double vp = V[(size_t)k * n + p], vq = V[(size_t)k * n + q];
+                    V[(size_t)k * n + p] = c * vp - s * vq;
+                    V[(size_t)k * n + q] = s * vp + c * vq;
+                }
+            }
+        }
+    }
+    return -1;
+}
+
+struct Ukf {
+    slam_config cfg;
+    FilterNoise nz;
+    int L_max, math;
+    int timestep = 0, M = 0, flags = 0;
+    std::vector<double> x_t, x_pred, P_t, P_pred, sqtP, Xp4;  // Xp4: rows 0..3 of X_pred, [4][2n+1]
+    std::vector<int> ids;
+    int n_sq = 0;          // dimension sqtP currently has
+    int last_sweeps = 0;
+
+    int n() const { return 4 + 2 * M; }
+    static constexpr float W_0 = 0.2f;  // filter.h:207
+
+    Ukf(const slam_config& c, int Lm, int mth) : cfg(c), nz(effective_noise(c)), L_max(Lm), math(mth) { reset_ctor(); }
+
+    template <class MP> float fcos(float a) const {  // unqualified cos(float): float overload or double function
+        double s, c; MP::sincos((double)a, &s, &c);
+        return (float)c;
+    }
+    template <class MP> double tcos(float a) const { double s, c; MP::sincos((double)a, &s, &c); return cfg.ukf_float_trig ? (double)(float)c : c; }
+    template <class MP> double tsin(float a) const { double s, c; MP::sincos((double)a, &s, &c); return cfg.ukf_float_trig ? (double)(float)s : s; }
+
+    void reset_ctor() {  // UKF::UKF ukf.cpp:3-23
+        timestep = 0; M = 0; flags = 0; ids.clear();
+        x_t.assign(4, 0.0); x_pred.assign(4, 0.0);
+        P_t.assign(16, 0.0);
+        P_t[0] = 0.01 * 0.01; P_t[5] = 0.01 * 0.01; P_t[10] = 0.005 * 0.005; P_t[15] = 0.005 * 0.005;
+        P_pred = P_t;
+        sqtP.clear(); n_sq = 0;
+    }
+    template <class MP> void init_t(float x0, float y0, float yaw0) {  // ukf.cpp:31-45
+        reset_ctor();
+        x_t[0] = x0; x_t[1] = y0; x_t[2] = tcos<MP>(yaw0); x_t[3] = tsin<MP>(yaw0);
+    }
+    void init(float x0, float y0, float yaw0) { math == MATH_DET ? init_t<DetMath>(x0, y0, yaw0) : init_t<LibmMath>(x0, y0, yaw0); }
+
+    template <class MP> float yaw_of(const double* v) const {  // (float) remainder(atan2(v[3], v[2]), 2*pi)
+        return (float)remainder(MP::atan2(v[3], v[2]), slam::kTwoPi);
+    }
+
+    // weight of sigma point i (ukf.cpp:174-176): (1-W_0)/(2n) evaluated in float, Wts(0) = W_0
+    double wt(int i, int nn) const { return i == 0 ? (double)W_0 : (double)((1 - W_0) / (2 * nn)); }
+
+    template <class MP> void prediction_stage(float u_d, float u_th) {
+        const int nn = n();
+        // ---- nearestSPD (ukf.cpp:106-123) + matrix square root (ukf.cpp:208) ----
+        std::vector<double> Y((size_t)nn * nn), V((size_t)nn * nn);
+        const float scale_f = (2 * M + 4) / (1 - W_0);   // int / float -> float   ukf.cpp:114
+        const double scale = (double)scale_f;
+        for (int r = 0; r < nn; ++r)
+            for (int c = 0; c < nn; ++c) Y[(size_t)r * nn + c] = (0.5 * (P_t[(size_t)r * nn + c] + P_t[(size_t)c * nn + r])) * scale;
+        const int sweeps = jacobi_round_robin(Y.data(), V.data(), nn, 60);
+        last_sweeps = sweeps;
+        if (sweeps < 0) {
+            // ukf.cpp:209-211: the exception is swallowed and the stale sqtP is reused.  A stale matrix of the wrong
+            // size cannot be used: keep the instance running with a zero spread and flag it.
+            flags |= SLAM_INST_SQRT_FAILED;
+            if (n_sq != nn) { sqtP.assign((size_t)nn * nn, 0.0); n_sq = nn; }
+        } else {
+            std::vector<double> sd(nn);
+            for (int k = 0; k < nn; ++k) {
+                const double d = Y[(size_t)k * nn + k];
+                sd[k] = sqrt(d > 0.00000001 ? d : 0.00000001);   // cwiseMax(1e-8) then principal sqrt
+            }
+            sqtP.assign((size_t)nn * nn, 0.0); n_sq = nn;
+            for (int r = 0; r < nn; ++r)
+                for (int c = 0; c <= r; ++c) {
+                    double acc = 0.0;
+                    for (int k = 0; k < nn; ++k) acc = acc + (V[(size_t)r * nn + k] * sd[k]) * V[(size_t)c * nn + k];
+                    sqtP[(size_t)r * nn + c] = acc; sqtP[(size_t)c * nn + r] = acc;
+                }
+        }
+        // ---- sigma points through the motion model (ukf.cpp:214-226, 125-135); rows >= 4 are copied ----
+        const int ns = 2 * nn + 1;
+        Xp4.assign((size_t)4 * ns, 0.0);
+        const float dd = u_d + cfg.v_d;
+        for (int i = 0; i < ns; ++i) {
+            double v[4];
+            for (int r = 0; r < 4; ++r) {
+                if (i == 0) v[r] = x_t[r];
+                else if (i <= nn) v[r] = x_t[r] + sqtP[(size_t)r * nn + (i - 1)];
+                else v[r] = x_t[r] - sqtP[(size_t)r * nn + (i - 1 - nn)];
+            }
+            const float yaw = yaw_of<MP>(v);
+            if (cfg.ukf_float_trig) {
+                Xp4[(size_t)0 * ns + i] = v[0] + (double)(dd * (float)tcos<MP>(yaw));   // float * float
+                Xp4[(size_t)1 * ns + i] = v[1] + (double)(dd * (float)tsin<MP>(yaw));
+            } else {
+                Xp4[(size_t)0 * ns + i] = v[0] + (double)dd * tcos<MP>(yaw);
+                Xp4[(size_t)1 * ns + i] = v[1] + (double)dd * tsin<MP>(yaw);
+            }
+            const float new_yaw = (float)remainder((double)(yaw + u_th + cfg.v_th), slam::kTwoPi);  // float adds
+            Xp4[(size_t)2 * ns + i] = tcos<MP>(new_yaw);
+            Xp4[(size_t)3 * ns + i] = tsin<MP>(new_yaw);
+        }
+        // ---- weighted mean (ukf.cpp:228-232) and covariance (ukf.cpp:235-240), sequential in i ----
+        x_pred.assign(nn, 0.0);
+        for (int r = 0; r < nn; ++r) {
+            double acc = 0.0;
+            for (int i = 0; i < ns; ++i) acc = acc + wt(i, nn) * xpred_elem(r, i, nn);
+            x_pred[r] = acc;
+        }
+        P_pred.assign((size_t)nn * nn, 0.0);
+        std::vector<double> D((size_t)nn * ns);
+        for (int r = 0; r < nn; ++r)
+            for (int i = 0; i < ns; ++i) D[(size_t)r * ns + i] = xpred_elem(r, i, nn) - x_pred[r];
+        for (int r = 0; r < nn; ++r)
+            for (int c = 0; c < nn; ++c) {
+                double acc = 0.0;
+                for (int i = 0; i < ns; ++i) acc = acc + (wt(i, nn) * D[(size_t)r * ns + i]) * D[(size_t)c * ns + i];
+                P_pred[(size_t)r * nn + c] = acc;
+            }
+        // + Q (ukf.cpp:182-186, 240): signed diagonal from the yaw of x_t
+        const float yaw = yaw_of<MP>(x_t.data());
+        P_pred[0] = P_pred[0] + nz.V00 * tcos<MP>(yaw);
+        P_pred[(size_t)1 * nn + 1] = P_pred[(size_t)1 * nn + 1] + nz.V00 * tsin<MP>(yaw);
+        P_pred[(size_t)2 * nn + 2] = P_pred[(size_t)2 * nn + 2] + nz.V11 * tcos<MP>(yaw);
+        P_pred[(size_t)3 * nn + 3] = P_pred[(size_t)3 * nn + 3] + nz.V11 * tsin<MP>(yaw);
+    }
+
+    // X_pred(r, i): rows 0..3 from the motion model, rows >= 4 = the sigma point itself
+    double xpred_elem(int r, int i, int nn) const {
+        const int ns = 2 * nn + 1;
+        if (r < 4) return Xp4[(size_t)r * ns + i];
+        if (i == 0) return x_t[r];
+        if (i <= nn) return x_t[r] + sqtP[(size_t)r * nn + (i - 1)];
+        return x_t[r] - sqtP[(size_t)r * nn + (i - 1 - nn)];
+    }
+
+    template <class MP> void landmark_update(int j, float r_m, float b_m) {  // ukf.cpp:293-349 (SLAM mode)
+        const int nn = n(), ns = 2 * nn + 1, li = 2 * j + 4;
+        const float yaw = yaw_of<MP>(x_t.data());  // sensingModel takes yaw from x_t (ukf.cpp:139)
+        std::vector<double> Z0(ns), Z1(ns);
+        for (int i = 0; i < ns; ++i) {
+            const double dx = xpred_elem(li, i, nn) - xpred_elem(0, i, nn), dy = xpred_elem(li + 1, i, nn) - xpred_elem(1, i, nn);
+            Z0[i] = ::sqrt(MP::sq(dx) + MP::sq(dy)) + (double)cfg.w_r;
+            Z1[i] = remainder((MP::atan2(dy, dx) - (double)yaw) + (double)cfg.w_b, slam::kTwoPi);
+        }
+        double z0 = 0.0;
+        for (int i = 0; i < ns; ++i) z0 = z0 + wt(i, nn) * Z0[i];   // z_est(1) is never accumulated (ukf.cpp:310-314)
+        double S[4] = {0, 0, 0, 0};
+        for (int i = 0; i < ns; ++i) {
+            const double d0 = Z0[i] - z0, d1 = remainder(Z1[i] - 0.0, slam::kTwoPi);
+            const double w0 = wt(i, nn) * d0, w1 = wt(i, nn) * d1;
+            S[0] = S[0] + w0 * d0; S[1] = S[1] + w0 * d1; S[2] = S[2] + w1 * d0; S[3] = S[3] + w1 * d1;
+        }
+        S[0] = S[0] + nz.W00; S[1] = S[1] + 0.0; S[2] = S[2] + 0.0; S[3] = S[3] + nz.W11;
+        std::vector<double> C((size_t)nn * 2);
+        for (int r = 0; r < nn; ++r) {
+            double c0 = 0.0, c1 = 0.0;
+            for (int i = 0; i < ns; ++i) {
+                const double wd = wt(i, nn) * (xpred_elem(r, i, nn) - x_pred[r]);
+                const double d0 = Z0[i] - z0, d1 = remainder(Z1[i] - 0.0, slam::kTwoPi);
+                c0 = c0 + wd * d0; c1 = c1 + wd * d1;
+            }
+            C[(size_t)2 * r] = c0; C[(size_t)2 * r + 1] = c1;
+        }
+        double Si[4];
+        if (!inv2x2_lu(S, Si)) flags |= SLAM_INST_S_SINGULAR;
+        std::vector<double> K((size_t)nn * 2), KS((size_t)nn * 2);
+        const double i0 = (double)r_m - z0, i1 = remainder((double)b_m - 0.0, slam::kTwoPi);
+        for (int r = 0; r < nn; ++r) {
+            K[(size_t)2 * r] = C[(size_t)2 * r] * Si[0] + C[(size_t)2 * r + 1] * Si[2];
+            K[(size_t)2 * r + 1] = C[(size_t)2 * r] * Si[1] + C[(size_t)2 * r + 1] * Si[3];
+        }
+        for (int r = 0; r < nn; ++r) {
+            x_pred[r] = x_pred[r] + (K[(size_t)2 * r] * i0 + K[(size_t)2 * r + 1] * i1);
+            KS[(size_t)2 * r] = K[(size_t)2 * r] * S[0] + K[(size_t)2 * r + 1] * S[2];
+            KS[(size_t)2 * r + 1] = K[(size_t)2 * r] * S[1] + K[(size_t)2 * r + 1] * S[3];
+        }
+        for (int r = 0; r < nn; ++r)
+            for (int c = 0; c < nn; ++c)
+                P_pred[(size_t)r * nn + c] = P_pred[(size_t)r * nn + c] - (KS[(size_t)2 * r] * K[(size_t)2 * c] + KS[(size_t)2 * r + 1] * K[(size_t)2 * c + 1]);
+    }
+
+    template <class MP> void landmark_insertion(int id, float r_m, float b_m) {  // ukf.cpp:351-372
+        const int nn = n();
+        const float yaw = yaw_of<MP>(x_pred.data());
+        const float ang = yaw + b_m;
+        x_pred.resize(nn + 2);
+        if (cfg.ukf_float_trig) {
+            x_pred[nn] = x_pred[0] + (double)(r_m * (float)tcos<MP>(ang));
+            x_pred[nn + 1] = x_pred[1] + (double)(r_m * (float)tsin<MP>(ang));
+        } else {
+            x_pred[nn] = x_pred[0] + (double)r_m * tcos<MP>(ang);
+            x_pred[nn + 1] = x_pred[1] + (double)r_m * tsin<MP>(ang);
+        }
+        ids.push_back(id);
+        std::vector<double> Pn((size_t)(nn + 2) * (nn + 2), 0.0);
+        for (int r = 0; r < nn; ++r)
+            for (int c = 0; c < nn; ++c) Pn[(size_t)r * (nn + 2) + c] = P_pred[(size_t)r * nn + c];
+        Pn[(size_t)nn * (nn + 2) + nn] = nz.W00;
+        Pn[(size_t)(nn + 1) * (nn + 2) + nn + 1] = nz.W11;
+        P_pred.swap(Pn);
+        M += 1;
+    }
+
+    template <class MP> int update_t(float fwd, float ang, const float* meas, int k) {
+        timestep += 1;                                    // ukf.cpp:164
+        prediction_stage<MP>(fwd, ang);                   // ukf.cpp:189
+        std::vector<int> fresh;                           // ukf.cpp:251-287: updates first, insertions last
+        for (int l = 0; l < k; ++l) {
+            const int id = (int)meas[3 * l];
+            int j = -1;
+            for (int q = 0; q < M; ++q)
+                if (ids[q] == id) { j = q; break; }
+            if (j < 0) fresh.push_back(l);
+            else landmark_update<MP>(j, meas[3 * l + 1], meas[3 * l + 2]);
+        }
+        for (int l : fresh) {
+            if (M >= L_max) { flags |= SLAM_INST_CAPACITY; continue; }
+            landmark_insertion<MP>((int)meas[3 * l], meas[3 * l + 1], meas[3 * l + 2]);
+        }
+        x_t = x_pred; P_t = P_pred;                       // ukf.cpp:289-290
+        bool fin = true;
+        for (double v : x_t) fin = fin && std::isfinite(v);
+        for (double v : P_t) fin = fin && std::isfinite(v);
+        if (!fin) flags |= SLAM_INST_NONFINITE;
+        return flags;
+    }
+    int update(float fwd, float ang, const float* meas, int k) {
+        return math == MATH_DET ? update_t<DetMath>(fwd, ang, meas, k) : update_t<LibmMath>(fwd, ang, meas, k);
+    }
+    double yaw_est() const { return remainder(math == MATH_DET ? DetMath::atan2(x_t[3], x_t[2]) : LibmMath::atan2(x_t[3], x_t[2]), slam::kTwoPi); }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* orc_ukf_create(const slam_config* cfg, int L_max, int math) { return new Ukf(*cfg, L_max, math); }
+void orc_ukf_destroy(void* h) { delete (Ukf*)h; }
+void orc_ukf_init(void* h, float x0, float y0, float yaw0) { ((Ukf*)h)->init(x0, y0, yaw0); }
+int orc_ukf_update(void* h, float fwd, float ang, const float* meas, int k) { return ((Ukf*)h)->update(fwd, ang, meas, k); }
+void orc_ukf_get(void* h, double* x, double* P, int* M, int* ids, int* timestep, int* sweeps) {
+    Ukf* u = (Ukf*)h;
+    const int n = u->n();
+    if (x) memcpy(x, u->x_t.data(), sizeof(double) * n);
+    if (P) memcpy(P, u->P_t.data(), sizeof(double) * n * n);
+    if (M) *M = u->M;
+    if (ids) memcpy(ids, u->ids.data(), sizeof(int) * u->M);
+    if (timestep) *timestep = u->timestep;
+    if (sweeps) *sweeps = u->last_sweeps;
+}
+// matrix square root probe: sqtP of nearestSPD(scale * P) for a given symmetric-ish P (n x n row-major)
+int orc_ukf_sqrt_probe(const double* P, int n, double scale, double* out) {
+    std::vector<double> Y((size_t)n * n), V((size_t)n * n);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) Y[(size_t)r * n + c] = (0.5 * (P[(size_t)r * n + c] + P[(size_t)c * n + r])) * scale;
+    const int sweeps = jacobi_round_robin(Y.data(), V.data(), n, 60);
+    if (sweeps < 0) return -1;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c <= r; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) {
+                const double d = Y[(size_t)k * n + k];
+                acc = acc + (V[(size_t)r * n + k] * sqrt(d > 0.00000001 ? d : 0.00000001)) * V[(size_t)c * n + k];
+            }
+            out[(size_t)r * n + c] = acc; out[(size_t)c * n + r] = acc;
+        }
+    return sweeps;
+}
+
+// batch runner: lockstep simulator + UKF, like orc_run_ekf_batch (outputs use n_max = 4 + 2*L_max)
+double orc_run_ukf_batch(const slam_config* cfg, int L_max, int math, const double* map_xy, int L, const float* cmds, int T,
+                         uint64_t seed, int64_t inst0, int B, int nthreads, double* x_out, double* P_out, int* M_out,
+                         int* ids_out, double* avg_err, int* flags, double* truth_out, const double* vision) {
+    const int n_max = 4 + 2 * L_max;
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+        std::vector<float> meas((size_t)3 * std::max(L, 1));
+        for (;;) {
+            const int b = next.fetch_add(1);
+            if (b >= B) break;
+            Ukf ukf(*cfg, L_max, math);
+            ukf.init((float)cfg->init_x, (float)cfg->init_y, (float)cfg->init_yaw);
+            Sim sim;
+            sim.cfg = *cfg; sim.L = L; sim.math = math; sim.map.assign(map_xy, map_xy + 2 * L);
+            sim.xv[0] = cfg->init_x; sim.xv[1] = cfg->init_y; sim.xv[2] = cfg->init_yaw;
+            double errsum = 0.0;
+            for (int t = 0; t < T; ++t) {
+                int k = 0;
+                if (vision) { sim.cfg.range_max = vision[3 * t]; sim.cfg.fov_min = vision[3 * t + 1]; sim.cfg.fov_max = vision[3 * t + 2]; }
+                auto draw = [&](int pair, int which) {
+                    double u0, u1;
+                    slam::noise_pair(seed, (uint64_t)(inst0 + b), (uint32_t)t, (uint32_t)pair, &u0, &u1);
+                    return which ? u1 : u0;
+                };
+                if (math == MATH_DET) sim.step_t<DetMath>(cmds[2 * t], cmds[2 * t + 1], draw, meas.data(), nullptr, &k);
+                else sim.step_t<LibmMath>(cmds[2 * t], cmds[2 * t + 1], draw, meas.data(), nullptr, &k);
+                ukf.update(cmds[2 * t], cmds[2 * t + 1], meas.data(), k);
+                errsum = errsum + (math == MATH_DET ? step_pos_error<DetMath>(wire_f32(ukf.x_t[0]), wire_f32(ukf.x_t[1]), sim.xv[0], sim.xv[1])
+                                                    : step_pos_error<LibmMath>(wire_f32(ukf.x_t[0]), wire_f32(ukf.x_t[1]), sim.xv[0], sim.xv[1]));
+            }
+            const int n = ukf.n();
+            if (x_out) memcpy(x_out + (size_t)b * n_max, ukf.x_t.data(), sizeof(double) * n);
+            if (P_out) memcpy(P_out + (size_t)b * n_max * n_max, ukf.P_t.data(), sizeof(double) * n * n);
+            if (M_out) M_out[b] = ukf.M;
+            if (ids_out) memcpy(ids_out + (size_t)b * L_max, ukf.ids.data(), sizeof(int) * ukf.M);
+            if (avg_err) avg_err[b] = T > 0 ? errsum / T : 0.0;
+            if (flags) flags[b] = ukf.flags;
+            if (truth_out) { truth_out[3 * b] = sim.xv[0]; truth_out[3 * b + 1] = sim.xv[1]; truth_out[3 * b + 2] = sim.xv[2]; }
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int i = 1; i < nthreads; ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // extern "C"
