@@ -54,7 +54,7 @@ static constexpr int kEkfMaxLandmarks = 50;
 hipError_t launch_ekf_step(const EkfStepParams& p, int waves_per_filter, hipStream_t stream);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)
-hipError_t launch_algorithmic_bytes(const int32_t* M, int B, double* out, hipStream_t stream);
+hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, double* out, hipStream_t stream);
 
 // fill x/P/M/... for Filter::init (ekf.cpp:4-21,29-34)
 struct EkfInitParams {

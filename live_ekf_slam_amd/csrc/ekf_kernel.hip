@@ -56,17 +56,17 @@ hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, hipStream_t stream) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void alg_bytes_kernel(const int32_t* M, int B, double* out) {
+__global__ void alg_bytes_kernel(const int32_t* M, int B, int base, double* out) {
     double acc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
-        const double n = 3.0 + 2.0 * M[i];
+        const double n = (double)base + 2.0 * M[i];
         acc += 2.0 * (n * n + n) * 8.0;
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-hipError_t launch_algorithmic_bytes(const int32_t* M, int B, double* out, hipStream_t stream) {
-    hipLaunchKernelGGL(alg_bytes_kernel, dim3(64), dim3(256), 0, stream, M, B, out);
+hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, double* out, hipStream_t stream) {
+    hipLaunchKernelGGL(alg_bytes_kernel, dim3(64), dim3(256), 0, stream, M, B, base, out);
     return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@
 #include "../../include/slam_batch.h"
 #include "slam_math.h"
 #include "slam_rng.h"
+#include "sim_device.h"
 
 namespace slam {
 
@@ -169,55 +170,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __syncthreads();
     SLAM_STAMP(0);   // initial loads
     if (p.sim) {
-        if (tid < 64) {  // one wavefront advances the truth and scans the map in ascending id (sim_node.py:209-243)
-            const uint64_t inst = (uint64_t)(p.inst0 + b);
-            double u0, u1;
-            noise_pair(p.seed, inst, p.step, 0u, &u0, &u1);
-            double d = ((double)p.fwd + (2 * p.sV00) * u0) - p.sV00;        // sim_node.py:216
-            double hdg = ((double)p.ang + (2 * p.sV11) * u1) - p.sV11;      // :217
-            d = (p.d_max < d) ? p.d_max : d;                                 // min(d, d_max)        :219
-            d = (0.0 < d) ? d : 0.0;                                         // max(0, .)
-            hdg = (p.th_max < hdg) ? p.th_max : hdg;                         // :220
-            hdg = (-p.th_max < hdg) ? hdg : -p.th_max;
-            double s, c;
-            det_sincos(tth, &s, &c);
-            tx = tx + d * c;                                                 // :222 (yaw not wrapped)
-            ty = ty + d * s;
-            tth = tth + hdg;
-            int count = 0;
-#pragma unroll 1
-            for (int base = 0; base < p.L; base += 64) {
-                const int id = base + lane;
-                bool vis = false;
-                double r = 0.0, beta = 0.0;
-                if (id < p.L) {
-                    if (base > 0) { lmx = p.map[2 * id]; lmy = p.map[2 * id + 1]; }   // ids 0..63 were prefetched
-                    const double dx = lmx - tx, dy = lmy - ty;
-                    r = sqrt(dx * dx + dy * dy);
-                    const double gb = det_atan2(dy, dx);
-                    beta = remainder(gb - tth, kTwoPi);
-                    vis = !(r > p.range_max) && (beta > p.fov_min && beta < p.fov_max);
-                }
-                const unsigned long long mask = __ballot(vis);
-                const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-                if (vis && pos < KCAP) {  // noise in visible-id order (sim_node.py:245-249), float32 wire format
-                    double v0, v1;
-                    noise_pair(p.seed, inst, p.step, (uint32_t)(1 + pos), &v0, &v1);
-                    const double rn = (r + (2 * p.sW00) * v0) - p.sW00;
-                    const double bn = (beta + (2 * p.sW11) * v1) - p.sW11;
-                    s_meas[3 * pos] = (float)id;
-                    s_meas[3 * pos + 1] = (float)rn;
-                    s_meas[3 * pos + 2] = (float)bn;
-                }
-                count += __popcll(mask);
-            }
-            if (lane == 0) {
-                s_misc[0] = count < KCAP ? count : KCAP;
-                p.truth[3 * (size_t)b] = tx;
-                p.truth[3 * (size_t)b + 1] = ty;
-                p.truth[3 * (size_t)b + 2] = tth;
-            }
-        }
+        if (tid < 64)   // one wavefront advances the truth and scans the map in ascending id (sim_node.py:209-243)
+            sim_wave<KCAP>(p, b, lane, tx, ty, tth, lmx, lmy, s_meas, &s_misc[0]);
     } else {
         int kk = p.meas_count_in[b];
         kk = kk < p.k_stride_in ? kk : p.k_stride_in;

@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "ekf_kernel.h"
+#include "slam_math.h"
+#include "ukf_kernel.h"
 
 namespace {
 
@@ -59,6 +61,8 @@ struct slam_handle {
     float* dmeas = nullptr; int32_t* dcount = nullptr; int k_stride = 0;   // staging / last-measurement dump
     double* dscalar = nullptr;
     unsigned long long* dprof = nullptr;
+    double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
+    int base = 3;                                     // state offset of the first landmark: 3 (EKF) or 4 (UKF)
     bool dump_meas = false;
 };
 
@@ -85,6 +89,47 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
     p.dbg = h->dbg;
     p.prof = (h->dbg & 4) ? h->dprof : nullptr;
+}
+
+void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2]) {
+    memset(&p, 0, sizeof(p));
+    p.P = h->dP; p.P_out = h->dP2; p.x = h->dx; p.sqtP = h->dsq; p.n_sq = h->dnsq;
+    p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
+    p.truth = h->dtruth; p.err_sum = h->derr; p.map = h->dmap; p.L = h->L;
+    p.fwd = cmd[0]; p.ang = cmd[1];
+    const slam_config& c = h->cfg;
+    p.v_d = c.v_d; p.v_th = c.v_th; p.w_r = c.w_r; p.w_b = c.w_b;
+    if (c.replicate_vw_quirk) { p.V00 = c.W_00; p.V11 = c.W_11; p.W00 = 1.0; p.W11 = 1.0; }
+    else { p.V00 = c.V_00; p.V11 = c.V_11; p.W00 = c.W_00; p.W11 = c.W_11; }
+    p.float_trig = c.ukf_float_trig;
+    p.sV00 = c.V_00; p.sV11 = c.V_11; p.sW00 = c.W_00; p.sW11 = c.W_11;
+    p.d_max = c.d_max; p.th_max = c.th_max;
+    p.range_max = h->range_max; p.fov_min = h->fov_min; p.fov_max = h->fov_max;
+    p.seed = h->seed; p.inst0 = h->inst0; p.step = h->step;
+    p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
+}
+
+// one timestep, either filter kind; `sim` = device-side measurement generator
+int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas, const int32_t* d_count, int k_stride) {
+    if (h->kind == SLAM_EKF_SLAM) {
+        slam::EkfStepParams p;
+        fill_params(h, p, cmd);
+        p.sim = sim;
+        p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
+        if (sim && h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
+        HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+    } else {
+        slam::UkfStepParams p;
+        fill_ukf_params(h, p, cmd);
+        p.sim = sim;
+        p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
+        if (sim && h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
+        HIP_TRY(slam::launch_ukf_sqrt(p, h->stream));   // nearestSPD + sqrt (ukf.cpp:106-123,208)
+        HIP_TRY(slam::launch_ukf_step(p, h->stream));   // predictionStage + updateStage (ukf.cpp:197-372)
+    }
+    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
+    h->step += 1;
+    return SLAM_OK;
 }
 
 int ensure_meas_buffers(slam_handle* h, int k_stride) {
@@ -175,14 +220,16 @@ int slam_config_load(slam_config* c, const char* path) {
 int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtype, int device, slam_handle** out) {
     if (!cfg || !out) return fail(SLAM_ERR_ARG, "NULL argument");
     if (batch <= 0 || L_max <= 0) return fail(SLAM_ERR_ARG, "batch and L_max must be positive");
-    if (kind != SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "filter kind %d not available in this build (EKF_SLAM only)", kind);
+    if (kind != SLAM_EKF_SLAM && kind != SLAM_UKF_SLAM)
+        return fail(SLAM_ERR_UNSUPPORTED, "filter kind %d not available in this build (EKF_SLAM, UKF_SLAM)", kind);
     if (dtype != SLAM_F64) return fail(SLAM_ERR_UNSUPPORTED, "only fp64 state storage is implemented");
-    if (L_max > slam::kEkfMaxLandmarks)
+    if (L_max > (kind == SLAM_UKF_SLAM ? slam::kUkfMaxLandmarks : slam::kEkfMaxLandmarks))
         return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the register-resident kernel limit %d", L_max, slam::kEkfMaxLandmarks);
     HIP_TRY(hipSetDevice(device));
     slam_handle* h = new slam_handle();
     h->cfg = *cfg; h->kind = kind; h->B = batch; h->L_max = L_max; h->dtype = dtype; h->device = device;
-    h->n_max = 3 + 2 * L_max;
+    h->base = (kind == SLAM_UKF_SLAM) ? 4 : 3;
+    h->n_max = h->base + 2 * L_max;
     h->pstride = round_up(h->n_max * h->n_max + 1, 32);   // 256-byte aligned per-filter slab
     h->xstride = round_up(h->n_max + 1, 2);
     h->range_max = cfg->range_max; h->fov_min = cfg->fov_min; h->fov_max = cfg->fov_max;
@@ -206,6 +253,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMalloc(&h->derr, sizeof(double) * B),
         hipMalloc(&h->dscalar, sizeof(double) * 4),
         hipMalloc(&h->dprof, sizeof(unsigned long long) * 16 * B),
+        kind == SLAM_UKF_SLAM ? hipMalloc(&h->dsq, sizeof(double) * B * h->pstride) : hipSuccess,
+        kind == SLAM_UKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -225,7 +274,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -252,13 +301,26 @@ int slam_set_vision(slam_handle* h, double range_max, double fov_min, double fov
 int slam_init(slam_handle* h, float x0, float y0, float yaw0) {
     if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
-    slam::EkfInitParams p;
-    p.P = h->dP; p.x = h->dx; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
-    p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride;
-    p.x0 = x0; p.y0 = y0; p.yaw0 = yaw0;
-    // the simulator starts from the un-rounded YAML pose (sim_node.py:361); the filter gets float args
-    p.tx = h->cfg.init_x; p.ty = h->cfg.init_y; p.tyaw = h->cfg.init_yaw;
-    HIP_TRY(slam::launch_ekf_init(p, h->stream));
+    if (h->kind == SLAM_EKF_SLAM) {
+        slam::EkfInitParams p;
+        p.P = h->dP; p.x = h->dx; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
+        p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride;
+        p.x0 = x0; p.y0 = y0; p.yaw0 = yaw0;
+        // the simulator starts from the un-rounded YAML pose (sim_node.py:361); the filter gets float args
+        p.tx = h->cfg.init_x; p.ty = h->cfg.init_y; p.tyaw = h->cfg.init_yaw;
+        HIP_TRY(slam::launch_ekf_init(p, h->stream));
+    } else {
+        slam::UkfInitParams p;
+        p.P = h->dP; p.x = h->dx; p.n_sq = h->dnsq; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
+        p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride;
+        double s, c;   // x_t << x_0, y_0, cos(yaw_0), sin(yaw_0) with a float argument (ukf.cpp:33)
+        slam::det_sincos((double)yaw0, &s, &c);
+        p.x0 = x0; p.y0 = y0;
+        p.c0 = h->cfg.ukf_float_trig ? (double)(float)c : c;
+        p.s0 = h->cfg.ukf_float_trig ? (double)(float)s : s;
+        p.tx = h->cfg.init_x; p.ty = h->cfg.init_y; p.tyaw = h->cfg.init_yaw;
+        HIP_TRY(slam::launch_ukf_init(p, h->stream));
+    }
     h->step = 0;
     h->inited = true;
     return SLAM_OK;
@@ -279,14 +341,7 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
     if (!h || !cmd || !d_meas || !d_count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
-    slam::EkfStepParams p;
-    fill_params(h, p, cmd);
-    p.sim = 0;
-    p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
-    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
-    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
-    h->step += 1;
-    return SLAM_OK;
+    return launch_step(h, cmd, 0, d_meas, d_count, k_stride);
 }
 
 int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* count, int k_stride) {
@@ -301,14 +356,7 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
     HIP_TRY(hipMemcpyAsync(h->dcount, count, sizeof(int32_t) * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
     // host buffers may be reused by the caller right after return (ekf.cpp:64 copies the message)
     HIP_TRY(hipStreamSynchronize(h->stream));
-    slam::EkfStepParams p;
-    fill_params(h, p, cmd);
-    p.sim = 0;
-    p.meas_in = h->dmeas; p.meas_count_in = h->dcount; p.k_stride_in = h->k_stride;
-    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
-    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
-    h->step += 1;
-    return SLAM_OK;
+    return launch_step(h, cmd, 0, h->dmeas, h->dcount, h->k_stride);
 }
 
 int slam_step_sim(slam_handle* h, const float cmd[2]) {
@@ -316,14 +364,7 @@ int slam_step_sim(slam_handle* h, const float cmd[2]) {
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
     HIP_TRY(hipSetDevice(h->device));
-    slam::EkfStepParams p;
-    fill_params(h, p, cmd);
-    p.sim = 1;
-    if (h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
-    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
-    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
-    h->step += 1;
-    return SLAM_OK;
+    return launch_step(h, cmd, 1, nullptr, nullptr, 0);
 }
 
 int slam_run_sim(slam_handle* h, const float* cmds, int T) {
@@ -335,8 +376,8 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     return SLAM_OK;
 }
 
-int slam_predict(slam_handle*, const float*) { return fail(SLAM_ERR_UNSUPPORTED, "predictionStage/updateStage split exists only for the UKF (filter.h:187-188)"); }
-int slam_update_dev(slam_handle*, const float*, const int32_t*, int) { return fail(SLAM_ERR_UNSUPPORTED, "predictionStage/updateStage split exists only for the UKF (filter.h:187-188)"); }
+int slam_predict(slam_handle*, const float*) { return fail(SLAM_ERR_UNSUPPORTED, "separate predictionStage/updateStage entry points (filter.h:187-188) are not in this build; slam_step runs both"); }
+int slam_update_dev(slam_handle*, const float*, const int32_t*, int) { return fail(SLAM_ERR_UNSUPPORTED, "separate predictionStage/updateStage entry points (filter.h:187-188) are not in this build; slam_step runs both"); }
 
 int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, int32_t* ids, int32_t* ts) {
     if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
@@ -344,7 +385,7 @@ int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, i
     HIP_TRY(hipStreamSynchronize(h->stream));
     int32_t m = 0;
     HIP_TRY(hipMemcpy(&m, h->dM + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
-    const int n = 3 + 2 * m;
+    const int n = h->base + 2 * m;
     if (M) *M = m;
     if (x) HIP_TRY(hipMemcpy(x, h->dx + (size_t)inst * h->xstride, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (P) HIP_TRY(hipMemcpy(P, h->dP + (size_t)inst * h->pstride, sizeof(double) * n * n, hipMemcpyDeviceToHost));
@@ -416,7 +457,7 @@ int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
     if (!h || !bytes) return fail(SLAM_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->dscalar, 0, sizeof(double), h->stream));
-    HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->dscalar, h->stream));
+    HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->base, h->dscalar, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(bytes, h->dscalar, sizeof(double), hipMemcpyDeviceToHost));
     return SLAM_OK;

@@ -1,0 +1,58 @@
+// ukf_kernel.h — parameter block and launchers of the UKF-SLAM step kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slam {
+
+// One timestep of UKF::update (ukf.cpp:161-372) for every instance = two launches:
+//   ukf_sqrt_kernel : nearestSPD + matrix square root of P_t (ukf.cpp:106-123,208)      -> sqtP
+//   ukf_step_kernel : sigma points, motion model, weighted mean / covariance, landmark updates and insertions
+//                     (ukf.cpp:214-372), optionally preceded by the measurement generator (sim_node.py:209-250)
+struct UkfStepParams {
+    // ---- filter state in HBM ----
+    const double* P;    // [B][pstride]  P_t packed row-major n x n, n = 4+2*M[b]
+    double* P_out;      // [B][pstride]  next P_t (ping-pong with P)
+    double* x;          // [B][xstride]  x_t = [x, y, cos, sin, landmarks...]
+    double* sqtP;       // [B][pstride]  scratch: matrix square root, n x n row-major (symmetric)
+    int32_t* n_sq;      // [B]           dimension of the matrix currently held in sqtP
+    int32_t* M;         // [B]
+    int32_t* ids;       // [B][L_max]
+    int32_t* flags;     // [B]
+    int32_t* timestep;  // [B]
+    // ---- simulator state ----
+    double* truth;      // [B][3]
+    double* err_sum;    // [B]
+    const double* map;  // [L][2]
+    int32_t L;
+    // ---- measurements ----
+    const float* meas_in; const int32_t* meas_count_in; int32_t k_stride_in;
+    float* meas_out; int32_t* meas_count_out; int32_t k_stride_out;
+    float fwd, ang;
+    // ---- filter config (filter.h:105-121) ----
+    float v_d, v_th, w_r, w_b;
+    double V00, V11, W00, W11;
+    int32_t float_trig;  // unqualified cos/sin(float): float overload (1) or double function (0)
+    // ---- simulator config ----
+    double sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max;
+    uint64_t seed;
+    int64_t inst0;
+    uint32_t step;
+    int32_t B, L_max, pstride, xstride;
+    int32_t sim;
+};
+
+static constexpr int kUkfMaxLandmarks = 50;   // n = 4 + 2L <= 104
+
+hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream);
+hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream);
+
+struct UkfInitParams {
+    double* P; double* x; int32_t* n_sq; int32_t* M; int32_t* flags; int32_t* timestep; double* truth; double* err_sum;
+    int32_t B, pstride, xstride;
+    double x0, y0, c0, s0;   // x_t = (x_0, y_0, cos(yaw_0), sin(yaw_0)) as the reference stores them (ukf.cpp:33)
+    double tx, ty, tyaw;
+};
+hipError_t launch_ukf_init(const UkfInitParams& p, hipStream_t stream);
+
+}  // namespace slam

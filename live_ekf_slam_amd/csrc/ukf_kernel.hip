@@ -1,0 +1,570 @@
+// ukf_kernel.hip — UKF-SLAM step for gfx950 (MI355X): UKF::update of the reference
+// (ekf_ws/src/localization_pkg/src/ukf.cpp:161-372) as two kernels per timestep, one workgroup per instance.
+//
+//  ukf_sqrt_kernel  nearestSPD + principal matrix square root (ukf.cpp:106-123,208).  The reference calls Eigen's
+//                   SelfAdjointEigenSolver and MatrixFunctions sqrt; here: cyclic Jacobi in PARALLEL (round-robin)
+//                   ORDER entirely in LDS — A packed lower-triangular (exact symmetry by construction), V^T full —
+//                   n/2 disjoint rotations per round, every pair-block B' = R_i^T B R_j and every V row-pair an
+//                   independent work item.  This O(n^3 * sweeps) fp64 phase dominates the UKF; it is LDS / fp64-VALU
+//                   bound, not HBM bound.
+//  ukf_step_kernel  sigma points through the motion model, weighted mean and covariance (sequential in the sigma
+//                   index exactly like the reference's accumulation loops), all landmark updates (the reference never
+//                   redraws sigma points, so K and S of every update are independent of P), insertions, and ONE
+//                   pass that forms P_pred, adds Q, subtracts the K S K^T terms and writes P_t in its final packed
+//                   leading dimension.  sqtP lives in LDS; P is never staged.
+//
+// Arithmetic: plain IEEE fp64 (-ffp-contract=off), same operation order as the CPU oracle
+// (oracle/slam_oracle_ukf.cpp) so results are bit-identical; the reference's float truncations are real fp32 ops.
+#include "ukf_kernel.h"
+
+#include "../../include/slam_batch.h"
+#include "sim_device.h"
+#include "slam_math.h"
+#include "slam_rng.h"
+
+namespace slam {
+
+namespace {
+
+constexpr float kW0 = 0.2f;  // filter.h:207
+
+__device__ __forceinline__ bool inv2x2_lu_ukf(const double S[4], double Si[4]) {  // MatrixXd::inverse() (ukf.cpp:339)
+    const bool sw = fabs(S[2]) > fabs(S[0]);
+    const double a00 = sw ? S[2] : S[0], a01 = sw ? S[3] : S[1];
+    const double a10 = sw ? S[0] : S[2], a11 = sw ? S[1] : S[3];
+    const double l = a10 / a00;
+    const double u11 = a11 - l * a01;
+    const bool ok = (a00 != 0.0) && (u11 != 0.0);
+    {
+        const double r0 = sw ? 0.0 : 1.0, r1 = sw ? 1.0 : 0.0;
+        const double y1 = r1 - l * r0;
+        const double x1 = y1 / u11;
+        Si[0] = (r0 - a01 * x1) / a00;
+        Si[2] = x1;
+    }
+    {
+        const double r0 = sw ? 1.0 : 0.0, r1 = sw ? 0.0 : 1.0;
+        const double y1 = r1 - l * r0;
+        const double x1 = y1 / u11;
+        Si[1] = (r0 - a01 * x1) / a00;
+        Si[3] = x1;
+    }
+    return ok;
+}
+
+// unqualified cos / sin on a float argument (ukf.cpp:39-42,129-133,183-186,358-359)
+__device__ __forceinline__ void tsincos(float a, int float_trig, double* s, double* c) {
+    double ss, cc;
+    det_sincos((double)a, &ss, &cc);
+    *s = float_trig ? (double)(float)ss : ss;
+    *c = float_trig ? (double)(float)cc : cc;
+}
+
+__device__ __forceinline__ float yaw_of(double c, double s) {  // (float) remainder(atan2(x3, x2), 2 pi)
+    return (float)remainder(det_atan2(s, c), kTwoPi);
+}
+
+__device__ __forceinline__ double block_max(double v, double* s_red, int tid, int tpb) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w = __shfl_down(v, o);
+        v = v > w ? v : w;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    double r = s_red[0];
+    for (int i = 1; i < tpb / 64; ++i) r = r > s_red[i] ? r : s_red[i];
+    return r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// nearestSPD + sqrt
+// ------------------------------------------------------------------------------------------------------------------
+template <int NMAX, int TPB>
+__global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
+    constexpr int MMAX = NMAX / 2;
+    __shared__ double sA[NMAX * (NMAX + 1) / 2];   // packed lower triangle: A(r,c), r >= c, at r(r+1)/2 + c
+    __shared__ double sVt[NMAX * NMAX];            // V transposed: Vt[p*n + k] = V(k, p)
+    __shared__ double s_cs[MMAX], s_sn[MMAX], s_tn[MMAX], s_sd[NMAX];
+    __shared__ int s_pp[MMAX], s_qq[MMAX];
+    __shared__ double s_red[TPB / 64];
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (p.flags[b] & SLAM_INST_INDEX_OOR) return;
+    const int M = p.M[b];
+    const int n = 4 + 2 * M, m = n / 2;
+    const double* __restrict__ Pb = p.P + (size_t)b * p.pstride;
+    double* __restrict__ Sq = p.sqtP + (size_t)b * p.pstride;
+    auto AT = [&](int r, int c) -> double& { return r >= c ? sA[r * (r + 1) / 2 + c] : sA[c * (c + 1) / 2 + r]; };
+
+    const float scale_f = (float)(2 * M + 4) / (1 - kW0);   // ukf.cpp:114, evaluated in float
+    const double scale = (double)scale_f;
+    for (int e = tid; e < n * n; e += TPB) {
+        const int r = e / n, c = e - r * n;
+        if (c <= r) sA[r * (r + 1) / 2 + c] = (0.5 * (Pb[(size_t)r * n + c] + Pb[(size_t)c * n + r])) * scale;
+        sVt[e] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    const int nb = m * (m - 1) / 2;
+    bool converged = false;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dmx = 0.0;
+        for (int e = tid; e < n * (n + 1) / 2; e += TPB) {
+            // packed index -> (r, c)
+            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while (r * (r + 1) / 2 > e) --r;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            const int c = e - r * (r + 1) / 2;
+            const double v = fabs(sA[e]);
+            if (r == c) dmx = dmx > v ? dmx : v; else off = off > v ? off : v;
+        }
+        off = block_max(off, s_red, tid, TPB);
+        dmx = block_max(dmx, s_red, tid, TPB);
+        if (!(off > 1e-15 * dmx)) { converged = true; break; }
+#pragma unroll 1
+        for (int t = 0; t < n - 1; ++t) {
+            if (tid < m) {  // rotation parameters of this round's pairs (round-robin: position 0 fixed)
+                const int k = tid;
+                const int a = (k == 0) ? 0 : 1 + ((k - 1 + t) % (n - 1));
+                const int k2 = n - 1 - k;
+                const int bq = 1 + ((k2 - 1 + t) % (n - 1));
+                const int pidx = a < bq ? a : bq, qidx = a < bq ? bq : a;
+                const double app = AT(pidx, pidx), aqq = AT(qidx, qidx), apq = AT(qidx, pidx);
+                double c = 1.0, s = 0.0, tt = 0.0;
+                if (apq != 0.0) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + tt * tt);
+                    s = tt * c;
+                }
+                s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
+            }
+            __syncthreads();
+            const int items = nb + m + m * n;
+#pragma unroll 1
+            for (int it = tid; it < items; it += TPB) {
+                if (it < nb) {  // pair-block (i, j), i > j:  B' = R_i^T B R_j
+                    int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)it)) * 0.5f);
+                    while (i * (i - 1) / 2 > it) --i;
+                    while ((i + 1) * i / 2 <= it) ++i;
+                    const int j = it - i * (i - 1) / 2;
+                    const int pi = s_pp[i], qi = s_qq[i], pj = s_pp[j], qj = s_qq[j];
+                    const double ci = s_cs[i], si = s_sn[i], cj = s_cs[j], sj = s_sn[j];
+                    double& e00 = AT(pi, pj); double& e01 = AT(pi, qj); double& e10 = AT(qi, pj); double& e11 = AT(qi, qj);
+                    const double b00 = e00, b01 = e01, b10 = e10, b11 = e11;
+                    const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
+                    const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
+                    e00 = t00 * cj - t01 * sj; e01 = t00 * sj + t01 * cj;
+                    e10 = t10 * cj - t11 * sj; e11 = t10 * sj + t11 * cj;
+                } else if (it < nb + m) {  // diagonal block
+                    const int i = it - nb;
+                    const int pq = s_pp[i], qq = s_qq[i];
+                    const double app = AT(pq, pq), aqq = AT(qq, qq), apq = AT(qq, pq);
+                    AT(pq, pq) = app - s_tn[i] * apq;
+                    AT(qq, qq) = aqq + s_tn[i] * apq;
+                    if (apq != 0.0) AT(qq, pq) = 0.0;
+                } else {  // V <- V J for one row k of one pair
+                    const int e = it - nb - m;
+                    const int i = e / n, k = e - i * n;
+                    const int pq = s_pp[i], qq = s_qq[i];
+                    const double c = s_cs[i], s = s_sn[i];
+                    const double vp = sVt[pq * n + k], vq = sVt[qq * n + k];
+                    sVt[pq * n + k] = c * vp - s * vq;
+                    sVt[qq * n + k] = s * vp + c * vq;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!converged) {
+        // ukf.cpp:209-211 swallows the exception and reuses the stale sqtP.  A stale matrix of another size cannot be
+        // used: zero it.  Flag the instance either way.
+        if (p.n_sq[b] != n)
+            for (int e = tid; e < n * n; e += TPB) Sq[e] = 0.0;
+        if (tid == 0) { p.flags[b] = p.flags[b] | SLAM_INST_SQRT_FAILED; p.n_sq[b] = n; }
+        return;
+    }
+    for (int k = tid; k < n; k += TPB) {
+        const double d = sA[k * (k + 1) / 2 + k];
+        s_sd[k] = sqrt(d > 0.00000001 ? d : 0.00000001);   // cwiseMax(1e-8), then the principal square root
+    }
+    __syncthreads();
+    for (int e = tid; e < n * (n + 1) / 2; e += TPB) {
+        int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > e) --r;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        const int c = e - r * (r + 1) / 2;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < n; ++k) acc = acc + (sVt[k * n + r] * s_sd[k]) * sVt[k * n + c];
+        Sq[(size_t)r * n + c] = acc;
+        Sq[(size_t)c * n + r] = acc;
+    }
+    if (tid == 0) p.n_sq[b] = n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// prediction + update
+// ------------------------------------------------------------------------------------------------------------------
+template <int NMAX, int TPB, int KU>
+__global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
+    constexpr int LDN = NMAX + 2;
+    constexpr int NS = 2 * NMAX + 1;
+    constexpr int LMAX = (NMAX - 4) / 2;
+    constexpr int KCAP = LMAX > 0 ? LMAX : 1;
+
+    __shared__ double sS[NMAX * NMAX];        // sqtP (symmetric), row-major with the CURRENT n as leading dimension
+    __shared__ double sX4[4 * NS];            // rows 0..3 of X_pred
+    __shared__ double sZ0[NS], sD1[NS];       // range estimates; wrapped bearing differences
+    __shared__ double s_xt[LDN], s_xp0[LDN], s_xp[LDN];
+    __shared__ double sK[KU * NMAX * 4];      // per update: K[r][0..1], (K S)[r][0..1]
+    __shared__ double s_sc[16];
+    __shared__ float s_meas[3 * KCAP];
+    __shared__ int s_ids[LMAX > 0 ? LMAX : 1];
+    __shared__ int s_upd[KCAP], s_ins[KCAP];  // detections to update (landmark slot) / to insert (detection index)
+    __shared__ int s_misc[8];                 // k, n_upd, n_ins, capacity, singular
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    int flags = p.flags[b];
+    const int M_old = p.M[b];
+    const int n = 4 + 2 * M_old, ns = 2 * n + 1;
+    double* __restrict__ Pout = p.P_out + (size_t)b * p.pstride;
+    double* __restrict__ xb = p.x + (size_t)b * p.xstride;
+    const double* __restrict__ Sq = p.sqtP + (size_t)b * p.pstride;
+
+    // prologue loads
+    for (int i = tid; i < LDN; i += TPB) { const double v = i < n ? xb[i] : 0.0; s_xt[i] = v; }
+    for (int i = tid; i < M_old; i += TPB) s_ids[i] = p.ids[(size_t)b * p.L_max + i];
+    if (tid < 8) s_misc[tid] = 0;
+    double tx = 0.0, ty = 0.0, tth = 0.0, lmx = 0.0, lmy = 0.0;
+    if (p.sim && tid < 64) {
+        tx = p.truth[3 * (size_t)b]; ty = p.truth[3 * (size_t)b + 1]; tth = p.truth[3 * (size_t)b + 2];
+        if (tid < p.L) { lmx = p.map[2 * tid]; lmy = p.map[2 * tid + 1]; }
+    }
+    for (int e = tid; e < n * n; e += TPB) sS[e] = Sq[e];
+    __syncthreads();
+
+    // ---- measurements ----
+    if (p.sim) {
+        if (tid < 64) sim_wave<KCAP>(p, b, lane, tx, ty, tth, lmx, lmy, s_meas, &s_misc[0]);
+    } else {
+        int kk = p.meas_count_in[b];
+        kk = kk < p.k_stride_in ? kk : p.k_stride_in;
+        kk = kk < KCAP ? kk : KCAP;
+        kk = kk < 0 ? 0 : kk;
+        for (int i = tid; i < 3 * kk; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
+        if (tid == 0) s_misc[0] = kk;
+    }
+    __syncthreads();
+    const int k = s_misc[0];
+    if (p.sim && p.meas_out != nullptr) {
+        for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB) p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = s_meas[i];
+        if (tid == 0) p.meas_count_out[b] = k;
+    }
+
+    // ---- association (ukf.cpp:256-277): known landmarks are updated first, unknown ids inserted afterwards ----
+    if (tid < 64) {
+        int found = -1;
+        bool valid = lane < k;
+        const int myid = valid ? (int)s_meas[3 * lane] : -1;
+#pragma unroll 1
+        for (int l = 0; l < k; ++l) {
+            const int id = (int)s_meas[3 * l];
+            int f = -1;
+#pragma unroll 1
+            for (int j0 = 0; j0 < M_old && f < 0; j0 += 64) {
+                const int j = j0 + lane;
+                const unsigned long long mm = __ballot(j < M_old && s_ids[j] == id);
+                if (mm != 0ull) f = j0 + (__ffsll((long long)mm) - 1);
+            }
+            if (lane == l) found = f;
+        }
+        (void)myid;
+        const unsigned long long um = __ballot(valid && found >= 0);
+        const unsigned long long im = __ballot(valid && found < 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (valid && found >= 0) s_upd[__popcll(um & below)] = (found << 8) | lane;   // slot, detection index
+        if (valid && found < 0) s_ins[__popcll(im & below)] = lane;
+        if (lane == 0) { s_misc[1] = __popcll(um); s_misc[2] = __popcll(im); }
+    }
+
+    // ---- sigma points through the motion model (ukf.cpp:214-226,125-135); only rows 0..3 change ----
+    const float u_d = p.fwd, u_th = p.ang;
+    const float dd = u_d + p.v_d;
+    for (int i = tid; i < ns; i += TPB) {
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (i == 0) v[r] = s_xt[r];
+            else if (i <= n) v[r] = s_xt[r] + sS[(i - 1) * n + r];
+            else v[r] = s_xt[r] - sS[(i - 1 - n) * n + r];
+        }
+        const float yaw = yaw_of(v[2], v[3]);
+        double sy, cy;
+        tsincos(yaw, p.float_trig, &sy, &cy);
+        if (p.float_trig) {
+            sX4[0 * ns + i] = v[0] + (double)(dd * (float)cy);   // float * float (ukf.cpp:129)
+            sX4[1 * ns + i] = v[1] + (double)(dd * (float)sy);
+        } else {
+            sX4[0 * ns + i] = v[0] + (double)dd * cy;
+            sX4[1 * ns + i] = v[1] + (double)dd * sy;
+        }
+        const float new_yaw = (float)remainder((double)(yaw + u_th + p.v_th), kTwoPi);   // float adds (ukf.cpp:131)
+        double sn, cn;
+        tsincos(new_yaw, p.float_trig, &sn, &cn);
+        sX4[2 * ns + i] = cn;
+        sX4[3 * ns + i] = sn;
+    }
+    __syncthreads();
+    const int n_upd = s_misc[1], n_insq = s_misc[2];
+
+    const double w0 = (double)kW0;
+    const double wi = (double)((1 - kW0) / (2 * n));   // float arithmetic (ukf.cpp:174-175)
+    auto xpred_elem = [&](int r, int i) -> double {    // X_pred(r, i)
+        if (r < 4) return sX4[r * ns + i];
+        if (i == 0) return s_xt[r];
+        if (i <= n) return s_xt[r] + sS[(i - 1) * n + r];
+        return s_xt[r] - sS[(i - 1 - n) * n + r];
+    };
+
+    // ---- weighted mean (ukf.cpp:228-232), sequential in i ----
+    for (int r = tid; r < n; r += TPB) {
+        double acc = 0.0;
+        acc = acc + w0 * xpred_elem(r, 0);
+#pragma unroll 1
+        for (int i = 1; i < ns; ++i) acc = acc + wi * xpred_elem(r, i);
+        s_xp0[r] = acc;
+        s_xp[r] = acc;
+    }
+    if (tid == 0) {  // process noise diagonal (ukf.cpp:182-186) and the sensing-model yaw (ukf.cpp:139), both from x_t
+        const float yaw = yaw_of(s_xt[2], s_xt[3]);
+        double sy, cy;
+        tsincos(yaw, p.float_trig, &sy, &cy);
+        s_sc[0] = p.V00 * cy; s_sc[1] = p.V00 * sy; s_sc[2] = p.V11 * cy; s_sc[3] = p.V11 * sy;
+        s_sc[4] = (double)yaw;
+    }
+    __syncthreads();
+
+    // ---- landmark updates (ukf.cpp:293-349); K and S never depend on P (sigma points are not redrawn) ----
+    const int nfin_ins = (M_old + n_insq <= p.L_max && M_old + n_insq <= LMAX) ? n_insq : ((p.L_max < LMAX ? p.L_max : LMAX) - M_old);
+    if (nfin_ins < n_insq) flags |= SLAM_INST_CAPACITY;
+    const int n_fin = n + 2 * nfin_ins;
+    int done = 0;        // updates already applied to Pout by earlier passes
+    bool first_pass = true;
+    while (first_pass || done < n_upd) {
+        const int ug = (n_upd - done) < KU ? (n_upd - done) : KU;
+#pragma unroll 1
+        for (int u = 0; u < ug; ++u) {
+            const int packed = s_upd[done + u];
+            const int li = 2 * (packed >> 8) + 4, l = packed & 0xff;
+            const float r_m = s_meas[3 * l + 1], b_m = s_meas[3 * l + 2];
+            const double yaw_s = s_sc[4];
+            for (int i = tid; i < ns; i += TPB) {
+                const double dx = xpred_elem(li, i) - xpred_elem(0, i), dy = xpred_elem(li + 1, i) - xpred_elem(1, i);
+                sZ0[i] = sqrt(dx * dx + dy * dy) + (double)p.w_r;
+                const double z1 = remainder((det_atan2(dy, dx) - yaw_s) + (double)p.w_b, kTwoPi);
+                sD1[i] = remainder(z1 - 0.0, kTwoPi);   // z_est(1) stays 0 (ukf.cpp:310-314)
+            }
+            __syncthreads();
+            if (tid == 0) {  // leader: z_est(0), S (sequential in i), S^-1, innovation
+                double z0 = 0.0;
+                z0 = z0 + w0 * sZ0[0];
+#pragma unroll 1
+                for (int i = 1; i < ns; ++i) z0 = z0 + wi * sZ0[i];
+                double S[4] = {0.0, 0.0, 0.0, 0.0}, Si[4];
+#pragma unroll 1
+                for (int i = 0; i < ns; ++i) {
+                    const double w = i == 0 ? w0 : wi;
+                    const double d0 = sZ0[i] - z0, d1 = sD1[i];
+                    const double a0 = w * d0, a1 = w * d1;
+                    S[0] = S[0] + a0 * d0; S[1] = S[1] + a0 * d1; S[2] = S[2] + a1 * d0; S[3] = S[3] + a1 * d1;
+                }
+                S[0] = S[0] + p.W00; S[1] = S[1] + 0.0; S[2] = S[2] + 0.0; S[3] = S[3] + p.W11;
+                if (!inv2x2_lu_ukf(S, Si)) s_misc[4] = 1;
+                s_sc[5] = z0;
+                s_sc[6] = S[0]; s_sc[7] = S[1]; s_sc[8] = S[2]; s_sc[9] = S[3];
+                s_sc[10] = Si[0]; s_sc[11] = Si[1]; s_sc[12] = Si[2]; s_sc[13] = Si[3];
+                s_sc[14] = (double)r_m - z0;
+                s_sc[15] = remainder((double)b_m - 0.0, kTwoPi);
+            }
+            __syncthreads();
+            {
+                const double z0 = s_sc[5];
+                double* Ku = sK + (size_t)u * NMAX * 4;
+                for (int r = tid; r < n; r += TPB) {
+                    const double xr = s_xp[r];   // CURRENT x_pred (ukf.cpp:330)
+                    double c0 = 0.0, c1 = 0.0;
+#pragma unroll 1
+                    for (int i = 0; i < ns; ++i) {
+                        const double wd = (i == 0 ? w0 : wi) * (xpred_elem(r, i) - xr);
+                        c0 = c0 + wd * (sZ0[i] - z0);
+                        c1 = c1 + wd * sD1[i];
+                    }
+                    const double k0 = c0 * s_sc[10] + c1 * s_sc[12];
+                    const double k1 = c0 * s_sc[11] + c1 * s_sc[13];
+                    Ku[4 * r + 0] = k0; Ku[4 * r + 1] = k1;
+                    Ku[4 * r + 2] = k0 * s_sc[6] + k1 * s_sc[8];    // (K S)[r][0]
+                    Ku[4 * r + 3] = k0 * s_sc[7] + k1 * s_sc[9];    // (K S)[r][1]
+                    s_xp[r] = xr + (k0 * s_sc[14] + k1 * s_sc[15]);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- P pass: P_pred = sum_i (w_i d_r) d_c + Q, minus the K S K^T terms; 4 x 4 register tiles ----
+        {
+            const int nt = (n + 3) / 4;
+            unsigned hiacc = 0u;
+            for (int tile = tid; tile < nt * nt; tile += TPB) {
+                const int r0 = 4 * (tile / nt), c0 = 4 * (tile % nt);
+                double acc[4][4];
+                if (first_pass) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
+                    double xr[4], xc[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { xr[a] = r0 + a < n ? s_xp0[r0 + a] : 0.0; xc[a] = c0 + a < n ? s_xp0[c0 + a] : 0.0; }
+#pragma unroll 1
+                    for (int i = 0; i < ns; ++i) {
+                        const double w = i == 0 ? w0 : wi;
+                        double dr[4], dc[4];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            dr[a] = r0 + a < n ? xpred_elem(r0 + a, i) - xr[a] : 0.0;
+                            dc[a] = c0 + a < n ? xpred_elem(c0 + a, i) - xc[a] : 0.0;
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const double wd = w * dr[a];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[a][c] = acc[a][c] + wd * dc[c];
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        if (r0 == c0 && r0 + a < 4) acc[a][a] = acc[a][a] + s_sc[r0 + a];   // + Q (signed diagonal)
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[a][c] = (r0 + a < n && c0 + c < n) ? Pout[(size_t)(r0 + a) * n_fin + c0 + c] : 0.0;
+                }
+#pragma unroll 1
+                for (int u = 0; u < ug; ++u) {
+                    const double* Ku = sK + (size_t)u * NMAX * 4;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (r0 + a >= n) continue;
+                        const double ks0 = Ku[4 * (r0 + a) + 2], ks1 = Ku[4 * (r0 + a) + 3];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c0 + c < n) acc[a][c] = acc[a][c] - (ks0 * Ku[4 * (c0 + c) + 0] + ks1 * Ku[4 * (c0 + c) + 1]);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (r0 + a < n && c0 + c < n) {
+                            Pout[(size_t)(r0 + a) * n_fin + c0 + c] = acc[a][c];
+                            const unsigned h = (unsigned)(__double_as_longlong(acc[a][c]) >> 32) & 0x7fffffffu;
+                            hiacc = hiacc > h ? hiacc : h;
+                        }
+            }
+            if (__syncthreads_or(hiacc >= 0x7ff00000u)) flags |= SLAM_INST_NONFINITE;
+        }
+        done += ug;
+        first_pass = false;
+    }
+
+    // ---- landmark insertions (ukf.cpp:351-372): P = blkdiag(P_pred, W) per new landmark, x_pred grows ----
+    if (tid == 0) {
+        for (int q = 0; q < nfin_ins; ++q) {
+            const int l = s_ins[q];
+            const float r_m = s_meas[3 * l + 1], b_m = s_meas[3 * l + 2];
+            const int nn = n + 2 * q;
+            const float yaw = yaw_of(s_xp[2], s_xp[3]);
+            const float ang = yaw + b_m;
+            double sa, ca;
+            tsincos(ang, p.float_trig, &sa, &ca);
+            if (p.float_trig) {
+                s_xp[nn] = s_xp[0] + (double)(r_m * (float)ca);
+                s_xp[nn + 1] = s_xp[1] + (double)(r_m * (float)sa);
+            } else {
+                s_xp[nn] = s_xp[0] + (double)r_m * ca;
+                s_xp[nn + 1] = s_xp[1] + (double)r_m * sa;
+            }
+            s_ids[M_old + q] = (int)s_meas[3 * l];
+        }
+    }
+    for (int e = tid; e < n_fin * n_fin; e += TPB) {   // new rows / cols: zeros, W on the diagonal
+        const int r = e / n_fin, c = e - r * n_fin;
+        if (r >= n || c >= n) Pout[e] = (r == c) ? (((r - n) & 1) ? p.W11 : p.W00) : 0.0;
+    }
+    __syncthreads();
+
+    // ---- x_t = x_pred (ukf.cpp:289) and bookkeeping ----
+    unsigned hx = 0u;
+    for (int i = tid; i < n_fin; i += TPB) {
+        const double v = s_xp[i];
+        xb[i] = v;
+        const unsigned h = (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu;
+        hx = hx > h ? hx : h;
+    }
+    if (__syncthreads_or(hx >= 0x7ff00000u)) flags |= SLAM_INST_NONFINITE;
+    if (s_misc[4]) flags |= SLAM_INST_S_SINGULAR;
+    const int M_new = M_old + nfin_ins;
+    if (M_new != M_old)
+        for (int i = tid; i < M_new; i += TPB) p.ids[(size_t)b * p.L_max + i] = s_ids[i];
+    if (tid == 0) {
+        p.M[b] = M_new;
+        p.flags[b] = flags | (p.flags[b] & SLAM_INST_SQRT_FAILED);
+        p.timestep[b] = p.timestep[b] + 1;
+        if (p.sim) {
+            const double ex = (double)(float)s_xp[0] - tx, ey = (double)(float)s_xp[1] - ty;
+            p.err_sum[b] = p.err_sum[b] + sqrt(ex * ex + ey * ey);
+        }
+    }
+}
+
+hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
+    const int nmax = 4 + 2 * p.L_max;
+    if (nmax <= 44) hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.B), dim3(256), 0, stream, p);
+    else if (nmax <= 104) hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024>), dim3(p.B), dim3(1024), 0, stream, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
+    const int nmax = 4 + 2 * p.L_max;
+    if (nmax <= 44) hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.B), dim3(256), 0, stream, p);
+    else if (nmax <= 104) hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.B), dim3(1024), 0, stream, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+__global__ void ukf_init_kernel(const UkfInitParams p) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    double* P = p.P + (size_t)b * p.pstride;
+    double* x = p.x + (size_t)b * p.xstride;
+    for (int i = 0; i < 16; ++i) P[i] = 0.0;
+    P[0] = 0.01 * 0.01; P[5] = 0.01 * 0.01; P[10] = 0.005 * 0.005; P[15] = 0.005 * 0.005;   // ukf.cpp:9-13
+    x[0] = p.x0; x[1] = p.y0; x[2] = p.c0; x[3] = p.s0;                                       // ukf.cpp:33
+    p.M[b] = 0; p.flags[b] = 0; p.timestep[b] = 0; p.n_sq[b] = 0;
+    p.truth[3 * (size_t)b] = p.tx; p.truth[3 * (size_t)b + 1] = p.ty; p.truth[3 * (size_t)b + 2] = p.tyaw;
+    p.err_sum[b] = 0.0;
+}
+hipError_t launch_ukf_init(const UkfInitParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(ukf_init_kernel, dim3((p.B + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace slam

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .config import SlamConfig, default_config, EKF_SLAM, F64
+from .config import SlamConfig, default_config, EKF_SLAM, UKF_SLAM, F64
 
 
 def _d(a):
@@ -227,3 +227,28 @@ class BatchedEKF(BatchedFilter):
         lm[0::3] = s["ids"]; lm[1::3] = x[3::2]; lm[2::3] = x[4::2]
         return dict(timestep=s["timestep"], x_v=np.float32(x[0]), y_v=np.float32(x[1]), yaw_v=np.float32(x[2]),
                     M=M, landmarks=lm, P=s["P"].astype(np.float32).ravel())  # P row-major (ekf.cpp:211-217)
+
+
+class BatchedUKF(BatchedFilter):
+    """UKF-SLAM (reference: class UKF, filter.h:177-223, ukf.cpp).  State x = [x, y, cos(yaw), sin(yaw), landmarks]."""
+
+    kind = UKF_SLAM
+
+    def _n(self, M):
+        return 4 + 2 * M
+
+    # -- UKF::getStateVector (ukf.cpp:47-53; the reference's fixed-size Vector3d bug is not replicated) --
+    def getStateVector(self, instance=0):
+        x = self.get_state(instance)["x"]
+        return np.concatenate([[x[0], x[1], np.remainder(np.arctan2(x[3], x[2]) + np.pi, 2 * np.pi) - np.pi], x[4:]])
+
+    # -- UKF::publishState payload (ukf.cpp:60-104, UKFState.msg) without the sigma-point dump X --
+    def publishState(self, instance=0):
+        import math
+        s = self.get_state(instance)
+        x, M = s["x"], s["M"]
+        lm = np.empty(3 * M, dtype=np.float32)
+        lm[0::3] = s["ids"]; lm[1::3] = x[4::2]; lm[2::3] = x[5::2]
+        yaw = math.remainder(math.atan2(x[3], x[2]), 2 * 3.14159265358979323846)
+        return dict(timestep=s["timestep"], x_v=np.float32(x[0]), y_v=np.float32(x[1]), yaw_v=np.float32(yaw),
+                    M=M, landmarks=lm, P=s["P"].astype(np.float32).ravel())
