@@ -17,6 +17,8 @@
 // (oracle/slam_oracle_ukf.cpp) so results are bit-identical; the reference's float truncations are real fp32 ops.
 #include "ukf_kernel.h"
 
+#include <stdlib.h>
+
 #include "../../include/slam_batch.h"
 #include "sim_device.h"
 #include "slam_math.h"
@@ -109,19 +111,41 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     __syncthreads();
 
     const int nb = m * (m - 1) / 2;
+    const int items = nb + m + m * n;
+    // The work items a thread owns are the same in every round: decode them once.
+    //   kind 0: pair-block (i, j), i > j      B' = R_i^T B R_j
+    //   kind 1: diagonal block of pair i
+    //   kind 2: row k of V for pair i         V <- V J
+    constexpr int IT = (MMAX * (MMAX - 1) / 2 + MMAX + MMAX * NMAX + TPB - 1) / TPB;
+    int desc[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int it = tid + TPB * u;
+        int d = -1;
+        if (it < nb) {
+            int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)it)) * 0.5f);
+            while (i * (i - 1) / 2 > it) --i;
+            while ((i + 1) * i / 2 <= it) ++i;
+            d = (i << 8) | (it - i * (i - 1) / 2);
+        } else if (it < nb + m) {
+            d = (1 << 16) | ((it - nb) << 8);
+        } else if (it < items) {
+            const int e = it - nb - m;
+            const int i = e / n;
+            d = (2 << 16) | (i << 8) | (e - i * n);
+        }
+        desc[u] = d;
+    }
     bool converged = false;
 #pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: every off-diagonal element exactly zero (reachable through the small-element rule below)
         double off = 0.0;
-        for (int e = tid; e < n * (n + 1) / 2; e += TPB) {
-            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);   // packed index -> row
-            while (r * (r + 1) / 2 > e) --r;
-            while ((r + 1) * (r + 2) / 2 <= e) ++r;
-            const int c = e - r * (r + 1) / 2;
-            const double v = fabs(sA[e]);
-            if (r != c) off = off > v ? off : v;
-        }
+        for (int r = tid / 2; r < n; r += TPB / 2)          // two threads per row, strictly-lower part
+            for (int c = (tid & 1); c < r; c += 2) {
+                const double v = fabs(sA[r * (r + 1) / 2 + c]);
+                off = off > v ? off : v;
+            }
         off = block_max(off, s_red, tid, TPB);
         if (off == 0.0) { converged = true; break; }
 #pragma unroll 1
@@ -147,14 +171,13 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                 s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
             }
             __syncthreads();
-            const int items = nb + m + m * n;
-#pragma unroll 1
-            for (int it = tid; it < items; it += TPB) {
-                if (it < nb) {  // pair-block (i, j), i > j:  B' = R_i^T B R_j
-                    int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)it)) * 0.5f);
-                    while (i * (i - 1) / 2 > it) --i;
-                    while ((i + 1) * i / 2 <= it) ++i;
-                    const int j = it - i * (i - 1) / 2;
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const int d = desc[u];
+                if (d < 0) continue;
+                const int kind = d >> 16, i = (d >> 8) & 0xff, jk = d & 0xff;
+                if (kind == 0) {
+                    const int j = jk;
                     const int pi = s_pp[i], qi = s_qq[i], pj = s_pp[j], qj = s_qq[j];
                     const double ci = s_cs[i], si = s_sn[i], cj = s_cs[j], sj = s_sn[j];
                     double& e00 = AT(pi, pj); double& e01 = AT(pi, qj); double& e10 = AT(qi, pj); double& e11 = AT(qi, qj);
@@ -163,16 +186,14 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
                     e00 = t00 * cj - t01 * sj; e01 = t00 * sj + t01 * cj;
                     e10 = t10 * cj - t11 * sj; e11 = t10 * sj + t11 * cj;
-                } else if (it < nb + m) {  // diagonal block
-                    const int i = it - nb;
+                } else if (kind == 1) {
                     const int pq = s_pp[i], qq = s_qq[i];
                     const double app = AT(pq, pq), aqq = AT(qq, qq), apq = AT(qq, pq);
                     AT(pq, pq) = app - s_tn[i] * apq;
                     AT(qq, qq) = aqq + s_tn[i] * apq;
                     if (apq != 0.0) AT(qq, pq) = 0.0;
-                } else {  // V <- V J for one row k of one pair
-                    const int e = it - nb - m;
-                    const int i = e / n, k = e - i * n;
+                } else {
+                    const int k = jk;
                     const int pq = s_pp[i], qq = s_qq[i];
                     const double c = s_cs[i], s = s_sn[i];
                     const double vp = sVt[pq * n + k], vq = sVt[qq * n + k];
@@ -537,19 +558,53 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     }
 }
 
+// Tuning: threads per instance.  At BASELINE's batch of 4096 only 16 instances share a CU, so wide workgroups win
+// (measured: n<=44 256 threads, n<=104 1024 threads); env SLAM_UKF_TPB = <sqrt threads>*10000 + <step threads> overrides (tools/gpu_ukf_time.py).
+static int env_tpb(int which, int dflt) {
+    const char* e = getenv("SLAM_UKF_TPB");
+    if (!e) return dflt;
+    const int v = atoi(e);
+    const int t = which == 0 ? v / 10000 : v % 10000;
+    return t > 0 ? t : dflt;
+}
+
 hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
     const int nmax = 4 + 2 * p.L_max;
-    if (nmax <= 44) hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.B), dim3(256), 0, stream, p);
-    else if (nmax <= 104) hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024>), dim3(p.B), dim3(1024), 0, stream, p);
-    else return hipErrorInvalidValue;
+    if (nmax <= 44) {
+        switch (env_tpb(0, 256)) {
+            case 128: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 128>), dim3(p.B), dim3(128), 0, stream, p); break;
+            case 64: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 64>), dim3(p.B), dim3(64), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.B), dim3(256), 0, stream, p); break;
+        }
+    } else if (nmax <= 104) {
+        switch (env_tpb(0, 1024)) {
+            case 512: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 512>), dim3(p.B), dim3(512), 0, stream, p); break;
+            case 256: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 256>), dim3(p.B), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024>), dim3(p.B), dim3(1024), 0, stream, p); break;
+        }
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
     const int nmax = 4 + 2 * p.L_max;
-    if (nmax <= 44) hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.B), dim3(256), 0, stream, p);
-    else if (nmax <= 104) hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.B), dim3(1024), 0, stream, p);
-    else return hipErrorInvalidValue;
+    if (nmax <= 44) {
+        switch (env_tpb(1, 128)) {
+            case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.B), dim3(64), 0, stream, p); break;
+            case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.B), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.B), dim3(128), 0, stream, p); break;
+        }
+    } else if (nmax <= 104) {
+        switch (env_tpb(1, 1024)) {
+            case 256: hipLaunchKernelGGL((ukf_step_kernel<104, 256, 8>), dim3(p.B), dim3(256), 0, stream, p); break;
+            case 512: hipLaunchKernelGGL((ukf_step_kernel<104, 512, 8>), dim3(p.B), dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.B), dim3(1024), 0, stream, p); break;
+        }
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
