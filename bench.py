@@ -52,6 +52,62 @@ def cpu_baseline(lm, cmds, vis, L, seconds_budget=20.0):
                                     "sample": f"{Bf} instances x {T} steps, oracle MODE_FAST (structure-exploiting), {rf['seconds']:.1f} s"}}
 
 
+def ukf_flops_per_step(n, sweeps, k):
+    """Algorithmic fp64 FLOPs of one UKF step at state size n: parallel-order Jacobi
+    (pair-blocks 24, V row-pairs 6 flops), sqtP = V sqrt(D) V^T (lower triangle), weighted covariance, k updates."""
+    m = n // 2
+    per_round = 24 * (m * (m - 1) // 2) + 4 * m + 6 * m * n
+    jacobi = sweeps * (n - 1) * per_round
+    sqt = 3 * n * (n * (n + 1) // 2)
+    cov = (2 * n + 1) * (3 * n * n + 2 * n)
+    upd = k * ((2 * n + 1) * (6 * n + 20) + 6 * n * n)
+    return jacobi + sqt + cov + upd
+
+
+def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
+    """Secondary line: UKF-SLAM steps/s (BASELINE configs[2]: batch 4096, L=20).  Compute-bound (fp64 VALU / LDS)."""
+    import live_ekf_slam_amd as S
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, K, W, PRE = args.landmarks, args.batch, args.steps, args.warmup, min(args.preroll, 20)
+    T = 1 + PRE + W + K
+    lm, cmds = make_scenario(1234, L, T)
+    f = S.BatchedUKF(B, L, device=local_rank).readParams()
+    stream = torch.cuda.Stream(device=dev)
+    f.set_stream(stream.cuda_stream)
+    f.set_map(lm); f.set_seed(2025); f.set_instance_offset(rank * B); f.init(0.0, 0.0, 0.0)
+    with torch.cuda.stream(stream):
+        f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
+        f.run_sim(cmds[1:1 + PRE + W])
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        f.run_sim(cmds[1 + PRE + W:])
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+    M = f.landmark_counts(); n = 4 + 2 * int(round(M.mean()))
+    flops = ukf_flops_per_step(n, 9, 1.24 if L <= 20 else 1.7) * B
+    step_ms = ev0.elapsed_time(ev1) / K
+    line = {"metric": "UKF predict-update steps/sec (secondary; BASELINE configs[2] shape)", "value": round(B * K / wall, 1),
+            "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"UKF-SLAM fused sim+update step, L={L} (n={n}, {2 * n + 1} sigma points), batch={B}, steady state",
+                       "instances_flagged": int((f.status() != 0).sum()), "avg_position_error_m": round(float(f.error_stats().mean()), 5),
+                       "parity": "bit-exact vs CPU oracle (tests/test_parity_ukf_gpu.py)"},
+            "roofline": {"bound": "fp64-valu", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
+                         "frac": round(flops / (step_ms * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
+                         "note": "algorithmic FLOPs (9 Jacobi sweeps) / step time of both kernels; latency- and LDS-bound, see DESIGN.md"}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        vis = np.tile([3.0, -1.57, 1.57], (60, 1)); vis[0] = [1e9, -4.0, 4.0]
+        r1 = O.run_ukf_batch(lm, cmds[:60], 8 if L <= 20 else 1, L, nthreads=1, want_P=False, vision=vis)
+        line["cpu_baseline"] = {"value": round((8 if L <= 20 else 1) * 60 / r1["seconds"], 1), "unit": "steps/s", "cores": 1, "kind": "port",
+                                "sample": f"oracle UKF, {(8 if L <= 20 else 1)} instances x 60 steps, 1 thread, {r1['seconds']:.1f} s"}
+    print(json.dumps(line), flush=True)
+    f.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +118,8 @@ def main():
     ap.add_argument("--preroll", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waves-per-filter", type=int, default=0)
+    ap.add_argument("--filter", choices=["ekf", "ukf"], default="ekf",
+                    help="ekf = the headline metric (default); ukf = BASELINE configs[2]-style secondary line")
     args = ap.parse_args()
 
     import torch
@@ -85,6 +143,8 @@ def main():
     from live_ekf_slam_amd.parallel import gather_error_stats, reduce_summary
     from live_ekf_slam_amd.scenario import make_scenario
 
+    if args.filter == "ukf":
+        return bench_ukf(args, torch, dist, rank, local_rank, world, dev)
     L, B, K, W, PRE = args.landmarks, args.batch, args.steps, args.warmup, args.preroll
     T = 1 + PRE + W + K
     lm, cmds = make_scenario(1234, L, T)
