@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--preroll", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waves-per-filter", type=int, default=0)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="storage type of x and P in HBM (arithmetic is fp64 either way); f64 is the headline metric")
     ap.add_argument("--filter", choices=["ekf", "ukf"], default="ekf",
                     help="ekf = the headline metric (default); ukf = BASELINE configs[2]-style secondary line")
     args = ap.parse_args()
@@ -150,7 +152,7 @@ def main():
     lm, cmds = make_scenario(1234, L, T)
     vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]
 
-    f = S.BatchedEKF(B, L, device=local_rank).readParams()
+    f = S.BatchedEKF(B, L, device=local_rank, dtype=S.F32 if args.dtype == "f32" else S.F64).readParams()
     stream = torch.cuda.Stream(device=dev)
     f.set_stream(stream.cuda_stream)            # kernels run on a stream torch.cuda.Event can see
     f.set_map(lm); f.set_seed(2025); f.set_instance_offset(rank * B); f.init(0.0, 0.0, 0.0)
@@ -205,13 +207,14 @@ def main():
             "metric": "EKF predict-update steps/sec @ L=50, batch=65536; fp64 state RMSE vs ref",
             "value": round(value, 1), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype if args.dtype == "f64" else "f64 arithmetic, f32 storage", "data": "synthetic",
             "config": {"workload": f"EKF-SLAM fused sim+update step, L={L} random landmarks (n={n_state}), "
                                    f"batch={B} instances per GPU, steady state (all landmarks mapped), "
                                    "device-generated range-bearing measurements",
                        "batch_per_gpu": B, "global_batch": B * world, "landmarks": L, "state_dim": n_state,
                        "min_M": int(M.min()), "parallelism": f"instance-sharded x{world}, no per-step collective",
                        "state_rmse_vs_oracle": 0.0, "parity": "bit-exact vs CPU oracle (tests/test_parity_gpu.py)",
+                       "storage": args.dtype,
                        "avg_position_error_m": round(float(mean_err), 5), "instances_flagged": int((flags != 0).sum())},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

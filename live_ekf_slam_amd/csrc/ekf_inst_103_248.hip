@@ -2,5 +2,5 @@
 // 4 detections per group, 8 register pairs in flight per lane
 #include "ekf_kernel_impl.h"
 namespace slam {
-template hipError_t launch_variant<103, 2, 4, 8>(const EkfStepParams&, hipStream_t);
+template hipError_t launch_variant<103, 2, 4, 8, double>(const EkfStepParams&, hipStream_t);
 }

@@ -2,5 +2,5 @@
 // 4 detections per group, 4 register pairs in flight per lane
 #include "ekf_kernel_impl.h"
 namespace slam {
-template hipError_t launch_variant<103, 4, 4, 4>(const EkfStepParams&, hipStream_t);
+template hipError_t launch_variant<103, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
 }

@@ -9,9 +9,11 @@ namespace slam {
 // preceded (SIM mode) by the measurement generator get_cmd (sim_node.py:209-250) for the same instance.
 struct EkfStepParams {
     // ---- filter state in HBM ----
-    const double* P;    // [B][pstride]  P_t: packed row-major n x n, leading dimension n = 3+2*M[b] (read)
-    double* P_out;      // [B][pstride]  P_t of the next step (written; the two buffers ping-pong)
-    double* x;          // [B][xstride]  x_t
+    // P and x are stored as fp64 (SLAM_F64) or fp32 (SLAM_F32); strides are in ELEMENTS of that type
+    const void* P;      // [B][pstride]  P_t: packed row-major n x n, leading dimension n = 3+2*M[b] (read)
+    void* P_out;        // [B][pstride]  P_t of the next step (written; the two buffers ping-pong)
+    void* x;            // [B][xstride]  x_t
+    double* scratch;    // [B][pstride] fp64, SLAM_F32 only: P between detection groups of one step (NULL for fp64)
     int32_t* M;         // [B]
     int32_t* ids;       // [B][L_max]    lm_IDs
     int32_t* flags;     // [B]           slam_instance_flags
@@ -51,15 +53,15 @@ struct EkfStepParams {
 static constexpr int kEkfMaxLandmarks = 50;
 
 // waves_per_filter: 0 = let the library pick; 2, 4 or 8 otherwise.
-hipError_t launch_ekf_step(const EkfStepParams& p, int waves_per_filter, hipStream_t stream);
+hipError_t launch_ekf_step(const EkfStepParams& p, int waves_per_filter, int f32_storage, hipStream_t stream);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)
-hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, double* out, hipStream_t stream);
+hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, int elem_bytes, double* out, hipStream_t stream);
 
 // fill x/P/M/... for Filter::init (ekf.cpp:4-21,29-34)
 struct EkfInitParams {
-    double* P; double* x; int32_t* M; int32_t* flags; int32_t* timestep; double* truth; double* err_sum;
-    int32_t B, pstride, xstride;
+    void* P; void* x; int32_t* M; int32_t* flags; int32_t* timestep; double* truth; double* err_sum;
+    int32_t B, pstride, xstride, f32_storage;
     float x0, y0, yaw0;
     double tx, ty, tyaw;
 };

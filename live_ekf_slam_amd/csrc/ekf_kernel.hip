@@ -9,81 +9,90 @@
 
 namespace slam {
 
-template <int NMAX, int W, int KG, int UNR>
+template <int NMAX, int W, int KG, int UNR, class ST>
 hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream);
-extern template hipError_t launch_variant<103, 4, 4, 4>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4, 3, 4>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 2, 3, 8>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 2, 4, 8>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 8, 4, 2>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4, 4, 8>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4, 2, 4>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 2, 4, 4>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 4, 4, 4>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 1, 4, 8>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 2, 4, 8>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 3, 4, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 2, 3, 8, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 2, 4, 8, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 8, 4, 2, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 4, 8, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 2, 4, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 2, 4, 4, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 1, 4, 8, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 2, 4, 8, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<103, 4, 4, 4, float>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 2, 4, 4, float>(const EkfStepParams&, hipStream_t);
 
 // NMAX only sizes the LDS arrays (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103).  `wpf` selects a tuning
 // variant: 0 = default, W (wavefronts per filter) or the 3-digit code W*100 + KG*10 + UNR.
-hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, hipStream_t stream) {
+hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, int f32_storage, hipStream_t stream) {
     const int nmax = 3 + 2 * p.L_max;
+    if (f32_storage) {  // fp32 storage of x and P (BASELINE configs[3]); one tuning variant per size class
+        if (nmax <= 43) return launch_variant<43, 2, 4, 4, float>(p, stream);
+        if (nmax <= 103) return launch_variant<103, 4, 4, 4, float>(p, stream);
+        return hipErrorInvalidValue;
+    }
     if (nmax <= 43) {
         switch (wpf) {
-            case 244: return launch_variant<43, 2, 4, 4>(p, stream);
-            case 444: return launch_variant<43, 4, 4, 4>(p, stream);
-            case 148: return launch_variant<43, 1, 4, 8>(p, stream);
-            case 248: return launch_variant<43, 2, 4, 8>(p, stream);
-            case 4: return launch_variant<43, 4, 4, 4>(p, stream);
-            case 1: return launch_variant<43, 1, 4, 8>(p, stream);
-            default: return launch_variant<43, 2, 4, 4>(p, stream);
+            case 244: return launch_variant<43, 2, 4, 4, double>(p, stream);
+            case 444: return launch_variant<43, 4, 4, 4, double>(p, stream);
+            case 148: return launch_variant<43, 1, 4, 8, double>(p, stream);
+            case 248: return launch_variant<43, 2, 4, 8, double>(p, stream);
+            case 4: return launch_variant<43, 4, 4, 4, double>(p, stream);
+            case 1: return launch_variant<43, 1, 4, 8, double>(p, stream);
+            default: return launch_variant<43, 2, 4, 4, double>(p, stream);
         }
     }
     if (nmax <= 103) {
         switch (wpf) {
-            case 444: return launch_variant<103, 4, 4, 4>(p, stream);
-            case 434: return launch_variant<103, 4, 3, 4>(p, stream);
-            case 238: return launch_variant<103, 2, 3, 8>(p, stream);
-            case 248: return launch_variant<103, 2, 4, 8>(p, stream);
-            case 842: return launch_variant<103, 8, 4, 2>(p, stream);
-            case 448: return launch_variant<103, 4, 4, 8>(p, stream);
-            case 424: return launch_variant<103, 4, 2, 4>(p, stream);
-            case 8: return launch_variant<103, 8, 4, 2>(p, stream);
-            case 2: return launch_variant<103, 2, 4, 8>(p, stream);
-            default: return launch_variant<103, 4, 4, 4>(p, stream);
+            case 444: return launch_variant<103, 4, 4, 4, double>(p, stream);
+            case 434: return launch_variant<103, 4, 3, 4, double>(p, stream);
+            case 238: return launch_variant<103, 2, 3, 8, double>(p, stream);
+            case 248: return launch_variant<103, 2, 4, 8, double>(p, stream);
+            case 842: return launch_variant<103, 8, 4, 2, double>(p, stream);
+            case 448: return launch_variant<103, 4, 4, 8, double>(p, stream);
+            case 424: return launch_variant<103, 4, 2, 4, double>(p, stream);
+            case 8: return launch_variant<103, 8, 4, 2, double>(p, stream);
+            case 2: return launch_variant<103, 2, 4, 8, double>(p, stream);
+            default: return launch_variant<103, 4, 4, 4, double>(p, stream);
         }
     }
     return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void alg_bytes_kernel(const int32_t* M, int B, int base, double* out) {
+__global__ void alg_bytes_kernel(const int32_t* M, int B, int base, int elem_bytes, double* out) {
     double acc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
         const double n = (double)base + 2.0 * M[i];
-        acc += 2.0 * (n * n + n) * 8.0;
+        acc += 2.0 * (n * n + n) * (double)elem_bytes;
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, double* out, hipStream_t stream) {
-    hipLaunchKernelGGL(alg_bytes_kernel, dim3(64), dim3(256), 0, stream, M, B, base, out);
+hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, int elem_bytes, double* out, hipStream_t stream) {
+    hipLaunchKernelGGL(alg_bytes_kernel, dim3(64), dim3(256), 0, stream, M, B, base, elem_bytes, out);
     return hipGetLastError();
 }
 
+template <class ST>
 __global__ void ekf_init_kernel(const EkfInitParams p) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.B) return;
-    double* P = p.P + (size_t)b * p.pstride;
-    double* x = p.x + (size_t)b * p.xstride;
-    for (int i = 0; i < 9; ++i) P[i] = 0.0;
-    P[0] = 0.01 * 0.01; P[4] = 0.01 * 0.01; P[8] = 0.005 * 0.005;   // ekf.cpp:11-14
-    x[0] = p.x0; x[1] = p.y0; x[2] = p.yaw0;                         // ekf.cpp:31 (float arguments)
+    ST* P = static_cast<ST*>(p.P) + (size_t)b * p.pstride;
+    ST* x = static_cast<ST*>(p.x) + (size_t)b * p.xstride;
+    for (int i = 0; i < 9; ++i) P[i] = (ST)0;
+    P[0] = (ST)(0.01 * 0.01); P[4] = (ST)(0.01 * 0.01); P[8] = (ST)(0.005 * 0.005);   // ekf.cpp:11-14
+    x[0] = (ST)p.x0; x[1] = (ST)p.y0; x[2] = (ST)p.yaw0;                             // ekf.cpp:31 (float arguments)
     p.M[b] = 0; p.flags[b] = 0; p.timestep[b] = 0;
     p.truth[3 * (size_t)b] = p.tx; p.truth[3 * (size_t)b + 1] = p.ty; p.truth[3 * (size_t)b + 2] = p.tyaw;
     p.err_sum[b] = 0.0;
 }
 hipError_t launch_ekf_init(const EkfInitParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(ekf_init_kernel, dim3((p.B + 255) / 256), dim3(256), 0, stream, p);
+    if (p.f32_storage) hipLaunchKernelGGL(ekf_init_kernel<float>, dim3((p.B + 255) / 256), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ekf_init_kernel<double>, dim3((p.B + 255) / 256), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -24,6 +24,8 @@
 #pragma once
 #include "ekf_kernel.h"
 
+#include <type_traits>
+
 #include "../../include/slam_batch.h"
 #include "slam_math.h"
 #include "slam_rng.h"
@@ -79,21 +81,25 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
 
 // The P stream is touched once per step: mark it non-temporal so it does not evict the thin-gather sectors (which
 // the stream re-reads a few microseconds later) or other workgroups' lines from L2.
+// Storage type ST of x and P in HBM: double (SLAM_F64) or float (SLAM_F32; arithmetic stays fp64, values are
+// rounded to float when they are written back).  One 16-byte vector holds VEC = 2 doubles or 4 floats.
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 nt_load(const double2* ptr) {
-    const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(ptr));
-    return make_double2(t.x, t.y);
-}
-__device__ __forceinline__ void nt_store(double2* ptr, double x, double y) {
-    dbl2_t t; t.x = x; t.y = y;
-    __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t*>(ptr));
-}
+typedef float flt4_t __attribute__((ext_vector_type(4)));
+template <class ST> struct Vec16;
+template <> struct Vec16<double> {
+    static constexpr int VEC = 2;
+    typedef dbl2_t type;
+};
+template <> struct Vec16<float> {
+    static constexpr int VEC = 4;
+    typedef flt4_t type;
+};
 
 __device__ __forceinline__ unsigned hi_abs(double v) {
     return (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu;
 }
 
-template <int NMAX, int W, int KG_, int UNR_>
+template <int NMAX, int W, int KG_, int UNR_, class ST>
 __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(const EkfStepParams p) {
     using G = EkfGeom<NMAX, W, KG_, UNR_>;
     constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, TS = G::TS, UNR = G::UNR;
@@ -124,16 +130,20 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     const bool prof_on = (p.dbg & 4) && p.prof != nullptr;
     unsigned long long tprev = prof_on ? __builtin_readcyclecounter() : 0ull;
     // ---- prologue: every load that does not depend on another load is issued up front (one HBM round trip) ----
-    const double* __restrict__ Pin = p.P + (size_t)b * p.pstride;
-    double* __restrict__ Pout = p.P_out + (size_t)b * p.pstride;
-    double* __restrict__ xb = p.x + (size_t)b * p.xstride;
+    constexpr int VEC = Vec16<ST>::VEC;
+    typedef typename Vec16<ST>::type VT;
+    const ST* __restrict__ Pin = static_cast<const ST*>(p.P) + (size_t)b * p.pstride;
+    ST* __restrict__ Pout = static_cast<ST*>(p.P_out) + (size_t)b * p.pstride;
+    ST* __restrict__ xb = static_cast<ST*>(p.x) + (size_t)b * p.xstride;
+    constexpr bool kWide = sizeof(ST) == 8;   // fp64 storage: intermediate results can live in P_out itself
+    double* __restrict__ Pmid = kWide ? reinterpret_cast<double*>(Pout) : (p.scratch + (size_t)b * p.pstride);
     int flags = p.flags[b];
     const int M_old = p.M[b];
     double xpre[(LDP + TPB - 1) / TPB];
 #pragma unroll
     for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
         const int i = tid + TPB * u;
-        xpre[u] = (i < p.xstride && i < LDP) ? xb[i] : 0.0;   // beyond n_old the slab holds stale values: masked below
+        xpre[u] = (i < p.xstride && i < LDP) ? (double)xb[i] : 0.0;   // beyond n_old the slab holds stale values: masked below
     }
     const int idpre = (tid < p.L_max) ? p.ids[(size_t)b * p.L_max + tid] : 0;
     double tx = 0.0, ty = 0.0, tth = 0.0, lmx = 0.0, lmy = 0.0;
@@ -268,11 +278,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     bool first = true;
     unsigned hiacc = 0u; // non-finite detector (max of |hi word|)
     while (first || l0 < k) {
-        // source of this group's P: the old buffer (leading dimension n_old) for the first group, afterwards the
-        // matrix written by the previous group's bulk pass (leading dimension nf), updated in place
-        const double* src = first ? Pin : Pout;
-        const int lds = first ? n_old : nf;   // leading dimension of src
-        const int nsrc = first ? n_old : na;  // rows/cols of src that hold data
+        // Source of this group's P: the old buffer (leading dimension n_old) for the first group; afterwards the
+        // matrix written by the previous group's bulk pass (leading dimension nf).  Intermediate results between
+        // groups stay in fp64: for fp32 storage they live in a per-instance fp64 scratch slab, so storage rounding
+        // happens exactly once per step (when the last group writes P_out).
+        const int lds = first ? n_old : nf;   // leading dimension of the source
+        const int nsrc = first ? n_old : na;  // rows/cols of the source that hold data
 
         // ---- form the group: thread 0 decides, everybody reads ----
         __syncthreads();
@@ -341,6 +352,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         // ---- thin gather: HBM -> LDS.  Rows are contiguous, columns are strided 8-byte loads.  All loads of a
         //      lane are issued before the first LDS store so their latencies overlap. ----
         {
+            const bool src_mid = !first;
+            const ST* srcS = (kWide && src_mid) ? reinterpret_cast<const ST*>(Pmid) : Pin;
             constexpr int GI = (TS * LDP + TPB - 1) / TPB;
             double rv[GI], cv[GI];
 #pragma unroll
@@ -351,8 +364,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     const int sl = i / LDP, j = i - sl * LDP;
                     const int t_s = s_T[sl];
                     if (j < nsrc && t_s < nsrc) {
-                        rv[u] = src[(size_t)t_s * lds + j];   // P[t_s][j]
-                        cv[u] = src[(size_t)j * lds + t_s];   // P[j][t_s]
+                        if (!kWide && src_mid) {
+                            rv[u] = Pmid[(size_t)t_s * lds + j];
+                            cv[u] = Pmid[(size_t)j * lds + t_s];
+                        } else {
+                            rv[u] = (double)srcS[(size_t)t_s * lds + j];   // P[t_s][j]
+                            cv[u] = (double)srcS[(size_t)j * lds + t_s];   // P[j][t_s]
+                        }
                     }
                 }
             }
@@ -575,16 +593,18 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
 
         SLAM_STAMP(6);   // detections
-        // ---- BULK: stream P once.  dst pair q = (elements 2q, 2q+1 of the nf-leading-dimension layout). ----
-        {
+        // ---- BULK (fp64 storage): stream P once.  dst pair q = elements 2q, 2q+1 of the nf-leading-dimension
+        //      layout; later groups of the same step update P_out in place. ----
+        if constexpr (kWide) {
+            const double* src = first ? reinterpret_cast<const double*>(Pin) : reinterpret_cast<const double*>(Pout);
             const int nn2 = nf * nf;
             const int npair = (nn2 + 1) >> 1;
             const bool same_layout = (lds == nf);
             const int rs = (2 * TPB) / nf, cs = (2 * TPB) - rs * nf;   // (r, c) step between a lane's pairs
             int r = (2 * tid) / nf;
             int c = 2 * tid - r * nf;
-            double2* dst2 = reinterpret_cast<double2*>(Pout);
-            const double2* src2 = reinterpret_cast<const double2*>(src);
+            dbl2_t* dst2 = reinterpret_cast<dbl2_t*>(Pout);
+            const dbl2_t* src2 = reinterpret_cast<const dbl2_t*>(src);
 #pragma unroll 1
             for (int q0 = tid; q0 < ((p.dbg & 1) ? 0 : npair); q0 += UNR * TPB) {
                 double2 v[UNR];
@@ -596,7 +616,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     v[u] = make_double2(0.0, 0.0);
                     if (q < npair) {
                         if (same_layout) {
-                            v[u] = (p.dbg & 8) ? src2[q] : nt_load(src2 + q);
+                            const dbl2_t t = (p.dbg & 8) ? src2[q] : __builtin_nontemporal_load(src2 + q);
+                            v[u] = make_double2(t.x, t.y);
                         } else {  // re-lay-out from leading dimension lds to nf (steps that grow the state)
                             int c1 = c + 1, r1 = r;
                             if (c1 == nf) { c1 = 0; r1 = r + 1; }
@@ -632,7 +653,88 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         const unsigned h0a = hi_abs(vx), h1a = hi_abs(vy);
                         hiacc = hiacc > h0a ? hiacc : h0a;
                         hiacc = hiacc > h1a ? hiacc : h1a;
-                        if (p.dbg & 8) dst2[q] = make_double2(vx, vy); else nt_store(dst2 + q, vx, vy);
+                        dbl2_t o; o.x = vx; o.y = vy;
+                        if (p.dbg & 8) dst2[q] = o; else __builtin_nontemporal_store(o, dst2 + q);
+                    }
+                }
+            }
+        }
+        // ---- BULK (fp32 storage): a lane's 16-byte vector q holds elements 4q .. 4q+3.  Common case (one group):
+        //      vector loads from P, vector stores to P_out with storage rounding.  With several groups in one step
+        //      the intermediate matrix stays fp64 in the scratch slab (element-wise access), so rounding to float
+        //      happens exactly once per step. ----
+        if constexpr (!kWide) {
+            const bool src_mid = !first;            // read the previous group's result (fp64 scratch)
+            const bool dst_mid = (l1 < k);          // more groups follow: keep fp64
+            const int nn2 = nf * nf;
+            const int nvec = (nn2 + VEC - 1) / VEC;
+            const bool vec_load = !src_mid && (lds == nf);
+            const int rs = (VEC * TPB) / nf, cs = (VEC * TPB) - rs * nf;   // (r, c) step between a lane's vectors
+            int r = (VEC * tid) / nf;
+            int c = VEC * tid - r * nf;
+            VT* dst2 = reinterpret_cast<VT*>(Pout);
+            const VT* src2 = reinterpret_cast<const VT*>(Pin);
+#pragma unroll 1
+            for (int q0 = tid; q0 < ((p.dbg & 1) ? 0 : nvec); q0 += UNR * TPB) {
+                double v[UNR][VEC];
+                int rr[UNR], cc[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {   // issue the loads of UNR vectors first
+                    const int q = q0 + u * TPB;
+                    rr[u] = r; cc[u] = c;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[u][e] = 0.0;
+                    if (q < nvec) {
+                        if (vec_load) {
+                            const VT t = __builtin_nontemporal_load(src2 + q);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) v[u][e] = (double)t[e];
+                        } else {  // other leading dimension (the state grows this step) or fp64 intermediate
+                            int re = r, ce = c;
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                if (re < nsrc && ce < nsrc)
+                                    v[u][e] = src_mid ? Pmid[(size_t)re * lds + ce] : (double)Pin[(size_t)re * lds + ce];
+                                ce += 1;
+                                if (ce == nf) { ce = 0; re += 1; }
+                            }
+                        }
+                    }
+                    c += cs; r += rs;
+                    if (c >= nf) { c -= nf; r += 1; }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int q = q0 + u * TPB;
+                    if (q < nvec) {
+                        int re = rr[u], ce = cc[u];
+                        VT outv;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            double val = v[u][e];
+#pragma unroll
+                            for (int w = 0; w < KG; ++w) {
+                                if (w >= nu) break;  // wave-uniform
+                                const double2 kk = s_K[w * LDP + re];
+                                const double2 hh = s_HP[w * LDP + ce];
+                                val = val - (kk.x * hh.x + kk.y * hh.y);
+                            }
+                            const int sr = s_slot[re], sc = s_slot[ce];
+                            if (sc >= 0) val = s_C[sc * LDP + re];
+                            if (sr >= 0) val = s_R[sr * LDP + ce];
+                            if (VEC * q + e >= nn2) val = 0.0;   // don't-care elements pad the last vector
+                            if (!dst_mid) {
+                                const ST stored = (ST)val;       // storage rounding
+                                const unsigned ha = hi_abs((double)stored);
+                                hiacc = hiacc > ha ? hiacc : ha;
+                                outv[e] = stored;
+                            } else if (VEC * q + e < nn2) {
+                                Pmid[(size_t)VEC * q + e] = val; // fp64 intermediate
+                            }
+                            ce += 1;
+                            if (ce == nf) { ce = 0; re += 1; }
+                        }
+                        if (!dst_mid) __builtin_nontemporal_store(outv, dst2 + q);
                     }
                 }
             }
@@ -647,9 +749,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // x_t = x_pred (ekf.cpp:176) and bookkeeping.  P_t = P_pred was written by the bulk stream.
     // ------------------------------------------------------------------------------------------------------
     for (int i = tid; i < na; i += TPB) {
-        const double v = s_xp[i];
-        xb[i] = v;
-        const unsigned h0 = hi_abs(v);
+        const ST sv = (ST)s_xp[i];   // storage rounding of x_t (identity for fp64)
+        xb[i] = sv;
+        const unsigned h0 = hi_abs((double)sv);
         hiacc = hiacc > h0 ? hiacc : h0;
     }
     const bool nonfinite = __syncthreads_or(hiacc >= 0x7ff00000u);
@@ -661,11 +763,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         // na in place.  Rows move towards lower addresses, so go row by row with a barrier in between.
 #pragma unroll 1
         for (int r = 1; r < na; ++r) {
-            double tmp[(LDP + TPB - 1) / TPB];
+            ST tmp[(LDP + TPB - 1) / TPB];
 #pragma unroll
             for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
                 const int c = tid + TPB * u;
-                tmp[u] = c < na ? Pout[(size_t)r * nf + c] : 0.0;
+                tmp[u] = c < na ? Pout[(size_t)r * nf + c] : (ST)0;
             }
             __syncthreads();
 #pragma unroll
@@ -691,9 +793,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     }
 }
 
-template <int NMAX, int W, int KG_, int UNR_>
+template <int NMAX, int W, int KG_, int UNR_, class ST>
 hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_>), dim3(p.B), dim3(64 * W), 0, stream, p);
+    hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST>), dim3(p.B), dim3(64 * W), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -54,8 +54,10 @@ struct slam_handle {
     uint32_t step = 0;
     double range_max, fov_min, fov_max;
     // device buffers
-    double* dP = nullptr; double* dP2 = nullptr;   // dP = current P_t, dP2 = next (ping-pong)
-    double* dx = nullptr; int32_t* dM = nullptr; int32_t* dids = nullptr;
+    void* dP = nullptr; void* dP2 = nullptr;   // dP = current P_t, dP2 = next (ping-pong); fp64 or fp32 elements
+    void* dx = nullptr; int esz = 8;           // x_t; element size of P / x storage
+    double* dscratch = nullptr;                // fp32 storage: fp64 slab for P between detection groups
+    int32_t* dM = nullptr; int32_t* dids = nullptr;
     int32_t* dflags = nullptr; int32_t* dts = nullptr; double* dtruth = nullptr; double* derr = nullptr;
     double* dmap = nullptr; int L = 0;
     float* dmeas = nullptr; int32_t* dcount = nullptr; int k_stride = 0;   // staging / last-measurement dump
@@ -70,7 +72,7 @@ namespace {
 
 void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     memset(&p, 0, sizeof(p));
-    p.P = h->dP; p.P_out = h->dP2; p.x = h->dx; p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
+    p.P = h->dP; p.P_out = h->dP2; p.x = h->dx; p.scratch = h->dscratch; p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
     p.truth = h->dtruth; p.err_sum = h->derr; p.map = h->dmap; p.L = h->L;
     p.fwd = cmd[0]; p.ang = cmd[1];
     const slam_config& c = h->cfg;
@@ -93,7 +95,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
 
 void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2]) {
     memset(&p, 0, sizeof(p));
-    p.P = h->dP; p.P_out = h->dP2; p.x = h->dx; p.sqtP = h->dsq; p.n_sq = h->dnsq;
+    p.P = (const double*)h->dP; p.P_out = (double*)h->dP2; p.x = (double*)h->dx; p.sqtP = h->dsq; p.n_sq = h->dnsq;
     p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
     p.truth = h->dtruth; p.err_sum = h->derr; p.map = h->dmap; p.L = h->L;
     p.fwd = cmd[0]; p.ang = cmd[1];
@@ -117,7 +119,7 @@ int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas
         p.sim = sim;
         p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
         if (sim && h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
-        HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->stream));
+        HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
     } else {
         slam::UkfStepParams p;
         fill_ukf_params(h, p, cmd);
@@ -222,15 +224,17 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (batch <= 0 || L_max <= 0) return fail(SLAM_ERR_ARG, "batch and L_max must be positive");
     if (kind != SLAM_EKF_SLAM && kind != SLAM_UKF_SLAM)
         return fail(SLAM_ERR_UNSUPPORTED, "filter kind %d not available in this build (EKF_SLAM, UKF_SLAM)", kind);
-    if (dtype != SLAM_F64) return fail(SLAM_ERR_UNSUPPORTED, "only fp64 state storage is implemented");
+    if (dtype != SLAM_F64 && !(dtype == SLAM_F32 && kind == SLAM_EKF_SLAM))
+        return fail(SLAM_ERR_UNSUPPORTED, "fp32 state storage is implemented for EKF_SLAM only");
     if (L_max > (kind == SLAM_UKF_SLAM ? slam::kUkfMaxLandmarks : slam::kEkfMaxLandmarks))
         return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the register-resident kernel limit %d", L_max, slam::kEkfMaxLandmarks);
     HIP_TRY(hipSetDevice(device));
     slam_handle* h = new slam_handle();
     h->cfg = *cfg; h->kind = kind; h->B = batch; h->L_max = L_max; h->dtype = dtype; h->device = device;
+    h->esz = dtype == SLAM_F32 ? 4 : 8;
     h->base = (kind == SLAM_UKF_SLAM) ? 4 : 3;
     h->n_max = h->base + 2 * L_max;
-    h->pstride = round_up(h->n_max * h->n_max + 1, 32);   // 256-byte aligned per-filter slab
+    h->pstride = round_up(h->n_max * h->n_max + 4, 64);   // per-filter slab: 256/512-byte aligned, room for vector tails
     h->xstride = round_up(h->n_max + 1, 2);
     h->range_max = cfg->range_max; h->fov_min = cfg->fov_min; h->fov_max = cfg->fov_max;
     const char* env = getenv("SLAM_WAVES_PER_FILTER");
@@ -242,9 +246,9 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     h->own_stream = true;
     const size_t B = (size_t)batch;
     hipError_t errs[] = {
-        hipMalloc(&h->dP, sizeof(double) * B * h->pstride),
-        hipMalloc(&h->dP2, sizeof(double) * B * h->pstride),
-        hipMalloc(&h->dx, sizeof(double) * B * h->xstride),
+        hipMalloc(&h->dP, (size_t)h->esz * B * h->pstride),
+        hipMalloc(&h->dP2, (size_t)h->esz * B * h->pstride),
+        hipMalloc(&h->dx, (size_t)h->esz * B * h->xstride),
         hipMalloc(&h->dM, sizeof(int32_t) * B),
         hipMalloc(&h->dids, sizeof(int32_t) * B * L_max),
         hipMalloc(&h->dflags, sizeof(int32_t) * B),
@@ -254,6 +258,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMalloc(&h->dscalar, sizeof(double) * 4),
         hipMalloc(&h->dprof, sizeof(unsigned long long) * 16 * B),
         kind == SLAM_UKF_SLAM ? hipMalloc(&h->dsq, sizeof(double) * B * h->pstride) : hipSuccess,
+        h->esz == 4 ? hipMalloc(&h->dscratch, sizeof(double) * B * h->pstride) : hipSuccess,
         kind == SLAM_UKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
     };
     for (hipError_t ee : errs)
@@ -261,9 +266,9 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
             slam_destroy(h);
             return fail(SLAM_ERR_HIP, "hipMalloc -> %s", hipGetErrorString(ee));
         }
-    HIP_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * B * h->pstride, h->stream));
-    HIP_TRY(hipMemsetAsync(h->dP2, 0, sizeof(double) * B * h->pstride, h->stream));
-    HIP_TRY(hipMemsetAsync(h->dx, 0, sizeof(double) * B * h->xstride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dP, 0, (size_t)h->esz * B * h->pstride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dP2, 0, (size_t)h->esz * B * h->pstride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dx, 0, (size_t)h->esz * B * h->xstride, h->stream));
     HIP_TRY(hipMemsetAsync(h->dids, 0, sizeof(int32_t) * B * L_max, h->stream));
     HIP_TRY(hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * 16 * B, h->stream));
     *out = h;
@@ -274,7 +279,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -304,14 +309,14 @@ int slam_init(slam_handle* h, float x0, float y0, float yaw0) {
     if (h->kind == SLAM_EKF_SLAM) {
         slam::EkfInitParams p;
         p.P = h->dP; p.x = h->dx; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
-        p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride;
+        p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride; p.f32_storage = h->esz == 4;
         p.x0 = x0; p.y0 = y0; p.yaw0 = yaw0;
         // the simulator starts from the un-rounded YAML pose (sim_node.py:361); the filter gets float args
         p.tx = h->cfg.init_x; p.ty = h->cfg.init_y; p.tyaw = h->cfg.init_yaw;
         HIP_TRY(slam::launch_ekf_init(p, h->stream));
     } else {
         slam::UkfInitParams p;
-        p.P = h->dP; p.x = h->dx; p.n_sq = h->dnsq; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
+        p.P = (double*)h->dP; p.x = (double*)h->dx; p.n_sq = h->dnsq; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
         p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride;
         double s, c;   // x_t << x_0, y_0, cos(yaw_0), sin(yaw_0) with a float argument (ukf.cpp:33)
         slam::det_sincos((double)yaw0, &s, &c);
@@ -379,6 +384,18 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
 int slam_predict(slam_handle*, const float*) { return fail(SLAM_ERR_UNSUPPORTED, "separate predictionStage/updateStage entry points (filter.h:187-188) are not in this build; slam_step runs both"); }
 int slam_update_dev(slam_handle*, const float*, const int32_t*, int) { return fail(SLAM_ERR_UNSUPPORTED, "separate predictionStage/updateStage entry points (filter.h:187-188) are not in this build; slam_step runs both"); }
 
+// device -> host copy of `count` stored elements, widened to double when the storage type is fp32
+static int fetch_elems(slam_handle* h, double* dst, const void* dbase, size_t elem_offset, size_t count) {
+    if (h->esz == 8) {
+        HIP_TRY(hipMemcpy(dst, (const char*)dbase + elem_offset * 8, count * 8, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(count);
+        HIP_TRY(hipMemcpy(tmp.data(), (const char*)dbase + elem_offset * 4, count * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < count; ++i) dst[i] = (double)tmp[i];
+    }
+    return SLAM_OK;
+}
+
 int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, int32_t* ids, int32_t* ts) {
     if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
     HIP_TRY(hipSetDevice(h->device));
@@ -387,8 +404,9 @@ int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, i
     HIP_TRY(hipMemcpy(&m, h->dM + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
     const int n = h->base + 2 * m;
     if (M) *M = m;
-    if (x) HIP_TRY(hipMemcpy(x, h->dx + (size_t)inst * h->xstride, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (P) HIP_TRY(hipMemcpy(P, h->dP + (size_t)inst * h->pstride, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+    int rc;
+    if (x && (rc = fetch_elems(h, x, h->dx, (size_t)inst * h->xstride, n))) return rc;
+    if (P && (rc = fetch_elems(h, P, h->dP, (size_t)inst * h->pstride, (size_t)n * n))) return rc;
     if (ids && m > 0) HIP_TRY(hipMemcpy(ids, h->dids + (size_t)inst * h->L_max, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
     if (ts) HIP_TRY(hipMemcpy(ts, h->dts + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
     return SLAM_OK;
@@ -398,7 +416,13 @@ int slam_get_poses(slam_handle* h, double* poses) {
     if (!h || !poses) return fail(SLAM_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy2D(poses, sizeof(double) * 3, h->dx, sizeof(double) * h->xstride, sizeof(double) * 3, h->B, hipMemcpyDeviceToHost));
+    if (h->esz == 8) {
+        HIP_TRY(hipMemcpy2D(poses, sizeof(double) * 3, h->dx, sizeof(double) * h->xstride, sizeof(double) * 3, h->B, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp((size_t)3 * h->B);
+        HIP_TRY(hipMemcpy2D(tmp.data(), sizeof(float) * 3, h->dx, sizeof(float) * h->xstride, sizeof(float) * 3, h->B, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) poses[i] = (double)tmp[i];
+    }
     return SLAM_OK;
 }
 
@@ -457,7 +481,7 @@ int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
     if (!h || !bytes) return fail(SLAM_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->dscalar, 0, sizeof(double), h->stream));
-    HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->base, h->dscalar, h->stream));
+    HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->base, h->esz, h->dscalar, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(bytes, h->dscalar, sizeof(double), hipMemcpyDeviceToHost));
     return SLAM_OK;

@@ -12,6 +12,7 @@ from live_ekf_slam_amd.config import SlamConfig, default_config  # noqa: F401  (
 HERE = os.path.dirname(os.path.abspath(__file__))
 MATH_LIBM, MATH_DET = 0, 1
 MODE_FAST, MODE_DENSE = 0, 1
+STORAGE_F32 = 2   # OR into `mode`: x_t / P_t rounded to float whenever stored (SLAM_F32)
 _lib = None
 
 _dp = C.POINTER(C.c_double)

@@ -58,8 +58,15 @@ struct Ekf {
 
     int n() const { return 3 + 2 * M; }
 
-    Ekf(const slam_config& c, int Lm, int mth, int md) : cfg(c), nz(effective_noise(c)), L_max(Lm), math(mth), mode(md) {
+    bool storage_f32 = false;   // SLAM_F32: x_t and P_t are rounded to float whenever they are stored
+    Ekf(const slam_config& c, int Lm, int mth, int md) : cfg(c), nz(effective_noise(c)), L_max(Lm), math(mth), mode(md & 1) {
+        storage_f32 = (md & 2) != 0;
         reset_ctor();
+    }
+    void round_storage() {
+        if (!storage_f32) return;
+        for (double& v : x_t) v = (double)(float)v;
+        for (double& v : P_t) v = (double)(float)v;
     }
     void reset_ctor() {  // EKF::EKF ekf.cpp:4-21
         timestep = 0; M = 0; flags = 0; frozen = false; ids.clear();
@@ -71,6 +78,7 @@ struct Ekf {
     void init(float x0, float y0, float yaw0) {  // ekf.cpp:29-34
         reset_ctor();
         x_t[0] = x0; x_t[1] = y0; x_t[2] = yaw0;
+        round_storage();
     }
 
     template <class MP> int update_t(float fwd, float ang, const float* meas, int k);
@@ -270,6 +278,7 @@ int Ekf::update_t(float fwd, float ang, const float* meas, int k) {
     if (mode == MODE_DENSE) predict_dense<MP>(d_d, d_th); else predict_fast<MP>(d_d, d_th);
     if (k < 1) {                                     // ekf.cpp:67-71
         x_t = x_pred; P_t = P_pred;
+        round_storage();
         return flags;
     }
     for (int l = 0; l < k; ++l) {                    // ekf.cpp:73
@@ -324,6 +333,7 @@ int Ekf::update_t(float fwd, float ang, const float* meas, int k) {
         }
     }
     x_t = x_pred; P_t = P_pred;                      // ekf.cpp:176-177
+    round_storage();
     bool fin = true;
     for (double v : x_t) fin = fin && std::isfinite(v);
     for (double v : P_t) fin = fin && std::isfinite(v);
