@@ -49,8 +49,10 @@ struct EkfStepParams {
     int32_t dbg;  // timing experiments only (env SLAM_DEBUG_FLAGS): 1 = skip bulk stream, 2 = skip detections, 4 = phase timers
 };
 
-// Largest landmark capacity of the instantiated variants (n = 3+2L <= 103; the limit is LDS, not registers).
-static constexpr int kEkfMaxLandmarks = 50;
+// Largest landmark capacity of the instantiated variants (n = 3+2L <= 203; the limit is LDS, not registers).
+// fp32 storage is instantiated up to 50 landmarks.
+static constexpr int kEkfMaxLandmarks = 100;
+static constexpr int kEkfMaxLandmarksF32 = 50;
 
 // waves_per_filter: 0 = let the library pick; 2, 4 or 8 otherwise.
 hipError_t launch_ekf_step(const EkfStepParams& p, int waves_per_filter, int f32_storage, hipStream_t stream);

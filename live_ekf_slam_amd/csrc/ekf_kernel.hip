@@ -23,6 +23,7 @@ extern template hipError_t launch_variant<43, 4, 4, 4, double>(const EkfStepPara
 extern template hipError_t launch_variant<43, 1, 4, 8, double>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<43, 2, 4, 8, double>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<103, 4, 4, 4, float>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<203, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<43, 2, 4, 4, float>(const EkfStepParams&, hipStream_t);
 
 // NMAX only sizes the LDS arrays (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103).  `wpf` selects a tuning
@@ -59,6 +60,7 @@ hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, int f32_storage, hip
             default: return launch_variant<103, 4, 4, 4, double>(p, stream);
         }
     }
+    if (nmax <= 203) return launch_variant<203, 4, 4, 4, double>(p, stream);   // L_max <= 100: only the LDS arrays grow
     return hipErrorInvalidValue;
 }
 

@@ -38,7 +38,7 @@ struct EkfGeom {
     static constexpr int TPB = 64 * W;
     static constexpr int LDP = (NMAX + 2) & ~1;          // LDS row length (> NMAX, even)
     static constexpr int LMAX = (NMAX - 3) / 2;
-    static constexpr int KCAP = LMAX > 0 ? LMAX : 1;     // detections held per step
+    static constexpr int KCAP = LMAX > 64 ? 64 : (LMAX > 0 ? LMAX : 1);   // detections held per step (one wavefront associates them)
     static constexpr int KG = KG_;                       // detections per group
     static constexpr int TS = 3 + 2 * KG;                // thin rows / cols held in LDS
     static constexpr int UNR = UNR_;                     // register pairs in flight per lane in the bulk stream
@@ -185,14 +185,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     } else {
         int kk = p.meas_count_in[b];
         kk = kk < p.k_stride_in ? kk : p.k_stride_in;
-        kk = kk < KCAP ? kk : KCAP;
         kk = kk < 0 ? 0 : kk;
-        for (int i = tid; i < 3 * kk; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
+        const int kc = kk < KCAP ? kk : KCAP;
+        for (int i = tid; i < 3 * kc; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
         if (tid == 0) s_misc[0] = kk;
     }
     __syncthreads();
     SLAM_STAMP(1);   // measurement generation / fetch
-    const int k = s_misc[0];
+    if (s_misc[0] > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than one wavefront associates
+    const int k = s_misc[0] < KCAP ? s_misc[0] : KCAP;
     if (p.sim && p.meas_out != nullptr) {
         for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB)
             p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = s_meas[i];

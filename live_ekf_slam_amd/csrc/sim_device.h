@@ -10,7 +10,7 @@ namespace slam {
 // (seed, inst0, step, fwd, ang, sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max, map, L, truth).
 // tx, ty, tth: the instance's true pose (prefetched), advanced in place; lmx, lmy: prefetched map entry of id = lane.
 // Writes the [id, range, bearing] float32 triplets of the visible landmarks (ascending id) to s_meas and their
-// count (capped at KCAP) to *s_count; lane 0 stores the new truth pose.
+// count to *s_count (triplets beyond KCAP are not stored; the caller caps and flags); lane 0 stores the new truth pose.
 template <int KCAP, class P>
 __device__ __forceinline__ void sim_wave(const P& p, int b, int lane, double& tx, double& ty, double& tth, double lmx,
                                          double lmy, float* s_meas, int* s_count) {
@@ -56,7 +56,7 @@ __device__ __forceinline__ void sim_wave(const P& p, int b, int lane, double& tx
         count += __popcll(mask);
     }
     if (lane == 0) {
-        *s_count = count < KCAP ? count : KCAP;
+        *s_count = count;   // the caller caps at KCAP and flags the overflow
         p.truth[3 * (size_t)b] = tx;
         p.truth[3 * (size_t)b + 1] = ty;
         p.truth[3 * (size_t)b + 2] = tth;

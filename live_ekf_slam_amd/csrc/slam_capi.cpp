@@ -226,7 +226,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         return fail(SLAM_ERR_UNSUPPORTED, "filter kind %d not available in this build (EKF_SLAM, UKF_SLAM)", kind);
     if (dtype != SLAM_F64 && !(dtype == SLAM_F32 && kind == SLAM_EKF_SLAM))
         return fail(SLAM_ERR_UNSUPPORTED, "fp32 state storage is implemented for EKF_SLAM only");
-    if (L_max > (kind == SLAM_UKF_SLAM ? slam::kUkfMaxLandmarks : slam::kEkfMaxLandmarks))
+    if (L_max > (kind == SLAM_UKF_SLAM ? slam::kUkfMaxLandmarks : (dtype == SLAM_F32 ? slam::kEkfMaxLandmarksF32 : slam::kEkfMaxLandmarks)))
         return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the register-resident kernel limit %d", L_max, slam::kEkfMaxLandmarks);
     HIP_TRY(hipSetDevice(device));
     slam_handle* h = new slam_handle();

@@ -278,13 +278,14 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     } else {
         int kk = p.meas_count_in[b];
         kk = kk < p.k_stride_in ? kk : p.k_stride_in;
-        kk = kk < KCAP ? kk : KCAP;
         kk = kk < 0 ? 0 : kk;
-        for (int i = tid; i < 3 * kk; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
+        const int kc = kk < KCAP ? kk : KCAP;
+        for (int i = tid; i < 3 * kc; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
         if (tid == 0) s_misc[0] = kk;
     }
     __syncthreads();
-    const int k = s_misc[0];
+    if (s_misc[0] > KCAP) flags |= SLAM_INST_CAPACITY;
+    const int k = s_misc[0] < KCAP ? s_misc[0] : KCAP;
     if (p.sim && p.meas_out != nullptr) {
         for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB) p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = s_meas[i];
         if (tid == 0) p.meas_count_out[b] = k;

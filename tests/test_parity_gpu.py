@@ -258,3 +258,23 @@ def test_fp32_storage_variant(S, oracle, L, T, B):
     assert np.abs(r64["x"] - r["x"]).max() < 5e-3 and abs(r64["avg_err"].mean() - r["avg_err"].mean()) < 1e-3
     assert abs(f.algorithmic_bytes() - sum(2 * ((3 + 2 * m) ** 2 + 3 + 2 * m) * 4 for m in r["M"])) < 1
     f.close()
+
+
+def test_large_state_100_landmarks(S, oracle):
+    """n = 203 (L = 100): the streaming kernel has no register-imposed limit on n; only the LDS arrays grow."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 100, 120, 12
+    lm, cmds = make_scenario(77, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1))
+    for t in (2, 30, 60, 90, 110):
+        vis[t] = [7.5, -3.2, 3.2]       # wide looks: many insertions / updates per step, but <= 64 detections
+    f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(4); f.init(0, 0, 0)
+    for t in range(T):
+        f.set_vision(*vis[t]); f.update_sim(cmds[t])
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=4, nthreads=4, vision=vis)
+    assert np.array_equal(f.landmark_counts(), r["M"]) and r["M"].max() > 50
+    assert np.array_equal(f.status(), r["flags"])
+    for b in range(B):
+        n = 3 + 2 * r["M"][b]
+        _assert_state_equal(f.get_state(b), dict(M=r["M"][b], ids=r["ids"][b, :r["M"][b]], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    f.close()
