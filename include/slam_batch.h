@@ -86,7 +86,9 @@ int slam_config_load(slam_config* cfg, const char* yaml_path);
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
 /* Replaces the filter factory `std::make_unique<EKF|UKF>()` + `filter->readParams(config)`
- * (localization_node.cpp:33-47).  batch = number of instances on THIS device, L_max = landmark capacity. */
+ * (localization_node.cpp:33-47).  batch = number of instances on THIS device, L_max = landmark capacity
+ * (EKF_SLAM: <= 100 in fp64, <= 50 in fp32 storage; UKF_SLAM: <= 50; UKF_LOC: ignored, the state holds no landmarks).
+ * dtype SLAM_F32 (fp32 storage of x and P, fp64 arithmetic) is available for EKF_SLAM. */
 int slam_create(const slam_config* cfg, int filter_kind, int batch, int L_max, int dtype, int device,
                 slam_handle** out);
 int slam_destroy(slam_handle* h);

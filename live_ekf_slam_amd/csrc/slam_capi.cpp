@@ -64,6 +64,7 @@ struct slam_handle {
     double* dscalar = nullptr;
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
+    float* dmapf = nullptr;                           // UKF_LOC: the known map as float32 [id, x, y] triplets
     int base = 3;                                     // state offset of the first landmark: 3 (EKF) or 4 (UKF)
     bool dump_meas = false;
 };
@@ -109,6 +110,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.range_max = h->range_max; p.fov_min = h->fov_min; p.fov_max = h->fov_max;
     p.seed = h->seed; p.inst0 = h->inst0; p.step = h->step;
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
+    p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
 }
 
 // one timestep, either filter kind; `sim` = device-side measurement generator
@@ -222,17 +224,18 @@ int slam_config_load(slam_config* c, const char* path) {
 int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtype, int device, slam_handle** out) {
     if (!cfg || !out) return fail(SLAM_ERR_ARG, "NULL argument");
     if (batch <= 0 || L_max <= 0) return fail(SLAM_ERR_ARG, "batch and L_max must be positive");
-    if (kind != SLAM_EKF_SLAM && kind != SLAM_UKF_SLAM)
-        return fail(SLAM_ERR_UNSUPPORTED, "filter kind %d not available in this build (EKF_SLAM, UKF_SLAM)", kind);
+    if (kind != SLAM_EKF_SLAM && kind != SLAM_UKF_SLAM && kind != SLAM_UKF_LOC)
+        return fail(SLAM_ERR_ARG, "unknown filter kind %d", kind);
+    if (kind == SLAM_UKF_LOC) L_max = 1;   // localisation only: the state never holds landmarks
     if (dtype != SLAM_F64 && !(dtype == SLAM_F32 && kind == SLAM_EKF_SLAM))
         return fail(SLAM_ERR_UNSUPPORTED, "fp32 state storage is implemented for EKF_SLAM only");
-    if (L_max > (kind == SLAM_UKF_SLAM ? slam::kUkfMaxLandmarks : (dtype == SLAM_F32 ? slam::kEkfMaxLandmarksF32 : slam::kEkfMaxLandmarks)))
+    if (L_max > (kind != SLAM_EKF_SLAM ? slam::kUkfMaxLandmarks : (dtype == SLAM_F32 ? slam::kEkfMaxLandmarksF32 : slam::kEkfMaxLandmarks)))
         return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the register-resident kernel limit %d", L_max, slam::kEkfMaxLandmarks);
     HIP_TRY(hipSetDevice(device));
     slam_handle* h = new slam_handle();
     h->cfg = *cfg; h->kind = kind; h->B = batch; h->L_max = L_max; h->dtype = dtype; h->device = device;
     h->esz = dtype == SLAM_F32 ? 4 : 8;
-    h->base = (kind == SLAM_UKF_SLAM) ? 4 : 3;
+    h->base = (kind == SLAM_EKF_SLAM) ? 3 : 4;
     h->n_max = h->base + 2 * L_max;
     h->pstride = round_up(h->n_max * h->n_max + 4, 64);   // per-filter slab: 256/512-byte aligned, room for vector tails
     h->xstride = round_up(h->n_max + 1, 2);
@@ -257,9 +260,9 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMalloc(&h->derr, sizeof(double) * B),
         hipMalloc(&h->dscalar, sizeof(double) * 4),
         hipMalloc(&h->dprof, sizeof(unsigned long long) * 16 * B),
-        kind == SLAM_UKF_SLAM ? hipMalloc(&h->dsq, sizeof(double) * B * h->pstride) : hipSuccess,
+        kind != SLAM_EKF_SLAM ? hipMalloc(&h->dsq, sizeof(double) * B * h->pstride) : hipSuccess,
         h->esz == 4 ? hipMalloc(&h->dscratch, sizeof(double) * B * h->pstride) : hipSuccess,
-        kind == SLAM_UKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
+        kind != SLAM_EKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -279,7 +282,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -338,6 +341,13 @@ int slam_set_map(slam_handle* h, const double* map_xy, int L) {
     HIP_TRY(hipMalloc(&h->dmap, sizeof(double) * 2 * (size_t)L));
     HIP_TRY(hipMemcpyAsync(h->dmap, map_xy, sizeof(double) * 2 * (size_t)L, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->kind == SLAM_UKF_LOC) {   // trueMapCallback: filter->map = [id, x, y] float32 (localization_node.cpp:152-156)
+        std::vector<float> trip((size_t)3 * L);
+        for (int i = 0; i < L; ++i) { trip[3 * i] = (float)i; trip[3 * i + 1] = (float)map_xy[2 * i]; trip[3 * i + 2] = (float)map_xy[2 * i + 1]; }
+        if (h->dmapf) { hipFree(h->dmapf); h->dmapf = nullptr; }
+        HIP_TRY(hipMalloc(&h->dmapf, sizeof(float) * trip.size()));
+        HIP_TRY(hipMemcpy(h->dmapf, trip.data(), sizeof(float) * trip.size(), hipMemcpyHostToDevice));
+    }
     h->L = L;
     return SLAM_OK;
 }
@@ -345,6 +355,7 @@ int slam_set_map(slam_handle* h, const double* map_xy, int L) {
 int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_count, int k_stride) {
     if (!h || !cmd || !d_meas || !d_count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
     HIP_TRY(hipSetDevice(h->device));
     return launch_step(h, cmd, 0, d_meas, d_count, k_stride);
 }
@@ -353,6 +364,7 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
     if (!h || !cmd || !meas || !count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
     int rc = ensure_meas_buffers(h, k_stride);
     if (rc) return rc;
     // pack to the staging stride

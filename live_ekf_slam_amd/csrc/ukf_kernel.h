@@ -40,6 +40,8 @@ struct UkfStepParams {
     uint32_t step;
     int32_t B, L_max, pstride, xstride;
     int32_t sim;
+    int32_t loc;          // 1 = FilterChoice::UKF_LOC: every detection updates against the known map (ukf.cpp:146-154)
+    const float* mapf;    // [L][3] float32 {id, x, y}: `filter->map` as it arrives on /truth/landmarks
 };
 
 static constexpr int kUkfMaxLandmarks = 50;   // n = 4 + 2L <= 104

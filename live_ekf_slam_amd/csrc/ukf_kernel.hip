@@ -94,7 +94,6 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     __shared__ double s_red[TPB / 64];
 
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (p.flags[b] & SLAM_INST_INDEX_OOR) return;
     const int M = p.M[b];
     const int n = 4 + 2 * M, m = n / 2;
     const double* __restrict__ Pb = p.P + (size_t)b * p.pstride;
@@ -306,14 +305,15 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
                 const unsigned long long mm = __ballot(j < M_old && s_ids[j] == id);
                 if (mm != 0ull) f = j0 + (__ffsll((long long)mm) - 1);
             }
-            if (lane == l) found = f;
+            if (lane == l) found = p.loc ? ((id >= 0 && id < p.L) ? id : -2) : f;
         }
         (void)myid;
+        if (__ballot(valid && found == -2) != 0ull && lane == 0) s_misc[5] = 1;   // LOC: id outside the known map
         const unsigned long long um = __ballot(valid && found >= 0);
-        const unsigned long long im = __ballot(valid && found < 0);
+        const unsigned long long im = __ballot(valid && found == -1);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (valid && found >= 0) s_upd[__popcll(um & below)] = (found << 8) | lane;   // slot, detection index
-        if (valid && found < 0) s_ins[__popcll(im & below)] = lane;
+        if (valid && found == -1) s_ins[__popcll(im & below)] = lane;
         if (lane == 0) { s_misc[1] = __popcll(um); s_misc[2] = __popcll(im); }
     }
 
@@ -388,8 +388,9 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
             const int li = 2 * (packed >> 8) + 4, l = packed & 0xff;
             const float r_m = s_meas[3 * l + 1], b_m = s_meas[3 * l + 2];
             const double yaw_s = s_sc[4];
+            const double mx = p.loc ? (double)p.mapf[3 * (packed >> 8) + 1] : 0.0, my = p.loc ? (double)p.mapf[3 * (packed >> 8) + 2] : 0.0;
             for (int i = tid; i < ns; i += TPB) {
-                const double dx = xpred_elem(li, i) - xpred_elem(0, i), dy = xpred_elem(li + 1, i) - xpred_elem(1, i);
+                const double dx = (p.loc ? mx : xpred_elem(li, i)) - xpred_elem(0, i), dy = (p.loc ? my : xpred_elem(li + 1, i)) - xpred_elem(1, i);
                 sZ0[i] = sqrt(dx * dx + dy * dy) + (double)p.w_r;
                 const double z1 = remainder((det_atan2(dy, dx) - yaw_s) + (double)p.w_b, kTwoPi);
                 sD1[i] = remainder(z1 - 0.0, kTwoPi);   // z_est(1) stays 0 (ukf.cpp:310-314)
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     }
     if (__syncthreads_or(hx >= 0x7ff00000u)) flags |= SLAM_INST_NONFINITE;
     if (s_misc[4]) flags |= SLAM_INST_S_SINGULAR;
+    if (s_misc[5]) flags |= SLAM_INST_INDEX_OOR;
     const int M_new = M_old + nfin_ins;
     if (M_new != M_old)
         for (int i = tid; i < M_new; i += TPB) p.ids[(size_t)b * p.L_max + i] = s_ids[i];

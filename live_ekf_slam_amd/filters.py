@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .config import SlamConfig, default_config, EKF_SLAM, UKF_SLAM, F64
+from .config import SlamConfig, default_config, EKF_SLAM, UKF_LOC, UKF_SLAM, F64
 
 
 def _d(a):
@@ -252,3 +252,13 @@ class BatchedUKF(BatchedFilter):
         yaw = math.remainder(math.atan2(x[3], x[2]), 2 * 3.14159265358979323846)
         return dict(timestep=s["timestep"], x_v=np.float32(x[0]), y_v=np.float32(x[1]), yaw_v=np.float32(yaw),
                     M=M, landmarks=lm, P=s["P"].astype(np.float32).ravel())
+
+
+class BatchedUKFLoc(BatchedUKF):
+    """UKF localisation against the known map (FilterChoice::UKF_LOC, localization_node.cpp:39-41, ukf.cpp:146-154):
+    the state is the vehicle only; every detection updates against `set_map`'s landmark of the same id."""
+
+    kind = UKF_LOC
+
+    def __init__(self, batch, device=0):
+        super().__init__(batch, 1, device)

@@ -58,6 +58,7 @@ def lib():
         L.orc_ukf_update.argtypes = [C.c_void_p, C.c_float, C.c_float, _fp, C.c_int]
         L.orc_ukf_get.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip]
         L.orc_ukf_sqrt_probe.argtypes = [_dp, C.c_int, C.c_double, _dp]
+        L.orc_ukf_set_loc_map.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_run_ukf_batch.restype = C.c_double
         L.orc_run_ukf_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int, C.c_uint64,
                                         C.c_int64, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp, _ip, _dp, _dp]
@@ -180,6 +181,11 @@ class OracleUKF:
             lib().orc_ukf_destroy(self.h)
             self.h = None
 
+    def set_loc_map(self, map_xy):
+        """Switch to UKF_LOC (localisation against the known map)."""
+        m = np.ascontiguousarray(map_xy, dtype=np.float64)
+        lib().orc_ukf_set_loc_map(self.h, _d(m), m.shape[0])
+
     def init(self, x0=0.0, y0=0.0, yaw0=0.0):
         lib().orc_ukf_init(self.h, x0, y0, yaw0)
 
@@ -204,8 +210,9 @@ def ukf_sqrt_probe(P, scale):
     return out, sweeps
 
 
-def run_ukf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, nthreads=1, want_P=True, vision=None):
-    cfg = cfg or default_config()
+def run_ukf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, nthreads=1, want_P=True, vision=None, loc=False):
+    cfg = (cfg or default_config()).copy()
+    cfg.reserved[0] = 1 if loc else 0
     map_xy = np.ascontiguousarray(map_xy, dtype=np.float64); cmds = np.ascontiguousarray(cmds, dtype=np.float32)
     L, T, nmax = map_xy.shape[0], cmds.shape[0], 4 + 2 * L_max
     x = np.zeros((B, nmax)); P = np.zeros((B, nmax * nmax)) if want_P else None

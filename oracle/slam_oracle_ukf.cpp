@@ -112,6 +112,8 @@ struct Ukf {
     std::vector<int> ids;
     int n_sq = 0;          // dimension sqtP currently has
     int last_sweeps = 0;
+    bool loc = false;      // FilterChoice::UKF_LOC: localisation only, landmarks come from the known map (ukf.cpp:146-154)
+    std::vector<float> mapf;   // `filter->map`: [id, x, y] float32 triplets (localization_node.cpp:152-156)
 
     int n() const { return 4 + 2 * M; }
     static constexpr float W_0 = 0.2f;  // filter.h:207
@@ -232,12 +234,14 @@ struct Ukf {
         return x_t[r] - sqtP[(size_t)r * nn + (i - 1 - nn)];
     }
 
-    template <class MP> void landmark_update(int j, float r_m, float b_m) {  // ukf.cpp:293-349 (SLAM mode)
+    // j: landmark slot (SLAM) or the landmark's id = its row in the known map (LOC, ukf.cpp:300-302)
+    template <class MP> void landmark_update(int j, float r_m, float b_m) {  // ukf.cpp:293-349
         const int nn = n(), ns = 2 * nn + 1, li = 2 * j + 4;
+        const double mx = loc ? (double)mapf[(size_t)j * 3 + 1] : 0.0, my = loc ? (double)mapf[(size_t)j * 3 + 2] : 0.0;
         const float yaw = yaw_of<MP>(x_t.data());  // sensingModel takes yaw from x_t (ukf.cpp:139)
         std::vector<double> Z0(ns), Z1(ns);
         for (int i = 0; i < ns; ++i) {
-            const double dx = xpred_elem(li, i, nn) - xpred_elem(0, i, nn), dy = xpred_elem(li + 1, i, nn) - xpred_elem(1, i, nn);
+            const double dx = (loc ? mx : xpred_elem(li, i, nn)) - xpred_elem(0, i, nn), dy = (loc ? my : xpred_elem(li + 1, i, nn)) - xpred_elem(1, i, nn);
             Z0[i] = ::sqrt(MP::sq(dx) + MP::sq(dy)) + (double)cfg.w_r;
             Z1[i] = remainder((MP::atan2(dy, dx) - (double)yaw) + (double)cfg.w_b, slam::kTwoPi);
         }
@@ -309,6 +313,11 @@ struct Ukf {
             int j = -1;
             for (int q = 0; q < M; ++q)
                 if (ids[q] == id) { j = q; break; }
+            if (loc) {   // ukf.cpp:272-276: every detection is an update against the known map
+                if (id >= 0 && (size_t)id * 3 + 2 < mapf.size()) landmark_update<MP>(id, meas[3 * l + 1], meas[3 * l + 2]);
+                else flags |= SLAM_INST_INDEX_OOR;   // std::vector out of range: undefined behaviour in the reference
+                continue;
+            }
             if (j < 0) fresh.push_back(l);
             else landmark_update<MP>(j, meas[3 * l + 1], meas[3 * l + 2]);
         }
@@ -334,6 +343,13 @@ struct Ukf {
 extern "C" {
 
 void* orc_ukf_create(const slam_config* cfg, int L_max, int math) { return new Ukf(*cfg, L_max, math); }
+// switch to UKF_LOC with the true map [L][2] (the wire format is float32 [id, x, y])
+void orc_ukf_set_loc_map(void* h, const double* map_xy, int L) {
+    Ukf* u = (Ukf*)h;
+    u->loc = true;
+    u->mapf.resize((size_t)3 * L);
+    for (int i = 0; i < L; ++i) { u->mapf[3 * i] = (float)i; u->mapf[3 * i + 1] = (float)map_xy[2 * i]; u->mapf[3 * i + 2] = (float)map_xy[2 * i + 1]; }
+}
 void orc_ukf_destroy(void* h) { delete (Ukf*)h; }
 void orc_ukf_init(void* h, float x0, float y0, float yaw0) { ((Ukf*)h)->init(x0, y0, yaw0); }
 int orc_ukf_update(void* h, float fwd, float ang, const float* meas, int k) { return ((Ukf*)h)->update(fwd, ang, meas, k); }
@@ -378,6 +394,10 @@ double orc_run_ukf_batch(const slam_config* cfg, int L_max, int math, const doub
             const int b = next.fetch_add(1);
             if (b >= B) break;
             Ukf ukf(*cfg, L_max, math);
+            if (cfg->reserved[0] == 1) {   // reserved[0] = 1: UKF_LOC with the simulator's map
+                ukf.loc = true; ukf.mapf.resize((size_t)3 * L);
+                for (int i = 0; i < L; ++i) { ukf.mapf[3 * i] = (float)i; ukf.mapf[3 * i + 1] = (float)map_xy[2 * i]; ukf.mapf[3 * i + 2] = (float)map_xy[2 * i + 1]; }
+            }
             ukf.init((float)cfg->init_x, (float)cfg->init_y, (float)cfg->init_yaw);
             Sim sim;
             sim.cfg = *cfg; sim.L = L; sim.math = math; sim.map.assign(map_xy, map_xy + 2 * L);

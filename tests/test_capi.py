@@ -89,7 +89,7 @@ def test_bad_arguments_return_error_codes():
     assert L.slam_create(C.byref(c), 1, 4, 101, 0, 0, C.byref(h)) == -3         # above kernel capacity
     assert b"limit" in L.slam_last_error()
     assert L.slam_create(C.byref(c), 3, 4, 20, 1, 0, C.byref(h)) == -3          # f32 storage: EKF only
-    assert L.slam_create(C.byref(c), 2, 4, 20, 0, 0, C.byref(h)) == -3          # UKF_LOC not in this build
+    assert L.slam_create(C.byref(c), 9, 4, 20, 0, 0, C.byref(h)) == -1          # unknown filter kind
     assert L.slam_step_sim(None, None) == -1
     assert L.slam_destroy(None) == 0
 

@@ -83,3 +83,32 @@ def test_ukf_many_detections_and_config_switches(S, oracle):
             _eq(g.get_state(b), dict(M=L, ids=r["ids"][b], x=r["x"][b], P=r["P"][b].reshape(44, 44)))
         assert np.all(np.isfinite(f.poses()))
         f.close(); g.close()
+
+
+def test_ukf_loc_mode(S, oracle):
+    """FilterChoice::UKF_LOC (ukf.cpp:146-154, localization_node.cpp:39-41,152-156): vehicle-only state, every
+    detection updates against the known (float32) map; host-fed reference stream and device-generated streams."""
+    g = load_golden("sim_seed0_L20_T1000.npz")
+    B = 3
+    f = S.BatchedUKFLoc(B).readParams()
+    with pytest.raises(S.SlamError):
+        f.init(0, 0, 0); f.update((0.1, 0.0), [])        # no map yet (localization_node.cpp:113-116)
+    f.set_map(g["map"]); f.init(0.0, 0.0, 0.0)
+    u = oracle.OracleUKF(L_max=1); u.set_loc_map(g["map"]); u.init(0, 0, 0)
+    for t in range(300):
+        k = int(g["meas_count"][t])
+        f.update(g["cmds"][t], g["meas"][t, :k].ravel()); u.update(g["cmds"][t, 0], g["cmds"][t, 1], g["meas"][t, :k])
+        if t % 25 == 24:
+            _eq(f.get_state(B - 1), u.state())
+    so = u.state()
+    assert so["M"] == 0 and so["x"].shape == (4,)
+    assert np.hypot(*(so["x"][:2] - g["truth"][299][:2])) < 0.5
+    f.close()
+    from live_ekf_slam_amd.scenario import make_scenario
+    lm, cmds = make_scenario(1234, 20, 200)
+    f = S.BatchedUKFLoc(32).readParams(); f.set_map(lm); f.set_seed(8); f.init(0, 0, 0); f.run_sim(cmds)
+    r = oracle.run_ukf_batch(lm, cmds, 32, 1, seed=8, nthreads=4, loc=True)
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
+    for b in range(32):
+        _eq(f.get_state(b), dict(M=0, ids=r["ids"][b, :0], x=r["x"][b, :4], P=r["P"][b, :16].reshape(4, 4)))
+    f.close()
