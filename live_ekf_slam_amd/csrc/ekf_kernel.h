@@ -32,6 +32,11 @@ struct EkfStepParams {
     int32_t k_stride_out;
     // ---- command (Command.msg) ----
     float fwd, ang;
+    // multi-step launch (SIM mode only): the kernel runs T consecutive timesteps per instance, step t with command
+    // cmds[2t], cmds[2t+1] and RNG step index step+t, ping-ponging P -> P_out -> P ...; the result is in P_out when T
+    // is odd and in P when T is even.  cmds == NULL: T = 1 with (fwd, ang).
+    const float* cmds;
+    int32_t T;
     // ---- filter config after readCommonParams (filter.h:105-121), effective V / W ----
     float v_d, v_th, w_r, w_b;
     double V00, V11, W00, W11;

@@ -95,11 +95,20 @@ template <> struct Vec16<float> {
     typedef flt4_t type;
 };
 
+// identity the optimiser cannot see through: index arithmetic derived from the result is recomputed where it is
+// used instead of being hoisted to the top of the kernel and kept in registers across every phase
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ unsigned hi_abs(double v) {
     return (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu;
 }
 
-template <int NMAX, int W, int KG_, int UNR_, class ST>
+// MULTI = false: one timestep per launch (slam_step / slam_step_dev / slam_step_sim); MULTI = true: p.T timesteps per
+// launch with the per-instance state resident on chip (slam_run_sim).  Same code, the loop is compiled out for T = 1.
+template <int NMAX, int W, int KG_, int UNR_, class ST, bool MULTI>
 __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(const EkfStepParams p) {
     using G = EkfGeom<NMAX, W, KG_, UNR_>;
     constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, TS = G::TS, UNR = G::UNR;
@@ -114,9 +123,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ float s_meas[3 * KCAP];
     __shared__ int s_ids[LMAX > 0 ? LMAX : 1];
     __shared__ int s_didx[KCAP];          // per detection: landmark number (>= M_old: inserted this step), -1 dropped
-    __shared__ int s_T[TS];               // thin index set of the current group
+    __shared__ int s_T[TS];               // thin slot -> state index, -1 = free.  Slots 0..2 = vehicle rows for good;
+                                          // landmarks occupy the pairs (3+2j, 4+2j) and stay resident while detected
     __shared__ signed char s_slot[LDP];   // state index -> thin slot or -1
+    __shared__ signed char s_need[TS];    // slot was (re)assigned: 1 = gather from HBM, 2 = new landmark (zero)
     __shared__ int s_misc[8];             // k, n_insert, freeze, capacity, l1, nT, singular-S
+    __shared__ double s_keep[4 + 2 * 64]; // values that live across the timesteps of one launch: true pose, error
+                                          // sum, map entries of ids 0..63 (kept out of registers on purpose)
 
     // row 2 / col 2 of P_t (predict operands) live in the K buffer, which is idle until the first update
     double* const s_r2 = reinterpret_cast<double*>(s_K);
@@ -132,13 +145,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // ---- prologue: every load that does not depend on another load is issued up front (one HBM round trip) ----
     constexpr int VEC = Vec16<ST>::VEC;
     typedef typename Vec16<ST>::type VT;
-    const ST* __restrict__ Pin = static_cast<const ST*>(p.P) + (size_t)b * p.pstride;
-    ST* __restrict__ Pout = static_cast<ST*>(p.P_out) + (size_t)b * p.pstride;
+    // T consecutive timesteps per launch: the two P buffers ping-pong, x_t / ids / truth / thin rows stay on chip
+    const int T = MULTI ? p.T : 1;
+    ST* const PA = const_cast<ST*>(static_cast<const ST*>(p.P)) + (size_t)b * p.pstride;
+    ST* const PB = static_cast<ST*>(p.P_out) + (size_t)b * p.pstride;
+    ST* const Pfinal = (T & 1) ? PB : PA;     // where the host expects P_t after T steps
     ST* __restrict__ xb = static_cast<ST*>(p.x) + (size_t)b * p.xstride;
     constexpr bool kWide = sizeof(ST) == 8;   // fp64 storage: intermediate results can live in P_out itself
-    double* __restrict__ Pmid = kWide ? reinterpret_cast<double*>(Pout) : (p.scratch + (size_t)b * p.pstride);
     int flags = p.flags[b];
-    const int M_old = p.M[b];
+    const int M_init = p.M[b];
     double xpre[(LDP + TPB - 1) / TPB];
 #pragma unroll
     for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
@@ -146,19 +161,21 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         xpre[u] = (i < p.xstride && i < LDP) ? (double)xb[i] : 0.0;   // beyond n_old the slab holds stale values: masked below
     }
     const int idpre = (tid < p.L_max) ? p.ids[(size_t)b * p.L_max + tid] : 0;
-    double tx = 0.0, ty = 0.0, tth = 0.0, lmx = 0.0, lmy = 0.0;
+    double keep0 = 0.0, keep1 = 0.0, keep2 = 0.0;
     if (p.sim && tid < 64) {
-        tx = p.truth[3 * (size_t)b];
-        ty = p.truth[3 * (size_t)b + 1];
-        tth = p.truth[3 * (size_t)b + 2];
-        if (tid < p.L) { lmx = p.map[2 * tid]; lmy = p.map[2 * tid + 1]; }
+        if (tid < 3) keep0 = p.truth[3 * (size_t)b + tid];
+        if (tid == 3) keep0 = p.err_sum[b];
+        if (tid < p.L) { keep1 = p.map[2 * tid]; keep2 = p.map[2 * tid + 1]; }
     }
-    const int n_old = 3 + 2 * M_old;
+    const int n_init = 3 + 2 * M_init;
+    const int ts0 = p.timestep[b];
 
     if (flags & SLAM_INST_INDEX_OOR) {
         // frozen instance (the reference node died here, filter.h:5): carry the state into the other buffer
-        const int nn = n_old * n_old;
-        for (int i = tid; i < nn; i += TPB) Pout[i] = Pin[i];
+        if (Pfinal != PA) {
+            const int nn = n_init * n_init;
+            for (int i = tid; i < nn; i += TPB) Pfinal[i] = PA[i];
+        }
         return;
     }
 
@@ -166,12 +183,60 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
         const int i = tid + TPB * u;
         if (i < LDP) {
-            const double v = i < n_old ? xpre[u] : 0.0;
+            const double v = i < n_init ? xpre[u] : 0.0;
             s_xt[i] = v;
             s_xp[i] = v;
         }
     }
-    if (tid < M_old) s_ids[tid] = idpre;
+    if (tid < M_init) s_ids[tid] = idpre;
+    if (tid < 64) {
+        if (tid < 4) s_keep[tid] = keep0;
+        s_keep[4 + tid] = keep1;
+        s_keep[4 + 64 + tid] = keep2;
+    }
+#pragma unroll 1
+    for (int i = tid; i < LDP; i += TPB) s_slot[i] = (signed char)(i < 3 ? i : -1);
+    if (tid < TS) {
+        s_T[tid] = tid < 3 ? tid : -1;
+        s_need[tid] = (signed char)(tid < 3 ? 1 : 0);
+    }
+
+    // state -> HBM at the end of the launch (or when the instance freezes): x_t lives in s_xt
+    auto finish = [&](int steps_done, int Mf, int fl) {
+        const int nfin = 3 + 2 * Mf;
+        for (int i = tid; i < nfin; i += TPB) xb[i] = (ST)s_xt[i];
+        if (Mf != M_init) {
+            for (int i = tid; i < Mf; i += TPB) p.ids[(size_t)b * p.L_max + i] = s_ids[i];
+        }
+        if (tid == 0) {
+            p.M[b] = Mf;
+            p.flags[b] = fl;
+            p.timestep[b] = ts0 + steps_done;
+            if (p.sim) p.err_sum[b] = s_keep[3];
+        }
+    };
+
+    int M = M_init;
+    int na = n_init;     // active dimension
+    unsigned hiacc = 0u; // non-finite detector (max of |hi word|)
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+    const ST* __restrict__ Pin = (t & 1) ? PB : PA;
+    ST* __restrict__ Pout = (t & 1) ? PA : PB;
+    double* __restrict__ Pmid = kWide ? reinterpret_cast<double*>(Pout) : (p.scratch + (size_t)b * p.pstride);
+    const float fwd = MULTI ? p.cmds[2 * t] : p.fwd;
+    const float ang = MULTI ? p.cmds[2 * t + 1] : p.ang;
+    const uint32_t stepi = p.step + (uint32_t)t;
+    const int M_old = M;
+    const int n_old = na;
+    // pre-step state of a freezing instance into the buffer the host reads next
+    auto freeze = [&]() {
+        if (Pfinal != Pin) {
+            const int nn = n_old * n_old;
+            for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pin[i];
+        }
+        finish(t, M_old, flags | SLAM_INST_INDEX_OOR);
+    };
     if (tid < 8) s_misc[tid] = 0;
 
     // ------------------------------------------------------------------------------------------------------
@@ -180,8 +245,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __syncthreads();
     SLAM_STAMP(0);   // initial loads
     if (p.sim) {
-        if (tid < 64)   // one wavefront advances the truth and scans the map in ascending id (sim_node.py:209-243)
-            sim_wave<KCAP>(p, b, lane, tx, ty, tth, lmx, lmy, s_meas, &s_misc[0]);
+        if (tid < 64) { // one wavefront advances the truth and scans the map in ascending id (sim_node.py:209-243)
+            double tx = s_keep[0], ty = s_keep[1], tth = s_keep[2];
+            sim_wave<KCAP>(p, b, lane, fwd, ang, stepi, tx, ty, tth, s_keep[4 + lane], s_keep[4 + 64 + lane], s_meas,
+                           &s_misc[0]);
+            if (lane == 0) { s_keep[0] = tx; s_keep[1] = ty; s_keep[2] = tth; }
+        }
     } else {
         int kk = p.meas_count_in[b];
         kk = kk < p.k_stride_in ? kk : p.k_stride_in;
@@ -194,7 +263,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     SLAM_STAMP(1);   // measurement generation / fetch
     if (s_misc[0] > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than one wavefront associates
     const int k = s_misc[0] < KCAP ? s_misc[0] : KCAP;
-    if (p.sim && p.meas_out != nullptr) {
+    if (p.sim && p.meas_out != nullptr && t == T - 1) {
         for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB)
             p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = s_meas[i];
         if (tid == 0) p.meas_count_out[b] = k;
@@ -246,9 +315,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         n_ins = k;
     }
     if (s_misc[2]) {  // freeze in the pre-step state
-        const int nn = n_old * n_old;
-        for (int i = tid; i < nn; i += TPB) Pout[i] = Pin[i];
-        if (tid == 0) p.flags[b] = flags | SLAM_INST_INDEX_OOR;
+        freeze();
         return;
     }
     if (s_misc[3]) flags |= SLAM_INST_CAPACITY;
@@ -260,7 +327,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // (ekf.cpp:82-98) projects detections with the PREDICTED pose.  The covariance part of the prediction runs
     // on the thin rows/cols of the first group.
     if (tid == 0) {
-        const float d_d = p.fwd, d_th = p.ang;
+        const float d_d = fwd, d_th = ang;
         const double th = s_xt[2];
         double s, c;
         det_sincos(th, &s, &c);
@@ -273,11 +340,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // ------------------------------------------------------------------------------------------------------
     // groups of <= KG detections
     // ------------------------------------------------------------------------------------------------------
-    int M = M_old;
-    int na = n_old;      // active dimension
     int l0 = 0;
     bool first = true;
-    unsigned hiacc = 0u; // non-finite detector (max of |hi word|)
     while (first || l0 < k) {
         // Source of this group's P: the old buffer (leading dimension n_old) for the first group; afterwards the
         // matrix written by the previous group's bulk pass (leading dimension nf).  Intermediate results between
@@ -286,16 +350,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         const int lds = first ? n_old : nf;   // leading dimension of the source
         const int nsrc = first ? n_old : na;  // rows/cols of the source that hold data
 
-        // ---- form the group: thread 0 decides, everybody reads ----
-        __syncthreads();
-#pragma unroll 1
-        for (int i = tid; i < LDP; i += TPB) s_slot[i] = (signed char)-1;
+        // ---- form the group: thread 0 decides, everybody reads.  Thin rows/cols of landmarks that are detected
+        //      again stay where they are (their LDS copy IS the current P row); the others give their slot up. ----
         __syncthreads();
         if (tid == 0) {
-            int nT = 3, l1 = l0, na_g = na, M_g = M;
-            s_T[0] = 0; s_T[1] = 1; s_T[2] = 2;
-            s_slot[0] = 0; s_slot[1] = 1; s_slot[2] = 2;
+            int l1 = l0, na_g = na, M_g = M;
             int frz = 0;
+            int want[KG], nw = 0;
+#pragma unroll
+            for (int w = 0; w < KG; ++w) want[w] = -1;
 #pragma unroll 1
             while (l1 < k && l1 - l0 < KG) {
                 int idx;
@@ -324,18 +387,52 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 }
                 if (idx >= 0) {
                     const int ii = 3 + 2 * idx;
-                    if (s_slot[ii] < 0) {
-                        if (nT + 2 > TS) break;
-                        s_T[nT] = ii; s_slot[ii] = (signed char)nT;
-                        s_T[nT + 1] = ii + 1; s_slot[ii + 1] = (signed char)(nT + 1);
-                        nT += 2;
+                    bool have = false;
+#pragma unroll
+                    for (int w = 0; w < KG; ++w) have = have || (want[w] == ii);
+                    if (!have) {   // at most KG detections per group, so a pair is always free
+#pragma unroll
+                        for (int w = 0; w < KG; ++w)
+                            if (w == nw) want[w] = ii;
+                        nw += 1;
                     }
                     if (idx >= M_g) { M_g += 1; na_g += 2; }
                 }
                 l1 += 1;
             }
+            // release the pairs this group does not touch: the last bulk pass already wrote them to HBM
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const int ii = s_T[3 + 2 * j];
+                if (ii >= 0) {
+                    bool keep = false;
+#pragma unroll
+                    for (int w = 0; w < KG; ++w) keep = keep || (want[w] == ii);
+                    if (!keep) {
+                        s_slot[ii] = (signed char)-1; s_slot[ii + 1] = (signed char)-1;
+                        s_T[3 + 2 * j] = -1; s_T[4 + 2 * j] = -1;
+                    }
+                }
+            }
+            // every wanted landmark without a slot takes a free pair
+#pragma unroll
+            for (int w = 0; w < KG; ++w) {
+                const int ii = want[w];
+                if (ii >= 0 && s_slot[ii] < 0) {
+                    int j = 0;
+                    while (j < KG - 1 && s_T[3 + 2 * j] >= 0) ++j;
+                    s_T[3 + 2 * j] = ii; s_T[4 + 2 * j] = ii + 1;
+                    s_slot[ii] = (signed char)(3 + 2 * j); s_slot[ii + 1] = (signed char)(4 + 2 * j);
+                    const signed char nd = (signed char)(ii < nsrc ? 1 : 2);   // known landmark: gather, new one: zeros
+                    s_need[3 + 2 * j] = nd; s_need[4 + 2 * j] = nd;
+                }
+            }
+            int nT = 3;
+#pragma unroll
+            for (int j = 0; j < KG; ++j)
+                if (s_T[3 + 2 * j] >= 0) nT = 5 + 2 * j;
             s_misc[4] = l1;
-            s_misc[5] = nT;
+            s_misc[5] = nT;      // high-water mark: slots [3, nT) may contain free pairs (s_T < 0)
             s_misc[2] = frz;
         }
         __syncthreads();
@@ -343,9 +440,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         SLAM_STAMP(3);   // x_pred + group formation
         if (s_misc[2]) {
             // unknown-id quirk: the reference throws.  Freeze in the pre-step state.
-            const int nn = n_old * n_old;
-            for (int i = tid; i < nn; i += TPB) Pout[i] = Pin[i];
-            if (tid == 0) p.flags[b] = flags | SLAM_INST_INDEX_OOR;
+            freeze();
             return;
         }
         if (s_misc[3]) flags |= SLAM_INST_CAPACITY;
@@ -354,17 +449,18 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         //      lane are issued before the first LDS store so their latencies overlap. ----
         {
             const bool src_mid = !first;
+            const int tg = opaque(tid);
             const ST* srcS = (kWide && src_mid) ? reinterpret_cast<const ST*>(Pmid) : Pin;
             constexpr int GI = (TS * LDP + TPB - 1) / TPB;
             double rv[GI], cv[GI];
 #pragma unroll
             for (int u = 0; u < GI; ++u) {
-                const int i = tid + TPB * u;
+                const int i = tg + TPB * u;
                 rv[u] = 0.0; cv[u] = 0.0;
                 if (i < nT * LDP) {
                     const int sl = i / LDP, j = i - sl * LDP;
                     const int t_s = s_T[sl];
-                    if (j < nsrc && t_s < nsrc) {
+                    if (s_need[sl] == 1 && j < nsrc && t_s < nsrc) {
                         if (!kWide && src_mid) {
                             rv[u] = Pmid[(size_t)t_s * lds + j];
                             cv[u] = Pmid[(size_t)j * lds + t_s];
@@ -377,16 +473,18 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             }
 #pragma unroll
             for (int u = 0; u < GI; ++u) {
-                const int i = tid + TPB * u;
-                if (i < nT * LDP) { s_R[i] = rv[u]; s_C[i] = cv[u]; }
+                const int i = tg + TPB * u;
+                if (i < nT * LDP && s_need[i / LDP] != 0) { s_R[i] = rv[u]; s_C[i] = cv[u]; }
             }
         }
         __syncthreads();
+        if (tid < TS) s_need[tid] = 0;
         SLAM_STAMP(4);   // thin gather
         // ---- prediction stage on the thin copies (first group only), ekf.cpp:41-61 ----
         if (first) {
+            const int tp = opaque(tid);
             if (tid == 0) {  // leader: the scalars of F_x, F_v V F_v^T
-                const float d_d = p.fwd;
+                const float d_d = fwd;
                 double s, c;
                 det_sincos(s_xt[2], &s, &c);
                 const double cv = c * p.V00, sv = s * p.V00;
@@ -395,7 +493,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 s_sc[2] = cv * c; s_sc[3] = cv * s; s_sc[4] = sv * c; s_sc[5] = sv * s;
             }
 #pragma unroll 1
-            for (int i = tid; i < LDP; i += TPB) { s_r2[i] = s_R[2 * LDP + i]; s_c2[i] = s_C[2 * LDP + i]; }
+            for (int i = tp; i < LDP; i += TPB) { s_r2[i] = s_R[2 * LDP + i]; s_c2[i] = s_C[2 * LDP + i]; }
             __syncthreads();
             const double fa = s_sc[0], fb = s_sc[1];
             const double p22 = s_r2[2];
@@ -413,7 +511,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             };
             // only rows 0,1 / cols 0,1 / (2,2) of P change: thin rows 0,1 and thin cols 0,1 entirely ...
 #pragma unroll 1
-            for (int i = tid; i < 2 * LDP; i += TPB) {
+            for (int i = tp; i < 2 * LDP; i += TPB) {
                 const int sl = i >= LDP ? 1 : 0, j = i - sl * LDP;
                 if (j < na) {
                     s_R[i] = predicted(s_R[i], sl, j);     // R[sl][j] = P[sl][j]
@@ -421,13 +519,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 }
             }
             // ... and entries 0,1 (+ the (2,2) element) of every other thin row / col
-            if (tid >= 2 && tid < nT) {
-                const int t_s = s_T[tid];
-                if (t_s < na) {
-                    s_R[tid * LDP + 0] = predicted(s_R[tid * LDP + 0], t_s, 0);
-                    s_R[tid * LDP + 1] = predicted(s_R[tid * LDP + 1], t_s, 1);
-                    s_C[tid * LDP + 0] = predicted(s_C[tid * LDP + 0], 0, t_s);
-                    s_C[tid * LDP + 1] = predicted(s_C[tid * LDP + 1], 1, t_s);
+            if (tp >= 2 && tp < nT) {
+                const int t_s = s_T[tp];
+                if ((unsigned)t_s < (unsigned)na) {
+                    s_R[tp * LDP + 0] = predicted(s_R[tp * LDP + 0], t_s, 0);
+                    s_R[tp * LDP + 1] = predicted(s_R[tp * LDP + 1], t_s, 1);
+                    s_C[tp * LDP + 0] = predicted(s_C[tp * LDP + 0], 0, t_s);
+                    s_C[tp * LDP + 1] = predicted(s_C[tp * LDP + 1], 1, t_s);
                     if (t_s == 2) {
                         s_R[2 * LDP + 2] = predicted(s_R[2 * LDP + 2], 2, 2);
                         s_C[2 * LDP + 2] = predicted(s_C[2 * LDP + 2], 2, 2);
@@ -442,6 +540,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         int nu = 0;  // updates recorded for the bulk pass
 #pragma unroll 1
         for (int l = l0; l < l1; ++l) {
+            const int td = opaque(tid);   // keeps per-lane index arithmetic from being hoisted out of the loops
             const int idx = s_didx[l];
             if (idx < 0 || (p.dbg & 2)) continue;  // dropped (capacity)
             const float r_m = s_meas[3 * l + 1], b_m = s_meas[3 * l + 2];
@@ -473,7 +572,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     const double* Cj = s_C + (si + 1) * LDP;
 #pragma unroll
                     for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
-                        const int c = tid + TPB * u;
+                        const int c = td + TPB * u;
                         double2 hp = make_double2(0.0, 0.0), ph = make_double2(0.0, 0.0);
                         if (c < na) {
                             const double p0 = s_R[c], p1 = s_R[LDP + c], p2 = s_R[2 * LDP + c], pi = Ri[c], pj = Rj[c];
@@ -508,7 +607,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     const double nu0 = s_sc[8], nu1 = s_sc[9];
 #pragma unroll
                     for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
-                        const int r = tid + TPB * u;
+                        const int r = td + TPB * u;
                         double2 kk = make_double2(0.0, 0.0);
                         if (r < na) {
                             kk.x = pht[u].x * si0 + pht[u].y * si2;
@@ -523,10 +622,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 __syncthreads();
                 // thin copies follow the same downdate  P -= K (H P)
 #pragma unroll 1
-                for (int i = tid; i < nT * LDP; i += TPB) {
+                for (int i = td; i < nT * LDP; i += TPB) {
                     const int sl = i / LDP, j = i - sl * LDP;
                     const int t_s = s_T[sl];
-                    if (j < na && t_s < na) {
+                    if (j < na && (unsigned)t_s < (unsigned)na) {
                         const double2 kt = Ku[t_s], hj = HPu[j], kj = Ku[j], ht = HPu[t_s];
                         s_R[i] = s_R[i] - (kt.x * hj.x + kt.y * hj.y);   // P[t_s][j]
                         s_C[i] = s_C[i] - (kj.x * ht.x + kj.y * ht.y);   // P[j][t_s]
@@ -550,7 +649,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 const double g02 = s_sc[0], g12 = s_sc[1];
                 // new rows G_x P[0:3,:] and new cols P[:,0:3] G_x^T
 #pragma unroll 1
-                for (int j = tid; j < no; j += TPB) {
+                for (int j = td; j < no; j += TPB) {
                     s_R[sa * LDP + j] = s_R[j] + g02 * s_R[2 * LDP + j];
                     s_R[sb * LDP + j] = s_R[LDP + j] + g12 * s_R[2 * LDP + j];
                     s_C[sa * LDP + j] = s_C[j] + s_C[2 * LDP + j] * g02;
@@ -575,11 +674,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     s_xp[no + 1] = s_sc[5];
                     s_ids[M] = p.id_known ? (int)s_meas[3 * l] : M;
                 }
-                if (tid >= 64 - TS && tid < 64) {  // cross entries of the other thin rows / cols
-                    const int sl = tid - (64 - TS);
+                if (td >= 64 - TS && td < 64) {  // cross entries of the other thin rows / cols
+                    const int sl = td - (64 - TS);
                     if (sl < nT && sl != sa && sl != sb) {
                         const int t_s = s_T[sl];
-                        if (t_s < no) {
+                        if ((unsigned)t_s < (unsigned)no) {
                             s_R[sl * LDP + no] = s_C[sa * LDP + t_s];       // P[t_s][no]
                             s_R[sl * LDP + no + 1] = s_C[sb * LDP + t_s];   // P[t_s][no+1]
                             s_C[sl * LDP + no] = s_R[sa * LDP + t_s];       // P[no][t_s]
@@ -602,12 +701,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int npair = (nn2 + 1) >> 1;
             const bool same_layout = (lds == nf);
             const int rs = (2 * TPB) / nf, cs = (2 * TPB) - rs * nf;   // (r, c) step between a lane's pairs
-            int r = (2 * tid) / nf;
-            int c = 2 * tid - r * nf;
+            const int tb = opaque(tid);
+            int r = (2 * tb) / nf;
+            int c = 2 * tb - r * nf;
             dbl2_t* dst2 = reinterpret_cast<dbl2_t*>(Pout);
             const dbl2_t* src2 = reinterpret_cast<const dbl2_t*>(src);
 #pragma unroll 1
-            for (int q0 = tid; q0 < ((p.dbg & 1) ? 0 : npair); q0 += UNR * TPB) {
+            for (int q0 = tb; q0 < ((p.dbg & 1) ? 0 : npair); q0 += UNR * TPB) {
                 double2 v[UNR];
                 int rr[UNR], cc[UNR];
 #pragma unroll
@@ -671,12 +771,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int nvec = (nn2 + VEC - 1) / VEC;
             const bool vec_load = !src_mid && (lds == nf);
             const int rs = (VEC * TPB) / nf, cs = (VEC * TPB) - rs * nf;   // (r, c) step between a lane's vectors
-            int r = (VEC * tid) / nf;
-            int c = VEC * tid - r * nf;
+            const int tb = opaque(tid);
+            int r = (VEC * tb) / nf;
+            int c = VEC * tb - r * nf;
             VT* dst2 = reinterpret_cast<VT*>(Pout);
             const VT* src2 = reinterpret_cast<const VT*>(Pin);
 #pragma unroll 1
-            for (int q0 = tid; q0 < ((p.dbg & 1) ? 0 : nvec); q0 += UNR * TPB) {
+            for (int q0 = tb; q0 < ((p.dbg & 1) ? 0 : nvec); q0 += UNR * TPB) {
                 double v[UNR][VEC];
                 int rr[UNR], cc[UNR];
 #pragma unroll
@@ -749,15 +850,28 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // ------------------------------------------------------------------------------------------------------
     // x_t = x_pred (ekf.cpp:176) and bookkeeping.  P_t = P_pred was written by the bulk stream.
     // ------------------------------------------------------------------------------------------------------
-    for (int i = tid; i < na; i += TPB) {
+    const int te = opaque(tid);
+    for (int i = te; i < na; i += TPB) {
         const ST sv = (ST)s_xp[i];   // storage rounding of x_t (identity for fp64)
-        xb[i] = sv;
+        s_xt[i] = (double)sv;
+        s_xp[i] = (double)sv;
         const unsigned h0 = hi_abs((double)sv);
         hiacc = hiacc > h0 ? hiacc : h0;
     }
+    if constexpr (!kWide) {
+        // resident thin rows/cols must equal what HBM holds: apply the storage rounding to them as well
+        if (t + 1 < T) {
+            const int nTl = s_misc[5];
+#pragma unroll 1
+            for (int i = te; i < nTl * LDP; i += TPB) {
+                s_R[i] = (double)(ST)s_R[i];
+                s_C[i] = (double)(ST)s_C[i];
+            }
+        }
+    }
+    if (s_misc[6]) flags |= SLAM_INST_S_SINGULAR;
     const bool nonfinite = __syncthreads_or(hiacc >= 0x7ff00000u);
     if (nonfinite) flags |= SLAM_INST_NONFINITE;
-    if (s_misc[6]) flags |= SLAM_INST_S_SINGULAR;
 
     if (na != nf) {
         // fewer insertions than provisioned (unknown-id mode over-estimates): re-pack from leading dimension nf to
@@ -767,36 +881,34 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             ST tmp[(LDP + TPB - 1) / TPB];
 #pragma unroll
             for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
-                const int c = tid + TPB * u;
+                const int c = te + TPB * u;
                 tmp[u] = c < na ? Pout[(size_t)r * nf + c] : (ST)0;
             }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
-                const int c = tid + TPB * u;
+                const int c = te + TPB * u;
                 if (c < na) Pout[(size_t)r * na + c] = tmp[u];
             }
             __syncthreads();
         }
     }
-    if (M != M_old) {
-        for (int i = tid; i < M; i += TPB) p.ids[(size_t)b * p.L_max + i] = s_ids[i];
+    if (tid == 0 && p.sim) {  // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
+        const double ex = (double)(float)s_xt[0] - s_keep[0], ey = (double)(float)s_xt[1] - s_keep[1];
+        s_keep[3] = s_keep[3] + sqrt(ex * ex + ey * ey);
     }
-    if (tid == 0) {
-        p.M[b] = M;
-        p.flags[b] = flags;
-        p.timestep[b] = p.timestep[b] + 1;
-        SLAM_STAMP(8);   // epilogue
-        if (p.sim) {  // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
-            const double ex = (double)(float)s_xp[0] - tx, ey = (double)(float)s_xp[1] - ty;
-            p.err_sum[b] = p.err_sum[b] + sqrt(ex * ex + ey * ey);
-        }
-    }
+    }   // timestep loop
+
+    finish(T, M, flags);
+    SLAM_STAMP(8);   // epilogue
 }
 
 template <int NMAX, int W, int KG_, int UNR_, class ST>
 hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST>), dim3(p.B), dim3(64 * W), 0, stream, p);
+    if (p.cmds != nullptr && p.T > 1)
+        hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST, true>), dim3(p.B), dim3(64 * W), 0, stream, p);
+    else   // a single step takes (fwd, ang); the host sets them to the first command of the chunk
+        hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST, false>), dim3(p.B), dim3(64 * W), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -7,18 +7,20 @@
 namespace slam {
 
 // Executed by ONE wavefront (lane = 0..63).  `P` is a step-parameter struct with the simulator fields
-// (seed, inst0, step, fwd, ang, sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max, map, L, truth).
-// tx, ty, tth: the instance's true pose (prefetched), advanced in place; lmx, lmy: prefetched map entry of id = lane.
+// (seed, inst0, sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max, map, L, truth).
+// fwd, ang: the commanded motion; step: RNG step index.  tx, ty, tth: the instance's true pose (prefetched),
+// advanced in place; lmx, lmy: prefetched map entry of id = lane.
 // Writes the [id, range, bearing] float32 triplets of the visible landmarks (ascending id) to s_meas and their
 // count to *s_count (triplets beyond KCAP are not stored; the caller caps and flags); lane 0 stores the new truth pose.
 template <int KCAP, class P>
-__device__ __forceinline__ void sim_wave(const P& p, int b, int lane, double& tx, double& ty, double& tth, double lmx,
-                                         double lmy, float* s_meas, int* s_count) {
+__device__ __forceinline__ void sim_wave(const P& p, int b, int lane, float fwd, float ang, uint32_t step, double& tx,
+                                         double& ty, double& tth, double lmx, double lmy, float* s_meas,
+                                         int* s_count) {
     const uint64_t inst = (uint64_t)(p.inst0 + b);
     double u0, u1;
-    noise_pair(p.seed, inst, p.step, 0u, &u0, &u1);
-    double d = ((double)p.fwd + (2 * p.sV00) * u0) - p.sV00;        // sim_node.py:216
-    double hdg = ((double)p.ang + (2 * p.sV11) * u1) - p.sV11;      // :217
+    noise_pair(p.seed, inst, step, 0u, &u0, &u1);
+    double d = ((double)fwd + (2 * p.sV00) * u0) - p.sV00;          // sim_node.py:216
+    double hdg = ((double)ang + (2 * p.sV11) * u1) - p.sV11;        // :217
     d = (p.d_max < d) ? p.d_max : d;                                 // min(d, d_max)        :219
     d = (0.0 < d) ? d : 0.0;                                         // max(0, .)
     hdg = (p.th_max < hdg) ? p.th_max : hdg;                         // :220
@@ -46,7 +48,7 @@ __device__ __forceinline__ void sim_wave(const P& p, int b, int lane, double& tx
         const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
         if (vis && pos < KCAP) {  // noise in visible-id order (sim_node.py:245-249), float32 wire format
             double v0, v1;
-            noise_pair(p.seed, inst, p.step, (uint32_t)(1 + pos), &v0, &v1);
+            noise_pair(p.seed, inst, step, (uint32_t)(1 + pos), &v0, &v1);
             const double rn = (r + (2 * p.sW00) * v0) - p.sW00;
             const double bn = (beta + (2 * p.sW11) * v1) - p.sW11;
             s_meas[3 * pos] = (float)id;

@@ -65,6 +65,8 @@ struct slam_handle {
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
     float* dmapf = nullptr;                           // UKF_LOC: the known map as float32 [id, x, y] triplets
+    float* dcmds = nullptr; int cmds_cap = 0;         // command sequence of a multi-step launch (slam_run_sim)
+    int run_chunk = 0;                                // timesteps per launch in slam_run_sim (0 = all of them)
     int base = 3;                                     // state offset of the first landmark: 3 (EKF) or 4 (UKF)
     bool dump_meas = false;
 };
@@ -244,6 +246,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (env) h->waves_per_filter = atoi(env);
     env = getenv("SLAM_DEBUG_FLAGS");
     if (env) h->dbg = atoi(env);
+    env = getenv("SLAM_RUN_CHUNK");   // timesteps per launch of slam_run_sim (1 = one launch per step)
+    if (env) h->run_chunk = atoi(env);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
@@ -282,7 +286,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -386,9 +390,37 @@ int slam_step_sim(slam_handle* h, const float cmd[2]) {
 
 int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     if (!h || !cmds || T < 0) return fail(SLAM_ERR_ARG, "bad argument");
-    for (int t = 0; t < T; ++t) {
-        int rc = slam_step_sim(h, cmds + 2 * (size_t)t);
-        if (rc) return rc;
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
+    if (T == 0) return SLAM_OK;
+    if (h->kind != SLAM_EKF_SLAM || h->dump_meas || h->run_chunk == 1) {
+        // one launch (pair) per timestep
+        for (int t = 0; t < T; ++t) {
+            int rc = slam_step_sim(h, cmds + 2 * (size_t)t);
+            if (rc) return rc;
+        }
+        return SLAM_OK;
+    }
+    // EKF: every workgroup carries its instance through a whole chunk of timesteps, keeping x_t, the landmark ids,
+    // the true pose and the thin rows/cols of P on chip; only the P stream touches HBM each step.
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->cmds_cap < T) {
+        if (h->dcmds) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(h->dcmds); h->dcmds = nullptr; }
+        HIP_TRY(hipMalloc(&h->dcmds, sizeof(float) * 2 * (size_t)T));
+        h->cmds_cap = T;
+    }
+    HIP_TRY(hipMemcpyAsync(h->dcmds, cmds, sizeof(float) * 2 * (size_t)T, hipMemcpyHostToDevice, h->stream));
+    const int chunk = h->run_chunk > 0 ? h->run_chunk : T;
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        const int tc = T - t0 < chunk ? T - t0 : chunk;
+        slam::EkfStepParams p;
+        fill_params(h, p, cmds + 2 * (size_t)t0);
+        p.sim = 1;
+        p.cmds = h->dcmds + 2 * (size_t)t0;
+        p.T = tc;
+        HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
+        if (tc & 1) std::swap(h->dP, h->dP2);
+        h->step += (uint32_t)tc;
     }
     return SLAM_OK;
 }

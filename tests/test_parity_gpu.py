@@ -121,6 +121,38 @@ def test_sim_step_parity(S, oracle, monkeypatch, L, T, B, wpf):
     f.close()
 
 
+@pytest.mark.parametrize("L,T,B,chunk,dtype,idknown,wide", [
+    (50, 301, 96, 0, "f64", 1, 0),      # the whole run in one launch (odd T: result lands in the other buffer)
+    (50, 300, 64, 7, "f64", 1, 1),      # odd chunks + a wide-sensor step inside a chunk (k = 50 > KG: several groups)
+    (20, 250, 64, 16, "f64", 0, 0),     # unknown-id association (over-provisioned leading dimension, re-pack)
+    (50, 200, 48, 0, "f32", 1, 1),      # fp32 storage: resident thin rows must carry the storage rounding
+    (20, 120, 64, 1, "f64", 1, 0),      # chunk 1 = one launch per step through the same entry point
+])
+def test_run_sim_multistep_launch_parity(S, oracle, monkeypatch, L, T, B, chunk, dtype, idknown, wide):
+    """slam_run_sim runs many timesteps per launch (x_t, ids, true pose and the thin rows/cols of P stay on chip,
+    P ping-pongs between its two buffers): same bits as the oracle, whatever the chunking."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    monkeypatch.setenv("SLAM_RUN_CHUNK", str(chunk))
+    lm, cmds = make_scenario(4321, L, T)
+    cfg = S.default_config(); cfg.landmark_id_is_known = idknown
+    if wide:
+        cfg.range_max = 1e9; cfg.fov_min = -4.0; cfg.fov_max = 4.0   # every landmark in view all the time
+    f = S.BatchedEKF(B, L, dtype=S.F32 if dtype == "f32" else S.F64).readParams(cfg)
+    f.set_map(lm); f.set_seed(99); f.set_instance_offset(123); f.init(0, 0, 0)
+    f.run_sim(cmds[:T // 3]); f.run_sim(cmds[T // 3:])          # two calls: state carries over between launches
+    mode = oracle.MODE_FAST | (oracle.STORAGE_F32 if dtype == "f32" else 0)
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=99, inst0=123, nthreads=8, cfg=cfg, mode=mode)
+    assert np.array_equal(f.landmark_counts(), r["M"]) and np.array_equal(f.truth(), r["truth"])
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.status(), r["flags"])
+    for b in range(B):
+        n = 3 + 2 * r["M"][b]
+        sg = f.get_state(b)
+        assert sg["timestep"] == T or r["flags"][b] != 0
+        _assert_state_equal(sg, dict(M=r["M"][b], ids=r["ids"][b, :r["M"][b]], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    assert r["M"].max() > 3
+    f.close()
+
+
 def test_many_detections_in_one_step_and_groups(S, oracle):
     """A wide sensor shows every landmark at once (k = L = 50 > KG): insertion path, grouping, then updates of all."""
     from live_ekf_slam_amd.scenario import make_scenario
