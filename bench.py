@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: EKF-SLAM predict–update steps/sec at L=50 (n=103), batch=65536 per GPU, fp64.
 
-A "step" (K of them are timed) is ONE pass of the hot path over the whole batch: one fused kernel launch that, for
-every instance, generates that instance's range-bearing measurements on the device (get_cmd, sim_node.py:209-250)
-and runs EKF::update (ekf.cpp:37-179).  `value` = instance-steps per second = batch * K / seconds (all ranks).
+A "step" (K of them are timed) is ONE pass of the hot path over the whole batch: for every instance, generate that
+instance's range-bearing measurements on the device (get_cmd, sim_node.py:209-250) and run EKF::update
+(ekf.cpp:37-179).  `value` = instance-steps per second = batch * K / seconds (all ranks).  The K timed steps go
+through slam_run_sim, which by default runs them in ONE launch of the fused kernel (every workgroup carries its
+instance through all K timesteps, keeping x_t, ids, the true pose and the thin rows of P on chip while P itself
+streams HBM -> HBM once per timestep); `--steps-per-launch 1` gives one launch per timestep instead.  The roofline
+object is per launch: algorithmic bytes of one launch = (steps in it) x sum_b 2(n_b^2+n_b)*8.
 
 Workload construction (deterministic, everything resident in HBM before the timed region):
   scenario seed 1234 -> random map of L landmarks + TSP command sequence (live_ekf_slam_amd/scenario.py ==
@@ -118,6 +122,8 @@ def main():
     ap.add_argument("--preroll", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waves-per-filter", type=int, default=0)
+    ap.add_argument("--steps-per-launch", type=int, default=0,
+                    help="timesteps one kernel launch carries (0 = all K timed steps in one launch, 1 = launch per step)")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="storage type of x and P in HBM (arithmetic is fp64 either way); f64 is the headline metric")
     ap.add_argument("--filter", choices=["ekf", "ukf"], default="ekf",
@@ -141,6 +147,8 @@ def main():
 
     if args.waves_per_filter:
         os.environ["SLAM_WAVES_PER_FILTER"] = str(args.waves_per_filter)
+    spl = args.steps_per_launch if args.steps_per_launch > 0 else max(args.steps, 1)
+    os.environ["SLAM_RUN_CHUNK"] = str(spl)
     import live_ekf_slam_amd as S
     from live_ekf_slam_amd.parallel import gather_error_stats, reduce_summary
     from live_ekf_slam_amd.scenario import make_scenario
@@ -165,8 +173,9 @@ def main():
 
     with torch.cuda.stream(stream):
         f.set_vision(*vis[0]); f.update_sim(cmds[0]); f.set_vision(*vis[1])
-        f.run_sim(cmds[1:1 + PRE])
-        f.run_sim(cmds[1 + PRE:1 + PRE + W])        # W untimed warm-up steps
+        for t in range(1, 1 + PRE):                  # pre-roll, one launch per step (slam_step_sim)
+            f.update_sim(cmds[t])
+        f.run_sim(cmds[1 + PRE:1 + PRE + W])        # W untimed warm-up steps through the timed entry point
         sync_all()
         alg_bytes = f.algorithmic_bytes()           # sum_b 2(n_b^2+n_b)*8 at the start of the timed window
         M = f.landmark_counts()
@@ -179,7 +188,8 @@ def main():
         sync_all()
         t1 = time.perf_counter()
     wall = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K           # average launch duration from HIP events on the launch stream
+    n_launch = (K + spl - 1) // spl
+    kernel_ms = ev0.elapsed_time(ev1) / n_launch    # average launch duration from HIP events on the launch stream
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -192,7 +202,8 @@ def main():
 
     if rank == 0:
         value = B * world * K / wall
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        launch_bytes = alg_bytes * K / n_launch     # M is constant over the window (all landmarks mapped)
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         n_state = 3 + 2 * int(round(M.mean()))
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -200,7 +211,7 @@ def main():
             try:
                 d = json.load(open(pmc))
                 if d.get("batch") == B and d.get("landmarks") == L:
-                    traffic = d.get("hbm_bytes_per_launch")
+                    traffic = d.get("hbm_bytes_per_step") * K / n_launch   # L2<->fabric bytes (rocprofv3 PMC)
             except Exception:
                 traffic = None
         line = {
@@ -218,8 +229,11 @@ def main():
                        "avg_position_error_m": round(float(mean_err), 5), "instances_flagged": int((flags != 0).sum())},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ekf_step_kernel<103,W>", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "ekf_step_kernel<103,4,4,4,%s,%s>" % ("double" if args.dtype == "f64" else "float",
+                                                                          "true" if spl > 1 else "false"),
+                         "kernel_ms": round(kernel_ms, 4), "launches": n_launch, "steps_per_launch": min(spl, K),
+                         "algorithmic_bytes_per_launch": launch_bytes,
+                         "algorithmic_bytes_per_step": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             lmc, cmdc = make_scenario(1234, L, 260)

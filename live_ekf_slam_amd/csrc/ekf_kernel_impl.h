@@ -120,14 +120,18 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ double2 s_K[KG * LDP];     // per update of the group: K[r][0..1]
     __shared__ double2 s_HP[KG * LDP];    // per update of the group: (H P)[0..1][c]
     __shared__ double s_sc[16];           // scalars computed by the leader lane (H entries, nu, S^-1, G_x ...)
-    __shared__ float s_meas[3 * KCAP];
+    __shared__ float s_meas[2 * 3 * KCAP];   // [step parity][detection][id, range, bearing]
     __shared__ int s_ids[LMAX > 0 ? LMAX : 1];
-    __shared__ int s_didx[KCAP];          // per detection: landmark number (>= M_old: inserted this step), -1 dropped
+    __shared__ int s_didx[2 * KCAP];      // [step parity] per detection: landmark number (>= M_old: inserted this
+                                          // step), -1 dropped
+    __shared__ int s_next[2 * 4];         // [step parity] raw detection count, insertions, freeze, capacity overflow
+    __shared__ double s_ps[2 * 10];       // [step parity] x_pred of the vehicle (3), F_x(0,2), F_x(1,2), F_v V F_v^T (4)
+    __shared__ int s_chunk;               // next chunk of the bulk stream (waves take chunks as they become free)
     __shared__ int s_T[TS];               // thin slot -> state index, -1 = free.  Slots 0..2 = vehicle rows for good;
                                           // landmarks occupy the pairs (3+2j, 4+2j) and stay resident while detected
     __shared__ signed char s_slot[LDP];   // state index -> thin slot or -1
     __shared__ signed char s_need[TS];    // slot was (re)assigned: 1 = gather from HBM, 2 = new landmark (zero)
-    __shared__ int s_misc[8];             // k, n_insert, freeze, capacity, l1, nT, singular-S
+    __shared__ int s_misc[8];             // -, -, freeze, capacity (unknown ids), l1, nT, singular-S
     __shared__ double s_keep[4 + 2 * 64]; // values that live across the timesteps of one launch: true pose, error
                                           // sum, map entries of ids 0..63 (kept out of registers on purpose)
 
@@ -219,75 +223,61 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     int M = M_init;
     int na = n_init;     // active dimension
     unsigned hiacc = 0u; // non-finite detector (max of |hi word|)
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-    const ST* __restrict__ Pin = (t & 1) ? PB : PA;
-    ST* __restrict__ Pout = (t & 1) ? PA : PB;
-    double* __restrict__ Pmid = kWide ? reinterpret_cast<double*>(Pout) : (p.scratch + (size_t)b * p.pstride);
-    const float fwd = MULTI ? p.cmds[2 * t] : p.fwd;
-    const float ang = MULTI ? p.cmds[2 * t + 1] : p.ang;
-    const uint32_t stepi = p.step + (uint32_t)t;
-    const int M_old = M;
-    const int n_old = na;
-    // pre-step state of a freezing instance into the buffer the host reads next
-    auto freeze = [&]() {
-        if (Pfinal != Pin) {
-            const int nn = n_old * n_old;
-            for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pin[i];
-        }
-        finish(t, M_old, flags | SLAM_INST_INDEX_OOR);
-    };
-    if (tid < 8) s_misc[tid] = 0;
 
-    // ------------------------------------------------------------------------------------------------------
-    // measurements: generate (sim_node.py:209-250) or fetch
-    // ------------------------------------------------------------------------------------------------------
-    __syncthreads();
-    SLAM_STAMP(0);   // initial loads
-    if (p.sim) {
-        if (tid < 64) { // one wavefront advances the truth and scans the map in ascending id (sim_node.py:209-243)
+    // Everything of timestep tn that does not depend on P, executed by ONE wavefront: the measurement generator
+    // (sim_node.py:209-250), the known-id association of the whole message (ekf.cpp:99-108; lane l <-> detection l)
+    // and the vehicle part of the prediction (ekf.cpp:41-59).  For tn > first step of the launch it runs inside the
+    // bulk stream of step tn-1 (the other wavefronts keep streaming), so its latency chain is off the critical path.
+    // Reads x_{tn} from s_xp (final x_pred of step tn-1), the current M / s_ids; writes the parity-tn buffers.
+    auto prestep = [&](int tn) {
+        const int qb = tn & 1;
+        float* meas = s_meas + qb * 3 * KCAP;
+        int* didx = s_didx + qb * KCAP;
+        int* nx = s_next + 4 * qb;
+        double* ps = s_ps + 10 * qb;
+        const float fwd_n = MULTI ? p.cmds[2 * tn] : p.fwd;
+        const float ang_n = MULTI ? p.cmds[2 * tn + 1] : p.ang;
+        int kraw;
+        if (p.sim) {
             double tx = s_keep[0], ty = s_keep[1], tth = s_keep[2];
-            sim_wave<KCAP>(p, b, lane, fwd, ang, stepi, tx, ty, tth, s_keep[4 + lane], s_keep[4 + 64 + lane], s_meas,
-                           &s_misc[0]);
+            kraw = sim_wave<KCAP>(p, b, lane, fwd_n, ang_n, p.step + (uint32_t)tn, tx, ty, tth, s_keep[4 + lane],
+                                  s_keep[4 + 64 + lane], meas);
             if (lane == 0) { s_keep[0] = tx; s_keep[1] = ty; s_keep[2] = tth; }
+        } else {
+            kraw = nx[0];   // EXT mode: the message was fetched by the prologue
         }
-    } else {
-        int kk = p.meas_count_in[b];
-        kk = kk < p.k_stride_in ? kk : p.k_stride_in;
-        kk = kk < 0 ? 0 : kk;
-        const int kc = kk < KCAP ? kk : KCAP;
-        for (int i = tid; i < 3 * kc; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
-        if (tid == 0) s_misc[0] = kk;
-    }
-    __syncthreads();
-    SLAM_STAMP(1);   // measurement generation / fetch
-    if (s_misc[0] > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than one wavefront associates
-    const int k = s_misc[0] < KCAP ? s_misc[0] : KCAP;
-    if (p.sim && p.meas_out != nullptr && t == T - 1) {
-        for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB)
-            p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = s_meas[i];
-        if (tid == 0) p.meas_count_out[b] = k;
-    }
-
-    // ------------------------------------------------------------------------------------------------------
-    // known-id association for the whole message up front (ekf.cpp:99-108): lane l <-> detection l
-    // ------------------------------------------------------------------------------------------------------
-    int n_ins = 0;  // insertions this step (exact for known ids, upper bound k otherwise)
-    if (p.id_known) {
-        if (tid < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        {   // x_pred of the vehicle (ekf.cpp:56-59) and the scalars of F_x, F_v V F_v^T (ekf.cpp:41-55)
+            const double x0 = (double)(ST)s_xp[0], x1 = (double)(ST)s_xp[1], th = (double)(ST)s_xp[2];
+            double sn, cs;
+            det_sincos(th, &sn, &cs);
+            const float dd = fwd_n + p.v_d;
+            const double cv = cs * p.V00, sv = sn * p.V00;
+            if (lane == 0) {
+                nx[0] = kraw;
+                ps[0] = x0 + (double)dd * cs;
+                ps[1] = x1 + (double)dd * sn;
+                ps[2] = remainder((th + (double)ang_n) + (double)p.v_th, kTwoPi);
+                ps[3] = (double)(-1 * fwd_n) * sn;  // F_x(0,2)
+                ps[4] = (double)fwd_n * cs;         // F_x(1,2)
+                ps[5] = cv * cs; ps[6] = cv * sn; ps[7] = sv * cs; ps[8] = sv * sn;
+            }
+        }
+        if (p.id_known) {
+            const int kn = kraw < KCAP ? kraw : KCAP;
             // lanes scan lm_IDs in parallel for each detection (first match wins, ekf.cpp:102-107); lane l then
             // keeps the result of detection l
             int idx = -1;
             bool isnew = false, dup = false;
-            const int myid = lane < k ? (int)s_meas[3 * lane] : -1;
+            const int myid = lane < kn ? (int)meas[3 * lane] : -1;
 #pragma unroll 1
-            for (int l = 0; l < k; ++l) {
-                const int id = (int)s_meas[3 * l];
+            for (int l = 0; l < kn; ++l) {
+                const int id = (int)meas[3 * l];
                 int found = -1;
 #pragma unroll 1
-                for (int j0 = 0; j0 < M_old && found < 0; j0 += 64) {
+                for (int j0 = 0; j0 < M && found < 0; j0 += 64) {
                     const int j = j0 + lane;
-                    const unsigned long long m = __ballot(j < M_old && s_ids[j] == id);
+                    const unsigned long long m = __ballot(j < M && s_ids[j] == id);
                     if (m != 0ull) found = j0 + (__ffsll((long long)m) - 1);
                 }
                 // among the NEW ids: has an earlier detection of this message the same id?
@@ -299,43 +289,73 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const unsigned long long dmask = __ballot(dup);
             const unsigned long long nmask = __ballot(isnew);
             const int rank = __popcll(nmask & ((1ull << lane) - 1ull));
-            if (isnew) idx = (M_old + rank < p.L_max && M_old + rank < LMAX) ? M_old + rank : -1;
-            if (lane < k) s_didx[lane] = idx;
+            if (isnew) idx = (M + rank < p.L_max && M + rank < LMAX) ? M + rank : -1;
+            if (lane < kn) didx[lane] = idx;
             if (lane == 0) {
-                int cnt = __popcll(nmask);
-                const int room = (p.L_max < LMAX ? p.L_max : LMAX) - M_old;
-                s_misc[3] = cnt > room ? 1 : 0;           // capacity overflow
-                s_misc[1] = cnt > room ? room : cnt;      // insertions
-                s_misc[2] = dmask != 0ull ? 1 : 0;        // freeze
+                const int cnt = __popcll(nmask);
+                const int room = (p.L_max < LMAX ? p.L_max : LMAX) - M;
+                nx[3] = cnt > room ? 1 : 0;           // capacity overflow
+                nx[1] = cnt > room ? room : cnt;      // insertions
+                nx[2] = dmask != 0ull ? 1 : 0;        // freeze
             }
         }
-        __syncthreads();
-        n_ins = s_misc[1];
-    } else {
-        n_ins = k;
+    };
+
+    if (!p.sim) {   // EXT mode (single step): fetch the message
+        int kk = p.meas_count_in[b];
+        kk = kk < p.k_stride_in ? kk : p.k_stride_in;
+        kk = kk < 0 ? 0 : kk;
+        const int kc = kk < KCAP ? kk : KCAP;
+        for (int i = tid; i < 3 * kc; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
+        if (tid == 0) s_next[0] = kk;
     }
-    if (s_misc[2]) {  // freeze in the pre-step state
+    __syncthreads();
+    SLAM_STAMP(0);   // initial loads
+    if (tid < 64) prestep(0);
+    SLAM_STAMP(1);   // measurements, association, motion scalars of the first step
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+    const ST* __restrict__ Pin = (t & 1) ? PB : PA;
+    ST* __restrict__ Pout = (t & 1) ? PA : PB;
+    double* __restrict__ Pmid = kWide ? reinterpret_cast<double*>(Pout) : (p.scratch + (size_t)b * p.pstride);
+    const int pb = t & 1;
+    const float* const meas_t = s_meas + pb * 3 * KCAP;
+    int* const didx_t = s_didx + pb * KCAP;
+    const int M_old = M;
+    const int n_old = na;
+    // pre-step state of a freezing instance into the buffer the host reads next
+    auto freeze = [&]() {
+        if (Pfinal != Pin) {
+            const int nn = n_old * n_old;
+            for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pin[i];
+        }
+        finish(t, M_old, flags | SLAM_INST_INDEX_OOR);
+    };
+    if (tid < 8) s_misc[tid] = 0;
+    __syncthreads();   // the pre-step results of this timestep are visible
+    const int kraw = s_next[4 * pb];
+    if (kraw > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than one wavefront associates
+    const int k = kraw < KCAP ? kraw : KCAP;
+    if (p.sim && p.meas_out != nullptr && t == T - 1) {
+        for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB)
+            p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = meas_t[i];
+        if (tid == 0) p.meas_count_out[b] = k;
+    }
+    const int n_ins = p.id_known ? s_next[4 * pb + 1] : k;  // insertions this step (upper bound k for unknown ids)
+    if (p.id_known && s_next[4 * pb + 2]) {  // freeze in the pre-step state
         freeze();
         return;
     }
-    if (s_misc[3]) flags |= SLAM_INST_CAPACITY;
+    if (p.id_known && s_next[4 * pb + 3]) flags |= SLAM_INST_CAPACITY;
     SLAM_STAMP(2);   // association
     int nf = n_old + 2 * n_ins;           // leading dimension of the matrix written this step
     nf = nf < NMAX ? nf : NMAX;
 
-    // x_pred of the vehicle (ekf.cpp:56-59); needed before the first group because unknown-id association
-    // (ekf.cpp:82-98) projects detections with the PREDICTED pose.  The covariance part of the prediction runs
-    // on the thin rows/cols of the first group.
-    if (tid == 0) {
-        const float d_d = fwd, d_th = ang;
-        const double th = s_xt[2];
-        double s, c;
-        det_sincos(th, &s, &c);
-        const float dd = d_d + p.v_d;
-        s_xp[0] = s_xt[0] + (double)dd * c;
-        s_xp[1] = s_xt[1] + (double)dd * s;
-        s_xp[2] = remainder((th + (double)d_th) + (double)p.v_th, kTwoPi);
-    }
+    // x_pred of the vehicle (ekf.cpp:56-59) was computed by the pre-step; it is needed before the first group because
+    // unknown-id association (ekf.cpp:82-98) projects detections with the PREDICTED pose.  The covariance part of the
+    // prediction runs on the thin rows/cols of the first group.
+    if (tid < 3) s_xp[tid] = s_ps[10 * pb + tid];
 
     // ------------------------------------------------------------------------------------------------------
     // groups of <= KG detections
@@ -363,10 +383,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             while (l1 < k && l1 - l0 < KG) {
                 int idx;
                 if (p.id_known) {
-                    idx = s_didx[l1];
+                    idx = didx_t[l1];
                 } else if (l1 == l0) {
                     // unknown ids (ekf.cpp:82-98): associate against the CURRENT x_pred, one detection per group
-                    const float r_m = s_meas[3 * l1 + 1], b_m = s_meas[3 * l1 + 2];
+                    const float r_m = meas_t[3 * l1 + 1], b_m = meas_t[3 * l1 + 2];
                     double s, c;
                     det_sincos(s_xp[2] + (double)b_m, &s, &c);
                     const float x_det = (float)(s_xp[0] + (double)r_m * c);
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     if (idx == -2) idx = (M_g < p.L_max && M_g < LMAX && na_g + 2 <= nf) ? M_g : -1;
                     if (idx == -1) s_misc[3] = 1;
                     if (idx >= 0 && idx < M_g && 2 * idx + 4 >= n_old) frz = 1;  // matched a landmark inserted this step
-                    s_didx[l1] = idx;
+                    didx_t[l1] = idx;
                 } else {
                     break;
                 }
@@ -431,6 +451,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 #pragma unroll
             for (int j = 0; j < KG; ++j)
                 if (s_T[3 + 2 * j] >= 0) nT = 5 + 2 * j;
+            s_chunk = 0;
             s_misc[4] = l1;
             s_misc[5] = nT;      // high-water mark: slots [3, nT) may contain free pairs (s_T < 0)
             s_misc[2] = frz;
@@ -483,19 +504,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         // ---- prediction stage on the thin copies (first group only), ekf.cpp:41-61 ----
         if (first) {
             const int tp = opaque(tid);
-            if (tid == 0) {  // leader: the scalars of F_x, F_v V F_v^T
-                const float d_d = fwd;
-                double s, c;
-                det_sincos(s_xt[2], &s, &c);
-                const double cv = c * p.V00, sv = s * p.V00;
-                s_sc[0] = (double)(-1 * d_d) * s;  // F_x(0,2)
-                s_sc[1] = (double)d_d * c;         // F_x(1,2)
-                s_sc[2] = cv * c; s_sc[3] = cv * s; s_sc[4] = sv * c; s_sc[5] = sv * s;
-            }
+            const double* const ps = s_ps + 10 * pb;   // F_x(0,2), F_x(1,2), F_v V F_v^T from the pre-step
 #pragma unroll 1
             for (int i = tp; i < LDP; i += TPB) { s_r2[i] = s_R[2 * LDP + i]; s_c2[i] = s_C[2 * LDP + i]; }
             __syncthreads();
-            const double fa = s_sc[0], fb = s_sc[1];
+            const double fa = ps[3], fb = ps[4];
             const double p22 = s_r2[2];
             auto predicted = [&](double t, int r, int cc) -> double {
                 const double f_r = r == 0 ? fa : fb;
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     if (r < 2) a2 = a2 + f_r * p22;
                     t = t + a2 * (cc == 0 ? fa : fb);
                 }
-                if (r < 2 && cc < 2) t = t + s_sc[2 + 2 * r + cc];  // + F_v V F_v^T
+                if (r < 2 && cc < 2) t = t + ps[5 + 2 * r + cc];    // + F_v V F_v^T
                 if (r == 2 && cc == 2) t = t + p.V11;
                 return t;
             };
@@ -541,9 +554,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 #pragma unroll 1
         for (int l = l0; l < l1; ++l) {
             const int td = opaque(tid);   // keeps per-lane index arithmetic from being hoisted out of the loops
-            const int idx = s_didx[l];
+            const int idx = didx_t[l];
             if (idx < 0 || (p.dbg & 2)) continue;  // dropped (capacity)
-            const float r_m = s_meas[3 * l + 1], b_m = s_meas[3 * l + 2];
+            const float r_m = meas_t[3 * l + 1], b_m = meas_t[3 * l + 2];
             const int ii = 3 + 2 * idx;
             if (idx < M) {
                 // ---------------- landmark update, ekf.cpp:110-140 ----------------
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     s_C[sb * LDP + no] = v01; s_C[sb * LDP + no + 1] = v11;
                     s_xp[no] = s_sc[4];
                     s_xp[no + 1] = s_sc[5];
-                    s_ids[M] = p.id_known ? (int)s_meas[3 * l] : M;
+                    s_ids[M] = p.id_known ? (int)meas_t[3 * l] : M;
                 }
                 if (td >= 64 - TS && td < 64) {  // cross entries of the other thin rows / cols
                     const int sl = td - (64 - TS);
@@ -693,32 +706,46 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
 
         SLAM_STAMP(6);   // detections
+        // ---- the last wavefront first closes the books of this step and prepares the next one; it joins the stream
+        //      when it is done (chunks are handed out dynamically, so the others simply take more of them) ----
+        if (l1 >= k && (tid >> 6) == W - 1) {
+            if (p.sim && lane == 0) {  // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
+                const double ex = (double)(float)s_xp[0] - s_keep[0], ey = (double)(float)s_xp[1] - s_keep[1];
+                s_keep[3] = s_keep[3] + sqrt(ex * ex + ey * ey);
+            }
+            if (t + 1 < T) prestep(t + 1);
+        }
         // ---- BULK (fp64 storage): stream P once.  dst pair q = elements 2q, 2q+1 of the nf-leading-dimension
         //      layout; later groups of the same step update P_out in place. ----
         if constexpr (kWide) {
             const double* src = first ? reinterpret_cast<const double*>(Pin) : reinterpret_cast<const double*>(Pout);
             const int nn2 = nf * nf;
-            const int npair = (nn2 + 1) >> 1;
+            const int npair = (p.dbg & 1) ? 0 : (nn2 + 1) >> 1;
             const bool same_layout = (lds == nf);
-            const int rs = (2 * TPB) / nf, cs = (2 * TPB) - rs * nf;   // (r, c) step between a lane's pairs
-            const int tb = opaque(tid);
-            int r = (2 * tb) / nf;
-            int c = 2 * tb - r * nf;
+            constexpr int CH = 64 * UNR;                      // pairs per chunk: UNR coalesced 1 KiB rows of a wave
+            const int rs = 128 / nf, cs = 128 - rs * nf;      // (r, c) step between a lane's consecutive pairs
             dbl2_t* dst2 = reinterpret_cast<dbl2_t*>(Pout);
             const dbl2_t* src2 = reinterpret_cast<const dbl2_t*>(src);
 #pragma unroll 1
-            for (int q0 = tb; q0 < ((p.dbg & 1) ? 0 : npair); q0 += UNR * TPB) {
+            for (;;) {
+                int ch = 0;
+                if (lane == 0) ch = atomicAdd(&s_chunk, 1);
+                ch = __builtin_amdgcn_readfirstlane(ch);
+                const int q0 = ch * CH + opaque(lane);
+                if (ch * CH >= npair) break;
+                int r = (2 * q0) / nf;
+                int c = 2 * q0 - r * nf;
                 double2 v[UNR];
                 int rr[UNR], cc[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {   // issue the loads of UNR pairs first
-                    const int q = q0 + u * TPB;
+                    const int q = q0 + u * 64;
                     rr[u] = r; cc[u] = c;
                     v[u] = make_double2(0.0, 0.0);
                     if (q < npair) {
                         if (same_layout) {
-                            const dbl2_t t = (p.dbg & 8) ? src2[q] : __builtin_nontemporal_load(src2 + q);
-                            v[u] = make_double2(t.x, t.y);
+                            const dbl2_t t2 = (p.dbg & 8) ? src2[q] : __builtin_nontemporal_load(src2 + q);
+                            v[u] = make_double2(t2.x, t2.y);
                         } else {  // re-lay-out from leading dimension lds to nf (steps that grow the state)
                             int c1 = c + 1, r1 = r;
                             if (c1 == nf) { c1 = 0; r1 = r + 1; }
@@ -731,7 +758,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int q = q0 + u * TPB;
+                    const int q = q0 + u * 64;
                     if (q < npair) {
                         const int r0 = rr[u], c0 = cc[u];
                         int c1 = c0 + 1, r1 = r0;
@@ -768,29 +795,34 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const bool src_mid = !first;            // read the previous group's result (fp64 scratch)
             const bool dst_mid = (l1 < k);          // more groups follow: keep fp64
             const int nn2 = nf * nf;
-            const int nvec = (nn2 + VEC - 1) / VEC;
+            const int nvec = (p.dbg & 1) ? 0 : (nn2 + VEC - 1) / VEC;
             const bool vec_load = !src_mid && (lds == nf);
-            const int rs = (VEC * TPB) / nf, cs = (VEC * TPB) - rs * nf;   // (r, c) step between a lane's vectors
-            const int tb = opaque(tid);
-            int r = (VEC * tb) / nf;
-            int c = VEC * tb - r * nf;
+            constexpr int CH = 64 * UNR;
+            const int rs = (VEC * 64) / nf, cs = (VEC * 64) - rs * nf;   // (r, c) step between a lane's vectors
             VT* dst2 = reinterpret_cast<VT*>(Pout);
             const VT* src2 = reinterpret_cast<const VT*>(Pin);
 #pragma unroll 1
-            for (int q0 = tb; q0 < ((p.dbg & 1) ? 0 : nvec); q0 += UNR * TPB) {
+            for (;;) {
+                int ch = 0;
+                if (lane == 0) ch = atomicAdd(&s_chunk, 1);
+                ch = __builtin_amdgcn_readfirstlane(ch);
+                const int q0 = ch * CH + opaque(lane);
+                if (ch * CH >= nvec) break;
+                int r = (VEC * q0) / nf;
+                int c = VEC * q0 - r * nf;
                 double v[UNR][VEC];
                 int rr[UNR], cc[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {   // issue the loads of UNR vectors first
-                    const int q = q0 + u * TPB;
+                    const int q = q0 + u * 64;
                     rr[u] = r; cc[u] = c;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[u][e] = 0.0;
                     if (q < nvec) {
                         if (vec_load) {
-                            const VT t = __builtin_nontemporal_load(src2 + q);
+                            const VT t4 = __builtin_nontemporal_load(src2 + q);
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) v[u][e] = (double)t[e];
+                            for (int e = 0; e < VEC; ++e) v[u][e] = (double)t4[e];
                         } else {  // other leading dimension (the state grows this step) or fp64 intermediate
                             int re = r, ce = c;
 #pragma unroll
@@ -803,11 +835,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         }
                     }
                     c += cs; r += rs;
-                    if (c >= nf) { c -= nf; r += 1; }
+                    while (c >= nf) { c -= nf; r += 1; }
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int q = q0 + u * TPB;
+                    const int q = q0 + u * 64;
                     if (q < nvec) {
                         int re = rr[u], ce = cc[u];
                         VT outv;
@@ -893,10 +925,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             __syncthreads();
         }
     }
-    if (tid == 0 && p.sim) {  // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
-        const double ex = (double)(float)s_xt[0] - s_keep[0], ey = (double)(float)s_xt[1] - s_keep[1];
-        s_keep[3] = s_keep[3] + sqrt(ex * ex + ey * ey);
-    }
+    if ((p.dbg & 32) && p.prof != nullptr && tid == 0 && t < 16) p.prof[(size_t)blockIdx.x * 16 + t] = wall_clock64();
     }   // timestep loop
 
     finish(T, M, flags);

@@ -10,12 +10,12 @@ namespace slam {
 // (seed, inst0, sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max, map, L, truth).
 // fwd, ang: the commanded motion; step: RNG step index.  tx, ty, tth: the instance's true pose (prefetched),
 // advanced in place; lmx, lmy: prefetched map entry of id = lane.
-// Writes the [id, range, bearing] float32 triplets of the visible landmarks (ascending id) to s_meas and their
-// count to *s_count (triplets beyond KCAP are not stored; the caller caps and flags); lane 0 stores the new truth pose.
+// Writes the [id, range, bearing] float32 triplets of the visible landmarks (ascending id) to s_meas and returns
+// their count (wave-uniform; triplets beyond KCAP are not stored, the caller caps and flags); lane 0 stores the new
+// truth pose.
 template <int KCAP, class P>
-__device__ __forceinline__ void sim_wave(const P& p, int b, int lane, float fwd, float ang, uint32_t step, double& tx,
-                                         double& ty, double& tth, double lmx, double lmy, float* s_meas,
-                                         int* s_count) {
+__device__ __forceinline__ int sim_wave(const P& p, int b, int lane, float fwd, float ang, uint32_t step, double& tx,
+                                        double& ty, double& tth, double lmx, double lmy, float* s_meas) {
     const uint64_t inst = (uint64_t)(p.inst0 + b);
     double u0, u1;
     noise_pair(p.seed, inst, step, 0u, &u0, &u1);
@@ -58,11 +58,11 @@ __device__ __forceinline__ void sim_wave(const P& p, int b, int lane, float fwd,
         count += __popcll(mask);
     }
     if (lane == 0) {
-        *s_count = count;   // the caller caps at KCAP and flags the overflow
         p.truth[3 * (size_t)b] = tx;
         p.truth[3 * (size_t)b + 1] = ty;
         p.truth[3 * (size_t)b + 2] = tth;
     }
+    return count;   // the caller caps at KCAP and flags the overflow
 }
 
 }  // namespace slam

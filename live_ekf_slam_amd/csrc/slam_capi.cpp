@@ -93,7 +93,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     p.seed = h->seed; p.inst0 = h->inst0; p.step = h->step;
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
     p.dbg = h->dbg;
-    p.prof = (h->dbg & 4) ? h->dprof : nullptr;
+    p.prof = (h->dbg & (4 | 32)) ? h->dprof : nullptr;
 }
 
 void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2]) {
@@ -542,6 +542,15 @@ int slam_debug_read_prof(slam_handle* h, unsigned long long out[16]) {
     for (int i = 0; i < 16; ++i) out[i] = 0;
     for (int b = 0; b < h->B; ++b)
         for (int i = 0; i < 16; ++i) out[i] += buf[(size_t)16 * b + i];
+    return SLAM_OK;
+}
+
+// debug only: the raw [B][16] buffer
+int slam_debug_read_prof_raw(slam_handle* h, unsigned long long* out) {
+    if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->dprof, sizeof(unsigned long long) * 16 * (size_t)h->B, hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 

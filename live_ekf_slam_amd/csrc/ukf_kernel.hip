@@ -273,7 +273,10 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
 
     // ---- measurements ----
     if (p.sim) {
-        if (tid < 64) sim_wave<KCAP>(p, b, lane, p.fwd, p.ang, p.step, tx, ty, tth, lmx, lmy, s_meas, &s_misc[0]);
+        if (tid < 64) {
+            const int cnt = sim_wave<KCAP>(p, b, lane, p.fwd, p.ang, p.step, tx, ty, tth, lmx, lmy, s_meas);
+            if (lane == 0) s_misc[0] = cnt;
+        }
     } else {
         int kk = p.meas_count_in[b];
         kk = kk < p.k_stride_in ? kk : p.k_stride_in;
