@@ -22,8 +22,7 @@ _ip = C.POINTER(C.c_int)
 
 def build(force=False):
     so = os.path.join(HERE, "libslam_oracle.so")
-    if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))   # no-op when up to date
     return so
 
 
@@ -62,6 +61,25 @@ def lib():
         L.orc_run_ukf_batch.restype = C.c_double
         L.orc_run_ukf_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int, C.c_uint64,
                                         C.c_int64, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp, _ip, _dp, _dp]
+        L.orc_pgs_create.restype = C.c_void_p
+        L.orc_pgs_create.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_pgs_destroy.argtypes = [C.c_void_p]
+        L.orc_pgs_init.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_pgs_set_secondary.argtypes = [C.c_void_p, _dp]
+        L.orc_pgs_update.argtypes = [C.c_void_p, C.c_float, C.c_float, _fp, C.c_int]
+        L.orc_pgs_solve.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+        L.orc_pgs_adopt.argtypes = [C.c_void_p]
+        L.orc_pgs_get.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _ip, _ip]
+        L.orc_pgs_connections.argtypes = [C.c_void_p, _ip, C.c_int]
+        L.orc_pgs_cost.restype = C.c_double
+        L.orc_pgs_cost.argtypes = [C.c_void_p, C.c_int]
+        L.orc_pgs_residuals.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
+        L.orc_pgs_gradient.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.orc_pgs_retract.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_run_pgs_batch.restype = C.c_double
+        L.orc_run_pgs_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int,
+                                        C.c_uint64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp, _ip, _ip, _ip, _dp, _dp, _dp,
+                                        _fp, _ip]
         L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
         L.orc_noise_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
         for name in ("orc_det_sincos", "orc_libm_sincos"):
@@ -224,3 +242,95 @@ def run_ukf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MAT
                                    _d(x), _d(P) if want_P else None, _i(M), _i(ids), _d(err), _i(flags), _d(truth),
                                    _d(vision) if vision is not None else None)
     return dict(x=x, P=P, M=M, ids=ids, avg_err=err, flags=flags, truth=truth, seconds=secs)
+
+
+LIN_SCHUR, LIN_DENSE = 0, 1
+
+
+class OraclePoseGraph:
+    """One reference-equivalent PoseGraph instance (pose_graph.cpp, GTSAM implementation)."""
+
+    def __init__(self, cfg=None, N_max=1000, L_max=20, KP=8, math=MATH_DET):
+        self.cfg = cfg or default_config()
+        self.N_max, self.L_max, self.KP = N_max, L_max, KP
+        self.h = lib().orc_pgs_create(C.byref(self.cfg), N_max, L_max, KP, math)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pgs_destroy(self.h)
+            self.h = None
+
+    def init(self, x0=0.0, y0=0.0, yaw0=0.0):
+        lib().orc_pgs_init(self.h, x0, y0, yaw0)
+
+    def updateNaiveVehPoseEstimate(self, state_vector):
+        sv = np.ascontiguousarray(state_vector, dtype=np.float64)
+        lib().orc_pgs_set_secondary(self.h, _d(sv))
+
+    def update(self, fwd, ang, meas):
+        m = np.ascontiguousarray(np.asarray(meas, dtype=np.float32).reshape(-1, 3))
+        return lib().orc_pgs_update(self.h, float(np.float32(fwd)), float(np.float32(ang)), _f(m), m.shape[0])
+
+    def solve(self, lin_mode=LIN_SCHUR):
+        io = np.zeros(3, dtype=np.int32); do = np.zeros(3)
+        lib().orc_pgs_solve(self.h, lin_mode, _i(io), _d(do))
+        return dict(iterations=int(io[0]), trials=int(io[1]), flags=int(io[2]), err_init=do[0], err_final=do[1], lam=do[2])
+
+    def adopt(self):
+        lib().orc_pgs_adopt(self.h)
+
+    def values(self, which=1):
+        poses = np.zeros((self.N_max, 3)); lms = np.zeros((self.L_max, 2)); ids = np.zeros(self.L_max, dtype=np.int32)
+        ts = C.c_int(0); M = C.c_int(0)
+        lib().orc_pgs_get(self.h, which, _d(poses), _d(lms), C.byref(ts), C.byref(M), _i(ids))
+        return dict(poses=poses[:ts.value + 1].copy(), landmarks=lms[:M.value].copy(), timestep=ts.value, M=M.value, ids=ids[:M.value].copy())
+
+    def connections(self):
+        cap = self.N_max * self.KP
+        c = np.zeros((cap, 2), dtype=np.int32)
+        n = lib().orc_pgs_connections(self.h, _i(c), cap)
+        return c[:n].copy()
+
+    def cost(self, which=1):
+        return lib().orc_pgs_cost(self.h, which)
+
+    def residuals(self, poses, lms):
+        poses = np.ascontiguousarray(poses, dtype=np.float64); lms = np.ascontiguousarray(lms, dtype=np.float64).reshape(-1)
+        lms = lms if lms.size else np.zeros(2)
+        cap = 3 + 3 * self.N_max + 2 * self.N_max * self.KP
+        out = np.zeros(cap)
+        n = lib().orc_pgs_residuals(self.h, _d(poses), _d(lms), _d(out), cap)
+        return out[:n].copy()
+
+    def gradient(self, poses, lms):
+        poses = np.ascontiguousarray(poses, dtype=np.float64); lms = np.ascontiguousarray(lms, dtype=np.float64).reshape(-1, 2)
+        gp = np.zeros_like(poses); gl = np.zeros((max(len(lms), 1), 2))
+        lib().orc_pgs_gradient(self.h, _d(poses), _d(lms if lms.size else np.zeros(2)), _d(gp), _d(gl))
+        return gp, gl[:len(lms)]
+
+    def retract(self, poses, lms, dp, dl):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (poses, lms, dp, dl)]
+        a = [v if v.size else np.zeros(2) for v in a]
+        pn = np.zeros_like(a[0]); ln = np.zeros_like(a[1])
+        lib().orc_pgs_retract(self.h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(pn), _d(ln))
+        return pn, ln
+
+
+def run_pgs_batch(map_xy, cmds, B, L_max, KP=8, seed=2025, inst0=0, cfg=None, math=MATH_DET, lin_mode=LIN_SCHUR, nthreads=1,
+                  want_streams=False):
+    """Simulator + NaiveFilter secondary + graph building + one LM solve per instance (T commands -> T+1 poses)."""
+    cfg = cfg or default_config()
+    map_xy = np.ascontiguousarray(map_xy, dtype=np.float64); cmds = np.ascontiguousarray(cmds, dtype=np.float32)
+    L, T = map_xy.shape[0], cmds.shape[0]
+    N = T + 1
+    pose_init = np.zeros((B, N, 3)); pose_res = np.zeros((B, N, 3)); lm_res = np.zeros((B, L_max, 2))
+    M = np.zeros(B, dtype=np.int32); ids = np.zeros((B, L_max), dtype=np.int32)
+    istats = np.zeros((B, 3), dtype=np.int32); dstats = np.zeros((B, 3)); avg_err = np.zeros((B, 2)); truth = np.zeros((B, T, 2))
+    meas = np.zeros((B, T, KP, 3), dtype=np.float32) if want_streams else None
+    cnt = np.zeros((B, T), dtype=np.int32) if want_streams else None
+    secs = lib().orc_run_pgs_batch(C.byref(cfg), L_max, KP, math, lin_mode, _d(map_xy), L, _f(cmds), T, seed, inst0, B, nthreads,
+                                   _d(pose_init), _d(pose_res), _d(lm_res), _i(M), _i(ids), _i(istats), _d(dstats), _d(avg_err),
+                                   _d(truth), _f(meas) if want_streams else None, _i(cnt) if want_streams else None)
+    return dict(pose_init=pose_init, pose_res=pose_res, lm_res=lm_res, M=M, ids=ids, iterations=istats[:, 0], trials=istats[:, 1],
+                flags=istats[:, 2], err_init=dstats[:, 0], err_final=dstats[:, 1], lam=dstats[:, 2], avg_err_init=avg_err[:, 0],
+                avg_err_result=avg_err[:, 1], truth_xy=truth, meas=meas, cnt=cnt, seconds=secs)

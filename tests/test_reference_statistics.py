@@ -87,3 +87,18 @@ def test_gpu_ekf_matches_reference_published_error():
             errs.append(f.error_stats().copy())
             f.close()
         _check(np.concatenate(errs), REF["runs"][f"ekf_{regime}_noise_iter/ekf.csv"], f"GPU EKF {regime}")
+
+
+@pytest.mark.parametrize("regime", ["low", "high"])
+def test_oracle_pose_graph_matches_reference_published_error(oracle, regime):
+    """pose_graph (one-time solve, NaiveFilter secondary — params.yaml:60, data/naive_*_one_time/): both the error of
+    the initial graph (pose_graph_init.csv) and of the optimised graph (pose_graph_result.csv), with the plotter's
+    pose-i-vs-truth-i+1 alignment (plotting_node.py:203-206,432-434) and num_iterations = 1000 (999 commands)."""
+    ei, er = [], []
+    for s in range(N_SCEN):
+        lm, cmds = make_scenario(100 + s, 20, 999)
+        r = oracle.run_pgs_batch(lm, cmds, 8, 20, KP=8, seed=7 + s, cfg=_cfg(regime), nthreads=8)
+        assert np.all(r["flags"] == 0)
+        ei.append(r["avg_err_init"]); er.append(r["avg_err_result"])
+    _check(np.concatenate(ei), REF["runs"][f"naive_{regime}_noise_one_time/pose_graph_init.csv"], f"PGS init {regime}")
+    _check(np.concatenate(er), REF["runs"][f"naive_{regime}_noise_one_time/pose_graph_result.csv"], f"PGS result {regime}")
