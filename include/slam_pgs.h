@@ -1,0 +1,94 @@
+/* slam_pgs.h — C ABI of the MI355X batched pose-graph SLAM solver (part of libslam_hip.so).
+ *
+ * Drop-in boundary for the reference's `PoseGraph : Filter` with `implementation: gtsam`
+ * (ekf_ws/src/localization_pkg/src/pose_graph.cpp, class declaration filter.h:232-322): the graph-building calls of
+ * every timestep and `solvePoseGraph()` (gtsam::LevenbergMarquardtOptimizer, default parameters), for a batch of B
+ * independent graphs — Monte-Carlo instances that share the command sequence (BetweenFactors) and differ in their
+ * measurements and in the secondary filter's estimates.  Same conventions as slam_batch.h: plain pointers and sizes,
+ * int status codes (slam_status_code), text in slam_last_error(), one caller thread per handle, kernels on one stream.
+ *
+ * Not covered: `implementation: sesync | custom` (the reference itself throws for both, pose_graph.cpp:34-38),
+ * unknown landmark ids (the reference throws, pose_graph.cpp:137), `update_landmarks_after_adding` (false in
+ * params.yaml:63 and forced false when solving every iteration, pose_graph.cpp:45-48).
+ */
+#ifndef SLAM_PGS_H
+#define SLAM_PGS_H
+
+#include <stdint.h>
+
+#include "slam_batch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgs_handle pgs_handle;
+
+/* per-instance status bits (pgs_get_stats) */
+enum pgs_instance_flags {
+    PGS_INST_OK = 0,
+    PGS_INST_POSE_CAP = 1,        /* more timesteps than N_max: the surplus updates were dropped                 */
+    PGS_INST_LANDMARK_CAP = 2,    /* more distinct landmark ids than L_max: the surplus landmarks were dropped   */
+    PGS_INST_MEAS_CAP = 4,        /* more detections in one message than k_per_pose: the surplus were dropped    */
+    PGS_INST_NOT_CONVERGED = 8,   /* LM hit maxIterations (100) or the trial cap                                 */
+    PGS_INST_NONFINITE = 16
+};
+
+/* Replaces `std::make_unique<PoseGraph>()` + readParams (localization_node.cpp:45-47, pose_graph.cpp:12-66): noise
+ * models Diagonal::Sigmas(V00, V00, V11) for the BetweenFactors and Sigmas(W11, W00) for the BearingRangeFactors
+ * (pose_graph.cpp:52-54) from the EFFECTIVE V / W of Filter::readCommonParams (filter.h:105-121, incl. its quirk).
+ * N_max = pose capacity (num_iterations), L_max <= 255 landmarks, k_per_pose = detections stored per timestep. */
+int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_per_pose, int device, pgs_handle** out);
+int pgs_destroy(pgs_handle* h);
+int pgs_set_stream(pgs_handle* h, void* hip_stream);
+int pgs_set_instance_offset(pgs_handle* h, int64_t first_global_instance);
+int pgs_set_seed(pgs_handle* h, uint64_t seed);
+int pgs_set_map(pgs_handle* h, const double* map_xy, int L);      /* simulator only (pgs_run_sim) */
+
+/* PoseGraph::init (pose_graph.cpp:68-95): first pose node + PriorFactor with sigmas (1.3, 1.3, 1.2). */
+int pgs_init(pgs_handle* h, float x_0, float y_0, float yaw_0);
+
+/* One iterate() of localization_node.cpp:108-140 as seen by the pose graph:
+ *   updateNaiveVehPoseEstimate(sec_pose)   (pose_graph.cpp:97-119; sec_pose [batch][3] = the secondary filter's
+ *                                           x, y, yaw per instance; NULL keeps the previous estimate)
+ *   update(cmd, meas)                      (pose_graph.cpp:199-256 without the solve/stop logic of :201-214,258-266,
+ *                                           which belongs to the host mirror)
+ * meas [batch][k_stride][3] float32 {id, range, bearing}, meas_count [batch].  HOST pointers. */
+int pgs_update(pgs_handle* h, const float cmd[2], const float* meas, const int32_t* meas_count, int k_stride,
+               const double* sec_pose);
+/* Same with DEVICE pointers (e.g. the EKF engine's measurement dump and pose buffers). */
+int pgs_update_dev(pgs_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_meas_count, int k_stride,
+                   const double* d_sec_pose);
+/* T iterations with everything on the device: measurement generator get_cmd (sim_node.py:209-250) with the
+ * instance's noise stream, NaiveFilter::update as the secondary filter (filter.h:342-348, params.yaml:60), then the
+ * two calls above.  cmds [T][2] float32 host array. */
+int pgs_run_sim(pgs_handle* h, const float* cmds, int T);
+
+/* PoseGraph::solvePoseGraph (pose_graph.cpp:269-300) for every instance: LM from initial_estimate to `result`. */
+int pgs_solve(pgs_handle* h);
+/* `this->initial_estimate = this->result` (pose_graph.cpp:263, solve_graph_every_iteration). */
+int pgs_adopt_result(pgs_handle* h);
+
+/* PoseGraphState payload (pose_graph.cpp:302-387, PoseGraphState.msg): which = 0 initial_estimate, 1 result.
+ * poses [timestep+1][3] (x, y, yaw), landmarks [M][2], ids [M]; any pointer may be NULL. */
+int pgs_get_graph(pgs_handle* h, int instance, int which, double* poses, double* landmarks, int32_t* timestep,
+                  int32_t* M, int32_t* ids);
+/* msg_measurement_connections (pose_graph.cpp:176-177): pairs (timestep, landmark index; -1 for a first detection).
+ * conn [cap][2]; *n = number of pairs (may exceed cap). */
+int pgs_get_connections(pgs_handle* h, int instance, int32_t* conn, int cap, int32_t* n);
+/* Per instance [batch]: LM iterations, lambda trials, status bits; initial / final objective 0.5*sum|e|^2, final lambda. */
+int pgs_get_stats(pgs_handle* h, int32_t* iterations, int32_t* trials, int32_t* flags, double* err_init,
+                  double* err_final, double* lambda);
+/* compute_average_error as the pose-graph plot calls it (plotting_node.py:203-213,432-434) against the simulator's
+ * true poses (pgs_run_sim), per instance [batch]; which = 0 initial graph, 1 result. */
+int pgs_error_stats(pgs_handle* h, int which, double* per_instance_avg_err);
+/* Work of the LAST pgs_solve summed over instances and trials: algorithmic FLOP of the Schur-complement SYRK
+ * (2 * rows * cols * k per computed tile) and the number of LM trials launched. */
+int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launched);
+int pgs_sync(pgs_handle* h);
+int pgs_timestep(const pgs_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_PGS_H */

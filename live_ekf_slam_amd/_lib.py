@@ -1,4 +1,4 @@
-"""ctypes loader for the in-tree HIP extension libslam_hip.so (C ABI: include/slam_batch.h).
+"""ctypes loader for the in-tree HIP extension libslam_hip.so (C ABI: include/slam_batch.h, include/slam_pgs.h).
 
 There is no CPU fallback: if the library is missing or a HIP call fails, an exception is raised.
 """
@@ -21,7 +21,7 @@ class SlamError(RuntimeError):
     """Raised for any non-zero return of the C ABI (the reference signals errors by C++ exceptions)."""
 
 
-# name -> (restype, argtypes); every symbol include/slam_batch.h declares
+# name -> (restype, argtypes); every symbol include/slam_batch.h and include/slam_pgs.h declare
 SIGNATURES = {
     "slam_config_default": (C.c_int, [C.POINTER(SlamConfig)]),
     "slam_config_load": (C.c_int, [C.POINTER(SlamConfig), C.c_char_p]),
@@ -51,6 +51,26 @@ SIGNATURES = {
     "slam_state_dim_max": (C.c_int, [_H]),
     "slam_algorithmic_bytes": (C.c_int, [_H, _dp]),
     "slam_math_probe": (C.c_int, [_dp, _dp, _dp, C.c_int, C.c_int]),
+    # include/slam_pgs.h
+    "pgs_create": (C.c_int, [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "pgs_destroy": (C.c_int, [_H]),
+    "pgs_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "pgs_set_instance_offset": (C.c_int, [_H, C.c_int64]),
+    "pgs_set_seed": (C.c_int, [_H, C.c_uint64]),
+    "pgs_set_map": (C.c_int, [_H, _dp, C.c_int]),
+    "pgs_init": (C.c_int, [_H, C.c_float, C.c_float, C.c_float]),
+    "pgs_update": (C.c_int, [_H, _fp, _fp, _ip, C.c_int, _dp]),
+    "pgs_update_dev": (C.c_int, [_H, _fp, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pgs_run_sim": (C.c_int, [_H, _fp, C.c_int]),
+    "pgs_solve": (C.c_int, [_H]),
+    "pgs_adopt_result": (C.c_int, [_H]),
+    "pgs_get_graph": (C.c_int, [_H, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _ip]),
+    "pgs_get_connections": (C.c_int, [_H, C.c_int, _ip, C.c_int, _ip]),
+    "pgs_get_stats": (C.c_int, [_H, _ip, _ip, _ip, _dp, _dp, _dp]),
+    "pgs_error_stats": (C.c_int, [_H, C.c_int, _dp]),
+    "pgs_last_solve_work": (C.c_int, [_H, _dp, _ip]),
+    "pgs_sync": (C.c_int, [_H]),
+    "pgs_timestep": (C.c_int, [_H]),
     "slam_last_error": (C.c_char_p, []),
     "slam_version": (C.c_char_p, []),
 }

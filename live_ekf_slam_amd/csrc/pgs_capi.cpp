@@ -1,0 +1,338 @@
+// pgs_capi.cpp — C ABI (include/slam_pgs.h) over the pose-graph kernels.  Host side only: owns the device memory,
+// the stream and the lockstep timestep; every numeric operation happens in pgs_kernel.hip.  No CPU fallback.
+#include "../../include/slam_pgs.h"
+
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "capi_internal.h"
+#include "pgs_kernel.h"
+
+#define fail slam_internal_fail
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(SLAM_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct pgs_handle {
+    slam_config cfg;
+    int B, N_max, L_max, KP, LD, device;
+    int timestep = 0;
+    bool inited = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t seed = 2025;
+    int64_t inst0 = 0;
+    slam::PgsParams p;
+    std::vector<void*> allocs;
+    float* dcmds = nullptr;
+    float* dmeas = nullptr; int32_t* dcount = nullptr; double* dsec = nullptr; int k_stride = 0;
+    double* dout = nullptr;
+    int max_trials = 400;
+    double last_syrk_flop = 0.0;
+    int last_trials = 0;
+};
+
+namespace {
+
+template <class T>
+int dalloc(pgs_handle* h, T** out, size_t count) {
+    void* ptr = nullptr;
+    HIP_TRY(hipMalloc(&ptr, sizeof(T) * (count ? count : 1)));
+    h->allocs.push_back(ptr);
+    *out = (T*)ptr;
+    return SLAM_OK;
+}
+
+#define TRY(expr)                   \
+    do {                            \
+        const int rc_ = (expr);     \
+        if (rc_ != SLAM_OK) return rc_; \
+    } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int check(pgs_handle* h) {
+    if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return SLAM_OK;
+}
+
+int ensure_staging(pgs_handle* h, int k_stride) {
+    if (h->dmeas && h->k_stride >= k_stride) return SLAM_OK;
+    if (h->dmeas) { hipFree(h->dmeas); h->dmeas = nullptr; }
+    HIP_TRY(hipMalloc((void**)&h->dmeas, sizeof(float) * 3 * (size_t)k_stride * h->B));
+    h->k_stride = k_stride;
+    return SLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_per_pose, int device, pgs_handle** out) {
+    if (!cfg || !out) return fail(SLAM_ERR_ARG, "NULL argument");
+    if (batch <= 0 || N_max < 2 || L_max <= 0 || k_per_pose <= 0) return fail(SLAM_ERR_ARG, "batch, N_max (>= 2), L_max and k_per_pose must be positive");
+    if (L_max > 255) return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the pose-graph kernel limit 255", L_max);
+    if (!cfg->landmark_id_is_known) return fail(SLAM_ERR_UNSUPPORTED, "PGS with unknown landmark ID is not supported (the reference throws: pose_graph.cpp:137)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SLAM_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SLAM_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    pgs_handle* h = new pgs_handle();
+    h->cfg = *cfg; h->B = batch; h->N_max = N_max; h->L_max = L_max; h->KP = k_per_pose; h->device = device;
+    h->LD = round_up(2 * L_max + 1, 64);
+    if (const char* e = getenv("SLAM_PGS_MAX_TRIALS")) h->max_trials = atoi(e) > 0 ? atoi(e) : h->max_trials;
+    hipError_t e = hipStreamCreate(&h->stream);
+    if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
+    h->own_stream = true;
+    slam::PgsParams& p = h->p;
+    memset(&p, 0, sizeof(p));
+    p.B = batch; p.N_max = N_max; p.L_max = L_max; p.KP = k_per_pose; p.LD = h->LD; p.N = 1;
+    const size_t B = batch, N = N_max, L = L_max, K = (size_t)N_max * k_per_pose;
+    int rc = SLAM_OK;
+    auto A = [&](auto** ptr, size_t count) { if (rc == SLAM_OK) rc = dalloc(h, ptr, count); };
+    A(&p.pose0, B * N * 3); A(&p.lm0, B * L * 2); A(&p.pose1, B * N * 3); A(&p.lm1, B * L * 2);
+    A(&p.ids, B * L); A(&p.M, B); A(&p.flags, B);
+    A(&p.cnt, B * N); A(&p.mlm, B * K); A(&p.mnext, B * K); A(&p.lm_head, B * L); A(&p.lm_last, B * L); A(&p.lm_first, B * L);
+    A(&p.mb, B * K); A(&p.mr, B * K);
+    A(&h->dcmds, N * 2); p.cmds = h->dcmds;
+    A(&p.cur, B * 3); A(&p.truth, B * 3); A(&p.truth_hist, B * N * 2);
+    A(&p.pw, B * N * 3); A(&p.lw, B * L * 2); A(&p.pn, B * N * 3); A(&p.ln, B * L * 2);
+    A(&p.A, B * N * 9); A(&p.C, B * N * 9); A(&p.gp, B * N * 3); A(&p.E, B * K * 6); A(&p.Wl, B * K * 5);
+    A(&p.D, B * L * 3); A(&p.gl, B * L * 2); A(&p.Linv, B * N * 6); A(&p.G, B * N * 9);
+    p.y_stride = (int64_t)round_up(3 * N_max, 4) * h->LD;
+    A(&p.Y, B * (size_t)p.y_stride); A(&p.S, B * (size_t)h->LD * h->LD);
+    A(&p.dl, B * L * 2); A(&p.dp, B * N * 3);
+    A(&p.lambda, B); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
+    A(&p.iters, B); A(&p.trials, B); A(&p.state, B); A(&p.solve_ok, B); A(&p.n_active, 1);
+    A(&h->dcount, B); A(&h->dsec, B * 3); A(&h->dout, B);
+    if (rc != SLAM_OK) { pgs_destroy(h); return rc; }
+    hipMemsetAsync(p.truth_hist, 0, sizeof(double) * B * N * 2, h->stream);
+    hipMemsetAsync(p.cnt, 0, sizeof(int32_t) * B * N, h->stream);
+    // effective noise after Filter::readCommonParams (filter.h:105-121)
+    double V00, V11, W00, W11;
+    if (cfg->replicate_vw_quirk) { V00 = cfg->W_00; V11 = cfg->W_11; W00 = 1.0; W11 = 1.0; }
+    else { V00 = cfg->V_00; V11 = cfg->V_11; W00 = cfg->W_00; W11 = cfg->W_11; }
+    const double sp[3] = {1.3, 1.3, 1.2};                      // pose_graph.cpp:83
+    for (int k = 0; k < 3; ++k) p.w_prior[k] = 1.0 / sp[k];
+    p.w_btw[0] = 1.0 / V00; p.w_btw[1] = 1.0 / V00; p.w_btw[2] = 1.0 / V11;   // :52
+    p.w_meas[0] = 1.0 / W11; p.w_meas[1] = 1.0 / W00;                          // :54 (bearing, range)
+    p.sV00 = cfg->V_00; p.sV11 = cfg->V_11; p.sW00 = cfg->W_00; p.sW11 = cfg->W_11;
+    p.d_max = cfg->d_max; p.th_max = cfg->th_max;
+    p.range_max = cfg->range_max; p.fov_min = cfg->fov_min; p.fov_max = cfg->fov_max;
+    p.seed = h->seed; p.inst0 = 0;
+    *out = h;
+    return SLAM_OK;
+}
+
+int pgs_destroy(pgs_handle* h) {
+    if (!h) return SLAM_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void* ptr : h->allocs) hipFree(ptr);
+    if (h->dmeas) hipFree(h->dmeas);
+    if (h->p.map) hipFree((void*)h->p.map);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return SLAM_OK;
+}
+
+int pgs_set_stream(pgs_handle* h, void* s) {
+    TRY(check(h));
+    if (h->own_stream && h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
+    h->stream = (hipStream_t)s; h->own_stream = false;
+    return SLAM_OK;
+}
+int pgs_set_instance_offset(pgs_handle* h, int64_t first) { TRY(check(h)); h->inst0 = first; h->p.inst0 = first; return SLAM_OK; }
+int pgs_set_seed(pgs_handle* h, uint64_t seed) { TRY(check(h)); h->seed = seed; h->p.seed = seed; return SLAM_OK; }
+
+int pgs_set_map(pgs_handle* h, const double* map_xy, int L) {
+    TRY(check(h));
+    if (!map_xy || L <= 0) return fail(SLAM_ERR_ARG, "bad map");
+    if (h->p.map) { hipStreamSynchronize(h->stream); hipFree((void*)h->p.map); h->p.map = nullptr; }
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(double) * 2 * (size_t)L));
+    HIP_TRY(hipMemcpyAsync(d, map_xy, sizeof(double) * 2 * (size_t)L, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->p.map = d; h->p.L = L;
+    return SLAM_OK;
+}
+
+int pgs_init(pgs_handle* h, float x0, float y0, float yaw0) {
+    TRY(check(h));
+    h->timestep = 0; h->p.N = 1;
+    h->p.prior[0] = x0; h->p.prior[1] = y0; h->p.prior[2] = yaw0;
+    HIP_TRY(slam::pgs_launch_init(h->p, x0, y0, yaw0, h->stream));
+    h->inited = true;
+    return SLAM_OK;
+}
+
+int pgs_update_dev(pgs_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_count, int k_stride, const double* d_sec) {
+    TRY(check(h));
+    if (!h->inited) return fail(SLAM_ERR_STATE, "pgs_init must be called before pgs_update");
+    if (!cmd) return fail(SLAM_ERR_ARG, "cmd is NULL");
+    if (h->timestep + 1 >= h->N_max) return fail(SLAM_ERR_STATE, "pose capacity N_max = %d reached", h->N_max);
+    HIP_TRY(hipMemcpyAsync(h->dcmds + 2 * (size_t)h->timestep, cmd, sizeof(float) * 2, hipMemcpyHostToDevice, h->stream));
+    h->p.N = h->timestep + 1;
+    HIP_TRY(slam::pgs_launch_append(h->p, d_meas, d_count, k_stride, d_sec, h->stream));
+    h->timestep += 1;
+    h->p.N = h->timestep + 1;
+    return SLAM_OK;
+}
+
+int pgs_update(pgs_handle* h, const float cmd[2], const float* meas, const int32_t* count, int k_stride, const double* sec) {
+    TRY(check(h));
+    if (k_stride < 0 || (k_stride > 0 && (!meas || !count))) return fail(SLAM_ERR_ARG, "bad measurement arguments");
+    const int ks = k_stride > 0 ? k_stride : 1;
+    TRY(ensure_staging(h, ks));
+    if (k_stride > 0) {
+        HIP_TRY(hipMemcpyAsync(h->dmeas, meas, sizeof(float) * 3 * (size_t)k_stride * h->B, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->dcount, count, sizeof(int32_t) * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(h->dcount, 0, sizeof(int32_t) * (size_t)h->B, h->stream));
+    }
+    if (sec) HIP_TRY(hipMemcpyAsync(h->dsec, sec, sizeof(double) * 3 * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+    const int rc = pgs_update_dev(h, cmd, h->dmeas, h->dcount, ks, sec ? h->dsec : nullptr);
+    // the staging buffers are reused by the next call and the host arrays are pageable: finish the copies now
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return rc;
+}
+
+int pgs_run_sim(pgs_handle* h, const float* cmds, int T) {
+    TRY(check(h));
+    if (!h->inited) return fail(SLAM_ERR_STATE, "pgs_init must be called before pgs_run_sim");
+    if (!h->p.map) return fail(SLAM_ERR_STATE, "pgs_set_map must be called before pgs_run_sim");
+    if (!cmds || T <= 0) return fail(SLAM_ERR_ARG, "bad command sequence");
+    if (h->timestep + T >= h->N_max) return fail(SLAM_ERR_STATE, "timestep %d + %d commands exceed the pose capacity N_max = %d", h->timestep, T, h->N_max);
+    HIP_TRY(hipMemcpyAsync(h->dcmds + 2 * (size_t)h->timestep, cmds, sizeof(float) * 2 * (size_t)T, hipMemcpyHostToDevice, h->stream));
+    h->p.N = h->timestep + 1;
+    HIP_TRY(slam::pgs_launch_run_sim(h->p, T, (uint32_t)h->timestep, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // cmds is a pageable host array
+    h->timestep += T;
+    h->p.N = h->timestep + 1;
+    return SLAM_OK;
+}
+
+int pgs_solve(pgs_handle* h) {
+    TRY(check(h));
+    if (!h->inited) return fail(SLAM_ERR_STATE, "pgs_init must be called before pgs_solve");
+    h->p.N = h->timestep + 1;
+    HIP_TRY(slam::pgs_launch_lm_begin(h->p, h->stream));
+    int trials = 0;
+    for (; trials < h->max_trials; ++trials) {
+        HIP_TRY(hipMemsetAsync(h->p.n_active, 0, sizeof(int32_t), h->stream));
+        HIP_TRY(slam::pgs_launch_trial(h->p, h->stream));
+        int32_t active = 0;
+        HIP_TRY(hipMemcpyAsync(&active, h->p.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (active == 0) { trials += 1; break; }
+    }
+    h->last_trials = trials;
+    HIP_TRY(slam::pgs_launch_lm_end(h->p, h->stream));
+    return SLAM_OK;
+}
+
+int pgs_adopt_result(pgs_handle* h) {
+    TRY(check(h));
+    HIP_TRY(slam::pgs_launch_adopt(h->p, h->stream));
+    return SLAM_OK;
+}
+
+int pgs_get_graph(pgs_handle* h, int inst, int which, double* poses, double* lms, int32_t* timestep, int32_t* M, int32_t* ids) {
+    TRY(check(h));
+    if (inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "instance %d out of range", inst);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int32_t m = 0;
+    HIP_TRY(hipMemcpy(&m, h->p.M + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const double* ps = (which ? h->p.pose1 : h->p.pose0) + (size_t)inst * h->N_max * 3;
+    const double* ls = (which ? h->p.lm1 : h->p.lm0) + (size_t)inst * h->L_max * 2;
+    if (poses) HIP_TRY(hipMemcpy(poses, ps, sizeof(double) * 3 * (size_t)(h->timestep + 1), hipMemcpyDeviceToHost));
+    if (lms && m > 0) HIP_TRY(hipMemcpy(lms, ls, sizeof(double) * 2 * (size_t)m, hipMemcpyDeviceToHost));
+    if (ids && m > 0) HIP_TRY(hipMemcpy(ids, h->p.ids + (size_t)inst * h->L_max, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+    if (timestep) *timestep = h->timestep;
+    if (M) *M = m;
+    return SLAM_OK;
+}
+
+int pgs_get_connections(pgs_handle* h, int inst, int32_t* conn, int cap, int32_t* n) {
+    TRY(check(h));
+    if (inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "instance %d out of range", inst);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int N = h->timestep + 1;
+    std::vector<int32_t> cnt(N), mlm((size_t)N * h->KP);
+    HIP_TRY(hipMemcpy(cnt.data(), h->p.cnt + (size_t)inst * h->N_max, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mlm.data(), h->p.mlm + (size_t)inst * h->N_max * h->KP, sizeof(int32_t) * (size_t)N * h->KP, hipMemcpyDeviceToHost));
+    int nc = 0;
+    for (int i = 0; i < N; ++i)
+        for (int s = 0; s < cnt[i]; ++s) {
+            const int32_t v = mlm[(size_t)i * h->KP + s];
+            if (conn && nc < cap) { conn[2 * nc] = i; conn[2 * nc + 1] = (v & slam::kPgsFirstBit) ? -1 : v; }
+            nc += 1;
+        }
+    if (n) *n = nc;
+    return SLAM_OK;
+}
+
+int pgs_get_stats(pgs_handle* h, int32_t* iterations, int32_t* trials, int32_t* flags, double* err_init, double* err_final, double* lambda) {
+    TRY(check(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t B = h->B;
+    if (iterations) HIP_TRY(hipMemcpy(iterations, h->p.iters, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    if (trials) HIP_TRY(hipMemcpy(trials, h->p.trials, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    if (flags) HIP_TRY(hipMemcpy(flags, h->p.flags, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    if (err_init) HIP_TRY(hipMemcpy(err_init, h->p.err_init, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (err_final) HIP_TRY(hipMemcpy(err_final, h->p.error, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (lambda) HIP_TRY(hipMemcpy(lambda, h->p.lambda, sizeof(double) * B, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+int pgs_error_stats(pgs_handle* h, int which, double* out) {
+    TRY(check(h));
+    if (!out) return fail(SLAM_ERR_ARG, "NULL output");
+    h->p.N = h->timestep + 1;
+    HIP_TRY(slam::pgs_launch_avg_error(h->p, which, h->dout, h->stream));
+    HIP_TRY(hipMemcpyAsync(out, h->dout, sizeof(double) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launched) {
+    TRY(check(h));
+    // per trial and instance: lower-triangular 64x64 tiles of Y^T Y over k = 3N rows, trimmed by the first-detection pose
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t B = h->B;
+    std::vector<int32_t> M(B), tr(B), first(B * h->L_max);
+    HIP_TRY(hipMemcpy(M.data(), h->p.M, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tr.data(), h->p.trials, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first.data(), h->p.lm_first, sizeof(int32_t) * B * h->L_max, hipMemcpyDeviceToHost));
+    const int K3 = 3 * (h->timestep + 1);
+    double tot = 0.0;
+    for (size_t b = 0; b < B; ++b) {
+        const int m2 = 2 * M[b];
+        double per_trial = 0.0;
+        for (int ti = 0; ti * 64 <= m2; ++ti) {
+            int k0 = 0;
+            if (ti * 64 + 63 < m2) k0 = (3 * first[b * h->L_max + ti * 32]) & ~3;
+            const int rows = (m2 + 1 - ti * 64) < 64 ? (m2 + 1 - ti * 64) : 64;
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int cols = (m2 + 1 - tj * 64) < 64 ? (m2 + 1 - tj * 64) : 64;
+                const double elems = ti == tj ? 0.5 * rows * (rows + 1) : (double)rows * cols;
+                per_trial += 2.0 * elems * (K3 - k0);
+            }
+        }
+        tot += per_trial * tr[b];
+    }
+    if (syrk_flop) *syrk_flop = tot;
+    if (trials_launched) *trials_launched = h->last_trials;
+    return SLAM_OK;
+}
+
+int pgs_sync(pgs_handle* h) { TRY(check(h)); HIP_TRY(hipStreamSynchronize(h->stream)); return SLAM_OK; }
+int pgs_timestep(const pgs_handle* h) { return h ? h->timestep : -1; }
+
+}  // extern "C"

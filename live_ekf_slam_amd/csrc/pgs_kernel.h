@@ -1,0 +1,69 @@
+// pgs_kernel.h — parameter block and launchers of the batched pose-graph SLAM solver (gfx950).
+// Reference: ekf_ws/src/localization_pkg/src/pose_graph.cpp (PoseGraph with the GTSAM implementation): graph building
+// (:68-256) and solvePoseGraph (:269-300) = gtsam::LevenbergMarquardtOptimizer with default parameters.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slam {
+
+enum { PGS_FLAG_POSE_CAP = 1, PGS_FLAG_LM_CAP = 2, PGS_FLAG_MEAS_CAP = 4, PGS_FLAG_NOT_CONVERGED = 8, PGS_FLAG_NONFINITE = 16 };
+static constexpr int kPgsFirstBit = 1 << 30;   // mlm: this factor is the first detection of its landmark
+
+// One workgroup per instance in every kernel; instance b owns slab b of every array (strides in elements).
+struct PgsParams {
+    int32_t B, N_max, L_max, KP, LD;   // LD = leading dimension of Y / S = roundup(2*L_max + 1, 64)
+    int32_t N;                         // poses in the graph now (timestep + 1), the same for every instance
+    // ---- the graph (pose_graph.cpp: graph + initial_estimate + result) ----
+    double* pose0; double* lm0;        // initial_estimate: [B][N_max][3], [B][L_max][2]
+    double* pose1; double* lm1;        // result
+    int32_t* ids; int32_t* M; int32_t* flags;       // lm_IDs [B][L_max], M [B], status [B]
+    int32_t* cnt;                      // [B][N_max]      bearing-range factors attached to pose i
+    int32_t* mlm;                      // [B][N_max*KP]   landmark index of factor (i, s) | kPgsFirstBit
+    int32_t* mnext;                    // [B][N_max*KP]   next (newer) factor slot of the same landmark, -1 = none
+    int32_t* lm_head;                  // [B][L_max]      oldest factor slot of landmark j (-1: none stored)
+    int32_t* lm_last;                  // [B][L_max]      newest factor slot of landmark j
+    int32_t* lm_first;                 // [B][L_max]      pose index of the first detection of landmark j
+    double* mb; double* mr;            // [B][N_max*KP]   measured bearing / range (float32 wire values widened)
+    const float* cmds;                 // [N_max][2]      BetweenFactor measurements Pose2(fwd, 0, ang), shared
+    double* cur;                       // [B][3]          cur_veh_pose_estimate (secondary filter's pose)
+    // ---- simulator (pgs_run_sim) ----
+    double* truth;                     // [B][3]
+    double* truth_hist;                // [B][N_max][2]   true (x, y) after step t at row t-1
+    const double* map; int32_t L;
+    double sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max;
+    uint64_t seed; int64_t inst0;
+    // ---- LM work space ----
+    double* pw; double* lw;            // current values
+    double* pn; double* ln;            // candidate values
+    double* A; double* C; double* gp;  // [B][N_max*9], [B][N_max*9], [B][N_max*3]
+    double* E;                         // [B][N_max*KP*6]
+    double* Wl;                        // [B][N_max*KP*5]  per factor: Jl^T Jl (xx, xy, yy), -Jl^T e (x, y)
+    double* D; double* gl;             // [B][L_max*3], [B][L_max*2]
+    double* Linv; double* G;           // [B][N_max*6], [B][N_max*9]
+    double* Y;                         // [B][Yrows][LD]
+    int64_t y_stride;                  // elements per instance in Y
+    double* S;                         // [B][LD*LD]
+    double* dl; double* dp;            // [B][L_max*2], [B][N_max*3]
+    double* lambda; double* error; double* cur_error; double* err_init;
+    int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done
+    int32_t* n_active;                 // [1]
+    // ---- factor constants ----
+    double prior[3];
+    double w_prior[3], w_btw[3], w_meas[2];   // 1 / sigma
+};
+
+hipError_t pgs_launch_init(const PgsParams& p, float x0, float y0, float yaw0, hipStream_t s);
+// append one timestep: BetweenFactor is implied by cmds[t]; meas [B][k_stride][3], count [B] (device); sec_pose [B][3]
+// (device) or NULL to keep `cur`.  p.N = number of poses BEFORE the call.
+hipError_t pgs_launch_append(const PgsParams& p, const float* d_meas, const int32_t* d_count, int k_stride, const double* d_sec, hipStream_t s);
+// T timesteps of simulator + NaiveFilter secondary + append, on the device (cmds already in p.cmds)
+hipError_t pgs_launch_run_sim(const PgsParams& p, int T, uint32_t step0, hipStream_t s);
+hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s);
+hipError_t pgs_launch_trial(const PgsParams& p, hipStream_t s);      // one tryLambda for every active instance
+hipError_t pgs_launch_lm_end(const PgsParams& p, hipStream_t s);     // result = current values, flags
+hipError_t pgs_launch_adopt(const PgsParams& p, hipStream_t s);      // initial_estimate = result
+// avg position error (plotting_node.py:203-213 alignment) of initial (which = 0) / result (1) vs truth_hist: out [B]
+hipError_t pgs_launch_avg_error(const PgsParams& p, int which, double* out, hipStream_t s);
+
+}  // namespace slam

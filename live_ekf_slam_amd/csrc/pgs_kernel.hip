@@ -1,0 +1,951 @@
+// pgs_kernel.hip — batched pose-graph SLAM for gfx950 (MI355X): graph building + Levenberg–Marquardt solve of B
+// independent graphs (Monte-Carlo instances over one map / command sequence), one workgroup per instance.
+//
+// Reference path: PoseGraph::{init, updateNaiveVehPoseEstimate, update, onLandmarkMeasurement, solvePoseGraph}
+// (ekf_ws/src/localization_pkg/src/pose_graph.cpp:68-300) with `implementation: gtsam` (params.yaml:61).  The solve
+// is gtsam::LevenbergMarquardtOptimizer(graph, initial_estimate).optimize() with default parameters over
+//   PriorFactor<Pose2> (pose 0), BetweenFactor<Pose2> (t, t+1), BearingRangeFactor<Pose2, Point2> (t, landmark).
+// The factor definitions, the LM control flow and its constants are the ones documented in oracle/slam_oracle_pgs.cpp.
+//
+// MI355X design.  One LM trial (= one tryLambda of every active instance) is six launches:
+//   linearize   per pose: 3x3 Hessian blocks A_i, C_i (block-tridiagonal H_pp), 3x2 pose-landmark blocks E_k,
+//               gradient; per landmark: 2x2 block D_j, gradient (factors of one landmark are chained in a list)
+//   chain       poses are eliminated FIRST: block-tridiagonal Cholesky of H_pp + lambda I fused with the forward
+//               recurrence  Y_i = L_i^-1 (E_i - G_i Y_{i-1})  — one thread per landmark COLUMN, sequential over the
+//               poses; Y (3N x (2M+1), last column = transformed gradient) goes to HBM once
+//   syrk        Schur complement  S = D + lambda I - Y^T Y  on the landmarks with v_mfma_f64_16x16x4_f64 (the one
+//               GEMM-shaped piece: 2 * 3N * (2M)^2 / 2 FLOP), 64x64 tiles, k range trimmed by first-detection pose
+//   chol        dense blocked Cholesky of S (2M x 2M) + forward/backward substitution -> landmark step
+//   backsolve   pose step from the chain factor (forward/backward over the block-bidiagonal factor)
+//   evaluate    linearised and true cost of the candidate, retraction, GTSAM's accept / lambda / convergence logic
+// All per-instance decisions live on the device; the host only polls the number of active instances.
+#include "pgs_kernel.h"
+
+#include "slam_math.h"
+#include "slam_rng.h"
+#include "sim_device.h"
+
+namespace slam {
+namespace {
+
+typedef double dbl4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------
+// factors (whitened residuals / Jacobians); same formulas as the oracle, see there for the GTSAM definitions
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void prior_factor(const PgsParams& p, const double* ps, double e[3]) {
+    double s, c;
+    det_sincos(ps[2], &s, &c);
+    const double dx = p.prior[0] - ps[0], dy = p.prior[1] - ps[1];
+    e[0] = -(c * dx + s * dy) * p.w_prior[0];
+    e[1] = -(-s * dx + c * dy) * p.w_prior[1];
+    e[2] = -remainder(p.prior[2] - ps[2], kTwoPi) * p.w_prior[2];
+}
+
+template <bool JAC>
+__device__ __forceinline__ void between_factor(const PgsParams& p, const double* pa, const double* pb, float fwd, float ang,
+                                               double e[3], double J1[9]) {
+    double si, ci, sm, cm;
+    det_sincos(pa[2], &si, &ci);
+    det_sincos((double)ang, &sm, &cm);
+    const double dx = pb[0] - pa[0], dy = pb[1] - pa[1];
+    const double hx = ci * dx + si * dy, hy = -si * dx + ci * dy, hth = pb[2] - pa[2];
+    const double ux = hx - (double)fwd, uy = hy;
+    e[0] = (cm * ux + sm * uy) * p.w_btw[0];
+    e[1] = (-sm * ux + cm * uy) * p.w_btw[1];
+    e[2] = remainder(hth - (double)ang, kTwoPi) * p.w_btw[2];
+    if (JAC) {   // -Ad(h^-1)
+        double sh, ch;
+        det_sincos(hth, &sh, &ch);
+        const double xi = -(ch * hx + sh * hy), yi = sh * hx - ch * hy;
+        J1[0] = -ch * p.w_btw[0]; J1[1] = -sh * p.w_btw[0]; J1[2] = -yi * p.w_btw[0];
+        J1[3] = sh * p.w_btw[1];  J1[4] = -ch * p.w_btw[1]; J1[5] = xi * p.w_btw[1];
+        J1[6] = 0.0;              J1[7] = 0.0;              J1[8] = -p.w_btw[2];
+    }
+}
+
+template <bool JAC>
+__device__ __forceinline__ void bearing_range_factor(const PgsParams& p, const double* ps, const double* l, double b, double r,
+                                                     double e[2], double Jp[6], double Jl[4]) {
+    double s, c, sb, cb;
+    det_sincos(ps[2], &s, &c);
+    det_sincos(b, &sb, &cb);
+    const double dx = l[0] - ps[0], dy = l[1] - ps[1];
+    const double qx = c * dx + s * dy, qy = -s * dx + c * dy;
+    const double d2 = qx * qx + qy * qy, n = sqrt(d2);
+    const double cp = qx / n, sp = qy / n;
+    e[0] = det_atan2(cb * sp - sb * cp, cb * cp + sb * sp) * p.w_meas[0];
+    e[1] = (n - r) * p.w_meas[1];
+    if (JAC) {
+        Jp[0] = (qy / d2) * p.w_meas[0]; Jp[1] = (-qx / d2) * p.w_meas[0]; Jp[2] = -p.w_meas[0];
+        Jp[3] = (-qx / n) * p.w_meas[1]; Jp[4] = (-qy / n) * p.w_meas[1]; Jp[5] = 0.0;
+        Jl[0] = ((-qy / d2) * c + (qx / d2) * (-s)) * p.w_meas[0];
+        Jl[1] = ((-qy / d2) * s + (qx / d2) * c) * p.w_meas[0];
+        Jl[2] = (dx / n) * p.w_meas[1];
+        Jl[3] = (dy / n) * p.w_meas[1];
+    }
+}
+
+// per-instance views
+struct Inst {
+    const int32_t* cnt; const int32_t* mlm; const double* mb; const double* mr;
+};
+__device__ __forceinline__ Inst inst_view(const PgsParams& p, int b) {
+    Inst v;
+    v.cnt = p.cnt + (size_t)b * p.N_max;
+    v.mlm = p.mlm + (size_t)b * p.N_max * p.KP;
+    v.mb = p.mb + (size_t)b * p.N_max * p.KP;
+    v.mr = p.mr + (size_t)b * p.N_max * p.KP;
+    return v;
+}
+
+// deterministic block sum (fixed tree), result valid in every thread
+template <int TPB>
+__device__ __forceinline__ double block_sum(double v, double* s_buf) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    s_buf[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = TPB / 2; off > 0; off >>= 1) {
+        if (tid < off) s_buf[tid] = s_buf[tid] + s_buf[tid + off];
+        __syncthreads();
+    }
+    return s_buf[0];
+}
+
+// 0.5 * sum |whitened e|^2 of the factors owned by pose i: prior (i = 0), between (i, i+1), bearing-range at i
+__device__ __forceinline__ double pose_cost(const PgsParams& p, const Inst& g, const double* pose, const double* lm, int i, int N) {
+    double acc = 0.0, e[3];
+    if (i == 0) {
+        prior_factor(p, pose, e);
+        acc = acc + 0.5 * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+    }
+    if (i + 1 < N) {
+        between_factor<false>(p, pose + 3 * i, pose + 3 * (i + 1), p.cmds[2 * i], p.cmds[2 * i + 1], e, nullptr);
+        acc = acc + 0.5 * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+    }
+    const int kc = g.cnt[i];
+    for (int s = 0; s < kc; ++s) {
+        const size_t k = (size_t)i * p.KP + s;
+        const int j = g.mlm[k] & (kPgsFirstBit - 1);
+        bearing_range_factor<false>(p, pose + 3 * i, lm + 2 * j, g.mb[k], g.mr[k], e, nullptr, nullptr);
+        acc = acc + 0.5 * (e[0] * e[0] + e[1] * e[1]);
+    }
+    return acc;
+}
+
+template <int TPB>
+__device__ __forceinline__ double block_cost(const PgsParams& p, int b, const double* pose, const double* lm, double* s_buf) {
+    const Inst g = inst_view(p, b);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < p.N; i += TPB) acc = acc + pose_cost(p, g, pose, lm, i, p.N);
+    return block_sum<TPB>(acc, s_buf);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// graph building
+// ------------------------------------------------------------------------------------------------------------
+// PoseGraph::init (pose_graph.cpp:68-95)
+__global__ void pgs_init_kernel(const PgsParams p, double x0, double y0, double yaw0) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    double* ps = p.pose0 + (size_t)b * p.N_max * 3;
+    ps[0] = x0; ps[1] = y0; ps[2] = yaw0;
+    p.cur[3 * b] = x0; p.cur[3 * b + 1] = y0; p.cur[3 * b + 2] = yaw0;
+    p.truth[3 * b] = x0; p.truth[3 * b + 1] = y0; p.truth[3 * b + 2] = yaw0;
+    p.M[b] = 0; p.flags[b] = 0;
+    p.cnt[(size_t)b * p.N_max] = 0;
+    p.state[b] = 1; p.iters[b] = 0; p.trials[b] = 0;
+    p.error[b] = 0.0; p.err_init[b] = 0.0; p.lambda[b] = 0.0;
+}
+
+// The graph-building half of PoseGraph::update for ONE instance (pose_graph.cpp:216-256): pose node t1 from the
+// secondary filter's estimate, then one BearingRangeFactor per detection (getLandmarkIndexFromID :122-147,
+// onLandmarkMeasurement :150-178).  Sequential by design (ids are matched in message order).  The factors of one
+// landmark are chained oldest -> newest (lm_head / mnext) so the landmark's Hessian block can be summed without atomics.
+__device__ void append_step(const PgsParams& p, int b, int t1, const float* meas, int k) {
+    const double cx = p.cur[3 * b], cy = p.cur[3 * b + 1], cth = p.cur[3 * b + 2];
+    double* ps = p.pose0 + (size_t)b * p.N_max * 3 + 3 * t1;
+    ps[0] = cx; ps[1] = cy; ps[2] = cth;                       // initial_estimate.insert(key(t), cur) :248
+    int32_t* ids = p.ids + (size_t)b * p.L_max;
+    int32_t* mlm = p.mlm + (size_t)b * p.N_max * p.KP;
+    int32_t* mnext = p.mnext + (size_t)b * p.N_max * p.KP;
+    double* mb = p.mb + (size_t)b * p.N_max * p.KP;
+    double* mr = p.mr + (size_t)b * p.N_max * p.KP;
+    int32_t* lm_head = p.lm_head + (size_t)b * p.L_max;
+    int32_t* lm_last = p.lm_last + (size_t)b * p.L_max;
+    int32_t* lm_first = p.lm_first + (size_t)b * p.L_max;
+    double* lm0 = p.lm0 + (size_t)b * p.L_max * 2;
+    int M = p.M[b], flags = p.flags[b], used = 0;
+    for (int l = 0; l < k; ++l) {
+        const int id = (int)meas[3 * l];
+        const float r = meas[3 * l + 1], bb = meas[3 * l + 2];
+        int idx = -1;
+        for (int j = 0; j < M; ++j)
+            if (ids[j] == id) { idx = j; break; }
+        const bool first = idx < 0;
+        if (first) {
+            if (M >= p.L_max) { flags |= PGS_FLAG_LM_CAP; continue; }
+            idx = M; ids[M] = id; M += 1;
+            double s, c;                                       // :162  x_t(0) + range*cos(x_t(2)+bearing)
+            det_sincos(cth + (double)bb, &s, &c);
+            lm0[2 * idx] = cx + (double)r * c;
+            lm0[2 * idx + 1] = cy + (double)r * s;
+            lm_head[idx] = -1; lm_last[idx] = -1;
+            lm_first[idx] = t1;
+        }
+        if (used >= p.KP) { flags |= PGS_FLAG_MEAS_CAP; continue; }
+        const int slot = t1 * p.KP + used;                     // BearingRangeFactor(key(t), lmkey, Rot2(b), r) :174
+        mlm[slot] = idx | (first ? kPgsFirstBit : 0);
+        mb[slot] = (double)bb; mr[slot] = (double)r;
+        mnext[slot] = -1;
+        if (lm_last[idx] >= 0) mnext[lm_last[idx]] = slot; else lm_head[idx] = slot;
+        lm_last[idx] = slot;
+        used += 1;
+    }
+    p.cnt[(size_t)b * p.N_max + t1] = used;
+    p.M[b] = M; p.flags[b] = flags;
+}
+
+// updateNaiveVehPoseEstimate + update for host/device supplied measurements: one thread per instance
+__global__ void pgs_append_kernel(const PgsParams p, const float* meas, const int32_t* count, int k_stride, const double* sec) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    if (p.N >= p.N_max) { p.flags[b] |= PGS_FLAG_POSE_CAP; return; }
+    if (sec) { p.cur[3 * b] = sec[3 * b]; p.cur[3 * b + 1] = sec[3 * b + 1]; p.cur[3 * b + 2] = sec[3 * b + 2]; }
+    int k = count ? count[b] : 0;
+    k = k < k_stride ? k : k_stride;
+    k = k < 0 ? 0 : k;
+    append_step(p, b, p.N, meas + (size_t)b * k_stride * 3, k);
+}
+
+// T x { get_cmd (sim_node.py:209-250), NaiveFilter::update (filter.h:342-348), updateNaiveVehPoseEstimate, update }
+// for one instance per wavefront.  The secondary filter's state IS `cur` (the naive filter keeps nothing else).
+__global__ __launch_bounds__(64) void pgs_run_sim_kernel(const PgsParams p, int T, uint32_t step0) {
+    constexpr int KCAP = 64;
+    __shared__ float s_meas[3 * KCAP];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double tx = p.truth[3 * b], ty = p.truth[3 * b + 1], tth = p.truth[3 * b + 2];
+    double lmx = 0.0, lmy = 0.0;
+    if (lane < p.L) { lmx = p.map[2 * lane]; lmy = p.map[2 * lane + 1]; }
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const int i = p.N - 1 + t, t1 = i + 1;
+        if (t1 >= p.N_max) { if (lane == 0) p.flags[b] |= PGS_FLAG_POSE_CAP; break; }
+        const float fwd = p.cmds[2 * i], ang = p.cmds[2 * i + 1];
+        int k = sim_wave<KCAP>(p, b, lane, fwd, ang, step0 + (uint32_t)t, tx, ty, tth, lmx, lmy, s_meas);
+        if (k > KCAP) { k = KCAP; if (lane == 0) p.flags[b] |= PGS_FLAG_MEAS_CAP; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane == 0) {
+            double s, c;
+            const double th = p.cur[3 * b + 2];
+            det_sincos(th, &s, &c);
+            p.cur[3 * b] = p.cur[3 * b] + (double)fwd * c;
+            p.cur[3 * b + 1] = p.cur[3 * b + 1] + (double)fwd * s;
+            p.cur[3 * b + 2] = remainder(th + (double)ang, kTwoPi);
+            double* th_hist = p.truth_hist + ((size_t)b * p.N_max + (t1 - 1)) * 2;
+            th_hist[0] = tx; th_hist[1] = ty;
+            append_step(p, b, t1, s_meas, k);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LM: begin / linearize / chain / syrk / chol / backsolve / evaluate / end
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TPB = 256;
+
+__global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
+    __shared__ double s_buf[TPB];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = p.N, M = p.M[b];
+    double* pw = p.pw + (size_t)b * p.N_max * 3;
+    double* lw = p.lw + (size_t)b * p.L_max * 2;
+    const double* p0 = p.pose0 + (size_t)b * p.N_max * 3;
+    const double* l0 = p.lm0 + (size_t)b * p.L_max * 2;
+    for (int i = tid; i < 3 * N; i += TPB) pw[i] = p0[i];
+    for (int i = tid; i < 2 * M; i += TPB) lw[i] = l0[i];
+    __syncthreads();
+    const double err = block_cost<TPB>(p, b, pw, lw, s_buf);
+    if (tid == 0) {
+        p.error[b] = err; p.err_init[b] = err; p.cur_error[b] = err;
+        p.lambda[b] = 1e-5;                    // LevenbergMarquardtParams::lambdaInitial
+        p.iters[b] = 0; p.trials[b] = 0; p.state[b] = 0; p.solve_ok[b] = 1;
+        p.flags[b] &= ~(PGS_FLAG_NOT_CONVERGED | PGS_FLAG_NONFINITE);
+    }
+}
+
+// A += J^T J for a rows x 3 J (same order of operations as the oracle's add_JtJ)
+template <int ROWS>
+__device__ __forceinline__ void add_JtJ(double A[9], const double* J) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) v += J[3 * r + a] * J[3 * r + c];
+            A[3 * a + c] += v;
+        }
+}
+
+__global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (p.state[b]) return;
+    const int N = p.N, KP = p.KP, M = p.M[b];
+    const Inst g = inst_view(p, b);
+    const double* pose = p.pw + (size_t)b * p.N_max * 3;
+    const double* lm = p.lw + (size_t)b * p.L_max * 2;
+    double* Ab = p.A + (size_t)b * p.N_max * 9;
+    double* Cb = p.C + (size_t)b * p.N_max * 9;
+    double* gpb = p.gp + (size_t)b * p.N_max * 3;
+    double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
+    double* Wlb = p.Wl + (size_t)b * p.N_max * KP * 5;
+    for (int i = tid; i < N; i += TPB) {
+        double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0}, e[3], J1[9];
+        if (i == 0) {
+            prior_factor(p, pose, e);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { A[4 * k] += p.w_prior[k] * p.w_prior[k]; gg[k] += -e[k] * p.w_prior[k]; }
+        }
+        if (i > 0) {   // between (i-1, i): J2 = diag(w); H[i][i-1] = J2^T J1
+            between_factor<true>(p, pose + 3 * (i - 1), pose + 3 * i, p.cmds[2 * (i - 1)], p.cmds[2 * (i - 1) + 1], e, J1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { A[4 * k] += p.w_btw[k] * p.w_btw[k]; gg[k] += -e[k] * p.w_btw[k]; }
+            double* C = Cb + 9 * (i - 1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) C[3 * a + c] = p.w_btw[a] * J1[3 * a + c];
+        }
+        if (i + 1 < N) {   // between (i, i+1): J1
+            between_factor<true>(p, pose + 3 * i, pose + 3 * (i + 1), p.cmds[2 * i], p.cmds[2 * i + 1], e, J1);
+            add_JtJ<3>(A, J1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gg[a] += -(J1[a] * e[0] + J1[3 + a] * e[1] + J1[6 + a] * e[2]);
+        }
+        const int kc = g.cnt[i];
+        for (int s = 0; s < kc; ++s) {
+            const size_t k = (size_t)i * KP + s;
+            const int j = g.mlm[k] & (kPgsFirstBit - 1);
+            double e2[2], Jp[6], Jl[4];
+            bearing_range_factor<true>(p, pose + 3 * i, lm + 2 * j, g.mb[k], g.mr[k], e2, Jp, Jl);
+            add_JtJ<2>(A, Jp);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gg[a] += -(Jp[a] * e2[0] + Jp[3 + a] * e2[1]);
+            double* E = Eb + 6 * k;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) E[2 * a + c] = Jp[a] * Jl[c] + Jp[3 + a] * Jl[2 + c];
+            double* W = Wlb + 5 * k;
+            W[0] = Jl[0] * Jl[0] + Jl[2] * Jl[2];
+            W[1] = Jl[0] * Jl[1] + Jl[2] * Jl[3];
+            W[2] = Jl[1] * Jl[1] + Jl[3] * Jl[3];
+            W[3] = -(Jl[0] * e2[0] + Jl[2] * e2[1]);
+            W[4] = -(Jl[1] * e2[0] + Jl[3] * e2[1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ab[9 * i + k] = A[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gpb[3 * i + k] = gg[k];
+    }
+    __syncthreads();   // Wl of every factor is visible to the block
+    const int32_t* head = p.lm_head + (size_t)b * p.L_max;
+    const int32_t* mnext = p.mnext + (size_t)b * p.N_max * KP;
+    double* Db = p.D + (size_t)b * p.L_max * 3;
+    double* glb = p.gl + (size_t)b * p.L_max * 2;
+    for (int j = tid; j < M; j += TPB) {   // landmark j: chronological sum over its factors
+        double d0 = 0, d1 = 0, d2 = 0, g0 = 0, g1 = 0;
+        for (int k = head[j]; k >= 0; k = mnext[k]) {
+            const double* W = Wlb + 5 * (size_t)k;
+            d0 += W[0]; d1 += W[1]; d2 += W[2]; g0 += W[3]; g1 += W[4];
+        }
+        Db[3 * j] = d0; Db[3 * j + 1] = d1; Db[3 * j + 2] = d2;
+        glb[2 * j] = g0; glb[2 * j + 1] = g1;
+    }
+}
+
+// Block-tridiagonal Cholesky of H_pp + lambda I fused with the forward recurrence over the landmark columns.
+// thread c < 2M: landmark column; c == 2M: gradient column z; 2M < c < LD: zero padding (the MFMA tiles read it).
+__global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (p.state[b]) return;
+    const int N = p.N, KP = p.KP, LD = p.LD, m2 = 2 * p.M[b];
+    const double lambda = p.lambda[b];
+    const Inst g = inst_view(p, b);
+    const double* Ab = p.A + (size_t)b * p.N_max * 9;
+    const double* Cb = p.C + (size_t)b * p.N_max * 9;
+    const double* gpb = p.gp + (size_t)b * p.N_max * 3;
+    const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
+    double* Lb = p.Linv + (size_t)b * p.N_max * 6;
+    double* Gb = p.G + (size_t)b * p.N_max * 9;
+    double* Yb = p.Y + (size_t)b * p.y_stride;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    double I0 = 0, I1 = 0, I2 = 0, I3 = 0, I4 = 0, I5 = 0;
+    bool ok = true;
+    const int myj = c >> 1, myd = c & 1;
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+        const double* A = Ab + 9 * i;
+        double T0 = A[0] + lambda, T3 = A[3], T4 = A[4] + lambda, T6 = A[6], T7 = A[7], T8 = A[8] + lambda;
+        double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (i > 0) {   // G = C_{i-1} Linv_{i-1}^T ; T -= G G^T
+            const double* C = Cb + 9 * (i - 1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                G[3 * r + 0] = C[3 * r] * I0;
+                G[3 * r + 1] = C[3 * r] * I1 + C[3 * r + 1] * I2;
+                G[3 * r + 2] = (C[3 * r] * I3 + C[3 * r + 1] * I4) + C[3 * r + 2] * I5;
+            }
+            T0 -= (G[0] * G[0] + G[1] * G[1]) + G[2] * G[2];
+            T3 -= (G[3] * G[0] + G[4] * G[1]) + G[5] * G[2];
+            T4 -= (G[3] * G[3] + G[4] * G[4]) + G[5] * G[5];
+            T6 -= (G[6] * G[0] + G[7] * G[1]) + G[8] * G[2];
+            T7 -= (G[6] * G[3] + G[7] * G[4]) + G[8] * G[5];
+            T8 -= (G[6] * G[6] + G[7] * G[7]) + G[8] * G[8];
+        }
+        if (!(T0 > 0.0)) { ok = false; break; }
+        const double l00 = sqrt(T0), l10 = T3 / l00, l20 = T6 / l00;
+        const double t11 = T4 - l10 * l10;
+        if (!(t11 > 0.0)) { ok = false; break; }
+        const double l11 = sqrt(t11), l21 = (T7 - l20 * l10) / l11;
+        const double t22 = (T8 - l20 * l20) - l21 * l21;
+        if (!(t22 > 0.0)) { ok = false; break; }
+        const double l22 = sqrt(t22);
+        I0 = 1.0 / l00; I2 = 1.0 / l11; I5 = 1.0 / l22;
+        I1 = -(l10 * I0) * I2;
+        I4 = -(l21 * I2) * I5;
+        I3 = -(l20 * I0 + l21 * I1) * I5;
+        double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+        if (c == m2) { u0 = gpb[3 * i]; u1 = gpb[3 * i + 1]; u2 = gpb[3 * i + 2]; }
+        if (i > 0) {
+            u0 -= (G[0] * y0 + G[1] * y1) + G[2] * y2;
+            u1 -= (G[3] * y0 + G[4] * y1) + G[5] * y2;
+            u2 -= (G[6] * y0 + G[7] * y1) + G[8] * y2;
+        }
+        const int kc = g.cnt[i];
+        for (int s = 0; s < kc; ++s) {
+            const size_t k = (size_t)i * KP + s;
+            const int j = g.mlm[k] & (kPgsFirstBit - 1);
+            if (j == myj && c < m2) {
+                const double* E = Eb + 6 * k;
+                u0 += E[myd]; u1 += E[2 + myd]; u2 += E[4 + myd];
+            }
+        }
+        y0 = I0 * u0;
+        y1 = I1 * u0 + I2 * u1;
+        y2 = (I3 * u0 + I4 * u1) + I5 * u2;
+        if (c < LD) {
+            double* Yi = Yb + (size_t)3 * i * LD;
+            Yi[c] = y0; Yi[LD + c] = y1; Yi[2 * LD + c] = y2;
+        }
+        if (c == 0) {
+            double* L = Lb + 6 * i;
+            L[0] = I0; L[1] = I1; L[2] = I2; L[3] = I3; L[4] = I4; L[5] = I5;
+            double* Go = Gb + 9 * i;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Go[k] = G[k];
+        }
+    }
+    if (c == 0) p.solve_ok[b] = ok ? 1 : 0;
+}
+
+// S_ext = [D + lambda I, .; gl^T, .] - Y^T Y on 64x64 tiles of the lower triangle; 4 wavefronts x (32x32) each,
+// v_mfma_f64_16x16x4_f64.  Row 2M of S_ext is the right-hand side gl - Y^T z.
+__global__ __launch_bounds__(256) void pgs_syrk_kernel(const PgsParams p) {
+    const int b = blockIdx.y;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int LD = p.LD, m2 = 2 * p.M[b];
+    // decode the lower-triangular tile index
+    int ti = 0, t = blockIdx.x;
+    while (t >= ti + 1) { t -= ti + 1; ti += 1; }
+    const int tj = t;
+    if (ti * 64 > m2) return;                       // tile row holds nothing (rows > 2M)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wr = w >> 1, wc = w & 1;
+    if (ti == tj && wr == 0 && wc == 1) return;     // strictly upper part of a diagonal tile
+    const int rowbase = ti * 64 + wr * 32, colbase = tj * 64 + wc * 32;
+    if (rowbase > m2 || colbase > m2) return;
+    const int K3 = 3 * p.N;
+    int k0 = 0;
+    if (ti * 64 + 63 < m2) k0 = (3 * p.lm_first[(size_t)b * p.L_max + ti * 32]) & ~3;   // Y[k][c] == 0 before the first detection
+    const double* Yb = p.Y + (size_t)b * p.y_stride;
+    dbl4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+    const int kq = lane >> 4, cl = lane & 15;
+    constexpr int KU = 4;   // k-steps (of 4 rows) in flight
+#pragma unroll 1
+    for (int k = k0; k < K3; k += 4 * KU) {
+        double a[KU][2], bb[KU][2];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kk = k + 4 * u + kq;
+            const bool in = kk < K3;
+            const double* row = Yb + (size_t)(in ? kk : 0) * LD;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[u][h] = in ? row[rowbase + 16 * h + cl] : 0.0;
+                bb[u][h] = in ? row[colbase + 16 * h + cl] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
+    }
+    const double lambda = p.lambda[b];
+    const double* Db = p.D + (size_t)b * p.L_max * 3;
+    const double* glb = p.gl + (size_t)b * p.L_max * 2;
+    double* Sb = p.S + (size_t)b * LD * LD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = rowbase + 16 * i + kq + 4 * r4;   // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg
+                const int c = colbase + 16 * j + cl;
+                if (r > m2 || c > r) continue;
+                double v = -acc[i][j][r4];
+                if (r < m2) {
+                    if (c == r) v += Db[3 * (r >> 1) + ((r & 1) ? 2 : 0)] + lambda;
+                    else if ((c >> 1) == (r >> 1)) v += Db[3 * (r >> 1) + 1];
+                } else if (c < m2) {
+                    v += glb[c];
+                }
+                Sb[(size_t)r * LD + c] = v;
+            }
+}
+
+// Dense blocked Cholesky of S (2M x 2M, lower, in place; the right-hand-side row 2M rides along as one more panel row,
+// which IS the forward substitution) followed by the blocked backward substitution; dl = S^-1 rhs.
+__global__ __launch_bounds__(TPB) void pgs_chol_kernel(const PgsParams p) {
+    constexpr int NB = 16;
+    extern __shared__ double s_dyn[];
+    __shared__ double s_d[NB][NB + 1];
+    __shared__ int s_fail;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int LD = p.LD, m2 = 2 * p.M[b];
+    if (m2 == 0) return;
+    double* Sb = p.S + (size_t)b * LD * LD;
+    double* s_p = s_dyn;                 // panel [(rows below the block)][NB + 1]
+    double* s_y = s_dyn;                 // backward phase: y / x [m2]
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < m2; j0 += NB) {
+        const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
+        {
+            const int r = tid >> 4, c = tid & 15;
+            if (r < nb && c <= r) s_d[r][c] = Sb[(size_t)(j0 + r) * LD + j0 + c];
+        }
+        __syncthreads();
+        if (tid < 64) {   // factor the diagonal block: lane = row
+            const int r = tid;
+            for (int c = 0; c < nb; ++c) {
+                double d = s_d[c][c];
+                if (!(d > 0.0)) { if (r == 0) s_fail = 1; d = 1.0; }
+                d = sqrt(d);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (r == c) s_d[c][c] = d;
+                if (r > c && r < nb) s_d[r][c] = s_d[r][c] / d;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (r > c && r < nb)
+                    for (int c2 = c + 1; c2 <= r; ++c2) s_d[r][c2] = s_d[r][c2] - s_d[r][c] * s_d[c2][c];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+        }
+        __syncthreads();
+        {   // write the factored block back
+            const int r = tid >> 4, c = tid & 15;
+            if (r < nb && c <= r) Sb[(size_t)(j0 + r) * LD + j0 + c] = s_d[r][c];
+        }
+        const int rb = j0 + nb;              // first row below the block
+        const int R = m2 + 1 - rb;           // rows below, including the rhs row
+        for (int rr = tid; rr < R; rr += TPB) {   // panel: row (rb + rr) <- row * L_block^-T
+            double* row = Sb + (size_t)(rb + rr) * LD + j0;
+            double x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[c] = c < nb ? row[c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c < nb) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        if (k < c) v -= x[k] * s_d[c][k];
+                    x[c] = v / s_d[c][c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c < nb) row[c] = x[c];
+                s_p[rr * (NB + 1) + c] = x[c];
+            }
+        }
+        __syncthreads();
+        // trailing update on 4x4 register tiles of the lower triangle below the block (rhs row included, its
+        // diagonal element excluded by c <= r, c < m2)
+        const int nt = (R + 3) >> 2;
+        const int ntiles = nt * (nt + 1) / 2;
+        for (int t = tid; t < ntiles; t += TPB) {
+            int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while (tr * (tr + 1) / 2 > t) --tr;
+            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+            const int tc = t - tr * (tr + 1) / 2;
+            double pr[4][NB], acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < NB; ++k) pr[i][k] = (4 * tr + i < R) ? s_p[(4 * tr + i) * (NB + 1) + k] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double pc[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) pc[k] = (4 * tc + j < R) ? s_p[(4 * tc + j) * (NB + 1) + k] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) v += pr[i][k] * pc[k];
+                    acc[i][j] = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = rb + 4 * tr + i, c = rb + 4 * tc + j;
+                    if (r <= m2 && c <= r && c < m2) Sb[(size_t)r * LD + c] -= acc[i][j];
+                }
+        }
+        __syncthreads();
+    }
+    if (s_fail) { if (tid == 0) p.solve_ok[b] = 0; return; }
+    // backward substitution  L^T x = y  (y = row 2M of the factored matrix), blocks from the bottom
+    for (int c = tid; c < m2; c += TPB) s_y[c] = Sb[(size_t)m2 * LD + c];
+    __syncthreads();
+    const int nblk = (m2 + NB - 1) / NB;
+    for (int bi = nblk - 1; bi >= 0; --bi) {
+        const int j0 = bi * NB;
+        const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
+        {
+            const int r = tid >> 4, c = tid & 15;
+            if (r < nb && c <= r) s_d[r][c] = Sb[(size_t)(j0 + r) * LD + j0 + c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int c = nb - 1; c >= 0; --c) {
+                double v = s_y[j0 + c];
+                for (int k = c + 1; k < nb; ++k) v -= s_d[k][c] * s_y[j0 + k];
+                s_y[j0 + c] = v / s_d[c][c];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < j0; c += TPB) {   // y[c] -= sum_k L[j0+k][c] x[j0+k]  (rows of L: coalesced over c)
+            double v = s_y[c];
+            for (int k = 0; k < nb; ++k) v -= Sb[(size_t)(j0 + k) * LD + c] * s_y[j0 + k];
+            s_y[c] = v;
+        }
+        __syncthreads();
+    }
+    double* dlb = p.dl + (size_t)b * p.L_max * 2;
+    for (int c = tid; c < m2; c += TPB) dlb[c] = s_y[c];
+}
+
+// Pose step: H_pp dp = gp - E dl through the chain factor.  One wavefront per instance; chunks of 64 poses are
+// prepared lane-parallel (v = Linv u, Mx = Linv G), the 3-vector recurrence itself runs on lane 0 out of LDS.
+__global__ __launch_bounds__(64) void pgs_backsolve_kernel(const PgsParams p) {
+    __shared__ double s_v[64][3], s_M[64][9], s_z[64][3];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int N = p.N, KP = p.KP;
+    const Inst g = inst_view(p, b);
+    const double* gpb = p.gp + (size_t)b * p.N_max * 3;
+    const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
+    const double* Lb = p.Linv + (size_t)b * p.N_max * 6;
+    const double* Gb = p.G + (size_t)b * p.N_max * 9;
+    const double* dlb = p.dl + (size_t)b * p.L_max * 2;
+    double* dpb = p.dp + (size_t)b * p.N_max * 3;
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+    for (int base = 0; base < N; base += 64) {   // forward: z_i = Linv_i (u_i - G_i z_{i-1})
+        const int i = base + lane;
+        if (i < N) {
+            double u0 = gpb[3 * i], u1 = gpb[3 * i + 1], u2 = gpb[3 * i + 2];
+            const int kc = g.cnt[i];
+            for (int s = 0; s < kc; ++s) {
+                const size_t k = (size_t)i * KP + s;
+                const int j = g.mlm[k] & (kPgsFirstBit - 1);
+                const double* E = Eb + 6 * k;
+                const double d0 = dlb[2 * j], d1 = dlb[2 * j + 1];
+                u0 -= E[0] * d0 + E[1] * d1; u1 -= E[2] * d0 + E[3] * d1; u2 -= E[4] * d0 + E[5] * d1;
+            }
+            const double* I = Lb + 6 * i;
+            const double* G = Gb + 9 * i;
+            s_v[lane][0] = I[0] * u0;
+            s_v[lane][1] = I[1] * u0 + I[2] * u1;
+            s_v[lane][2] = (I[3] * u0 + I[4] * u1) + I[5] * u2;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                s_M[lane][cc] = I[0] * G[cc];
+                s_M[lane][3 + cc] = I[1] * G[cc] + I[2] * G[3 + cc];
+                s_M[lane][6 + cc] = (I[3] * G[cc] + I[4] * G[3 + cc]) + I[5] * G[6 + cc];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane == 0) {
+            const int n = (N - base) < 64 ? (N - base) : 64;
+            for (int l = 0; l < n; ++l) {
+                const double a0 = s_v[l][0] - ((s_M[l][0] * z0 + s_M[l][1] * z1) + s_M[l][2] * z2);
+                const double a1 = s_v[l][1] - ((s_M[l][3] * z0 + s_M[l][4] * z1) + s_M[l][5] * z2);
+                const double a2 = s_v[l][2] - ((s_M[l][6] * z0 + s_M[l][7] * z1) + s_M[l][8] * z2);
+                z0 = a0; z1 = a1; z2 = a2;
+                s_z[l][0] = z0; s_z[l][1] = z1; s_z[l][2] = z2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (i < N) { dpb[3 * i] = s_z[lane][0]; dpb[3 * i + 1] = s_z[lane][1]; dpb[3 * i + 2] = s_z[lane][2]; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    for (int top = N; top > 0; top -= 64) {      // backward: dp_i = Linv_i^T (z_i - G_{i+1}^T dp_{i+1})
+        const int base = top - 64 < 0 ? 0 : top - 64;
+        const int n = top - base;
+        const int i = base + lane;
+        if (lane < n) {
+            const double* I = Lb + 6 * i;
+            const double zz0 = dpb[3 * i], zz1 = dpb[3 * i + 1], zz2 = dpb[3 * i + 2];
+            s_v[lane][0] = (I[0] * zz0 + I[1] * zz1) + I[3] * zz2;     // Linv^T z
+            s_v[lane][1] = I[2] * zz1 + I[4] * zz2;
+            s_v[lane][2] = I[5] * zz2;
+            if (i + 1 < N) {   // Mx = Linv^T G_{i+1}^T
+                const double* G = Gb + 9 * (i + 1);
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {   // column cc of G^T = row cc of G
+                    s_M[lane][cc] = (I[0] * G[3 * cc] + I[1] * G[3 * cc + 1]) + I[3] * G[3 * cc + 2];
+                    s_M[lane][3 + cc] = I[2] * G[3 * cc + 1] + I[4] * G[3 * cc + 2];
+                    s_M[lane][6 + cc] = I[5] * G[3 * cc + 2];
+                }
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 9; ++cc) s_M[lane][cc] = 0.0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane == 0) {
+            for (int l = n - 1; l >= 0; --l) {
+                const double a0 = s_v[l][0] - ((s_M[l][0] * d0 + s_M[l][1] * d1) + s_M[l][2] * d2);
+                const double a1 = s_v[l][1] - ((s_M[l][3] * d0 + s_M[l][4] * d1) + s_M[l][5] * d2);
+                const double a2 = s_v[l][2] - ((s_M[l][6] * d0 + s_M[l][7] * d1) + s_M[l][8] * d2);
+                d0 = a0; d1 = a1; d2 = a2;
+                s_z[l][0] = d0; s_z[l][1] = d1; s_z[l][2] = d2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane < n) { dpb[3 * i] = s_z[lane][0]; dpb[3 * i + 1] = s_z[lane][1]; dpb[3 * i + 2] = s_z[lane][2]; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+}
+
+// linearised cost of the step, retraction, true cost of the candidate, then GTSAM's tryLambda / iterate /
+// defaultOptimize decisions for this instance (LevenbergMarquardtOptimizer.cpp, NonlinearOptimizer.cpp).
+__global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
+    __shared__ double s_buf[TPB];
+    __shared__ int s_accept;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (p.state[b]) return;
+    const int N = p.N, KP = p.KP, M = p.M[b];
+    const Inst g = inst_view(p, b);
+    double* pose = p.pw + (size_t)b * p.N_max * 3;
+    double* lm = p.lw + (size_t)b * p.L_max * 2;
+    double* pose_n = p.pn + (size_t)b * p.N_max * 3;
+    double* lm_n = p.ln + (size_t)b * p.L_max * 2;
+    const double* dp = p.dp + (size_t)b * p.N_max * 3;
+    const double* dl = p.dl + (size_t)b * p.L_max * 2;
+    const bool ok = p.solve_ok[b] != 0;
+    double newLin = 0.0, newError = 0.0;
+    if (ok) {
+        double acc = 0.0;
+        for (int i = tid; i < N; i += TPB) {   // 0.5 |J delta + e|^2 of the UNDAMPED linearisation
+            double e[3], J1[9];
+            if (i == 0) {
+                prior_factor(p, pose, e);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double v = e[k] + p.w_prior[k] * dp[k]; acc = acc + 0.5 * v * v; }
+            }
+            if (i + 1 < N) {
+                between_factor<true>(p, pose + 3 * i, pose + 3 * (i + 1), p.cmds[2 * i], p.cmds[2 * i + 1], e, J1);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double v = (e[r] + ((J1[3 * r] * dp[3 * i] + J1[3 * r + 1] * dp[3 * i + 1]) + J1[3 * r + 2] * dp[3 * i + 2])) + p.w_btw[r] * dp[3 * (i + 1) + r];
+                    acc = acc + 0.5 * v * v;
+                }
+            }
+            const int kc = g.cnt[i];
+            for (int s = 0; s < kc; ++s) {
+                const size_t k = (size_t)i * KP + s;
+                const int j = g.mlm[k] & (kPgsFirstBit - 1);
+                double e2[2], Jp[6], Jl[4];
+                bearing_range_factor<true>(p, pose + 3 * i, lm + 2 * j, g.mb[k], g.mr[k], e2, Jp, Jl);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const double v = (e2[r] + ((Jp[3 * r] * dp[3 * i] + Jp[3 * r + 1] * dp[3 * i + 1]) + Jp[3 * r + 2] * dp[3 * i + 2])) + (Jl[2 * r] * dl[2 * j] + Jl[2 * r + 1] * dl[2 * j + 1]);
+                    acc = acc + 0.5 * v * v;
+                }
+            }
+            // retract: p * Pose2(v)
+            double s, c;
+            det_sincos(pose[3 * i + 2], &s, &c);
+            pose_n[3 * i] = pose[3 * i] + (c * dp[3 * i] - s * dp[3 * i + 1]);
+            pose_n[3 * i + 1] = pose[3 * i + 1] + (s * dp[3 * i] + c * dp[3 * i + 1]);
+            pose_n[3 * i + 2] = remainder(pose[3 * i + 2] + dp[3 * i + 2], kTwoPi);
+        }
+        for (int a = tid; a < 2 * M; a += TPB) lm_n[a] = lm[a] + dl[a];
+        newLin = block_sum<TPB>(acc, s_buf);
+        __syncthreads();   // candidate values are visible to the block
+        newError = block_cost<TPB>(p, b, pose_n, lm_n, s_buf);
+    }
+    if (tid == 0) {
+        const double lambdaFactor = 10.0, lambdaUpper = 1e5, minFidelity = 1e-3, relTol = 1e-5, absTol = 1e-5;
+        const int maxIter = 100;
+        double lambda = p.lambda[b], error = p.error[b];
+        int iters = p.iters[b];
+        bool success = false, stop = false, end_inner = false;
+        if (ok) {
+            const double oldLin = error;
+            const double linChange = oldLin - newLin;
+            if (linChange >= 0.0) {
+                const double costChange = error - newError;
+                if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > minFidelity;
+                if (fabs(costChange) < relTol * error) stop = true;
+            }
+        }
+        if (success) {
+            lambda = lambda / lambdaFactor; error = newError; iters += 1; end_inner = true;
+        } else if (!stop) {
+            lambda = lambda * lambdaFactor;
+            if (lambda >= lambdaUpper) end_inner = true;
+        } else {
+            end_inner = true;
+        }
+        int done = 0, fl = 0;
+        if (end_inner) {   // defaultOptimize's loop condition
+            const double currentError = p.cur_error[b];
+            const double absDec = currentError - error, relDec = absDec / currentError;
+            if (!(fabs(error) <= 1.79769313486231570e308)) { done = 1; fl = PGS_FLAG_NONFINITE; }
+            else if (iters >= maxIter) { done = 1; fl = PGS_FLAG_NOT_CONVERGED; }
+            else if (error <= 0.0 || relDec <= relTol || absDec <= absTol) done = 1;
+            else p.cur_error[b] = error;
+        }
+        p.lambda[b] = lambda; p.error[b] = error; p.iters[b] = iters;
+        p.trials[b] += 1;
+        p.solve_ok[b] = 1;
+        if (done) { p.state[b] = 1; p.flags[b] |= fl; } else atomicAdd(p.n_active, 1);
+        s_accept = success ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_accept) {
+        for (int i = tid; i < 3 * N; i += TPB) pose[i] = pose_n[i];
+        for (int a = tid; a < 2 * M; a += TPB) lm[a] = lm_n[a];
+    }
+}
+
+// result <- current values (also for instances cut off by the trial cap)
+__global__ __launch_bounds__(TPB) void pgs_lm_end_kernel(const PgsParams p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = p.N, M = p.M[b];
+    const double* pw = p.pw + (size_t)b * p.N_max * 3;
+    const double* lw = p.lw + (size_t)b * p.L_max * 2;
+    double* p1 = p.pose1 + (size_t)b * p.N_max * 3;
+    double* l1 = p.lm1 + (size_t)b * p.L_max * 2;
+    for (int i = tid; i < 3 * N; i += TPB) p1[i] = pw[i];
+    for (int i = tid; i < 2 * M; i += TPB) l1[i] = lw[i];
+    if (tid == 0 && p.state[b] == 0) { p.state[b] = 1; p.flags[b] |= PGS_FLAG_NOT_CONVERGED; }
+}
+
+__global__ __launch_bounds__(TPB) void pgs_adopt_kernel(const PgsParams p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = p.N, M = p.M[b];
+    double* p0 = p.pose0 + (size_t)b * p.N_max * 3;
+    double* l0 = p.lm0 + (size_t)b * p.L_max * 2;
+    const double* p1 = p.pose1 + (size_t)b * p.N_max * 3;
+    const double* l1 = p.lm1 + (size_t)b * p.L_max * 2;
+    for (int i = tid; i < 3 * N; i += TPB) p0[i] = p1[i];
+    for (int i = tid; i < 2 * M; i += TPB) l0[i] = l1[i];
+}
+
+// compute_average_error as the pose-graph plot calls it (plotting_node.py:203-213,432-434): pose i of the message
+// (i < timestep, float32 on the wire) against true_poses[i] = the true pose after step i+1.
+__global__ __launch_bounds__(TPB) void pgs_avg_error_kernel(const PgsParams p, int which, double* out) {
+    __shared__ double s_buf[TPB];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ts = p.N - 1;
+    const double* pose = (which ? p.pose1 : p.pose0) + (size_t)b * p.N_max * 3;
+    const double* th = p.truth_hist + (size_t)b * p.N_max * 2;
+    double acc = 0.0;
+    for (int i = tid; i < ts; i += TPB) {
+        const double ex = (double)(float)pose[3 * i] - th[2 * i], ey = (double)(float)pose[3 * i + 1] - th[2 * i + 1];
+        acc = acc + sqrt(ex * ex + ey * ey);
+    }
+    const double tot = block_sum<TPB>(acc, s_buf);
+    if (tid == 0) out[b] = ts > 0 ? tot / ts : 0.0;
+}
+
+}  // namespace
+
+hipError_t pgs_launch_init(const PgsParams& p, float x0, float y0, float yaw0, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_init_kernel, dim3((p.B + 255) / 256), dim3(256), 0, s, p, (double)x0, (double)y0, (double)yaw0);
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_append(const PgsParams& p, const float* d_meas, const int32_t* d_count, int k_stride, const double* d_sec, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_append_kernel, dim3((p.B + 63) / 64), dim3(64), 0, s, p, d_meas, d_count, k_stride, d_sec);
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_run_sim(const PgsParams& p, int T, uint32_t step0, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_run_sim_kernel, dim3(p.B), dim3(64), 0, s, p, T, step0);
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_lm_begin_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_trial(const PgsParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+    hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.B), dim3(p.LD), 0, s, p);
+    const int nt = p.LD / 64;
+    hipLaunchKernelGGL(pgs_syrk_kernel, dim3(nt * (nt + 1) / 2, p.B), dim3(256), 0, s, p);
+    const size_t lds = sizeof(double) * (size_t)(p.LD + 1) * 17;
+    hipLaunchKernelGGL(pgs_chol_kernel, dim3(p.B), dim3(TPB), lds, s, p);
+    hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.B), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_lm_end(const PgsParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_lm_end_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_adopt(const PgsParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_adopt_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_avg_error(const PgsParams& p, int which, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_avg_error_kernel, dim3(p.B), dim3(TPB), 0, s, p, which, out);
+    return hipGetLastError();
+}
+
+}  // namespace slam

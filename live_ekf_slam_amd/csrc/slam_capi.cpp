@@ -14,6 +14,7 @@
 #include <utility>
 #include <vector>
 
+#include "capi_internal.h"
 #include "ekf_kernel.h"
 #include "slam_math.h"
 #include "ukf_kernel.h"
@@ -168,6 +169,14 @@ bool parse_scalar(const char* line, const char* key, double* out) {
 }  // namespace
 
 extern "C" {
+
+int slam_internal_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
 
 const char* slam_last_error(void) { return g_err; }
 const char* slam_version(void) { return "live_ekf_slam_amd 0.1 (gfx950)"; }

@@ -12,9 +12,12 @@ from live_ekf_slam_amd.config import SlamConfig, default_config
 
 
 def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "slam_batch.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(slam_[a-z_0-9]+)\s*\(", txt)))
+    out = set()
+    for hdr in ("slam_batch.h", "slam_pgs.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b((?:slam|pgs)_[a-z_0-9]+)\s*\(", txt))
+    return sorted(out)
 
 
 def test_library_exports_every_declared_symbol():

@@ -102,3 +102,20 @@ def test_oracle_pose_graph_matches_reference_published_error(oracle, regime):
         ei.append(r["avg_err_init"]); er.append(r["avg_err_result"])
     _check(np.concatenate(ei), REF["runs"][f"naive_{regime}_noise_one_time/pose_graph_init.csv"], f"PGS init {regime}")
     _check(np.concatenate(er), REF["runs"][f"naive_{regime}_noise_one_time/pose_graph_result.csv"], f"PGS result {regime}")
+
+
+@pytest.mark.gpu
+def test_gpu_pose_graph_matches_reference_published_error():
+    import live_ekf_slam_amd as S
+    for regime in ("low", "high"):
+        ei, er = [], []
+        for s in range(N_SCEN):
+            lm, cmds = make_scenario(100 + s, 20, 999)
+            pg = S.BatchedPoseGraph(32, num_iterations=1000, L_max=20, k_per_pose=8).readParams(_cfg(regime))
+            pg.set_map(lm); pg.set_seed(7 + s); pg.init(0.0, 0.0, 0.0)
+            pg.run_sim(cmds); pg.solvePoseGraph()
+            assert np.all(pg.stats()["flags"] == 0)
+            ei.append(pg.error_stats(0)); er.append(pg.error_stats(1))
+            pg.close()
+        _check(np.concatenate(ei), REF["runs"][f"naive_{regime}_noise_one_time/pose_graph_init.csv"], f"GPU PGS init {regime}")
+        _check(np.concatenate(er), REF["runs"][f"naive_{regime}_noise_one_time/pose_graph_result.csv"], f"GPU PGS result {regime}")
