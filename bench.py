@@ -112,6 +112,81 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
     f.close()
 
 
+def bench_pgs(args, torch, dist, rank, local_rank, world, dev):
+    """Secondary line: pose-graph SLAM solves/s (BASELINE configs[4]: 1000 poses x 200 landmarks, batched LM).
+    One "step" = solvePoseGraph() of every instance of the batch from its initial estimate (one-time mode,
+    pose_graph.cpp:208-214,269-300).  Graphs are built on the device (simulator + NaiveFilter secondary) before the
+    timed region.  Roofline object: the Schur-complement SYRK (v_mfma_f64_16x16x4_f64), its algorithmic FLOP over its
+    HIP-event time, against the 78.6 TFLOP/s fp64 matrix peak."""
+    import live_ekf_slam_amd as S
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, K, W = args.landmarks, args.batch, args.steps, args.warmup
+    N = args.poses
+    lm, cmds = make_scenario(1234, L, N - 1)
+    pg = S.BatchedPoseGraph(B, num_iterations=N, L_max=L, k_per_pose=args.k_per_pose, device=local_rank).readParams()
+    stream = torch.cuda.Stream(device=dev)
+    pg.set_stream(stream.cuda_stream)
+    pg.set_map(lm); pg.set_seed(2025); pg.set_instance_offset(rank * B); pg.init(0.0, 0.0, 0.0)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        pg.run_sim(cmds)
+        for _ in range(W):
+            pg.solvePoseGraph()
+        pg.set_profiling(True)
+        sync_all()
+        t0 = time.perf_counter()
+        kms = {}
+        flop = 0.0
+        trials_launched = 0
+        for _ in range(K):
+            pg.solvePoseGraph()
+            for k, v in pg.last_solve_kernel_ms().items():
+                kms[k] = kms.get(k, 0.0) + v
+            f_, t_ = pg.last_solve_work(); flop += f_; trials_launched += t_
+        sync_all()
+        wall = time.perf_counter() - t0
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    st = pg.stats()
+    e0, e1 = pg.error_stats(0), pg.error_stats(1)
+    if rank == 0:
+        syrk_tf = flop / (kms["syrk"] * 1e-3) / 1e12 if kms.get("syrk", 0) > 0 else 0.0
+        M = np.array([pg.get_graph(b, 1)["M"] for b in range(min(B, 8))])
+        line = {"metric": "pose-graph SLAM solves/sec (secondary; BASELINE configs[4] shape)", "value": round(B * world * K / wall, 2),
+                "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"pose-graph SLAM one-time LM solve, {N} poses x {L} landmarks (mapped: {int(M.min())}-{int(M.max())}), "
+                                       f"batch={B} graphs per GPU, device-built graphs (simulator + NaiveFilter secondary)",
+                           "batch_per_gpu": B, "poses": N, "landmarks": L, "lm_trials_launched_per_solve": trials_launched / K,
+                           "lm_iterations_mean": float(st["iterations"].mean()), "lm_trials_mean": float(st["trials"].mean()),
+                           "instances_flagged": int((st["flags"] != 0).sum()),
+                           "avg_position_error_m": {"initial": round(float(e0.mean()), 4), "result": round(float(e1.mean()), 4)},
+                           "parity": "tolerance 1e-7 m vs CPU oracle, identical LM iteration / trial counts (tests/test_parity_pgs_gpu.py)",
+                           "kernel_ms_per_solve": {k: round(v / K, 3) for k, v in kms.items()}},
+                "roofline": {"bound": "mfma", "achieved": round(syrk_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(syrk_tf / 78.6, 4),
+                             "traffic": None, "kernel": "pgs_syrk_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms": round(kms.get("syrk", 0.0) / K, 3),
+                             "algorithmic_flop_per_solve": flop / K}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            Bc = 4 if L >= 100 else 16
+            r = O.run_pgs_batch(lm, cmds, Bc, L, KP=args.k_per_pose, seed=2025, nthreads=1)
+            line["cpu_baseline"] = {"value": round(Bc / r["seconds"], 3), "unit": "solves/s", "cores": 1, "kind": "port",
+                                    "sample": f"oracle pose-graph LM (same elimination order, scalar loops), {Bc} graphs of the same workload, 1 thread, {r['seconds']:.1f} s"}
+        print(json.dumps(line), flush=True)
+    pg.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,9 +201,17 @@ def main():
                     help="timesteps one kernel launch carries (0 = all K timed steps in one launch, 1 = launch per step)")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="storage type of x and P in HBM (arithmetic is fp64 either way); f64 is the headline metric")
-    ap.add_argument("--filter", choices=["ekf", "ukf"], default="ekf",
-                    help="ekf = the headline metric (default); ukf = BASELINE configs[2]-style secondary line")
+    ap.add_argument("--filter", choices=["ekf", "ukf", "pgs"], default="ekf",
+                    help="ekf = the headline metric (default); ukf / pgs = BASELINE configs[2] / configs[4]-style secondary lines")
+    ap.add_argument("--poses", type=int, default=1000, help="pgs: poses per graph (num_iterations)")
+    ap.add_argument("--k-per-pose", type=int, default=32, help="pgs: detections stored per timestep")
     args = ap.parse_args()
+    if args.filter == "pgs":   # configs[4] defaults unless given explicitly
+        argv = " ".join(sys.argv[1:])
+        if "--landmarks" not in argv: args.landmarks = 200
+        if "--batch" not in argv: args.batch = 256
+        if "--steps" not in argv: args.steps = 5
+        if "--warmup" not in argv: args.warmup = 1
 
     import torch
     import torch.distributed as dist
@@ -155,6 +238,8 @@ def main():
 
     if args.filter == "ukf":
         return bench_ukf(args, torch, dist, rank, local_rank, world, dev)
+    if args.filter == "pgs":
+        return bench_pgs(args, torch, dist, rank, local_rank, world, dev)
     L, B, K, W, PRE = args.landmarks, args.batch, args.steps, args.warmup, args.preroll
     T = 1 + PRE + W + K
     lm, cmds = make_scenario(1234, L, T)

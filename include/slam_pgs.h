@@ -85,6 +85,10 @@ int pgs_error_stats(pgs_handle* h, int which, double* per_instance_avg_err);
 /* Work of the LAST pgs_solve summed over instances and trials: algorithmic FLOP of the Schur-complement SYRK
  * (2 * rows * cols * k per computed tile) and the number of LM trials launched. */
 int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launched);
+/* Per-kernel timing of pgs_solve with HIP events on the handle's stream (off by default).  ms[6] = total milliseconds
+ * of the LAST solve spent in {linearize, chain, syrk, chol, backsolve, evaluate}, summed over its trials. */
+int pgs_set_profiling(pgs_handle* h, int on);
+int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]);
 int pgs_sync(pgs_handle* h);
 int pgs_timestep(const pgs_handle* h);
 

@@ -69,6 +69,8 @@ SIGNATURES = {
     "pgs_get_stats": (C.c_int, [_H, _ip, _ip, _ip, _dp, _dp, _dp]),
     "pgs_error_stats": (C.c_int, [_H, C.c_int, _dp]),
     "pgs_last_solve_work": (C.c_int, [_H, _dp, _ip]),
+    "pgs_set_profiling": (C.c_int, [_H, C.c_int]),
+    "pgs_last_solve_kernel_ms": (C.c_int, [_H, _dp]),
     "pgs_sync": (C.c_int, [_H]),
     "pgs_timestep": (C.c_int, [_H]),
     "slam_last_error": (C.c_char_p, []),

@@ -33,8 +33,10 @@ struct pgs_handle {
     float* dmeas = nullptr; int32_t* dcount = nullptr; double* dsec = nullptr; int k_stride = 0;
     double* dout = nullptr;
     int max_trials = 400;
-    double last_syrk_flop = 0.0;
     int last_trials = 0;
+    bool profiling = false;                  // per-kernel hipEvent timing of pgs_solve (pgs_set_profiling)
+    std::vector<hipEvent_t> events;
+    double kernel_ms[slam::kPgsTrialKernels] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -104,6 +106,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     A(&p.cur, B * 3); A(&p.truth, B * 3); A(&p.truth_hist, B * N * 2);
     A(&p.pw, B * N * 3); A(&p.lw, B * L * 2); A(&p.pn, B * N * 3); A(&p.ln, B * L * 2);
     A(&p.A, B * N * 9); A(&p.C, B * N * 9); A(&p.gp, B * N * 3); A(&p.E, B * K * 6); A(&p.Wl, B * K * 5);
+    A(&p.evt_start, B * (L + 1)); A(&p.evt_pose, B * K); A(&p.slot_pos, B * K); A(&p.Elm, B * K * 6);
     A(&p.D, B * L * 3); A(&p.gl, B * L * 2); A(&p.Linv, B * N * 6); A(&p.G, B * N * 9);
     p.y_stride = (int64_t)round_up(3 * N_max, 4) * h->LD;
     A(&p.Y, B * (size_t)p.y_stride); A(&p.S, B * (size_t)h->LD * h->LD);
@@ -135,6 +138,7 @@ int pgs_destroy(pgs_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void* ptr : h->allocs) hipFree(ptr);
+    for (hipEvent_t e : h->events) hipEventDestroy(e);
     if (h->dmeas) hipFree(h->dmeas);
     if (h->p.map) hipFree((void*)h->p.map);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -226,7 +230,15 @@ int pgs_solve(pgs_handle* h) {
     int trials = 0;
     for (; trials < h->max_trials; ++trials) {
         HIP_TRY(hipMemsetAsync(h->p.n_active, 0, sizeof(int32_t), h->stream));
-        HIP_TRY(slam::pgs_launch_trial(h->p, h->stream));
+        for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
+            if (h->profiling) {
+                const size_t need = (size_t)(trials + 1) * (slam::kPgsTrialKernels + 1);
+                while (h->events.size() < need) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->events.push_back(e); }
+                if (k == 0) HIP_TRY(hipEventRecord(h->events[(size_t)trials * (slam::kPgsTrialKernels + 1)], h->stream));
+            }
+            HIP_TRY(slam::pgs_launch_trial_kernel(h->p, k, h->stream));
+            if (h->profiling) HIP_TRY(hipEventRecord(h->events[(size_t)trials * (slam::kPgsTrialKernels + 1) + k + 1], h->stream));
+        }
         int32_t active = 0;
         HIP_TRY(hipMemcpyAsync(&active, h->p.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -234,6 +246,17 @@ int pgs_solve(pgs_handle* h) {
     }
     h->last_trials = trials;
     HIP_TRY(slam::pgs_launch_lm_end(h->p, h->stream));
+    if (h->profiling) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int k = 0; k < slam::kPgsTrialKernels; ++k) h->kernel_ms[k] = 0.0;
+        for (int t = 0; t < trials; ++t)
+            for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
+                float ms = 0.f;
+                const size_t e0 = (size_t)t * (slam::kPgsTrialKernels + 1) + k;
+                HIP_TRY(hipEventElapsedTime(&ms, h->events[e0], h->events[e0 + 1]));
+                h->kernel_ms[k] += ms;
+            }
+    }
     return SLAM_OK;
 }
 
@@ -332,6 +355,13 @@ int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launch
     return SLAM_OK;
 }
 
+int pgs_set_profiling(pgs_handle* h, int on) { TRY(check(h)); h->profiling = on != 0; return SLAM_OK; }
+int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]) {
+    TRY(check(h));
+    if (!ms) return fail(SLAM_ERR_ARG, "NULL output");
+    for (int k = 0; k < slam::kPgsTrialKernels; ++k) ms[k] = h->kernel_ms[k];
+    return SLAM_OK;
+}
 int pgs_sync(pgs_handle* h) { TRY(check(h)); HIP_TRY(hipStreamSynchronize(h->stream)); return SLAM_OK; }
 int pgs_timestep(const pgs_handle* h) { return h ? h->timestep : -1; }
 

@@ -39,6 +39,11 @@ struct PgsParams {
     double* A; double* C; double* gp;  // [B][N_max*9], [B][N_max*9], [B][N_max*3]
     double* E;                         // [B][N_max*KP*6]
     double* Wl;                        // [B][N_max*KP*5]  per factor: Jl^T Jl (xx, xy, yy), -Jl^T e (x, y)
+    // factors regrouped by (landmark, time) for the chain kernel; built by lm_begin
+    int32_t* evt_start;                // [B][L_max+1]    first event of landmark j
+    int32_t* evt_pose;                 // [B][N_max*KP]   pose index of event e
+    int32_t* slot_pos;                 // [B][N_max*KP]   factor slot -> event position
+    double* Elm;                       // [B][N_max*KP*6] E blocks in event order
     double* D; double* gl;             // [B][L_max*3], [B][L_max*2]
     double* Linv; double* G;           // [B][N_max*6], [B][N_max*9]
     double* Y;                         // [B][Yrows][LD]
@@ -60,7 +65,9 @@ hipError_t pgs_launch_append(const PgsParams& p, const float* d_meas, const int3
 // T timesteps of simulator + NaiveFilter secondary + append, on the device (cmds already in p.cmds)
 hipError_t pgs_launch_run_sim(const PgsParams& p, int T, uint32_t step0, hipStream_t s);
 hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s);
-hipError_t pgs_launch_trial(const PgsParams& p, hipStream_t s);      // one tryLambda for every active instance
+// one tryLambda for every active instance = kernels 0..5 in order: linearize, chain, syrk, chol, backsolve, evaluate
+static constexpr int kPgsTrialKernels = 6;
+hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s);
 hipError_t pgs_launch_lm_end(const PgsParams& p, hipStream_t s);     // result = current values, flags
 hipError_t pgs_launch_adopt(const PgsParams& p, hipStream_t s);      // initial_estimate = result
 // avg position error (plotting_node.py:203-213 alignment) of initial (which = 0) / result (1) vs truth_hist: out [B]

@@ -267,6 +267,31 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     const double* l0 = p.lm0 + (size_t)b * p.L_max * 2;
     for (int i = tid; i < 3 * N; i += TPB) pw[i] = p0[i];
     for (int i = tid; i < 2 * M; i += TPB) lw[i] = l0[i];
+    {   // factors regrouped by landmark in chronological order: event e of landmark j sits at evt_start[j] + e
+        __shared__ int s_cnt[256];
+        const int32_t* head = p.lm_head + (size_t)b * p.L_max;
+        const int32_t* mnext = p.mnext + (size_t)b * p.N_max * p.KP;
+        int32_t* evt_start = p.evt_start + (size_t)b * (p.L_max + 1);
+        int32_t* evt_pose = p.evt_pose + (size_t)b * p.N_max * p.KP;
+        int32_t* slot_pos = p.slot_pos + (size_t)b * p.N_max * p.KP;
+        int c = 0;
+        if (tid < M)
+            for (int k = head[tid]; k >= 0; k = mnext[k]) ++c;
+        s_cnt[tid] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int j = 0; j < M; ++j) { const int v = s_cnt[j]; s_cnt[j] = run; run += v; }
+            s_cnt[M < 255 ? M : 255] = run;
+            evt_start[M] = run;
+        }
+        __syncthreads();
+        if (tid < M) {
+            int pos = s_cnt[tid];
+            evt_start[tid] = pos;
+            for (int k = head[tid]; k >= 0; k = mnext[k]) { evt_pose[pos] = k / p.KP; slot_pos[k] = pos; ++pos; }
+        }
+    }
     __syncthreads();
     const double err = block_cost<TPB>(p, b, pw, lw, s_buf);
     if (tid == 0) {
@@ -303,6 +328,8 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
     double* gpb = p.gp + (size_t)b * p.N_max * 3;
     double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
     double* Wlb = p.Wl + (size_t)b * p.N_max * KP * 5;
+    double* Elmb = p.Elm + (size_t)b * p.N_max * KP * 6;
+    const int32_t* slot_pos = p.slot_pos + (size_t)b * p.N_max * KP;
     for (int i = tid; i < N; i += TPB) {
         double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0}, e[3], J1[9];
         if (i == 0) {
@@ -340,6 +367,9 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) E[2 * a + c] = Jp[a] * Jl[c] + Jp[3 + a] * Jl[2 + c];
+            double* El = Elmb + 6 * (size_t)slot_pos[k];   // the same block in (landmark, time) order for the chain kernel
+#pragma unroll
+            for (int a = 0; a < 6; ++a) El[a] = E[a];
             double* W = Wlb + 5 * k;
             W[0] = Jl[0] * Jl[0] + Jl[2] * Jl[2];
             W[1] = Jl[0] * Jl[1] + Jl[2] * Jl[3];
@@ -369,98 +399,170 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
 }
 
 // Block-tridiagonal Cholesky of H_pp + lambda I fused with the forward recurrence over the landmark columns.
-// thread c < 2M: landmark column; c == 2M: gradient column z; 2M < c < LD: zero padding (the MFMA tiles read it).
+// Wavefront 0 is the PRODUCER: per chunk of 64 poses its lanes stage A_i, C_{i-1}, gp_i in LDS, lane 0 runs the
+// sequential 3x3 chain (G_i = C_{i-1} L_{i-1}^-T, L_i = chol(A_i + lambda I - G_i G_i^T), L_i^-1) and leaves
+// (L_i^-1, G_i, gp_i) in an LDS ring; it works one chunk ahead of the CONSUMER wavefronts, whose threads own one column
+// of Y each (c < 2M: landmark column, c == 2M: gradient column z) and apply  Y_i = L_i^-1 (E_i - G_i Y_{i-1}).
+// A column's non-zero E entries come from its landmark's chronological factor list (evt_*, Elm), prefetched one
+// event ahead, so the recurrence never searches the measurement slots.  One barrier per chunk.
+constexpr int CHAIN_CH = 64;
 __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
-    const int b = blockIdx.x, c = threadIdx.x;
+    __shared__ double s_in[CHAIN_CH][18];          // A (6 unique), C (9), gp (3)
+    __shared__ double s_ring[2][CHAIN_CH][18];     // Linv (6), G (9), gp (3)
+    __shared__ int s_fail;
+    const int b = blockIdx.x, tid = threadIdx.x;
     if (p.state[b]) return;
-    const int N = p.N, KP = p.KP, LD = p.LD, m2 = 2 * p.M[b];
+    const int N = p.N, LD = p.LD, m2 = 2 * p.M[b];
     const double lambda = p.lambda[b];
-    const Inst g = inst_view(p, b);
     const double* Ab = p.A + (size_t)b * p.N_max * 9;
     const double* Cb = p.C + (size_t)b * p.N_max * 9;
     const double* gpb = p.gp + (size_t)b * p.N_max * 3;
-    const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
     double* Lb = p.Linv + (size_t)b * p.N_max * 6;
     double* Gb = p.G + (size_t)b * p.N_max * 9;
     double* Yb = p.Y + (size_t)b * p.y_stride;
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    double I0 = 0, I1 = 0, I2 = 0, I3 = 0, I4 = 0, I5 = 0;
-    bool ok = true;
-    const int myj = c >> 1, myd = c & 1;
-#pragma unroll 1
-    for (int i = 0; i < N; ++i) {
-        const double* A = Ab + 9 * i;
-        double T0 = A[0] + lambda, T3 = A[3], T4 = A[4] + lambda, T6 = A[6], T7 = A[7], T8 = A[8] + lambda;
-        double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (i > 0) {   // G = C_{i-1} Linv_{i-1}^T ; T -= G G^T
-            const double* C = Cb + 9 * (i - 1);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                G[3 * r + 0] = C[3 * r] * I0;
-                G[3 * r + 1] = C[3 * r] * I1 + C[3 * r + 1] * I2;
-                G[3 * r + 2] = (C[3 * r] * I3 + C[3 * r + 1] * I4) + C[3 * r + 2] * I5;
-            }
-            T0 -= (G[0] * G[0] + G[1] * G[1]) + G[2] * G[2];
-            T3 -= (G[3] * G[0] + G[4] * G[1]) + G[5] * G[2];
-            T4 -= (G[3] * G[3] + G[4] * G[4]) + G[5] * G[5];
-            T6 -= (G[6] * G[0] + G[7] * G[1]) + G[8] * G[2];
-            T7 -= (G[6] * G[3] + G[7] * G[4]) + G[8] * G[5];
-            T8 -= (G[6] * G[6] + G[7] * G[7]) + G[8] * G[8];
-        }
-        if (!(T0 > 0.0)) { ok = false; break; }
-        const double l00 = sqrt(T0), l10 = T3 / l00, l20 = T6 / l00;
-        const double t11 = T4 - l10 * l10;
-        if (!(t11 > 0.0)) { ok = false; break; }
-        const double l11 = sqrt(t11), l21 = (T7 - l20 * l10) / l11;
-        const double t22 = (T8 - l20 * l20) - l21 * l21;
-        if (!(t22 > 0.0)) { ok = false; break; }
-        const double l22 = sqrt(t22);
-        I0 = 1.0 / l00; I2 = 1.0 / l11; I5 = 1.0 / l22;
-        I1 = -(l10 * I0) * I2;
-        I4 = -(l21 * I2) * I5;
-        I3 = -(l20 * I0 + l21 * I1) * I5;
-        double u0 = 0.0, u1 = 0.0, u2 = 0.0;
-        if (c == m2) { u0 = gpb[3 * i]; u1 = gpb[3 * i + 1]; u2 = gpb[3 * i + 2]; }
-        if (i > 0) {
-            u0 -= (G[0] * y0 + G[1] * y1) + G[2] * y2;
-            u1 -= (G[3] * y0 + G[4] * y1) + G[5] * y2;
-            u2 -= (G[6] * y0 + G[7] * y1) + G[8] * y2;
-        }
-        const int kc = g.cnt[i];
-        for (int s = 0; s < kc; ++s) {
-            const size_t k = (size_t)i * KP + s;
-            const int j = g.mlm[k] & (kPgsFirstBit - 1);
-            if (j == myj && c < m2) {
-                const double* E = Eb + 6 * k;
-                u0 += E[myd]; u1 += E[2 + myd]; u2 += E[4 + myd];
-            }
-        }
-        y0 = I0 * u0;
-        y1 = I1 * u0 + I2 * u1;
-        y2 = (I3 * u0 + I4 * u1) + I5 * u2;
-        if (c < LD) {
-            double* Yi = Yb + (size_t)3 * i * LD;
-            Yi[c] = y0; Yi[LD + c] = y1; Yi[2 * LD + c] = y2;
-        }
-        if (c == 0) {
-            double* L = Lb + 6 * i;
-            L[0] = I0; L[1] = I1; L[2] = I2; L[3] = I3; L[4] = I4; L[5] = I5;
-            double* Go = Gb + 9 * i;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Go[k] = G[k];
+    const bool producer = tid < 64;
+    const int c = tid - 64;                        // consumer column
+    const int nch = (N + CHAIN_CH - 1) / CHAIN_CH;
+    if (tid == 0) s_fail = 0;
+    // consumer state
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0;
+    int cur = 0, end = 0, next_i = 0x7fffffff;
+    const double* Elmb = p.Elm + (size_t)b * p.N_max * p.KP * 6;
+    const int32_t* evt_pose = p.evt_pose + (size_t)b * p.N_max * p.KP;
+    const int myd = c & 1;
+    if (!producer && c < m2) {
+        const int32_t* evt_start = p.evt_start + (size_t)b * (p.L_max + 1);
+        cur = evt_start[c >> 1]; end = evt_start[(c >> 1) + 1];
+        if (cur < end) {
+            next_i = evt_pose[cur];
+            e0 = Elmb[6 * (size_t)cur + myd]; e1 = Elmb[6 * (size_t)cur + 2 + myd]; e2 = Elmb[6 * (size_t)cur + 4 + myd];
         }
     }
-    if (c == 0) p.solve_ok[b] = ok ? 1 : 0;
+    // producer state (lane 0): Linv of the previous pose
+    double I0 = 0, I1 = 0, I2 = 0, I3 = 0, I4 = 0, I5 = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it <= nch; ++it) {
+        if (producer) {
+            if (it < nch) {
+                const int base = it * CHAIN_CH;
+                const int n = (N - base) < CHAIN_CH ? (N - base) : CHAIN_CH;
+                const int i = base + tid;
+                if (tid < n) {
+                    const double* A = Ab + 9 * i;
+                    s_in[tid][0] = A[0]; s_in[tid][1] = A[3]; s_in[tid][2] = A[4]; s_in[tid][3] = A[6]; s_in[tid][4] = A[7]; s_in[tid][5] = A[8];
+                    if (i > 0) {
+                        const double* C = Cb + 9 * (i - 1);
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) s_in[tid][6 + k] = C[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) s_in[tid][6 + k] = 0.0;
+                    }
+                    s_in[tid][15] = gpb[3 * i]; s_in[tid][16] = gpb[3 * i + 1]; s_in[tid][17] = gpb[3 * i + 2];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (tid == 0) {
+                    double (*out)[18] = s_ring[it & 1];
+                    bool ok = s_fail == 0;
+#pragma unroll 1
+                    for (int l = 0; l < n && ok; ++l) {
+                        const double* in = s_in[l];
+                        double G[9];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {   // G = C Linv_prev^T (zero for the first pose: C = 0)
+                            G[3 * r + 0] = in[6 + 3 * r] * I0;
+                            G[3 * r + 1] = in[6 + 3 * r] * I1 + in[6 + 3 * r + 1] * I2;
+                            G[3 * r + 2] = (in[6 + 3 * r] * I3 + in[6 + 3 * r + 1] * I4) + in[6 + 3 * r + 2] * I5;
+                        }
+                        const double T0 = (in[0] + lambda) - ((G[0] * G[0] + G[1] * G[1]) + G[2] * G[2]);
+                        const double T3 = in[1] - ((G[3] * G[0] + G[4] * G[1]) + G[5] * G[2]);
+                        const double T4 = (in[2] + lambda) - ((G[3] * G[3] + G[4] * G[4]) + G[5] * G[5]);
+                        const double T6 = in[3] - ((G[6] * G[0] + G[7] * G[1]) + G[8] * G[2]);
+                        const double T7 = in[4] - ((G[6] * G[3] + G[7] * G[4]) + G[8] * G[5]);
+                        const double T8 = (in[5] + lambda) - ((G[6] * G[6] + G[7] * G[7]) + G[8] * G[8]);
+                        if (!(T0 > 0.0)) { ok = false; break; }
+                        const double l00 = sqrt(T0), l10 = T3 / l00, l20 = T6 / l00;
+                        const double t11 = T4 - l10 * l10;
+                        if (!(t11 > 0.0)) { ok = false; break; }
+                        const double l11 = sqrt(t11), l21 = (T7 - l20 * l10) / l11;
+                        const double t22 = (T8 - l20 * l20) - l21 * l21;
+                        if (!(t22 > 0.0)) { ok = false; break; }
+                        const double l22 = sqrt(t22);
+                        I0 = 1.0 / l00; I2 = 1.0 / l11; I5 = 1.0 / l22;
+                        I1 = -(l10 * I0) * I2;
+                        I4 = -(l21 * I2) * I5;
+                        I3 = -(l20 * I0 + l21 * I1) * I5;
+                        double* o = out[l];
+                        o[0] = I0; o[1] = I1; o[2] = I2; o[3] = I3; o[4] = I4; o[5] = I5;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) o[6 + k] = G[k];
+                        o[15] = in[15]; o[16] = in[16]; o[17] = in[17];
+                    }
+                    if (!ok) s_fail = 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (tid < n && s_fail == 0) {   // factor to HBM for the pose back-substitution
+                    const double* o = s_ring[it & 1][tid];
+                    double* L = Lb + 6 * i;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) L[k] = o[k];
+                    double* Go = Gb + 9 * i;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Go[k] = o[6 + k];
+                }
+            }
+        } else if (it > 0 && c <= m2) {
+            const int base = (it - 1) * CHAIN_CH;
+            const int n = (N - base) < CHAIN_CH ? (N - base) : CHAIN_CH;
+            const double (*rg)[18] = s_ring[(it - 1) & 1];
+            double* Yi = Yb + (size_t)3 * base * LD + c;
+#pragma unroll 2
+            for (int l = 0; l < n; ++l) {
+                const int i = base + l;
+                const double* o = rg[l];
+                double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+                if (c == m2) { u0 = o[15]; u1 = o[16]; u2 = o[17]; }
+                u0 -= (o[6] * y0 + o[7] * y1) + o[8] * y2;      // G is zero for pose 0
+                u1 -= (o[9] * y0 + o[10] * y1) + o[11] * y2;
+                u2 -= (o[12] * y0 + o[13] * y1) + o[14] * y2;
+                if (i == next_i) {
+                    u0 += e0; u1 += e1; u2 += e2;
+                    cur += 1;
+                    if (cur < end) {
+                        next_i = evt_pose[cur];
+                        e0 = Elmb[6 * (size_t)cur + myd]; e1 = Elmb[6 * (size_t)cur + 2 + myd]; e2 = Elmb[6 * (size_t)cur + 4 + myd];
+                    } else {
+                        next_i = 0x7fffffff;
+                    }
+                }
+                y0 = o[0] * u0;
+                y1 = o[1] * u0 + o[2] * u1;
+                y2 = (o[3] * u0 + o[4] * u1) + o[5] * u2;
+                Yi[0] = y0; Yi[LD] = y1; Yi[2 * LD] = y2;
+                Yi += 3 * LD;
+            }
+        }
+        __syncthreads();
+        if (s_fail) break;
+    }
+    if (tid == 0) p.solve_ok[b] = s_fail ? 0 : 1;
 }
 
 // S_ext = [D + lambda I, .; gl^T, .] - Y^T Y on 64x64 tiles of the lower triangle; 4 wavefronts x (32x32) each,
 // v_mfma_f64_16x16x4_f64.  Row 2M of S_ext is the right-hand side gl - Y^T z.
 __global__ __launch_bounds__(256) void pgs_syrk_kernel(const PgsParams p) {
-    const int b = blockIdx.y;
+    // XCD-aware placement: workgroup id w runs on XCD (w mod 8).  All tiles of one instance read the same Y, k chunk
+    // by k chunk and roughly in step, so they are given ids that share one XCD (one L2): id = 8 * q + xcd with
+    // q = (instance / 8) * ntiles + tile, instance = 8 * (q / ntiles) + xcd.
+    const int ntl = (p.LD / 64) * (p.LD / 64 + 1) / 2;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int b = (q / ntl) * 8 + xcd;
+    if (b >= p.B) return;
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
     // decode the lower-triangular tile index
-    int ti = 0, t = blockIdx.x;
+    int ti = 0, t = q % ntl;
     while (t >= ti + 1) { t -= ti + 1; ti += 1; }
     const int tj = t;
     if (ti * 64 > m2) return;                       // tile row holds nothing (rows > 2M)
@@ -592,40 +694,33 @@ __global__ __launch_bounds__(TPB) void pgs_chol_kernel(const PgsParams p) {
             }
         }
         __syncthreads();
-        // trailing update on 4x4 register tiles of the lower triangle below the block (rhs row included, its
-        // diagonal element excluded by c <= r, c < m2)
-        const int nt = (R + 3) >> 2;
-        const int ntiles = nt * (nt + 1) / 2;
-        for (int t = tid; t < ntiles; t += TPB) {
-            int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-            while (tr * (tr + 1) / 2 > t) --tr;
-            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-            const int tc = t - tr * (tr + 1) / 2;
-            double pr[4][NB], acc[4][4];
+        // trailing update  C -= P P^T  on 16x16 tiles of the lower triangle below the block (rhs row included) with
+        // v_mfma_f64_16x16x4_f64: four k = 4 steps per tile, operands from the LDS panel, C read-modify-written in HBM/L2
+        {
+            const int nt = (R + 15) >> 4;
+            const int ntiles = nt * (nt + 1) / 2;
+            const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
+            for (int t = w; t < ntiles; t += TPB / 64) {
+                int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+                while (tr * (tr + 1) / 2 > t) --tr;
+                while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+                const int tc = t - tr * (tr + 1) / 2;
+                dbl4_t acc;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int r = rb + 16 * tr + kq + 4 * r4, c = rb + 16 * tc + cl;
+                    acc[r4] = (r <= m2 && c <= r && c < m2) ? Sb[(size_t)r * LD + c] : 0.0;
+                }
+                const double* pa = s_p + (16 * tr + cl) * (NB + 1) + kq;
+                const double* pb = s_p + (16 * tc + cl) * (NB + 1) + kq;
 #pragma unroll
-                for (int k = 0; k < NB; ++k) pr[i][k] = (4 * tr + i < R) ? s_p[(4 * tr + i) * (NB + 1) + k] : 0.0;
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * q], pb[4 * q], acc, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double pc[NB];
-#pragma unroll
-                for (int k = 0; k < NB; ++k) pc[k] = (4 * tc + j < R) ? s_p[(4 * tc + j) * (NB + 1) + k] : 0.0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) v += pr[i][k] * pc[k];
-                    acc[i][j] = v;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int r = rb + 16 * tr + kq + 4 * r4, c = rb + 16 * tc + cl;
+                    if (r <= m2 && c <= r && c < m2) Sb[(size_t)r * LD + c] = acc[r4];
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = rb + 4 * tr + i, c = rb + 4 * tc + j;
-                    if (r <= m2 && c <= r && c < m2) Sb[(size_t)r * LD + c] -= acc[i][j];
-                }
         }
         __syncthreads();
     }
@@ -921,15 +1016,28 @@ hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t pgs_launch_trial(const PgsParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.B), dim3(TPB), 0, s, p);
-    hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.B), dim3(p.LD), 0, s, p);
-    const int nt = p.LD / 64;
-    hipLaunchKernelGGL(pgs_syrk_kernel, dim3(nt * (nt + 1) / 2, p.B), dim3(256), 0, s, p);
-    const size_t lds = sizeof(double) * (size_t)(p.LD + 1) * 17;
-    hipLaunchKernelGGL(pgs_chol_kernel, dim3(p.B), dim3(TPB), lds, s, p);
-    hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.B), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s) {
+    switch (which) {
+    case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.B), dim3(TPB), 0, s, p); break;
+    case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.B), dim3(64 + p.LD), 0, s, p); break;
+    case 2: {
+        const int nt = p.LD / 64;
+        hipLaunchKernelGGL(pgs_syrk_kernel, dim3(8 * (nt * (nt + 1) / 2) * ((p.B + 7) / 8)), dim3(256), 0, s, p);
+        break;
+    }
+    case 3: {
+        const size_t lds = sizeof(double) * (size_t)(p.LD + 16) * 17;
+        static bool attr_set = false;
+        if (!attr_set) {   // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB)
+            hipFuncSetAttribute((const void*)pgs_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(pgs_chol_kernel, dim3(p.B), dim3(TPB), lds, s, p);
+        break;
+    }
+    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.B), dim3(64), 0, s, p); break;
+    default: hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(p.B), dim3(TPB), 0, s, p); break;
+    }
     return hipGetLastError();
 }
 

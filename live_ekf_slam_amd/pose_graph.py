@@ -202,6 +202,14 @@ class BatchedPoseGraph:
         _lib.check(_lib.lib().pgs_last_solve_work(self.h, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def set_profiling(self, on=True):
+        self._need(); _lib.check(_lib.lib().pgs_set_profiling(self.h, int(on)))
+
+    def last_solve_kernel_ms(self):
+        """{kernel: total ms in the last solve} from HIP events on the handle's stream (set_profiling(True))."""
+        self._need(); ms = np.zeros(6); _lib.check(_lib.lib().pgs_last_solve_kernel_ms(self.h, _d(ms)))
+        return dict(zip(("linearize", "chain", "syrk", "chol", "backsolve", "evaluate"), ms.tolist()))
+
     def sync(self):
         self._need(); _lib.check(_lib.lib().pgs_sync(self.h))
 
