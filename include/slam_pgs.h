@@ -82,8 +82,9 @@ int pgs_get_stats(pgs_handle* h, int32_t* iterations, int32_t* trials, int32_t* 
 /* compute_average_error as the pose-graph plot calls it (plotting_node.py:203-213,432-434) against the simulator's
  * true poses (pgs_run_sim), per instance [batch]; which = 0 initial graph, 1 result. */
 int pgs_error_stats(pgs_handle* h, int which, double* per_instance_avg_err);
-/* Work of the LAST pgs_solve summed over instances and trials: algorithmic FLOP of the Schur-complement SYRK
- * (2 * rows * cols * k per computed tile) and the number of LM trials launched. */
+/* Work of the LAST pgs_solve summed over instances and their trials: algorithmic FLOP of the Schur-complement SYRK
+ * S_ext = D - Y^T Y (2 FLOP per stored lower-triangle element and per k where its row of Y^T can be non-zero, i.e. from
+ * the first detection of the row's landmark; independent of the kernel's tiling) and the number of LM trials launched. */
 int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launched);
 /* Per-kernel timing of pgs_solve with HIP events on the handle's stream (off by default).  ms[6] = total milliseconds
  * of the LAST solve spent in {linearize, chain, syrk, chol, backsolve, evaluate}, summed over its trials. */

@@ -33,6 +33,7 @@ struct pgs_handle {
     float* dmeas = nullptr; int32_t* dcount = nullptr; double* dsec = nullptr; int k_stride = 0;
     double* dout = nullptr;
     int max_trials = 400;
+    int syrk_tile = 0, syrk_switch = 512;    // SLAM_PGS_SYRK_TILE = 32 | 64 forces a variant; SLAM_PGS_SYRK_SWITCH = active count
     int last_trials = 0;
     bool profiling = false;                  // per-kernel hipEvent timing of pgs_solve (pgs_set_profiling)
     std::vector<hipEvent_t> events;
@@ -89,6 +90,8 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     h->cfg = *cfg; h->B = batch; h->N_max = N_max; h->L_max = L_max; h->KP = k_per_pose; h->device = device;
     h->LD = round_up(2 * L_max + 1, 64);
     if (const char* e = getenv("SLAM_PGS_MAX_TRIALS")) h->max_trials = atoi(e) > 0 ? atoi(e) : h->max_trials;
+    if (const char* e = getenv("SLAM_PGS_SYRK_TILE")) h->syrk_tile = atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0);
+    if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
@@ -114,6 +117,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     A(&p.lambda, B); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
     A(&p.iters, B); A(&p.trials, B); A(&p.state, B); A(&p.solve_ok, B); A(&p.n_active, 1);
     A(&h->dcount, B); A(&h->dsec, B * 3); A(&h->dout, B);
+    if (getenv("SLAM_PGS_PROF")) { A(&p.prof, B * 8); }
     if (rc != SLAM_OK) { pgs_destroy(h); return rc; }
     hipMemsetAsync(p.truth_hist, 0, sizeof(double) * B * N * 2, h->stream);
     hipMemsetAsync(p.cnt, 0, sizeof(int32_t) * B * N, h->stream);
@@ -228,7 +232,10 @@ int pgs_solve(pgs_handle* h) {
     h->p.N = h->timestep + 1;
     HIP_TRY(slam::pgs_launch_lm_begin(h->p, h->stream));
     int trials = 0;
+    int32_t active = h->B;
     for (; trials < h->max_trials; ++trials) {
+        // bulk trials: 64x64 wavefront tiles (operand reuse); straggler trials: 32x32 (4x the wavefronts per instance)
+        h->p.syrk_wave_tile = h->syrk_tile ? h->syrk_tile : (active >= h->syrk_switch ? 64 : 32);
         HIP_TRY(hipMemsetAsync(h->p.n_active, 0, sizeof(int32_t), h->stream));
         for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
             if (h->profiling) {
@@ -239,7 +246,7 @@ int pgs_solve(pgs_handle* h) {
             HIP_TRY(slam::pgs_launch_trial_kernel(h->p, k, h->stream));
             if (h->profiling) HIP_TRY(hipEventRecord(h->events[(size_t)trials * (slam::kPgsTrialKernels + 1) + k + 1], h->stream));
         }
-        int32_t active = 0;
+        active = 0;
         HIP_TRY(hipMemcpyAsync(&active, h->p.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (active == 0) { trials += 1; break; }
@@ -335,19 +342,11 @@ int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launch
     HIP_TRY(hipMemcpy(first.data(), h->p.lm_first, sizeof(int32_t) * B * h->L_max, hipMemcpyDeviceToHost));
     const int K3 = 3 * (h->timestep + 1);
     double tot = 0.0;
-    for (size_t b = 0; b < B; ++b) {
-        const int m2 = 2 * M[b];
+    for (size_t b = 0; b < B; ++b) {   // tiling-independent: every stored element of the lower triangle of S_ext, each
+        const int m2 = 2 * M[b];        // over the k range where its row of Y^T can be non-zero
         double per_trial = 0.0;
-        for (int ti = 0; ti * 64 <= m2; ++ti) {
-            int k0 = 0;
-            if (ti * 64 + 63 < m2) k0 = (3 * first[b * h->L_max + ti * 32]) & ~3;
-            const int rows = (m2 + 1 - ti * 64) < 64 ? (m2 + 1 - ti * 64) : 64;
-            for (int tj = 0; tj <= ti; ++tj) {
-                const int cols = (m2 + 1 - tj * 64) < 64 ? (m2 + 1 - tj * 64) : 64;
-                const double elems = ti == tj ? 0.5 * rows * (rows + 1) : (double)rows * cols;
-                per_trial += 2.0 * elems * (K3 - k0);
-            }
-        }
+        for (int r = 0; r < m2; ++r) per_trial += 2.0 * (r + 1) * (double)(K3 - 3 * first[b * h->L_max + (r >> 1)]);
+        per_trial += 2.0 * m2 * (double)K3;   // right-hand-side row gl - Y^T z
         tot += per_trial * tr[b];
     }
     if (syrk_flop) *syrk_flop = tot;
@@ -360,6 +359,14 @@ int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]) {
     TRY(check(h));
     if (!ms) return fail(SLAM_ERR_ARG, "NULL output");
     for (int k = 0; k < slam::kPgsTrialKernels; ++k) ms[k] = h->kernel_ms[k];
+    return SLAM_OK;
+}
+// debug only (not part of the ABI header): phase timers of the last chol launch, [batch][8] ticks of the 100 MHz clock
+int pgs_debug_prof(pgs_handle* h, unsigned long long* out) {
+    TRY(check(h));
+    if (!h->p.prof) return fail(SLAM_ERR_STATE, "set SLAM_PGS_PROF before pgs_create");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->p.prof, sizeof(unsigned long long) * 8 * (size_t)h->B, hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 int pgs_sync(pgs_handle* h) { TRY(check(h)); HIP_TRY(hipStreamSynchronize(h->stream)); return SLAM_OK; }

@@ -14,6 +14,7 @@ static constexpr int kPgsFirstBit = 1 << 30;   // mlm: this factor is the first 
 struct PgsParams {
     int32_t B, N_max, L_max, KP, LD;   // LD = leading dimension of Y / S = roundup(2*L_max + 1, 64)
     int32_t N;                         // poses in the graph now (timestep + 1), the same for every instance
+    int32_t syrk_wave_tile;            // 64 or 32: SYRK variant of the next trial (chosen by the host from the active count)
     // ---- the graph (pose_graph.cpp: graph + initial_estimate + result) ----
     double* pose0; double* lm0;        // initial_estimate: [B][N_max][3], [B][L_max][2]
     double* pose1; double* lm1;        // result
@@ -53,6 +54,7 @@ struct PgsParams {
     double* lambda; double* error; double* cur_error; double* err_init;
     int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done
     int32_t* n_active;                 // [1]
+    unsigned long long* prof;          // optional [B][8] phase timers of the chol kernel (100 MHz wall clock), debug only
     // ---- factor constants ----
     double prior[3];
     double w_prior[3], w_btw[3], w_meas[2];   // 1 / sigma

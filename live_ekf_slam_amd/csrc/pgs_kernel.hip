@@ -406,6 +406,16 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
 // A column's non-zero E entries come from its landmark's chronological factor list (evt_*, Elm), prefetched one
 // event ahead, so the recurrence never searches the measurement slots.  One barrier per chunk.
 constexpr int CHAIN_CH = 64;
+// 1 / sqrt(x) for x > 0 to ~1 ulp: hardware estimate refined by two Newton steps y <- y + y * (1 - x y^2) / 2
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-(x * y), y, 1.0);
+        y = __builtin_fma(y * 0.5, e, y);
+    }
+    return y;
+}
 __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
     __shared__ double s_in[CHAIN_CH][18];          // A (6 unique), C (9), gp (3)
     __shared__ double s_ring[2][CHAIN_CH][18];     // Linv (6), G (9), gp (3)
@@ -465,9 +475,14 @@ __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
                 if (tid == 0) {
                     double (*out)[18] = s_ring[it & 1];
                     bool ok = s_fail == 0;
+                    double in[18], nx[18];
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) in[k] = s_in[0][k];
 #pragma unroll 1
                     for (int l = 0; l < n && ok; ++l) {
-                        const double* in = s_in[l];
+                        const int ln = l + 1 < n ? l + 1 : l;       // next pose's inputs are fetched under this pose's chain
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) nx[k] = s_in[ln][k];
                         double G[9];
 #pragma unroll
                         for (int r = 0; r < 3; ++r) {   // G = C Linv_prev^T (zero for the first pose: C = 0)
@@ -481,15 +496,18 @@ __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
                         const double T6 = in[3] - ((G[6] * G[0] + G[7] * G[1]) + G[8] * G[2]);
                         const double T7 = in[4] - ((G[6] * G[3] + G[7] * G[4]) + G[8] * G[5]);
                         const double T8 = (in[5] + lambda) - ((G[6] * G[6] + G[7] * G[7]) + G[8] * G[8]);
+                        // 3x3 Cholesky through reciprocal square roots (v_rsq_f64 + two Newton steps, ~1 ulp): the three
+                        // pivots are the only long-latency operations on the sequential critical path of the solve
                         if (!(T0 > 0.0)) { ok = false; break; }
-                        const double l00 = sqrt(T0), l10 = T3 / l00, l20 = T6 / l00;
+                        I0 = rsqrt_nr(T0);
+                        const double l10 = T3 * I0, l20 = T6 * I0;
                         const double t11 = T4 - l10 * l10;
                         if (!(t11 > 0.0)) { ok = false; break; }
-                        const double l11 = sqrt(t11), l21 = (T7 - l20 * l10) / l11;
+                        I2 = rsqrt_nr(t11);
+                        const double l21 = (T7 - l20 * l10) * I2;
                         const double t22 = (T8 - l20 * l20) - l21 * l21;
                         if (!(t22 > 0.0)) { ok = false; break; }
-                        const double l22 = sqrt(t22);
-                        I0 = 1.0 / l00; I2 = 1.0 / l11; I5 = 1.0 / l22;
+                        I5 = rsqrt_nr(t22);
                         I1 = -(l10 * I0) * I2;
                         I4 = -(l21 * I2) * I5;
                         I3 = -(l20 * I0 + l21 * I1) * I5;
@@ -498,6 +516,8 @@ __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
 #pragma unroll
                         for (int k = 0; k < 9; ++k) o[6 + k] = G[k];
                         o[15] = in[15]; o[16] = in[16]; o[17] = in[17];
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) in[k] = nx[k];
                     }
                     if (!ok) s_fail = 1;
                 }
@@ -549,13 +569,20 @@ __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
     if (tid == 0) p.solve_ok[b] = s_fail ? 0 : 1;
 }
 
-// S_ext = [D + lambda I, .; gl^T, .] - Y^T Y on 64x64 tiles of the lower triangle; 4 wavefronts x (32x32) each,
-// v_mfma_f64_16x16x4_f64.  Row 2M of S_ext is the right-hand side gl - Y^T z.
-__global__ __launch_bounds__(256) void pgs_syrk_kernel(const PgsParams p) {
+// S_ext = [D + lambda I, .; gl^T, .] - Y^T Y on 128x128 tiles of the lower triangle; 4 wavefronts x (64x64) each = 4x4
+// accumulators of v_mfma_f64_16x16x4_f64 per wavefront (8 operand loads feed 16 MFMAs: the kernel is bound by the
+// L2 -> L1 operand stream, not by HBM, so the wave tile is as large as the register file allows).  Row 2M of S_ext is
+// the right-hand side gl - Y^T z.
+// WT = wavefront tile (64: bulk trials, most instances active; 32: straggler trials, where the few active instances need
+// more wavefronts each).  Workgroup tile SY_T = 2 * WT.
+template <int WT>
+__global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
+    constexpr int SY_T = 2 * WT, NI = WT / 16;
     // XCD-aware placement: workgroup id w runs on XCD (w mod 8).  All tiles of one instance read the same Y, k chunk
     // by k chunk and roughly in step, so they are given ids that share one XCD (one L2): id = 8 * q + xcd with
     // q = (instance / 8) * ntiles + tile, instance = 8 * (q / ntiles) + xcd.
-    const int ntl = (p.LD / 64) * (p.LD / 64 + 1) / 2;
+    const int ntr = (p.LD + SY_T - 1) / SY_T;
+    const int ntl = ntr * (ntr + 1) / 2;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int b = (q / ntl) * 8 + xcd;
     if (b >= p.B) return;
@@ -565,52 +592,70 @@ __global__ __launch_bounds__(256) void pgs_syrk_kernel(const PgsParams p) {
     int ti = 0, t = q % ntl;
     while (t >= ti + 1) { t -= ti + 1; ti += 1; }
     const int tj = t;
-    if (ti * 64 > m2) return;                       // tile row holds nothing (rows > 2M)
+    if (ti * SY_T > m2) return;                     // tile row holds nothing (rows > 2M)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wr = w >> 1, wc = w & 1;
     if (ti == tj && wr == 0 && wc == 1) return;     // strictly upper part of a diagonal tile
-    const int rowbase = ti * 64 + wr * 32, colbase = tj * 64 + wc * 32;
+    const int rowbase = ti * SY_T + wr * WT, colbase = tj * SY_T + wc * WT;
     if (rowbase > m2 || colbase > m2) return;
     const int K3 = 3 * p.N;
     int k0 = 0;
-    if (ti * 64 + 63 < m2) k0 = (3 * p.lm_first[(size_t)b * p.L_max + ti * 32]) & ~3;   // Y[k][c] == 0 before the first detection
+    // Y[k][c] == 0 before the first detection of column c's landmark, and landmarks are numbered in order of first
+    // detection: this wavefront's 64 rows are all zero before pose lm_first[rowbase / 2] (unless it holds the z row)
+    if (rowbase + WT - 1 < m2) k0 = (3 * p.lm_first[(size_t)b * p.L_max + (rowbase >> 1)]) & ~3;
     const double* Yb = p.Y + (size_t)b * p.y_stride;
-    dbl4_t acc[2][2];
+    dbl4_t acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NI; ++j) acc[i][j] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
     const int kq = lane >> 4, cl = lane & 15;
-    constexpr int KU = 4;   // k-steps (of 4 rows) in flight
+    // per-lane operand columns; columns >= LD do not exist (their products land in rows / cols that are never stored)
+    int ca[NI], cb[NI];
+#pragma unroll
+    for (int h = 0; h < NI; ++h) {
+        ca[h] = rowbase + 16 * h + cl; if (ca[h] >= LD) ca[h] = LD - 1;
+        cb[h] = colbase + 16 * h + cl; if (cb[h] >= LD) cb[h] = LD - 1;
+    }
+    constexpr int KU = WT == 64 ? 2 : 4;   // k-steps (of 4 rows) in flight
+    const int Kfull = k0 + ((K3 - k0) / (4 * KU)) * (4 * KU);
+    const double* row = Yb + (size_t)(k0 + kq) * LD;
 #pragma unroll 1
-    for (int k = k0; k < K3; k += 4 * KU) {
-        double a[KU][2], bb[KU][2];
+    for (int k = k0; k < Kfull; k += 4 * KU) {
+        double a[KU][NI], bb[KU][NI];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            const int kk = k + 4 * u + kq;
-            const bool in = kk < K3;
-            const double* row = Yb + (size_t)(in ? kk : 0) * LD;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                a[u][h] = in ? row[rowbase + 16 * h + cl] : 0.0;
-                bb[u][h] = in ? row[colbase + 16 * h + cl] : 0.0;
-            }
+            for (int h = 0; h < NI; ++h) { a[u][h] = row[ca[h]]; bb[u][h] = row[cb[h]]; }
+            row += (size_t)4 * LD;
         }
 #pragma unroll
         for (int u = 0; u < KU; ++u)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
+    }
+    for (int k = Kfull; k < K3; k += 4) {   // remainder, row-guarded
+        const int kk = k + kq;
+        const bool in = kk < K3;
+        double a[NI], bb[NI];
+#pragma unroll
+        for (int h = 0; h < NI; ++h) { a[h] = in ? row[ca[h]] : 0.0; bb[h] = in ? row[cb[h]] : 0.0; }
+        row += (size_t)4 * LD;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
     }
     const double lambda = p.lambda[b];
     const double* Db = p.D + (size_t)b * p.L_max * 3;
     const double* glb = p.gl + (size_t)b * p.L_max * 2;
     double* Sb = p.S + (size_t)b * LD * LD;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int r = rowbase + 16 * i + kq + 4 * r4;   // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg
@@ -629,10 +674,12 @@ __global__ __launch_bounds__(256) void pgs_syrk_kernel(const PgsParams p) {
 
 // Dense blocked Cholesky of S (2M x 2M, lower, in place; the right-hand-side row 2M rides along as one more panel row,
 // which IS the forward substitution) followed by the blocked backward substitution; dl = S^-1 rhs.
-__global__ __launch_bounds__(TPB) void pgs_chol_kernel(const PgsParams p) {
-    constexpr int NB = 16;
+constexpr int CTPB = 1024;   // 16 wavefronts: the factorisation is a chain of short latency-bound phases
+__global__ __launch_bounds__(CTPB) void pgs_chol_kernel(const PgsParams p) {
+    constexpr int NB = 16, NBL = 4;   // panel width: fewer, fatter panel steps (each costs several HBM/L2 round trips)
     extern __shared__ double s_dyn[];
     __shared__ double s_d[NB][NB + 1];
+    __shared__ double s_diag[NB], s_rdiag[NB];
     __shared__ int s_fail;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
@@ -642,37 +689,46 @@ __global__ __launch_bounds__(TPB) void pgs_chol_kernel(const PgsParams p) {
     double* s_p = s_dyn;                 // panel [(rows below the block)][NB + 1]
     double* s_y = s_dyn;                 // backward phase: y / x [m2]
     if (tid == 0) s_fail = 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
+#define PGS_STAMP(i) do { if (p.prof && tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } while (0)
     __syncthreads();
     for (int j0 = 0; j0 < m2; j0 += NB) {
         const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
         {
-            const int r = tid >> 4, c = tid & 15;
+            const int r = tid >> NBL, c = tid & (NB - 1);
             if (r < nb && c <= r) s_d[r][c] = Sb[(size_t)(j0 + r) * LD + j0 + c];
         }
         __syncthreads();
-        if (tid < 64) {   // factor the diagonal block: lane = row
-            const int r = tid;
+        PGS_STAMP(0);
+        {   // factor the diagonal block on an NB x NB thread grid: column by column, two barriers each.  The diagonal
+            // keeps its un-rooted pivot until the end; sqrt(pivot) and its reciprocal go to s_diag / s_rdiag.
+            const int r = tid >> NBL, c2 = tid & (NB - 1);
             for (int c = 0; c < nb; ++c) {
-                double d = s_d[c][c];
-                if (!(d > 0.0)) { if (r == 0) s_fail = 1; d = 1.0; }
-                d = sqrt(d);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (r == c) s_d[c][c] = d;
-                if (r > c && r < nb) s_d[r][c] = s_d[r][c] / d;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (r > c && r < nb)
-                    for (int c2 = c + 1; c2 <= r; ++c2) s_d[r][c2] = s_d[r][c2] - s_d[r][c] * s_d[c2][c];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (tid < NB * NB && c2 == c && r >= c && r < nb) {
+                    const double d = s_d[c][c];
+                    if (r == c) {
+                        if (!(d > 0.0)) s_fail = 1;
+                        const double sd = sqrt(d > 0.0 ? d : 1.0);
+                        s_diag[c] = sd; s_rdiag[c] = 1.0 / sd;
+                    } else {
+                        s_d[r][c] = s_d[r][c] / sqrt(d > 0.0 ? d : 1.0);
+                    }
+                }
+                __syncthreads();
+                if (tid < NB * NB && r > c && c2 > c && c2 <= r && r < nb) s_d[r][c2] = s_d[r][c2] - s_d[r][c] * s_d[c2][c];
+                __syncthreads();
             }
+            if (tid < nb) s_d[tid][tid] = s_diag[tid];
         }
         __syncthreads();
         {   // write the factored block back
-            const int r = tid >> 4, c = tid & 15;
+            const int r = tid >> NBL, c = tid & (NB - 1);
             if (r < nb && c <= r) Sb[(size_t)(j0 + r) * LD + j0 + c] = s_d[r][c];
         }
+        PGS_STAMP(1);
         const int rb = j0 + nb;              // first row below the block
         const int R = m2 + 1 - rb;           // rows below, including the rhs row
-        for (int rr = tid; rr < R; rr += TPB) {   // panel: row (rb + rr) <- row * L_block^-T
+        for (int rr = tid; rr < R; rr += CTPB) {   // panel: row (rb + rr) <- row * L_block^-T
             double* row = Sb + (size_t)(rb + rr) * LD + j0;
             double x[NB];
 #pragma unroll
@@ -684,8 +740,9 @@ __global__ __launch_bounds__(TPB) void pgs_chol_kernel(const PgsParams p) {
 #pragma unroll
                     for (int k = 0; k < NB; ++k)
                         if (k < c) v -= x[k] * s_d[c][k];
-                    x[c] = v / s_d[c][c];
+                    x[c] = v * s_rdiag[c];
                 }
+                asm volatile("" ::: "memory");   // keep the LDS reads of later columns from being hoisted (register pressure)
             }
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
@@ -694,66 +751,84 @@ __global__ __launch_bounds__(TPB) void pgs_chol_kernel(const PgsParams p) {
             }
         }
         __syncthreads();
+        PGS_STAMP(2);
         // trailing update  C -= P P^T  on 16x16 tiles of the lower triangle below the block (rhs row included) with
-        // v_mfma_f64_16x16x4_f64: four k = 4 steps per tile, operands from the LDS panel, C read-modify-written in HBM/L2
+        // v_mfma_f64_16x16x4_f64: NB / 4 k-steps per tile, operands from the LDS panel, C read-modify-written in HBM/L2
         {
             const int nt = (R + 15) >> 4;
             const int ntiles = nt * (nt + 1) / 2;
             const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
-            for (int t = w; t < ntiles; t += TPB / 64) {
-                int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-                while (tr * (tr + 1) / 2 > t) --tr;
-                while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-                const int tc = t - tr * (tr + 1) / 2;
-                dbl4_t acc;
+            constexpr int NW = CTPB / 64, TG = 4;   // TG tiles per wavefront in flight (their C loads are issued together)
+            for (int t0 = w; t0 < ntiles; t0 += NW * TG) {
+                dbl4_t acc[TG];
+                int trs[TG], tcs[TG];
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int r = rb + 16 * tr + kq + 4 * r4, c = rb + 16 * tc + cl;
-                    acc[r4] = (r <= m2 && c <= r && c < m2) ? Sb[(size_t)r * LD + c] : 0.0;
+                for (int g = 0; g < TG; ++g) {
+                    const int t = t0 + g * NW;
+                    int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+                    while (tr * (tr + 1) / 2 > t) --tr;
+                    while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+                    trs[g] = tr; tcs[g] = t - tr * (tr + 1) / 2;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int r = rb + 16 * tr + kq + 4 * r4, c = rb + 16 * tcs[g] + cl;
+                        acc[g][r4] = (t < ntiles && r <= m2 && c <= r && c < m2) ? Sb[(size_t)r * LD + c] : 0.0;
+                    }
                 }
-                const double* pa = s_p + (16 * tr + cl) * (NB + 1) + kq;
-                const double* pb = s_p + (16 * tc + cl) * (NB + 1) + kq;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * q], pb[4 * q], acc, 0, 0, 0);
+                for (int g = 0; g < TG; ++g) {
+                    if (t0 + g * NW >= ntiles) continue;
+                    const double* pa = s_p + (16 * trs[g] + cl) * (NB + 1) + kq;
+                    const double* pb = s_p + (16 * tcs[g] + cl) * (NB + 1) + kq;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int r = rb + 16 * tr + kq + 4 * r4, c = rb + 16 * tc + cl;
-                    if (r <= m2 && c <= r && c < m2) Sb[(size_t)r * LD + c] = acc[r4];
+                    for (int q = 0; q < NB / 4; ++q) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * q], pb[4 * q], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int r = rb + 16 * trs[g] + kq + 4 * r4, c = rb + 16 * tcs[g] + cl;
+                        if (r <= m2 && c <= r && c < m2) Sb[(size_t)r * LD + c] = acc[g][r4];
+                    }
                 }
             }
         }
         __syncthreads();
+        PGS_STAMP(3);
     }
     if (s_fail) { if (tid == 0) p.solve_ok[b] = 0; return; }
     // backward substitution  L^T x = y  (y = row 2M of the factored matrix), blocks from the bottom
-    for (int c = tid; c < m2; c += TPB) s_y[c] = Sb[(size_t)m2 * LD + c];
+    for (int c = tid; c < m2; c += CTPB) s_y[c] = Sb[(size_t)m2 * LD + c];
     __syncthreads();
     const int nblk = (m2 + NB - 1) / NB;
     for (int bi = nblk - 1; bi >= 0; --bi) {
         const int j0 = bi * NB;
         const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
         {
-            const int r = tid >> 4, c = tid & 15;
+            const int r = tid >> NBL, c = tid & (NB - 1);
             if (r < nb && c <= r) s_d[r][c] = Sb[(size_t)(j0 + r) * LD + j0 + c];
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {   // lane k owns y[j0 + k]; x_c is broadcast from lane c
+            double yk = tid < nb ? s_y[j0 + tid] : 0.0;
             for (int c = nb - 1; c >= 0; --c) {
-                double v = s_y[j0 + c];
-                for (int k = c + 1; k < nb; ++k) v -= s_d[k][c] * s_y[j0 + k];
-                s_y[j0 + c] = v / s_d[c][c];
+                const double xc = __shfl(yk, c, 64) / s_d[c][c];
+                if (tid == c) yk = xc;
+                if (tid < c) yk -= s_d[c][tid] * xc;
             }
+            if (tid < nb) s_y[j0 + tid] = yk;
         }
         __syncthreads();
-        for (int c = tid; c < j0; c += TPB) {   // y[c] -= sum_k L[j0+k][c] x[j0+k]  (rows of L: coalesced over c)
+        for (int c = tid; c < j0; c += CTPB) {   // y[c] -= sum_k L[j0+k][c] x[j0+k]  (rows of L: coalesced over c)
             double v = s_y[c];
             for (int k = 0; k < nb; ++k) v -= Sb[(size_t)(j0 + k) * LD + c] * s_y[j0 + k];
             s_y[c] = v;
         }
         __syncthreads();
     }
+    PGS_STAMP(4);
     double* dlb = p.dl + (size_t)b * p.L_max * 2;
-    for (int c = tid; c < m2; c += TPB) dlb[c] = s_y[c];
+    for (int c = tid; c < m2; c += CTPB) dlb[c] = s_y[c];
+    if (p.prof && tid == 0)
+        for (int i = 0; i < 6; ++i) p.prof[(size_t)b * 8 + i] = tacc[i];
+#undef PGS_STAMP
 }
 
 // Pose step: H_pp dp = gp - E dl through the chain factor.  One wavefront per instance; chunks of 64 poses are
@@ -1021,18 +1096,23 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.B), dim3(TPB), 0, s, p); break;
     case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.B), dim3(64 + p.LD), 0, s, p); break;
     case 2: {
-        const int nt = p.LD / 64;
-        hipLaunchKernelGGL(pgs_syrk_kernel, dim3(8 * (nt * (nt + 1) / 2) * ((p.B + 7) / 8)), dim3(256), 0, s, p);
+        if (p.syrk_wave_tile == 64) {
+            const int nt = (p.LD + 127) / 128;
+            hipLaunchKernelGGL(pgs_syrk_kernel<64>, dim3(8 * (nt * (nt + 1) / 2) * ((p.B + 7) / 8)), dim3(256), 0, s, p);
+        } else {
+            const int nt = (p.LD + 63) / 64;
+            hipLaunchKernelGGL(pgs_syrk_kernel<32>, dim3(8 * (nt * (nt + 1) / 2) * ((p.B + 7) / 8)), dim3(256), 0, s, p);
+        }
         break;
     }
     case 3: {
-        const size_t lds = sizeof(double) * (size_t)(p.LD + 16) * 17;
+        const size_t lds = sizeof(double) * (size_t)(p.LD + 16) * 17;   // panel rows x (NB + 1)
         static bool attr_set = false;
         if (!attr_set) {   // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB)
-            hipFuncSetAttribute((const void*)pgs_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            hipFuncSetAttribute((const void*)pgs_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(pgs_chol_kernel, dim3(p.B), dim3(TPB), lds, s, p);
+        hipLaunchKernelGGL(pgs_chol_kernel, dim3(p.B), dim3(CTPB), lds, s, p);
         break;
     }
     case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.B), dim3(64), 0, s, p); break;

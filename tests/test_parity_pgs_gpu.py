@@ -127,3 +127,28 @@ def test_capacity_flags_and_errors():
     cfg = default_config(); cfg.landmark_id_is_known = 0
     with pytest.raises(S.SlamError):       # pose_graph.cpp:137
         S.BatchedPoseGraph(1, 10, 2).readParams(cfg)
+
+
+def test_shard_invariance_and_determinism():
+    """Instances are keyed by GLOBAL index (pgs_set_instance_offset): a batch of 8 == two shards of 4, bit for bit."""
+    import live_ekf_slam_amd as S
+    L, T, KP = 20, 200, 8
+    lm, cmds = make_scenario(5, L, T)
+
+    def run(B, off):
+        pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams()
+        pg.set_map(lm); pg.set_seed(3); pg.set_instance_offset(off); pg.init(0.0, 0.0, 0.0)
+        pg.run_sim(cmds); pg.solvePoseGraph()
+        out = [pg.get_graph(b, 1) for b in range(B)], pg.stats(), pg.error_stats(1)
+        pg.close()
+        return out
+
+    whole, a, b = run(8, 0), run(4, 0), run(4, 4)
+    again = run(8, 0)
+    for i in range(8):
+        part = a if i < 4 else b
+        for key in ("poses", "landmarks", "ids"):
+            assert np.array_equal(whole[0][i][key], part[0][i % 4][key])
+            assert np.array_equal(whole[0][i][key], again[0][i][key])
+    assert np.array_equal(whole[2], np.concatenate([a[2], b[2]]))
+    assert np.array_equal(whole[1]["trials"], np.concatenate([a[1]["trials"], b[1]["trials"]]))
