@@ -112,6 +112,21 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
     f.close()
 
 
+def pgs_traffic(B, L, N):
+    """HBM-side bytes per solve of the SYRK kernel from the committed PMC passes (profiles/r01i_pgs/summary.json: FETCH_SIZE
+    + WRITE_SIZE in KiB, raw: the guide's x2 applies to 16 B/lane streams only and this kernel loads 8 B/lane), if the
+    profiled workload is the one being run; else null."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01i_pgs", "summary.json")))
+        c = d["bench_line"]["config"]
+        if (c["batch_per_gpu"], c["landmarks"], c["poses"]) != (B, L, N):
+            return None
+        k = d["kernels"]["pgs_syrk_kernel"]
+        return round((k["fetch_GB_per_solve_raw"] + k["write_GB_per_solve"]) * 1e9)
+    except Exception:
+        return None
+
+
 def bench_pgs(args, torch, dist, rank, local_rank, world, dev):
     """Secondary line: pose-graph SLAM solves/s (BASELINE configs[4]: 1000 poses x 200 landmarks, batched LM).
     One "step" = solvePoseGraph() of every instance of the batch from its initial estimate (one-time mode,
@@ -172,11 +187,11 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev):
                            "parity": "tolerance 1e-7 m vs CPU oracle, identical LM iteration / trial counts (tests/test_parity_pgs_gpu.py)",
                            "kernel_ms_per_solve": {k: round(v / K, 3) for k, v in kms.items()}},
                 "roofline": {"bound": "mfma", "achieved": round(syrk_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(syrk_tf / 78.6, 4),
-                             "traffic": None, "kernel": "pgs_syrk_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms": round(kms.get("syrk", 0.0) / K, 3),
+                             "traffic": pgs_traffic(B, L, N), "kernel": "pgs_syrk_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms": round(kms.get("syrk", 0.0) / K, 3),
                              "algorithmic_flop_per_solve": flop / K}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
-            Bc = 4 if L >= 100 else 16
+            Bc = 48 if L >= 100 else 256    # about 10-20 s of single-thread work
             r = O.run_pgs_batch(lm, cmds, Bc, L, KP=args.k_per_pose, seed=2025, nthreads=1)
             line["cpu_baseline"] = {"value": round(Bc / r["seconds"], 3), "unit": "solves/s", "cores": 1, "kind": "port",
                                     "sample": f"oracle pose-graph LM (same elimination order, scalar loops), {Bc} graphs of the same workload, 1 thread, {r['seconds']:.1f} s"}
