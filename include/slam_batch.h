@@ -124,7 +124,9 @@ int slam_step_sim(slam_handle* h, const float cmd[2]);
 /* T consecutive slam_step_sim calls; cmds = [T][2] float32 host array (precomputed trajectory,
  * sim_node.py:142-152). */
 int slam_run_sim(slam_handle* h, const float* cmds, int T);
-/* UKF only: the two public halves of UKF::update (filter.h:187-188). */
+/* UKF only: the two public halves of UKF::update, predictionStage(cmd) and updateStage(meas) (filter.h:187-188,
+ * ukf.cpp:197-291).  x_t / P_t change when the update stage finishes, exactly as in the reference; the pair gives
+ * bit-identical results to slam_step_dev.  d_meas / d_meas_count are DEVICE pointers (k_stride 0 = empty message). */
 int slam_predict(slam_handle* h, const float cmd[2]);
 int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_meas_count, int k_stride);
 
@@ -134,6 +136,9 @@ int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_meas_c
  * n x n matrix ROW-MAJOR with leading dimension n (EKFState.msg:12-13 order).  Any pointer may be NULL. */
 int slam_get_state(slam_handle* h, int instance, double* x, double* P, int32_t* M, int32_t* ids,
                    int32_t* timestep);
+/* UKF only — UKFState.X (ukf.cpp:92-101, UKFState.msg): the sigma points of the last prediction stage, COLUMN-major
+ * rows x cols = n x (2n+1) with n = 4 + 2*M at the start of that step; X needs n_max*(2*n_max+1) doubles (may be NULL). */
+int slam_get_sigma_points(slam_handle* h, int instance, double* X, int32_t* rows, int32_t* cols);
 /* Vehicle pose estimate (x, y, yaw) of every instance: [batch][3] (EKFState x_v,y_v,yaw_v). */
 int slam_get_poses(slam_handle* h, double* poses);
 int slam_get_landmark_counts(slam_handle* h, int32_t* M);            /* [batch] */

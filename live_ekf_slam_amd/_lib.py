@@ -40,6 +40,7 @@ SIGNATURES = {
     "slam_predict": (C.c_int, [_H, _fp]),
     "slam_update_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),
     "slam_get_state": (C.c_int, [_H, C.c_int, _dp, _dp, _ip, _ip, _ip]),
+    "slam_get_sigma_points": (C.c_int, [_H, C.c_int, _dp, _ip, _ip]),
     "slam_get_poses": (C.c_int, [_H, _dp]),
     "slam_get_landmark_counts": (C.c_int, [_H, _ip]),
     "slam_get_truth": (C.c_int, [_H, _dp]),

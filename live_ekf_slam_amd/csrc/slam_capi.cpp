@@ -65,6 +65,8 @@ struct slam_handle {
     double* dscalar = nullptr;
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
+    double* dxprev = nullptr;                         // UKF: x_t the last sigma points were drawn around
+    bool predicted = false; float pred_cmd[2] = {0.f, 0.f};   // UKF: slam_predict done, slam_update_dev pending
     float* dmapf = nullptr;                           // UKF_LOC: the known map as float32 [id, x, y] triplets
     float* dcmds = nullptr; int cmds_cap = 0;         // command sequence of a multi-step launch (slam_run_sim)
     int run_chunk = 0;                                // timesteps per launch in slam_run_sim (0 = all of them)
@@ -99,7 +101,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
 
 void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2]) {
     memset(&p, 0, sizeof(p));
-    p.P = (const double*)h->dP; p.P_out = (double*)h->dP2; p.x = (double*)h->dx; p.sqtP = h->dsq; p.n_sq = h->dnsq;
+    p.P = (const double*)h->dP; p.P_out = (double*)h->dP2; p.x = (double*)h->dx; p.sqtP = h->dsq; p.n_sq = h->dnsq; p.x_prev = h->dxprev;
     p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
     p.truth = h->dtruth; p.err_sum = h->derr; p.map = h->dmap; p.L = h->L;
     p.fwd = cmd[0]; p.ang = cmd[1];
@@ -276,6 +278,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dsq, sizeof(double) * B * h->pstride) : hipSuccess,
         h->esz == 4 ? hipMalloc(&h->dscratch, sizeof(double) * B * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
+        kind != SLAM_EKF_SLAM ? hipMalloc(&h->dxprev, sizeof(double) * B * h->xstride) : hipSuccess,
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -295,7 +298,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -434,8 +437,69 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     return SLAM_OK;
 }
 
-int slam_predict(slam_handle*, const float*) { return fail(SLAM_ERR_UNSUPPORTED, "separate predictionStage/updateStage entry points (filter.h:187-188) are not in this build; slam_step runs both"); }
-int slam_update_dev(slam_handle*, const float*, const int32_t*, int) { return fail(SLAM_ERR_UNSUPPORTED, "separate predictionStage/updateStage entry points (filter.h:187-188) are not in this build; slam_step runs both"); }
+// UKF::predictionStage / UKF::updateStage (filter.h:187-188, ukf.cpp:197-291) as two calls.  predictionStage only
+// writes members that updateStage consumes (sqtP, X, X_pred, x_pred, P_pred); x_t / P_t change when updateStage
+// finishes (ukf.cpp:289-290).  So the split is: predict = nearestSPD + sqrt (the kernel that dominates the step) with
+// the command remembered; update = the fused sigma-point / update / insertion kernel with that command.  The pair is
+// bit-identical to slam_step_dev.
+int slam_predict(slam_handle* h, const float cmd[2]) {
+    if (!h || !cmd) return fail(SLAM_ERR_ARG, "bad argument");
+    if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "EKF has no separate prediction stage: EKF::update does both (ekf.cpp:37-179); use slam_step");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    if (h->predicted) return fail(SLAM_ERR_STATE, "slam_predict called twice without slam_update_dev");
+    HIP_TRY(hipSetDevice(h->device));
+    slam::UkfStepParams p;
+    fill_ukf_params(h, p, cmd);
+    HIP_TRY(slam::launch_ukf_sqrt(p, h->stream));
+    h->pred_cmd[0] = cmd[0]; h->pred_cmd[1] = cmd[1];
+    h->predicted = true;
+    return SLAM_OK;
+}
+int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_count, int k_stride) {
+    if (!h || k_stride < 0 || (k_stride > 0 && (!d_meas || !d_count))) return fail(SLAM_ERR_ARG, "bad argument");
+    if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "EKF has no separate update stage (ekf.cpp:37-179); use slam_step");
+    if (!h->predicted) return fail(SLAM_ERR_STATE, "slam_update_dev needs a preceding slam_predict");
+    HIP_TRY(hipSetDevice(h->device));
+    if (k_stride == 0) {   // empty message for every instance
+        int rc = ensure_meas_buffers(h, 1);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(h->dcount, 0, sizeof(int32_t) * (size_t)h->B, h->stream));
+        d_meas = h->dmeas; d_count = h->dcount; k_stride = 1;
+    }
+    slam::UkfStepParams p;
+    fill_ukf_params(h, p, h->pred_cmd);
+    p.sim = 0;
+    p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
+    HIP_TRY(slam::launch_ukf_step(p, h->stream));
+    std::swap(h->dP, h->dP2);
+    h->step += 1;
+    h->predicted = false;
+    return SLAM_OK;
+}
+
+// UKFState.X (ukf.cpp:92-101): the sigma points of the last predictionStage, column-major n x (2n+1):
+// X = [x, x + sqtP(:,i), x - sqtP(:,i)] (ukf.cpp:214-219) around the x_t that step started from.
+int slam_get_sigma_points(slam_handle* h, int inst, double* X, int32_t* rows, int32_t* cols) {
+    if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
+    if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "sigma points exist for the UKF kinds only");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, h->dnsq + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (rows) *rows = n;
+    if (cols) *cols = n > 0 ? 2 * n + 1 : 0;
+    if (!X || n <= 0) return SLAM_OK;
+    std::vector<double> x(n), S((size_t)n * n);
+    HIP_TRY(hipMemcpy(x.data(), h->dxprev + (size_t)inst * h->xstride, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(S.data(), h->dsq + (size_t)inst * h->pstride, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+    for (int r = 0; r < n; ++r) X[r] = x[r];
+    for (int i = 0; i < n; ++i)
+        for (int r = 0; r < n; ++r) {
+            X[(size_t)(1 + i) * n + r] = x[r] + S[(size_t)r * n + i];
+            X[(size_t)(1 + n + i) * n + r] = x[r] - S[(size_t)r * n + i];
+        }
+    return SLAM_OK;
+}
 
 // device -> host copy of `count` stored elements, widened to double when the storage type is fp32
 static int fetch_elems(slam_handle* h, double* dst, const void* dbase, size_t elem_offset, size_t count) {

@@ -16,6 +16,7 @@ struct UkfStepParams {
     double* x;          // [B][xstride]  x_t = [x, y, cos, sin, landmarks...]
     double* sqtP;       // [B][pstride]  scratch: matrix square root, n x n row-major (symmetric)
     int32_t* n_sq;      // [B]           dimension of the matrix currently held in sqtP
+    double* x_prev;     // [B][xstride]  x_t the sigma points were drawn around (UKFState.X = [x, x + sqtP cols, x - sqtP cols])
     int32_t* M;         // [B]
     int32_t* ids;       // [B][L_max]
     int32_t* flags;     // [B]

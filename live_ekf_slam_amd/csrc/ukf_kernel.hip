@@ -260,7 +260,11 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     const double* __restrict__ Sq = p.sqtP + (size_t)b * p.pstride;
 
     // prologue loads
-    for (int i = tid; i < LDN; i += TPB) { const double v = i < n ? xb[i] : 0.0; s_xt[i] = v; }
+    for (int i = tid; i < LDN; i += TPB) {
+        const double v = i < n ? xb[i] : 0.0;
+        s_xt[i] = v;
+        if (i < n && p.x_prev) p.x_prev[(size_t)b * p.xstride + i] = v;   // centre of this step's sigma points (ukf.cpp:214)
+    }
     for (int i = tid; i < M_old; i += TPB) s_ids[i] = p.ids[(size_t)b * p.L_max + i];
     if (tid < 8) s_misc[tid] = 0;
     double tx = 0.0, ty = 0.0, tth = 0.0, lmx = 0.0, lmy = 0.0;

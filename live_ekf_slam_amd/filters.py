@@ -242,7 +242,26 @@ class BatchedUKF(BatchedFilter):
         x = self.get_state(instance)["x"]
         return np.concatenate([[x[0], x[1], np.remainder(np.arctan2(x[3], x[2]) + np.pi, 2 * np.pi) - np.pi], x[4:]])
 
-    # -- UKF::publishState payload (ukf.cpp:60-104, UKFState.msg) without the sigma-point dump X --
+    # -- UKF::predictionStage / UKF::updateStage (filter.h:187-188, ukf.cpp:197-291) --
+    def predictionStage(self, cmdMsg):
+        self._need()
+        _lib.check(_lib.lib().slam_predict(self.h, _f(self._cmd(cmdMsg))))
+
+    def updateStage(self, d_meas_ptr=None, d_count_ptr=None, k_stride=0):
+        """Measurements as DEVICE pointers ([B][k_stride][3] float32, [B] int32); none = empty message."""
+        self._need()
+        _lib.check(_lib.lib().slam_update_dev(self.h, C.c_void_p(d_meas_ptr), C.c_void_p(d_count_ptr), int(k_stride)))
+        self.timestep += 1
+
+    def sigma_points(self, instance=0):
+        """X of the last prediction stage, shape (n, 2n+1) (ukf.cpp:214-219)."""
+        self._need()
+        r = C.c_int32(0); c = C.c_int32(0)
+        X = np.zeros(self.n_max * (2 * self.n_max + 1))
+        _lib.check(_lib.lib().slam_get_sigma_points(self.h, int(instance), _d(X), C.byref(r), C.byref(c)))
+        return X[:r.value * c.value].reshape(c.value, r.value).T.copy()
+
+    # -- UKF::publishState payload (ukf.cpp:60-104, UKFState.msg); X column by column as the reference pushes it --
     def publishState(self, instance=0):
         import math
         s = self.get_state(instance)
@@ -251,7 +270,8 @@ class BatchedUKF(BatchedFilter):
         lm[0::3] = s["ids"]; lm[1::3] = x[4::2]; lm[2::3] = x[5::2]
         yaw = math.remainder(math.atan2(x[3], x[2]), 2 * 3.14159265358979323846)
         return dict(timestep=s["timestep"], x_v=np.float32(x[0]), y_v=np.float32(x[1]), yaw_v=np.float32(yaw),
-                    M=M, landmarks=lm, P=s["P"].astype(np.float32).ravel())
+                    M=M, landmarks=lm, P=s["P"].astype(np.float32).ravel(),
+                    X=self.sigma_points(instance).T.astype(np.float32).ravel())
 
 
 class BatchedUKFLoc(BatchedUKF):

@@ -112,3 +112,58 @@ def test_ukf_loc_mode(S, oracle):
     for b in range(32):
         _eq(f.get_state(b), dict(M=0, ids=r["ids"][b, :0], x=r["x"][b, :4], P=r["P"][b, :16].reshape(4, 4)))
     f.close()
+
+
+def test_prediction_and_update_stage_split_equals_fused_update(S):
+    """UKF::predictionStage + UKF::updateStage (filter.h:187-188) as two calls == UKF::update, bit for bit; the state
+    is untouched between the two calls (ukf.cpp:289-290), and UKFState.X holds the sigma points of that step."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")   # the runtime libslam_hip.so itself links (device buffers without torch)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    g = load_golden("sim_seed0_L20_T1000.npz")
+    B, L, T = 4, 20, 120
+    d_meas, d_cnt = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_meas), B * 8 * 3 * 4) == 0 and hip.hipMalloc(C.byref(d_cnt), B * 4) == 0
+    a = S.BatchedUKF(B, L).readParams(); a.init(0.0, 0.0, 0.0)
+    b = S.BatchedUKF(B, L).readParams(); b.init(0.0, 0.0, 0.0)
+    for t in range(T):
+        k = int(g["meas_count"][t])
+        cmd = S.Command(g["cmds"][t, 0], g["cmds"][t, 1])
+        a.update(cmd, g["meas"][t, :k].ravel())
+        before = b.get_state(1)
+        b.predictionStage(cmd)
+        mid = b.get_state(1)
+        assert np.array_equal(mid["x"], before["x"]) and np.array_equal(mid["P"], before["P"])
+        ks = 8
+        meas = np.zeros((B, ks, 3), dtype=np.float32)
+        meas[:, :k] = g["meas"][t, :k]
+        cnt = np.full(B, k, dtype=np.int32)
+        assert hip.hipMemcpy(d_meas, meas.ctypes.data_as(C.c_void_p), meas.nbytes, 1) == 0   # hipMemcpyHostToDevice
+        assert hip.hipMemcpy(d_cnt, cnt.ctypes.data_as(C.c_void_p), cnt.nbytes, 1) == 0
+        b.updateStage(d_meas.value, d_cnt.value, ks)
+        b.sync()
+        if t % 20 == 19 or t < 3:
+            for i in (0, B - 1):
+                _eq(b.get_state(i), a.get_state(i))
+            # sigma points of this step: X = [x, x + sqtP cols, x - sqtP cols] around the pre-step state, and
+            # sqtP^2 == nearestSPD scaling of the pre-step covariance (ukf.cpp:106-123,208,214-219)
+            X = b.sigma_points(1)
+            n = len(before["x"])
+            assert X.shape == (n, 2 * n + 1) and np.array_equal(X[:, 0], before["x"])
+            Sq = X[:, 1:n + 1] - X[:, [0]]
+            assert np.allclose(X[:, n + 1:] - X[:, [0]], -Sq, rtol=0, atol=1e-15)
+            scale = float(np.float32(2 * before["M"] + 4) / (np.float32(1) - np.float32(0.2)))
+            A = 0.5 * (before["P"] + before["P"].T) * scale
+            w, V = np.linalg.eigh(A)                       # nearestSPD clamps the spectrum at 1e-8 (ukf.cpp:119)
+            S_ref = (V * np.sqrt(np.maximum(w, 1e-8))) @ V.T
+            assert np.abs(Sq - S_ref).max() < 1e-9 * max(1.0, np.abs(S_ref).max())
+    pub = b.publishState(0)
+    n_prev = b.sigma_points(0).shape[0]
+    assert pub["X"].dtype == np.float32 and pub["X"].size == n_prev * (2 * n_prev + 1)
+    with pytest.raises(S.SlamError):
+        b.updateStage()                       # no prediction pending
+    e = S.BatchedEKF(2, 5).readParams(); e.init(0, 0, 0)
+    with pytest.raises(S.SlamError):
+        S._lib.check(S._lib.lib().slam_predict(e.h, (C.c_float * 2)(0.1, 0.0)))   # the EKF has no separate stages
+    a.close(); b.close(); e.close()
