@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void pgs_run_sim_kernel(const PgsParams p, int 
 // ------------------------------------------------------------------------------------------------------------
 // LM: begin / linearize / chain / syrk / chol / backsolve / evaluate / end
 // ------------------------------------------------------------------------------------------------------------
-constexpr int TPB = 256;
+constexpr int TPB = 512;   // threads of the per-pose kernels (two poses per thread at 1000 poses)
 
 __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     for (int i = tid; i < 3 * N; i += TPB) pw[i] = p0[i];
     for (int i = tid; i < 2 * M; i += TPB) lw[i] = l0[i];
     {   // factors regrouped by landmark in chronological order: event e of landmark j sits at evt_start[j] + e
-        __shared__ int s_cnt[256];
+        __shared__ int s_cnt[TPB];   // L_max <= 255 < TPB
         const int32_t* head = p.lm_head + (size_t)b * p.L_max;
         const int32_t* mnext = p.mnext + (size_t)b * p.N_max * p.KP;
         int32_t* evt_start = p.evt_start + (size_t)b * (p.L_max + 1);

@@ -34,7 +34,8 @@ def _compare(pg, r, B, check_init=True):
         assert np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max() < POSE_TOL
 
 
-@pytest.mark.parametrize("L,T,B,KP", [(20, 300, 16, 8), (20, 999, 4, 8), (100, 250, 6, 24)])
+@pytest.mark.parametrize("L,T,B,KP", [(20, 300, 16, 8), (20, 999, 4, 8), (100, 250, 6, 24),
+                                      (200, 999, 3, 32)])   # last: BASELINE configs[4] size, 1000 poses x 200 landmarks
 def test_sim_build_and_solve_match_oracle(oracle, L, T, B, KP):
     import live_ekf_slam_amd as S
     lm, cmds = make_scenario(321 + L, L, T)
