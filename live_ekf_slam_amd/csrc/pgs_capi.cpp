@@ -3,6 +3,7 @@
 #include "../../include/slam_pgs.h"
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -33,6 +34,7 @@ struct pgs_handle {
     float* dmeas = nullptr; int32_t* dcount = nullptr; double* dsec = nullptr; int k_stride = 0;
     double* dout = nullptr;
     int max_trials = 400;
+    bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
     int syrk_tile = 0, syrk_switch = 512;    // SLAM_PGS_SYRK_TILE = 32 | 64 forces a variant; SLAM_PGS_SYRK_SWITCH = active count
     int last_trials = 0;
     bool profiling = false;                  // per-kernel hipEvent timing of pgs_solve (pgs_set_profiling)
@@ -92,6 +94,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_MAX_TRIALS")) h->max_trials = atoi(e) > 0 ? atoi(e) : h->max_trials;
     if (const char* e = getenv("SLAM_PGS_SYRK_TILE")) h->syrk_tile = atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0);
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
+    h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
@@ -249,6 +252,7 @@ int pgs_solve(pgs_handle* h) {
         active = 0;
         HIP_TRY(hipMemcpyAsync(&active, h->p.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->trace) fprintf(stderr, "pgs trial %d: active %d\n", trials, (int)active);
         if (active == 0) { trials += 1; break; }
     }
     h->last_trials = trials;
