@@ -153,3 +153,31 @@ def test_shard_invariance_and_determinism():
             assert np.array_equal(whole[0][i][key], again[0][i][key])
     assert np.array_equal(whole[2], np.concatenate([a[2], b[2]]))
     assert np.array_equal(whole[1]["trials"], np.concatenate([a[1]["trials"], b[1]["trials"]]))
+
+
+def test_degenerate_graphs(oracle):
+    """Prior only (one pose), odometry only (no landmark ever seen), and a single landmark: same answers as the oracle."""
+    import live_ekf_slam_amd as S
+    cfg = default_config()
+    for T, meas_at in ((0, {}), (5, {}), (6, {2: [[4, 2.0, 0.3]], 4: [[4, 1.9, 0.25]]})):
+        pg = S.BatchedPoseGraph(2, num_iterations=T + 2, L_max=3, k_per_pose=2).readParams(cfg)
+        g = oracle.OraclePoseGraph(cfg, N_max=T + 2, L_max=3, KP=2)
+        naive = S.NaiveFilter()
+        pg.init(0.5, -0.25, 0.1); g.init(0.5, -0.25, 0.1); naive.init(0.5, -0.25, 0.1)
+        for t in range(T):
+            cmd = [0.1, 0.02 * (t % 3 - 1)]
+            naive.update(cmd)
+            sv = naive.getStateVector() + np.array([0.01 * t, -0.005 * t, 0.002 * t])   # a drifting secondary estimate
+            pg.updateNaiveVehPoseEstimate(sv); g.updateNaiveVehPoseEstimate(sv)
+            m = np.asarray(meas_at.get(t, []), dtype=np.float32).reshape(-1, 3)
+            pg.update(cmd, m); g.update(cmd[0], cmd[1], m)
+        pg.solvePoseGraph(); so = g.solve()
+        st = pg.stats()
+        assert st["flags"].tolist() == [so["flags"]] * 2 and st["iterations"].tolist() == [so["iterations"]] * 2
+        v = g.values(1)
+        for b in range(2):
+            gg = pg.get_graph(b, 1)
+            assert gg["M"] == v["M"] and np.abs(gg["poses"] - v["poses"]).max() < 1e-9
+            if v["M"]:
+                assert np.abs(gg["landmarks"] - v["landmarks"]).max() < 1e-9
+        pg.close()
