@@ -57,15 +57,17 @@ def cpu_baseline(lm, cmds, vis, L, seconds_budget=20.0):
 
 
 def ukf_flops_per_step(n, sweeps, k):
-    """Algorithmic fp64 FLOPs of one UKF step at state size n: parallel-order Jacobi
-    (pair-blocks 24, V row-pairs 6 flops), sqtP = V sqrt(D) V^T (lower triangle), weighted covariance, k updates."""
+    """Algorithmic fp64 FLOPs of one UKF step at state size n: warm-start transform V0^T (A V0) (lower
+    triangle of the second product), `sweeps` parallel-order Jacobi sweeps that rotate (pair-blocks 24, V row-pairs 6
+    flops), sqtP = V sqrt(D) V^T (lower triangle), weighted covariance, k updates."""
     m = n // 2
     per_round = 24 * (m * (m - 1) // 2) + 4 * m + 6 * m * n
     jacobi = sweeps * (n - 1) * per_round
+    warm = 2 * n ** 3 + n ** 3
     sqt = 3 * n * (n * (n + 1) // 2)
     cov = (2 * n + 1) * (3 * n * n + 2 * n)
     upd = k * ((2 * n + 1) * (6 * n + 20) + 6 * n * n)
-    return jacobi + sqt + cov + upd
+    return warm + jacobi + sqt + cov + upd
 
 
 def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
@@ -91,7 +93,7 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
     M = f.landmark_counts(); n = 4 + 2 * int(round(M.mean()))
-    flops = ukf_flops_per_step(n, 9, 1.24 if L <= 20 else 1.7) * B
+    flops = ukf_flops_per_step(n, 4, 1.24 if L <= 20 else 1.7) * B   # 4 rotating sweeps with the warm start (oracle: 5 incl. the zero-only one)
     step_ms = ev0.elapsed_time(ev1) / K
     line = {"metric": "UKF predict-update steps/sec (secondary; BASELINE configs[2] shape)", "value": round(B * K / wall, 1),
             "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 4),
@@ -101,7 +103,7 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
                        "parity": "bit-exact vs CPU oracle (tests/test_parity_ukf_gpu.py)"},
             "roofline": {"bound": "fp64-valu", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
                          "frac": round(flops / (step_ms * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
-                         "note": "algorithmic FLOPs (9 Jacobi sweeps) / step time of both kernels; latency- and LDS-bound, see DESIGN.md"}}
+                         "note": "algorithmic FLOPs (warm-started Jacobi: transform + 4 rotating sweeps) / step time of both kernels; LDS-bandwidth-bound, see DESIGN.md"}}
     if not args.no_cpu_baseline:
         from oracle import oracle as O
         vis = np.tile([3.0, -1.57, 1.57], (60, 1)); vis[0] = [1e9, -4.0, 4.0]

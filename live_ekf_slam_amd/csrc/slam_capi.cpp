@@ -66,6 +66,7 @@ struct slam_handle {
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
     double* dxprev = nullptr;                         // UKF: x_t the last sigma points were drawn around
+    double* dvt = nullptr; int32_t* dvage = nullptr;  // UKF: V^T of the last eigen-decomposition + warm-start age
     bool predicted = false; float pred_cmd[2] = {0.f, 0.f};   // UKF: slam_predict done, slam_update_dev pending
     float* dmapf = nullptr;                           // UKF_LOC: the known map as float32 [id, x, y] triplets
     float* dcmds = nullptr; int cmds_cap = 0;         // command sequence of a multi-step launch (slam_run_sim)
@@ -101,7 +102,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
 
 void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2]) {
     memset(&p, 0, sizeof(p));
-    p.P = (const double*)h->dP; p.P_out = (double*)h->dP2; p.x = (double*)h->dx; p.sqtP = h->dsq; p.n_sq = h->dnsq; p.x_prev = h->dxprev;
+    p.P = (const double*)h->dP; p.P_out = (double*)h->dP2; p.x = (double*)h->dx; p.sqtP = h->dsq; p.n_sq = h->dnsq; p.x_prev = h->dxprev; p.Vt_store = h->dvt; p.v_age = h->dvage;
     p.M = h->dM; p.ids = h->dids; p.flags = h->dflags; p.timestep = h->dts;
     p.truth = h->dtruth; p.err_sum = h->derr; p.map = h->dmap; p.L = h->L;
     p.fwd = cmd[0]; p.ang = cmd[1];
@@ -279,6 +280,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         h->esz == 4 ? hipMalloc(&h->dscratch, sizeof(double) * B * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dxprev, sizeof(double) * B * h->xstride) : hipSuccess,
+        kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvt, sizeof(double) * B * h->pstride) : hipSuccess,
+        kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvage, sizeof(int32_t) * B) : hipSuccess,
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -298,7 +301,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -335,7 +338,7 @@ int slam_init(slam_handle* h, float x0, float y0, float yaw0) {
         HIP_TRY(slam::launch_ekf_init(p, h->stream));
     } else {
         slam::UkfInitParams p;
-        p.P = (double*)h->dP; p.x = (double*)h->dx; p.n_sq = h->dnsq; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
+        p.P = (double*)h->dP; p.x = (double*)h->dx; p.n_sq = h->dnsq; p.v_age = h->dvage; p.M = h->dM; p.flags = h->dflags; p.timestep = h->dts; p.truth = h->dtruth; p.err_sum = h->derr;
         p.B = h->B; p.pstride = h->pstride; p.xstride = h->xstride;
         double s, c;   // x_t << x_0, y_0, cos(yaw_0), sin(yaw_0) with a float argument (ukf.cpp:33)
         slam::det_sincos((double)yaw0, &s, &c);

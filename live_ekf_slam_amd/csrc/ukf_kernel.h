@@ -16,6 +16,8 @@ struct UkfStepParams {
     double* x;          // [B][xstride]  x_t = [x, y, cos, sin, landmarks...]
     double* sqtP;       // [B][pstride]  scratch: matrix square root, n x n row-major (symmetric)
     int32_t* n_sq;      // [B]           dimension of the matrix currently held in sqtP
+    double* Vt_store;   // [B][pstride]  V^T of the last eigen-decomposition (n_sq x n_sq, row p = eigenvector p): warm start
+    int32_t* v_age;     // [B]           consecutive warm starts so far, -1 = no usable V
     double* x_prev;     // [B][xstride]  x_t the sigma points were drawn around (UKFState.X = [x, x + sqtP cols, x - sqtP cols])
     int32_t* M;         // [B]
     int32_t* ids;       // [B][L_max]
@@ -51,7 +53,7 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream);
 hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream);
 
 struct UkfInitParams {
-    double* P; double* x; int32_t* n_sq; int32_t* M; int32_t* flags; int32_t* timestep; double* truth; double* err_sum;
+    double* P; double* x; int32_t* n_sq; int32_t* v_age; int32_t* M; int32_t* flags; int32_t* timestep; double* truth; double* err_sum;
     int32_t B, pstride, xstride;
     double x0, y0, c0, s0;   // x_t = (x_0, y_0, cos(yaw_0), sin(yaw_0)) as the reference stores them (ukf.cpp:33)
     double tx, ty, tyaw;

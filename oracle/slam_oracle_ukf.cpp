@@ -29,13 +29,20 @@ using namespace orc;
 // A: n x n row-major, exactly symmetric on entry and kept so (only pair-blocks i >= j are computed, then mirrored).
 // V: n x n, columns = eigenvectors.  n is even (n = 4 + 2M).  Returns the number of sweeps, or -1 if not converged.
 // All rotations of a round read the matrix as it was at the start of the round (disjoint index pairs).
-int jacobi_round_robin(double* A, double* V, int n, int max_sweeps) {
+// warm = false: V starts as the identity and the small-element rule applies from the fourth sweep on (classical).
+// warm = true : the caller passes A = V0^T A0 V0 (nearly diagonal) and V = V0, the eigenvectors of the previous
+//               timestep; the small-element rule applies from the first sweep (the off-diagonal part is a small
+//               perturbation from the start), and a few sweeps instead of 8-10 reach convergence.
+constexpr int kUkfWarmMaxAge = 100;   // consecutive warm starts before a cold one (bounds the loss of orthogonality in V)
+int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = false) {
     const int m = n / 2;
     std::vector<int> pp(m), qq(m);
     std::vector<double> cs(m), sn(m), tn(m);
     std::vector<int> zr(m);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+    const int tiny_from = warm ? 0 : 3;
+    if (!warm)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         // convergence: every off-diagonal element is exactly zero (the small-element rule below makes that reachable)
         double off = 0.0;
@@ -53,7 +60,7 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps) {
                 // small-element rule (classical Jacobi): after three sweeps an off-diagonal element that cannot change
                 // either diagonal neighbour in fp64 is set to zero instead of being rotated away
                 const double g = 100.0 * fabs(apq);
-                const bool tiny = sweep >= 3 && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq));
+                const bool tiny = sweep >= tiny_from && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq));
                 zr[k] = tiny ? 1 : 0;
                 if (apq != 0.0 && !tiny) {
                     const double tau = (aqq - app) / (2.0 * apq);
@@ -112,6 +119,8 @@ struct Ukf {
     std::vector<int> ids;
     int n_sq = 0;          // dimension sqtP currently has
     int last_sweeps = 0;
+    std::vector<double> Vprev;   // eigenvectors of the previous nearestSPD matrix (n_sq x n_sq), warm start of the next
+    int v_age = -1;              // consecutive warm starts so far; -1 = no usable Vprev
     bool loc = false;      // FilterChoice::UKF_LOC: localisation only, landmarks come from the known map (ukf.cpp:146-154)
     std::vector<float> mapf;   // `filter->map`: [id, x, y] float32 triplets (localization_node.cpp:152-156)
 
@@ -134,6 +143,7 @@ struct Ukf {
         P_t[0] = 0.01 * 0.01; P_t[5] = 0.01 * 0.01; P_t[10] = 0.005 * 0.005; P_t[15] = 0.005 * 0.005;
         P_pred = P_t;
         sqtP.clear(); n_sq = 0;
+        Vprev.clear(); v_age = -1;
     }
     template <class MP> void init_t(float x0, float y0, float yaw0) {  // ukf.cpp:31-45
         reset_ctor();
@@ -156,8 +166,30 @@ struct Ukf {
         const double scale = (double)scale_f;
         for (int r = 0; r < nn; ++r)
             for (int c = 0; c < nn; ++c) Y[(size_t)r * nn + c] = (0.5 * (P_t[(size_t)r * nn + c] + P_t[(size_t)c * nn + r])) * scale;
-        const int sweeps = jacobi_round_robin(Y.data(), V.data(), nn, 60);
+        // Warm start (an implementation choice of this build, not of the reference: Eigen's solver has no such notion;
+        // the mathematical result Qv sqrt(D+) Qv^T is the same): rotate into the previous step's eigenbasis, extended by
+        // the identity for landmarks inserted since.  T = Y V0, B = V0^T T, sums in ascending k.
+        const bool warm = v_age >= 0 && v_age < kUkfWarmMaxAge && n_sq > 0 && n_sq <= nn;
+        if (warm) {
+            for (int r = 0; r < nn; ++r)
+                for (int c = 0; c < nn; ++c) V[(size_t)r * nn + c] = (r < n_sq && c < n_sq) ? Vprev[(size_t)r * n_sq + c] : (r == c ? 1.0 : 0.0);
+            std::vector<double> T((size_t)nn * nn);
+            for (int r = 0; r < nn; ++r)
+                for (int c = 0; c < nn; ++c) {
+                    double acc = 0.0;
+                    for (int k = 0; k < nn; ++k) acc = acc + Y[(size_t)r * nn + k] * V[(size_t)k * nn + c];
+                    T[(size_t)r * nn + c] = acc;
+                }
+            for (int r = 0; r < nn; ++r)
+                for (int c = 0; c <= r; ++c) {
+                    double acc = 0.0;
+                    for (int k = 0; k < nn; ++k) acc = acc + V[(size_t)k * nn + r] * T[(size_t)k * nn + c];
+                    Y[(size_t)r * nn + c] = acc; Y[(size_t)c * nn + r] = acc;
+                }
+        }
+        const int sweeps = jacobi_round_robin(Y.data(), V.data(), nn, 60, warm);
         last_sweeps = sweeps;
+        if (sweeps >= 0) { Vprev = V; v_age = warm ? v_age + 1 : 0; } else { v_age = -1; }
         if (sweeps < 0) {
             // ukf.cpp:209-211: the exception is swallowed and the stale sqtP is reused.  A stale matrix of the wrong
             // size cannot be used: keep the instance running with a zero spread and flag it.
