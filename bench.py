@@ -81,21 +81,31 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
     stream = torch.cuda.Stream(device=dev)
     f.set_stream(stream.cuda_stream)
     f.set_map(lm); f.set_seed(2025); f.set_instance_offset(rank * B); f.init(0.0, 0.0, 0.0)
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
     with torch.cuda.stream(stream):
         f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
         f.run_sim(cmds[1:1 + PRE + W])
-        torch.cuda.synchronize(dev)
+        sync_all()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
         f.run_sim(cmds[1 + PRE + W:])
         ev1.record(stream)
-        torch.cuda.synchronize(dev)
+        sync_all()
         wall = time.perf_counter() - t0
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
     M = f.landmark_counts(); n = 4 + 2 * int(round(M.mean()))
     flops = ukf_flops_per_step(n, 4, 1.24 if L <= 20 else 1.7) * B   # 4 rotating sweeps with the warm start (oracle: 5 incl. the zero-only one)
     step_ms = ev0.elapsed_time(ev1) / K
-    line = {"metric": "UKF predict-update steps/sec (secondary; BASELINE configs[2] shape)", "value": round(B * K / wall, 1),
+    line = {"metric": "UKF predict-update steps/sec (secondary; BASELINE configs[2] shape)", "value": round(B * world * K / wall, 1),
             "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"UKF-SLAM fused sim+update step, L={L} (n={n}, {2 * n + 1} sigma points), batch={B}, steady state",
@@ -104,14 +114,20 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
             "roofline": {"bound": "fp64-valu", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
                          "frac": round(flops / (step_ms * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
                          "note": "algorithmic FLOPs (warm-started Jacobi: transform + 4 rotating sweeps) / step time of both kernels; LDS-bandwidth-bound, see DESIGN.md"}}
-    if not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        vis = np.tile([3.0, -1.57, 1.57], (60, 1)); vis[0] = [1e9, -4.0, 4.0]
-        r1 = O.run_ukf_batch(lm, cmds[:60], 8 if L <= 20 else 1, L, nthreads=1, want_P=False, vision=vis)
-        line["cpu_baseline"] = {"value": round((8 if L <= 20 else 1) * 60 / r1["seconds"], 1), "unit": "steps/s", "cores": 1, "kind": "port",
-                                "sample": f"oracle UKF, {(8 if L <= 20 else 1)} instances x 60 steps, 1 thread, {r1['seconds']:.1f} s"}
-    print(json.dumps(line), flush=True)
+        Tc = min(T, 131)
+        Bc = 192 if L <= 20 else 16     # about 10 s of single-thread work
+        vis = np.tile([3.0, -1.57, 1.57], (Tc, 1)); vis[0] = [1e9, -4.0, 4.0]
+        r1 = O.run_ukf_batch(lm, cmds[:Tc], Bc, L, nthreads=1, want_P=False, vision=vis)
+        line["cpu_baseline"] = {"value": round(Bc * Tc / r1["seconds"], 1), "unit": "steps/s", "cores": 1, "kind": "port",
+                                "sample": f"oracle UKF (same warm-started Jacobi), {Bc} instances x {Tc} steps of the same scenario, 1 thread, {r1['seconds']:.1f} s"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     f.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def pgs_traffic(B, L, N):
