@@ -34,8 +34,10 @@ struct pgs_handle {
     float* dmeas = nullptr; int32_t* dcount = nullptr; double* dsec = nullptr; int k_stride = 0;
     double* dout = nullptr;
     int max_trials = 400;
+    bool p_notrim = false;
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
-    int syrk_tile = 0, syrk_switch = 512;    // SLAM_PGS_SYRK_TILE = 32 | 64 forces a variant; SLAM_PGS_SYRK_SWITCH = active count
+    int syrk_tile = 0, syrk_switch = 1 << 30;    // SLAM_PGS_SYRK_TILE = 32 | 64 forces a variant; SLAM_PGS_SYRK_SWITCH = active count from which
+                                             // the 64x64-per-wavefront variant is used (default: never — measured slower at every batch size)
     int last_trials = 0;
     bool profiling = false;                  // per-kernel hipEvent timing of pgs_solve (pgs_set_profiling)
     std::vector<hipEvent_t> events;
@@ -95,6 +97,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_SYRK_TILE")) h->syrk_tile = atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0);
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
     h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
+    h->p_notrim = getenv("SLAM_PGS_NOTRIM") != nullptr;
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
@@ -237,7 +240,8 @@ int pgs_solve(pgs_handle* h) {
     int trials = 0;
     int32_t active = h->B;
     for (; trials < h->max_trials; ++trials) {
-        // bulk trials: 64x64 wavefront tiles (operand reuse); straggler trials: 32x32 (4x the wavefronts per instance)
+        // 32x32 wavefront tiles by default; the 64x64 variant (more operand reuse, 4x fewer wavefronts) is kept for tuning
+        h->p.syrk_notrim = h->p_notrim ? 1 : 0;
         h->p.syrk_wave_tile = h->syrk_tile ? h->syrk_tile : (active >= h->syrk_switch ? 64 : 32);
         HIP_TRY(hipMemsetAsync(h->p.n_active, 0, sizeof(int32_t), h->stream));
         for (int k = 0; k < slam::kPgsTrialKernels; ++k) {

@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
     int k0 = 0;
     // Y[k][c] == 0 before the first detection of column c's landmark, and landmarks are numbered in order of first
     // detection: this wavefront's 64 rows are all zero before pose lm_first[rowbase / 2] (unless it holds the z row)
-    if (rowbase + WT - 1 < m2) k0 = (3 * p.lm_first[(size_t)b * p.L_max + (rowbase >> 1)]) & ~3;
+    if (rowbase + WT - 1 < m2 && !p.syrk_notrim) k0 = (3 * p.lm_first[(size_t)b * p.L_max + (rowbase >> 1)]) & ~3;
     const double* Yb = p.Y + (size_t)b * p.y_stride;
     dbl4_t acc[NI][NI];
 #pragma unroll
