@@ -181,3 +181,40 @@ def test_degenerate_graphs(oracle):
             if v["M"]:
                 assert np.abs(gg["landmarks"] - v["landmarks"]).max() < 1e-9
         pg.close()
+
+
+def test_update_dev_equals_update():
+    """pgs_update_dev (device buffers, e.g. another engine's measurement dump) == pgs_update (host buffers)."""
+    import ctypes as C
+    import live_ekf_slam_amd as S
+    from live_ekf_slam_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    B, T, L, KP = 3, 25, 6, 4
+    rng = np.random.default_rng(4)
+    a = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(); a.init(0.0, 0.0, 0.0)
+    b = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(); b.init(0.0, 0.0, 0.0)
+    d_meas, d_cnt, d_sec = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_meas), B * KP * 3 * 4) == 0 and hip.hipMalloc(C.byref(d_cnt), B * 4) == 0 and hip.hipMalloc(C.byref(d_sec), B * 3 * 8) == 0
+    pose = np.zeros((B, 3))
+    for t in range(T):
+        cmd = np.array([0.1, 0.03 * np.sin(0.3 * t)], dtype=np.float32)
+        pose = pose + np.array([0.1 * np.cos(pose[:, 2]), 0.1 * np.sin(pose[:, 2]), np.full(B, float(cmd[1]))]).T + rng.normal(0, 1e-3, (B, 3))
+        cnt = rng.integers(0, KP + 1, B).astype(np.int32)
+        meas = np.zeros((B, KP, 3), dtype=np.float32)
+        meas[:, :, 0] = rng.integers(0, L, (B, KP)); meas[:, :, 1] = rng.uniform(1, 3, (B, KP)); meas[:, :, 2] = rng.uniform(-1, 1, (B, KP))
+        a.updateNaiveVehPoseEstimate(pose); a.update(cmd, meas, cnt)
+        sec = np.ascontiguousarray(pose)
+        for dst, src in ((d_meas, meas), (d_cnt, cnt), (d_sec, sec)):
+            assert hip.hipMemcpy(dst, src.ctypes.data_as(C.c_void_p), src.nbytes, 1) == 0
+        _lib.check(_lib.lib().pgs_update_dev(b.h, cmd.ctypes.data_as(C.POINTER(C.c_float)), d_meas, d_cnt, KP, d_sec))
+        b.timestep += 1
+    a.solvePoseGraph(); b.solvePoseGraph()
+    for i in range(B):
+        for which in (0, 1):
+            ga, gb = a.get_graph(i, which), b.get_graph(i, which)
+            assert ga["M"] == gb["M"] and np.array_equal(ga["ids"], gb["ids"])
+            assert np.array_equal(ga["poses"], gb["poses"]) and np.array_equal(ga["landmarks"], gb["landmarks"])
+        assert np.array_equal(a.connections(i), b.connections(i))
+    a.close(); b.close()
