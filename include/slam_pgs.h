@@ -66,6 +66,10 @@ int pgs_run_sim(pgs_handle* h, const float* cmds, int T);
 
 /* PoseGraph::solvePoseGraph (pose_graph.cpp:269-300) for every instance: LM from initial_estimate to `result`. */
 int pgs_solve(pgs_handle* h);
+/* The solve splits the batch into `groups` contiguous ranges that run their LM loops on separate HIP streams (the
+ * latency-bound phases of one group overlap the bandwidth-bound phases of another); results do not depend on it.
+ * 0 = automatic (2 from 512 instances, else 1; 4 groups measured best in a process without other HIP streams). */
+int pgs_set_groups(pgs_handle* h, int groups);
 /* `this->initial_estimate = this->result` (pose_graph.cpp:263, solve_graph_every_iteration). */
 int pgs_adopt_result(pgs_handle* h);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "pgs_update_dev": (C.c_int, [_H, _fp, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pgs_run_sim": (C.c_int, [_H, _fp, C.c_int]),
     "pgs_solve": (C.c_int, [_H]),
+    "pgs_set_groups": (C.c_int, [_H, C.c_int]),
     "pgs_adopt_result": (C.c_int, [_H]),
     "pgs_get_graph": (C.c_int, [_H, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _ip]),
     "pgs_get_connections": (C.c_int, [_H, C.c_int, _ip, C.c_int, _ip]),

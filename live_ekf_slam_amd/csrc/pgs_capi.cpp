@@ -3,10 +3,12 @@
 #include "../../include/slam_pgs.h"
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "capi_internal.h"
@@ -34,7 +36,14 @@ struct pgs_handle {
     float* dmeas = nullptr; int32_t* dcount = nullptr; double* dsec = nullptr; int k_stride = 0;
     double* dout = nullptr;
     int max_trials = 400;
+    // solve groups: the batch is split into `groups` contiguous ranges whose LM loops run on their own streams, so
+    // the latency-bound phases of one group overlap the bandwidth-bound phases of another (0 = choose from the batch)
+    int groups = 0;
+    std::vector<hipStream_t> gstreams;
+    std::vector<hipEvent_t> gevents;
+    int32_t* h_active = nullptr;               // pinned host: per-group active counts
     bool p_notrim = false;
+    int chol_threads = 0, chol_switch = 256;   // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces; else 256 while > chol_switch instances are active
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
     int syrk_tile = 0, syrk_switch = 1 << 30;    // SLAM_PGS_SYRK_TILE = 32 | 64 forces a variant; SLAM_PGS_SYRK_SWITCH = active count from which
                                              // the 64x64-per-wavefront variant is used (default: never — measured slower at every batch size)
@@ -98,11 +107,15 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
     h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
     h->p_notrim = getenv("SLAM_PGS_NOTRIM") != nullptr;
+    if (const char* e = getenv("SLAM_PGS_GROUPS")) h->groups = atoi(e);
+    if (const char* e = getenv("SLAM_PGS_CHOL_THREADS")) h->chol_threads = atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0);
+    if (const char* e = getenv("SLAM_PGS_CHOL_SWITCH")) h->chol_switch = atoi(e);
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
     slam::PgsParams& p = h->p;
     memset(&p, 0, sizeof(p));
+    p.b_off = 0; p.b_cnt = batch;
     p.B = batch; p.N_max = N_max; p.L_max = L_max; p.KP = k_per_pose; p.LD = h->LD; p.N = 1;
     const size_t B = batch, N = N_max, L = L_max, K = (size_t)N_max * k_per_pose;
     int rc = SLAM_OK;
@@ -121,7 +134,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     A(&p.Y, B * (size_t)p.y_stride); A(&p.S, B * (size_t)h->LD * h->LD);
     A(&p.dl, B * L * 2); A(&p.dp, B * N * 3);
     A(&p.lambda, B); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
-    A(&p.iters, B); A(&p.trials, B); A(&p.state, B); A(&p.solve_ok, B); A(&p.n_active, 1);
+    A(&p.iters, B); A(&p.trials, B); A(&p.state, B); A(&p.solve_ok, B); A(&p.n_active, 16);
     A(&h->dcount, B); A(&h->dsec, B * 3); A(&h->dout, B);
     if (getenv("SLAM_PGS_PROF")) { A(&p.prof, B * 8); }
     if (rc != SLAM_OK) { pgs_destroy(h); return rc; }
@@ -149,6 +162,9 @@ int pgs_destroy(pgs_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void* ptr : h->allocs) hipFree(ptr);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
+    for (hipEvent_t e : h->gevents) hipEventDestroy(e);
+    for (hipStream_t st : h->gstreams) hipStreamDestroy(st);
+    if (h->h_active) hipHostFree(h->h_active);
     if (h->dmeas) hipFree(h->dmeas);
     if (h->p.map) hipFree((void*)h->p.map);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -232,48 +248,122 @@ int pgs_run_sim(pgs_handle* h, const float* cmds, int T) {
     return SLAM_OK;
 }
 
+namespace {
+
+// one tryLambda of the instances [p.b_off, p.b_off + p.b_cnt) on `stream`
+int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, hipStream_t stream, int trial_index, bool profile) {
+    p.syrk_notrim = h->p_notrim ? 1 : 0;
+    p.chol_threads = h->chol_threads ? h->chol_threads : (active_hint > h->chol_switch ? 256 : 1024);
+    // 32x32 wavefront tiles by default; the 64x64 variant (more operand reuse, 4x fewer wavefronts) is kept for tuning
+    p.syrk_wave_tile = h->syrk_tile ? h->syrk_tile : (active_hint >= h->syrk_switch ? 64 : 32);
+    HIP_TRY(hipMemsetAsync(p.n_active, 0, sizeof(int32_t), stream));
+    for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
+        if (profile) {
+            const size_t need = (size_t)(trial_index + 1) * (slam::kPgsTrialKernels + 1);
+            while (h->events.size() < need) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->events.push_back(e); }
+            if (k == 0) HIP_TRY(hipEventRecord(h->events[(size_t)trial_index * (slam::kPgsTrialKernels + 1)], stream));
+        }
+        HIP_TRY(slam::pgs_launch_trial_kernel(p, k, stream));
+        if (profile) HIP_TRY(hipEventRecord(h->events[(size_t)trial_index * (slam::kPgsTrialKernels + 1) + k + 1], stream));
+    }
+    return SLAM_OK;
+}
+
+}  // namespace
+
 int pgs_solve(pgs_handle* h) {
     TRY(check(h));
     if (!h->inited) return fail(SLAM_ERR_STATE, "pgs_init must be called before pgs_solve");
     h->p.N = h->timestep + 1;
-    HIP_TRY(slam::pgs_launch_lm_begin(h->p, h->stream));
-    int trials = 0;
-    int32_t active = h->B;
-    for (; trials < h->max_trials; ++trials) {
-        // 32x32 wavefront tiles by default; the 64x64 variant (more operand reuse, 4x fewer wavefronts) is kept for tuning
-        h->p.syrk_notrim = h->p_notrim ? 1 : 0;
-        h->p.syrk_wave_tile = h->syrk_tile ? h->syrk_tile : (active >= h->syrk_switch ? 64 : 32);
-        HIP_TRY(hipMemsetAsync(h->p.n_active, 0, sizeof(int32_t), h->stream));
-        for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
-            if (h->profiling) {
-                const size_t need = (size_t)(trials + 1) * (slam::kPgsTrialKernels + 1);
-                while (h->events.size() < need) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->events.push_back(e); }
-                if (k == 0) HIP_TRY(hipEventRecord(h->events[(size_t)trials * (slam::kPgsTrialKernels + 1)], h->stream));
-            }
-            HIP_TRY(slam::pgs_launch_trial_kernel(h->p, k, h->stream));
-            if (h->profiling) HIP_TRY(hipEventRecord(h->events[(size_t)trials * (slam::kPgsTrialKernels + 1) + k + 1], h->stream));
+    h->p.b_off = 0; h->p.b_cnt = h->B;
+    int G = h->groups > 0 ? h->groups : (h->B >= 512 ? 2 : 1);
+    if (G > 16) G = 16;
+    if (G > h->B) G = h->B;
+    if (h->profiling) G = 1;   // per-kernel timing wants the kernels of one stream back to back
+    if (G <= 1) {
+        HIP_TRY(slam::pgs_launch_lm_begin(h->p, h->stream));
+        int trials = 0;
+        int32_t active = h->B;
+        for (; trials < h->max_trials; ++trials) {
+            TRY(launch_trial(h, h->p, active, h->stream, trials, h->profiling));
+            active = 0;
+            HIP_TRY(hipMemcpyAsync(&active, h->p.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->trace) fprintf(stderr, "pgs trial %d: active %d\n", trials, (int)active);
+            if (active == 0) { trials += 1; break; }
         }
-        active = 0;
-        HIP_TRY(hipMemcpyAsync(&active, h->p.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->trace) fprintf(stderr, "pgs trial %d: active %d\n", trials, (int)active);
-        if (active == 0) { trials += 1; break; }
+        h->last_trials = trials;
+        HIP_TRY(slam::pgs_launch_lm_end(h->p, h->stream));
+        if (h->profiling) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            for (int k = 0; k < slam::kPgsTrialKernels; ++k) h->kernel_ms[k] = 0.0;
+            for (int t = 0; t < trials; ++t)
+                for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
+                    float ms = 0.f;
+                    const size_t e0 = (size_t)t * (slam::kPgsTrialKernels + 1) + k;
+                    HIP_TRY(hipEventElapsedTime(&ms, h->events[e0], h->events[e0 + 1]));
+                    h->kernel_ms[k] += ms;
+                }
+        }
+        return SLAM_OK;
     }
-    h->last_trials = trials;
-    HIP_TRY(slam::pgs_launch_lm_end(h->p, h->stream));
-    if (h->profiling) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        for (int k = 0; k < slam::kPgsTrialKernels; ++k) h->kernel_ms[k] = 0.0;
-        for (int t = 0; t < trials; ++t)
-            for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
-                float ms = 0.f;
-                const size_t e0 = (size_t)t * (slam::kPgsTrialKernels + 1) + k;
-                HIP_TRY(hipEventElapsedTime(&ms, h->events[e0], h->events[e0 + 1]));
-                h->kernel_ms[k] += ms;
+    // ---- G groups, each with its own stream and LM loop; the host serves them round-robin ----
+    while ((int)h->gstreams.size() < G) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); h->gstreams.push_back(st); }
+    while ((int)h->gevents.size() < G + 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->gevents.push_back(e); }
+    if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 16, hipHostMallocDefault));
+    HIP_TRY(hipEventRecord(h->gevents[G], h->stream));   // everything queued on the handle's stream so far comes first
+    std::vector<slam::PgsParams> gp(G, h->p);
+    std::vector<int> gtrials(G, 0);
+    std::vector<char> gdone(G, 0);
+    const int per = (h->B + G - 1) / G;
+    for (int g = 0; g < G; ++g) {
+        gp[g].b_off = g * per;
+        gp[g].b_cnt = (h->B - g * per) < per ? (h->B - g * per) : per;
+        gp[g].n_active = h->p.n_active + g;
+        if (gp[g].b_cnt <= 0) { gdone[g] = 1; continue; }
+        HIP_TRY(hipStreamWaitEvent(h->gstreams[g], h->gevents[G], 0));
+        HIP_TRY(slam::pgs_launch_lm_begin(gp[g], h->gstreams[g]));
+        TRY(launch_trial(h, gp[g], h->B, h->gstreams[g], 0, false));
+        HIP_TRY(hipMemcpyAsync(h->h_active + g, gp[g].n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
+        HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
+    }
+    // one host thread per group drives its LM loop (launch a trial, wait for its active count, decide); the HIP runtime
+    // is thread-safe and the groups touch disjoint instance ranges
+    std::vector<int> grc(G, SLAM_OK);
+    auto drive = [&](int g) -> int {
+        HIP_TRY(hipSetDevice(h->device));
+        for (;;) {
+            HIP_TRY(hipEventSynchronize(h->gevents[g]));
+            const int32_t active = h->h_active[g];
+            gtrials[g] += 1;
+            if (h->trace) fprintf(stderr, "pgs group %d trial %d: active %d\n", g, gtrials[g] - 1, (int)active);
+            if (active == 0 || gtrials[g] >= h->max_trials) {
+                HIP_TRY(slam::pgs_launch_lm_end(gp[g], h->gstreams[g]));
+                HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
+                return SLAM_OK;
             }
+            TRY(launch_trial(h, gp[g], active * G, h->gstreams[g], gtrials[g], false));
+            HIP_TRY(hipMemcpyAsync(h->h_active + g, gp[g].n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
+            HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
+        }
+    };
+    std::vector<std::thread> workers;
+    for (int g = 1; g < G; ++g)
+        if (!gdone[g]) workers.emplace_back([&, g]() { grc[g] = drive(g); });
+    if (!gdone[0]) grc[0] = drive(0);
+    for (auto& w : workers) w.join();
+    int max_trials = 0;
+    for (int g = 0; g < G; ++g) {
+        if (grc[g] != SLAM_OK) return grc[g];
+        if (gp[g].b_cnt > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->gevents[g], 0));   // the handle's stream continues after every group
+        max_trials = gtrials[g] > max_trials ? gtrials[g] : max_trials;
     }
+    h->last_trials = max_trials;
     return SLAM_OK;
 }
+
+// number of solve groups (0 = automatic: 2 from 512 instances)
+int pgs_set_groups(pgs_handle* h, int groups) { TRY(check(h)); h->groups = groups < 0 ? 0 : groups; return SLAM_OK; }
 
 int pgs_adopt_result(pgs_handle* h) {
     TRY(check(h));

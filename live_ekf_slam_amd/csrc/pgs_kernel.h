@@ -14,6 +14,8 @@ static constexpr int kPgsFirstBit = 1 << 30;   // mlm: this factor is the first 
 struct PgsParams {
     int32_t B, N_max, L_max, KP, LD;   // LD = leading dimension of Y / S = roundup(2*L_max + 1, 64)
     int32_t N;                         // poses in the graph now (timestep + 1), the same for every instance
+    int32_t b_off, b_cnt;              // LM kernels: the launch covers instances [b_off, b_off + b_cnt) (one solve group)
+    int32_t chol_threads;              // 1024 or 256: workgroup size of the dense Cholesky of the next trial
     int32_t syrk_notrim;               // experiment: do not trim the k range (tiles of an instance then march in step)
     int32_t syrk_wave_tile;            // 64 or 32: SYRK variant of the next trial (chosen by the host from the active count)
     // ---- the graph (pose_graph.cpp: graph + initial_estimate + result) ----

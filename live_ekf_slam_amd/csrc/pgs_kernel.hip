@@ -259,7 +259,7 @@ constexpr int TPB = 512;   // threads of the per-pose kernels (two poses per thr
 
 __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     const int N = p.N, M = p.M[b];
     double* pw = p.pw + (size_t)b * p.N_max * 3;
     double* lw = p.lw + (size_t)b * p.L_max * 2;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void add_JtJ(double A[9], const double* J) {
 }
 
 __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, KP = p.KP, M = p.M[b];
     const Inst g = inst_view(p, b);
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
     __shared__ double s_in[CHAIN_CH][18];          // A (6 unique), C (9), gp (3)
     __shared__ double s_ring[2][CHAIN_CH][18];     // Linv (6), G (9), gp (3)
     __shared__ int s_fail;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, LD = p.LD, m2 = 2 * p.M[b];
     const double lambda = p.lambda[b];
@@ -584,8 +584,9 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
     const int ntr = (p.LD + SY_T - 1) / SY_T;
     const int ntl = ntr * (ntr + 1) / 2;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int b = (q / ntl) * 8 + xcd;
-    if (b >= p.B) return;
+    const int bl = (q / ntl) * 8 + xcd;     // instance within the launched group
+    if (bl >= p.b_cnt) return;
+    const int b = bl + p.b_off;
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
     // decode the lower-triangular tile index
@@ -674,14 +675,16 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
 
 // Dense blocked Cholesky of S (2M x 2M, lower, in place; the right-hand-side row 2M rides along as one more panel row,
 // which IS the forward substitution) followed by the blocked backward substitution; dl = S^-1 rhs.
-constexpr int CTPB = 1024;   // 16 wavefronts: the factorisation is a chain of short latency-bound phases
+// CTPB threads per instance: 1024 when few instances are active (the factorisation is a chain of short latency-bound
+// phases: more wavefronts shorten each), 256 when many are (more instances resident per CU).
+template <int CTPB>
 __global__ __launch_bounds__(CTPB) void pgs_chol_kernel(const PgsParams p) {
     constexpr int NB = 16, NBL = 4;   // panel width: fewer, fatter panel steps (each costs several HBM/L2 round trips)
     extern __shared__ double s_dyn[];
     __shared__ double s_d[NB][NB + 1];
     __shared__ double s_diag[NB], s_rdiag[NB];
     __shared__ int s_fail;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
     if (m2 == 0) return;
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(CTPB) void pgs_chol_kernel(const PgsParams p) {
 // prepared lane-parallel (v = Linv u, Mx = Linv G), the 3-vector recurrence itself runs on lane 0 out of LDS.
 __global__ __launch_bounds__(64) void pgs_backsolve_kernel(const PgsParams p) {
     __shared__ double s_v[64][3], s_M[64][9], s_z[64][3];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, lane = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
     const int N = p.N, KP = p.KP;
     const Inst g = inst_view(p, b);
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(64) void pgs_backsolve_kernel(const PgsParams p) {
 __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
     __shared__ int s_accept;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, KP = p.KP, M = p.M[b];
     const Inst g = inst_view(p, b);
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
 
 // result <- current values (also for instances cut off by the trial cap)
 __global__ __launch_bounds__(TPB) void pgs_lm_end_kernel(const PgsParams p) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     const int N = p.N, M = p.M[b];
     const double* pw = p.pw + (size_t)b * p.N_max * 3;
     const double* lw = p.lw + (size_t)b * p.L_max * 2;
@@ -1087,21 +1090,21 @@ hipError_t pgs_launch_run_sim(const PgsParams& p, int T, uint32_t step0, hipStre
 }
 
 hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(pgs_lm_begin_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+    hipLaunchKernelGGL(pgs_lm_begin_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
     return hipGetLastError();
 }
 
 hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s) {
     switch (which) {
-    case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.B), dim3(TPB), 0, s, p); break;
-    case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.B), dim3(64 + p.LD), 0, s, p); break;
+    case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p); break;
+    case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.b_cnt), dim3(64 + p.LD), 0, s, p); break;
     case 2: {
         if (p.syrk_wave_tile == 64) {
             const int nt = (p.LD + 127) / 128;
-            hipLaunchKernelGGL(pgs_syrk_kernel<64>, dim3(8 * (nt * (nt + 1) / 2) * ((p.B + 7) / 8)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(pgs_syrk_kernel<64>, dim3(8 * (nt * (nt + 1) / 2) * ((p.b_cnt + 7) / 8)), dim3(256), 0, s, p);
         } else {
             const int nt = (p.LD + 63) / 64;
-            hipLaunchKernelGGL(pgs_syrk_kernel<32>, dim3(8 * (nt * (nt + 1) / 2) * ((p.B + 7) / 8)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(pgs_syrk_kernel<32>, dim3(8 * (nt * (nt + 1) / 2) * ((p.b_cnt + 7) / 8)), dim3(256), 0, s, p);
         }
         break;
     }
@@ -1109,20 +1112,22 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
         const size_t lds = sizeof(double) * (size_t)(p.LD + 16) * 17;   // panel rows x (NB + 1)
         static bool attr_set = false;
         if (!attr_set) {   // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB)
-            hipFuncSetAttribute((const void*)pgs_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            hipFuncSetAttribute((const void*)pgs_chol_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            hipFuncSetAttribute((const void*)pgs_chol_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(pgs_chol_kernel, dim3(p.B), dim3(CTPB), lds, s, p);
+        if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(p.b_cnt), dim3(256), lds, s, p); break; }
+        hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(p.b_cnt), dim3(1024), lds, s, p);
         break;
     }
-    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.B), dim3(64), 0, s, p); break;
-    default: hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(p.B), dim3(TPB), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.b_cnt), dim3(64), 0, s, p); break;
+    default: hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p); break;
     }
     return hipGetLastError();
 }
 
 hipError_t pgs_launch_lm_end(const PgsParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(pgs_lm_end_kernel, dim3(p.B), dim3(TPB), 0, s, p);
+    hipLaunchKernelGGL(pgs_lm_end_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
     return hipGetLastError();
 }
 

@@ -157,6 +157,10 @@ class BatchedPoseGraph:
         _lib.check(_lib.lib().pgs_solve(self.h))
         self.solved_pose_graph = True
 
+    def set_groups(self, groups):
+        """Number of concurrently solved sub-batches (separate HIP streams); 0 = automatic."""
+        self._need(); _lib.check(_lib.lib().pgs_set_groups(self.h, int(groups)))
+
     def adopt_result(self):
         self._need(); _lib.check(_lib.lib().pgs_adopt_result(self.h))
 
