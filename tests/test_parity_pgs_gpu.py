@@ -218,3 +218,24 @@ def test_update_dev_equals_update():
             assert np.array_equal(ga["poses"], gb["poses"]) and np.array_equal(ga["landmarks"], gb["landmarks"])
         assert np.array_equal(a.connections(i), b.connections(i))
     a.close(); b.close()
+
+
+def test_solve_groups_do_not_change_results():
+    """pgs_set_groups only changes which stream / host thread drives an instance's LM loop."""
+    import live_ekf_slam_amd as S
+    L, T, KP, B = 20, 150, 8, 10
+    lm, cmds = make_scenario(9, L, T)
+    out = []
+    for G in (1, 3, 16):
+        pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams()
+        pg.set_groups(G)
+        pg.set_map(lm); pg.set_seed(4); pg.init(0.0, 0.0, 0.0)
+        pg.run_sim(cmds); pg.solvePoseGraph()
+        out.append(([pg.get_graph(b, 1) for b in range(B)], pg.stats()))
+        pg.close()
+    for graphs, st in out[1:]:
+        for b in range(B):
+            assert np.array_equal(graphs[b]["poses"], out[0][0][b]["poses"])
+            assert np.array_equal(graphs[b]["landmarks"], out[0][0][b]["landmarks"])
+        for key in ("iterations", "trials", "flags", "err_final", "lam"):
+            assert np.array_equal(st[key], out[0][1][key])
