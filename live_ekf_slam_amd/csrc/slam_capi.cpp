@@ -67,6 +67,8 @@ struct slam_handle {
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
     double* dxprev = nullptr;                         // UKF: x_t the last sigma points were drawn around
     double* dvt = nullptr; int32_t* dvage = nullptr;  // UKF: V^T of the last eigen-decomposition + warm-start age
+    hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[2] = {nullptr, nullptr};   // UKF run_sim: second half of the batch
+    int ukf_split_min = 1024;                                                        // batch size from which it is used
     bool predicted = false; float pred_cmd[2] = {0.f, 0.f};   // UKF: slam_predict done, slam_update_dev pending
     float* dmapf = nullptr;                           // UKF_LOC: the known map as float32 [id, x, y] triplets
     float* dcmds = nullptr; int cmds_cap = 0;         // command sequence of a multi-step launch (slam_run_sim)
@@ -116,6 +118,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.range_max = h->range_max; p.fov_min = h->fov_min; p.fov_max = h->fov_max;
     p.seed = h->seed; p.inst0 = h->inst0; p.step = h->step;
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
+    p.b_off = 0; p.b_cnt = h->B;
     p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
 }
 
@@ -258,6 +261,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (env) h->waves_per_filter = atoi(env);
     env = getenv("SLAM_DEBUG_FLAGS");
     if (env) h->dbg = atoi(env);
+    env = getenv("SLAM_UKF_SPLIT_MIN");   // batch size from which UKF run_sim splits the batch over two streams
+    if (env) h->ukf_split_min = atoi(env);
     env = getenv("SLAM_RUN_CHUNK");   // timesteps per launch of slam_run_sim (1 = one launch per step)
     if (env) h->run_chunk = atoi(env);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -301,6 +306,7 @@ int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); hipEventDestroy(h->aux_ev[0]); hipEventDestroy(h->aux_ev[1]); }
     void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage};
     for (void* q : bufs)
         if (q) hipFree(q);
@@ -408,6 +414,36 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
     if (T == 0) return SLAM_OK;
+    if (h->kind != SLAM_EKF_SLAM && !h->dump_meas && h->B >= h->ukf_split_min) {
+        // UKF: two launches per timestep (LDS-bound eigen-sqrt, then the latency-heavier sigma-point kernel).  The two
+        // halves of the batch run on two streams and drift apart, so one half's sqrt overlaps the other's step kernel.
+        HIP_TRY(hipSetDevice(h->device));
+        if (!h->aux_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->aux_ev[0], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->aux_ev[1], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(h->aux_ev[0], h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_ev[0], 0));
+        const int half = h->B / 2;
+        for (int t = 0; t < T; ++t) {
+            slam::UkfStepParams p;
+            fill_ukf_params(h, p, cmds + 2 * (size_t)t);
+            p.sim = 1;
+            for (int part = 0; part < 2; ++part) {
+                p.b_off = part ? half : 0;
+                p.b_cnt = part ? h->B - half : half;
+                hipStream_t st = part ? h->aux_stream : h->stream;
+                HIP_TRY(slam::launch_ukf_sqrt(p, st));
+                HIP_TRY(slam::launch_ukf_step(p, st));
+            }
+            std::swap(h->dP, h->dP2);
+            h->step += 1;
+        }
+        HIP_TRY(hipEventRecord(h->aux_ev[1], h->aux_stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->aux_ev[1], 0));
+        return SLAM_OK;
+    }
     if (h->kind != SLAM_EKF_SLAM || h->dump_meas || h->run_chunk == 1) {
         // one launch (pair) per timestep
         for (int t = 0; t < T; ++t) {

@@ -42,6 +42,7 @@ struct UkfStepParams {
     int64_t inst0;
     uint32_t step;
     int32_t B, L_max, pstride, xstride;
+    int32_t b_off, b_cnt;  // the launch covers instances [b_off, b_off + b_cnt) (the batch is split over two streams)
     int32_t sim;
     int32_t loc;          // 1 = FilterChoice::UKF_LOC: every detection updates against the known map (ukf.cpp:146-154)
     const float* mapf;    // [L][3] float32 {id, x, y}: `filter->map` as it arrives on /truth/landmarks

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     __shared__ int s_pp[MMAX], s_qq[MMAX];
     __shared__ double s_red[TPB / 64];
 
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     const int M = p.M[b];
     const int n = 4 + 2 * M, m = n / 2;
     const double* __restrict__ Pb = p.P + (size_t)b * p.pstride;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     __shared__ int s_upd[KCAP], s_ins[KCAP];  // detections to update (landmark slot) / to insert (detection index)
     __shared__ int s_misc[8];                 // k, n_upd, n_ins, capacity, singular
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x, lane = tid & 63;
     int flags = p.flags[b];
     const int M_old = p.M[b];
     const int n = 4 + 2 * M_old, ns = 2 * n + 1;
@@ -624,15 +624,15 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
     const int nmax = 4 + 2 * p.L_max;
     if (nmax <= 44) {
         switch (env_tpb(0, 256)) {
-            case 128: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 128>), dim3(p.B), dim3(128), 0, stream, p); break;
-            case 64: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 64>), dim3(p.B), dim3(64), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.B), dim3(256), 0, stream, p); break;
+            case 128: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 128>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;
+            case 64: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 64>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
         }
     } else if (nmax <= 104) {
         switch (env_tpb(0, 1024)) {
-            case 512: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 512>), dim3(p.B), dim3(512), 0, stream, p); break;
-            case 256: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 256>), dim3(p.B), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024>), dim3(p.B), dim3(1024), 0, stream, p); break;
+            case 512: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 512>), dim3(p.b_cnt), dim3(512), 0, stream, p); break;
+            case 256: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024>), dim3(p.b_cnt), dim3(1024), 0, stream, p); break;
         }
     } else {
         return hipErrorInvalidValue;
@@ -644,15 +644,15 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
     const int nmax = 4 + 2 * p.L_max;
     if (nmax <= 44) {
         switch (env_tpb(1, 128)) {
-            case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.B), dim3(64), 0, stream, p); break;
-            case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.B), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.B), dim3(128), 0, stream, p); break;
+            case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
+            case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;
         }
     } else if (nmax <= 104) {
         switch (env_tpb(1, 1024)) {
-            case 256: hipLaunchKernelGGL((ukf_step_kernel<104, 256, 8>), dim3(p.B), dim3(256), 0, stream, p); break;
-            case 512: hipLaunchKernelGGL((ukf_step_kernel<104, 512, 8>), dim3(p.B), dim3(512), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.B), dim3(1024), 0, stream, p); break;
+            case 256: hipLaunchKernelGGL((ukf_step_kernel<104, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
+            case 512: hipLaunchKernelGGL((ukf_step_kernel<104, 512, 8>), dim3(p.b_cnt), dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.b_cnt), dim3(1024), 0, stream, p); break;
         }
     } else {
         return hipErrorInvalidValue;

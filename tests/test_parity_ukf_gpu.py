@@ -167,3 +167,26 @@ def test_prediction_and_update_stage_split_equals_fused_update(S):
     with pytest.raises(S.SlamError):
         S._lib.check(S._lib.lib().slam_predict(e.h, (C.c_float * 2)(0.1, 0.0)))   # the EKF has no separate stages
     a.close(); b.close(); e.close()
+
+
+def test_run_sim_two_stream_split_is_bit_identical(S, oracle, monkeypatch):
+    """Batches >= 1024 run their halves on two streams in run_sim: same results as one stream, and as the oracle."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 20, 40, 1024
+    lm, cmds = make_scenario(1234, L, T)
+    outs = []
+    for split_min in ("1000000", "1024"):
+        monkeypatch.setenv("SLAM_UKF_SPLIT_MIN", split_min)
+        f = S.BatchedUKF(B, L).readParams(); f.set_map(lm); f.set_seed(5); f.set_instance_offset(40); f.init(0, 0, 0)
+        f.run_sim(cmds[:T // 2]); f.run_sim(cmds[T // 2:])
+        outs.append((f.poses(), f.landmark_counts(), f.error_stats(), f.status(), [f.get_state(b) for b in (0, 511, 512, 1023)]))
+        f.close()
+    a, b = outs
+    for i in range(4):
+        assert np.array_equal(a[i], b[i])
+    for sa, sb in zip(a[4], b[4]):
+        _eq(sa, sb)
+    for k, inst in enumerate((0, 511, 512, 1023)):
+        r = oracle.run_ukf_batch(lm, cmds, 1, L, seed=5, inst0=40 + inst, nthreads=1)
+        n = 4 + 2 * r["M"][0]
+        _eq(b[4][k], dict(M=r["M"][0], ids=r["ids"][0, :r["M"][0]], x=r["x"][0, :n], P=r["P"][0, :n * n].reshape(n, n)))
