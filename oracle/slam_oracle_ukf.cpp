@@ -13,7 +13,10 @@
 // Two places where the reference delegates to Eigen routines whose rounding cannot be reproduced:
 //  * SelfAdjointEigenSolver + MatrixFunctions .sqrt() (ukf.cpp:116-122,208).  Mathematically sqtP = Qv sqrt(D+) Qv^T
 //    is unique; here it is computed with a cyclic Jacobi eigen-iteration in PARALLEL (round-robin) ORDER on the
-//    exactly-symmetric matrix, the same schedule the GPU kernel runs, so GPU == oracle bit for bit.
+//    exactly-symmetric matrix, the same schedule the GPU kernel runs, so GPU == oracle bit for bit.  From the second
+//    timestep on the iteration is WARM-STARTED in the previous step's eigenbasis (B = V0^T (A V0), V starts at V0,
+//    small-element rule from the first sweep; cold start every 100 steps) — an implementation choice shared with the
+//    kernel that halves the sweeps; the eigen-decomposition it converges to is the same mathematical object.
 //  * unqualified cos/sin on a float argument (ukf.cpp:39-42,129-133,183-186,358-359): float overload
 //    (cfg.ukf_float_trig = 1, default) or double function (0); SURVEY.md Appendix B.
 #include <atomic>
