@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslam_hip.so")
-SOURCES = ["ekf_inst_103_238.hip", "ekf_inst_103_248.hip", "ekf_inst_103_424.hip", "ekf_inst_103_434.hip", "ekf_inst_103_444.hip", "ekf_inst_203_444.hip", "ekf_inst_103_444_f32.hip", "ekf_inst_103_448.hip", "ekf_inst_103_842.hip", "ekf_inst_43_148.hip", "ekf_inst_43_244.hip", "ekf_inst_43_244_f32.hip", "ekf_inst_43_248.hip", "ekf_inst_43_444.hip", "ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp"]
+SOURCES = ["ekf_inst_103_238.hip", "ekf_inst_103_248.hip", "ekf_inst_103_424.hip", "ekf_inst_103_434.hip", "ekf_inst_103_444.hip", "ekf_inst_203_444.hip", "ekf_inst_103_444_f32.hip", "ekf_inst_103_448.hip", "ekf_inst_103_842.hip", "ekf_inst_43_148.hip", "ekf_inst_43_224.hip", "ekf_inst_43_124.hip", "ekf_inst_43_244.hip", "ekf_inst_43_244_f32.hip", "ekf_inst_43_248.hip", "ekf_inst_43_444.hip", "ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp"]
 HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h", "capi_internal.h", "../../include/slam_batch.h", "../../include/slam_pgs.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-function", "-x", "hip"]

@@ -22,6 +22,8 @@ extern template hipError_t launch_variant<43, 2, 4, 4, double>(const EkfStepPara
 extern template hipError_t launch_variant<43, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<43, 1, 4, 8, double>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<43, 2, 4, 8, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 2, 2, 4, double>(const EkfStepParams&, hipStream_t);
+extern template hipError_t launch_variant<43, 1, 2, 4, double>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<103, 4, 4, 4, float>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<203, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
 extern template hipError_t launch_variant<43, 2, 4, 4, float>(const EkfStepParams&, hipStream_t);
@@ -41,9 +43,13 @@ hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, int f32_storage, hip
             case 444: return launch_variant<43, 4, 4, 4, double>(p, stream);
             case 148: return launch_variant<43, 1, 4, 8, double>(p, stream);
             case 248: return launch_variant<43, 2, 4, 8, double>(p, stream);
+            case 224: return launch_variant<43, 2, 2, 4, double>(p, stream);
+            case 124: return launch_variant<43, 1, 2, 4, double>(p, stream);
             case 4: return launch_variant<43, 4, 4, 4, double>(p, stream);
             case 1: return launch_variant<43, 1, 4, 8, double>(p, stream);
-            default: return launch_variant<43, 2, 4, 4, double>(p, stream);
+            // large batches: one wavefront per filter and groups of 2 detections (smallest footprint, most filters
+            // resident per CU) win by ~10 %; small batches are latency-bound and prefer two wavefronts per filter
+            default: return p.B >= 16384 ? launch_variant<43, 1, 2, 4, double>(p, stream) : launch_variant<43, 2, 4, 4, double>(p, stream);
         }
     }
     if (nmax <= 103) {

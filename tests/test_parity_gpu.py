@@ -90,7 +90,7 @@ def test_update_on_reference_measurement_stream(S, oracle, monkeypatch, fixture,
     f.close()
 
 
-@pytest.mark.parametrize("L,T,B,wpf", [(20, 400, 192, 0), (50, 400, 96, 842), (50, 400, 96, 4)])
+@pytest.mark.parametrize("L,T,B,wpf", [(20, 400, 192, 0), (50, 400, 96, 842), (50, 400, 96, 4), (20, 400, 96, 124), (20, 300, 64, 224)])
 def test_sim_step_parity(S, oracle, monkeypatch, L, T, B, wpf):
     """Device-side generator + filter in one kernel vs oracle generator + oracle filter, per-instance noise
     streams keyed by global instance id; also the measurements themselves and the error statistic."""
