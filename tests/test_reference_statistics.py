@@ -147,3 +147,39 @@ def test_gpu_pose_graph_every_iteration_mode_matches_reference_published_error(o
         pg.close()
     ref = np.asarray(REF["runs"]["naive_low_noise_iter/pose_graph_result.csv"])
     assert ref.min() <= np.mean(errs) <= ref.max(), (np.mean(errs), ref.min(), ref.max())
+
+
+@pytest.mark.gpu
+def test_gpu_pose_graph_with_ekf_secondary_filter_matches_reference_published_error():
+    """`filter: pose_graph` + `filter_to_compare: ekf_slam` (params.yaml:11,60; localization_node.cpp:62-63,124-131): the
+    batched EKF engine is the secondary filter of the batched pose graph — both on the GPU, wired through the host like
+    the reference's iterate().  Reference data: data/ekf_low_noise_one_time/pose_graph_{init,result}.csv."""
+    import live_ekf_slam_amd as S
+    B, T, KS = 16, 999, 8
+    e_init, e_res = [], []
+    for s in range(5):
+        lm, cmds = make_scenario(100 + s, 20, T)
+        ekf = S.BatchedEKF(B, 20).readParams(_cfg("low"))
+        ekf.set_map(lm); ekf.set_seed(7 + s); ekf.init(0.0, 0.0, 0.0)
+        ekf.last_meas(KS)                                   # switch the measurement dump on
+        pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=20, k_per_pose=KS).readParams(_cfg("low"))
+        pg.init(0.0, 0.0, 0.0)
+        truth = np.zeros((B, T, 2))
+        for t in range(T):
+            ekf.update_sim(cmds[t])                         # filter_secondary->update(cmd, meas)        :125
+            meas, cnt = ekf.last_meas(KS)
+            truth[:, t] = ekf.truth()[:, :2]
+            pg.updateNaiveVehPoseEstimate(ekf.poses())      # filter->updateNaiveVehPoseEstimate(...)    :127
+            pg.update(cmds[t], meas, cnt)                   # filter->update(cmd, meas)                   :131
+        pg.solvePoseGraph()
+        assert np.all(pg.stats()["flags"] == 0) and np.all(ekf.status() == 0)
+        for which, acc in ((0, e_init), (1, e_res)):
+            for b in range(B):
+                est = pg.get_graph(b, which)["poses"][:T, :2].astype(np.float32).astype(np.float64)
+                acc.append(np.mean(np.hypot(est[:, 0] - truth[b, :, 0], est[:, 1] - truth[b, :, 1])))
+        ekf.close(); pg.close()
+    ref_i = np.asarray(REF["runs"]["ekf_low_noise_one_time/pose_graph_init.csv"])
+    ref_r = np.asarray(REF["runs"]["ekf_low_noise_one_time/pose_graph_result.csv"])
+    print("EKF-secondary pose graph: initial", np.mean(e_init), "result", np.mean(e_res), "reference", ref_i.mean(), ref_r.mean())
+    assert ref_i.min() * 0.9 <= np.mean(e_init) <= ref_i.max(), (np.mean(e_init), ref_i.min(), ref_i.max())
+    assert ref_r.min() <= np.mean(e_res) <= ref_r.max(), (np.mean(e_res), ref_r.min(), ref_r.max())
