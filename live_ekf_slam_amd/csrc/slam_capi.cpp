@@ -120,6 +120,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
     p.b_off = 0; p.b_cnt = h->B;
     p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
+    p.prof = (h->dbg & 4) ? h->dprof : nullptr;
 }
 
 // one timestep, either filter kind; `sim` = device-side measurement generator

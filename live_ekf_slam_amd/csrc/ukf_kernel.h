@@ -45,6 +45,7 @@ struct UkfStepParams {
     int32_t b_off, b_cnt;  // the launch covers instances [b_off, b_off + b_cnt) (the batch is split over two streams)
     int32_t sim;
     int32_t loc;          // 1 = FilterChoice::UKF_LOC: every detection updates against the known map (ukf.cpp:146-154)
+    unsigned long long* prof;   // optional [B][16] phase timers of the step kernel (debug), NULL otherwise
     const float* mapf;    // [L][3] float32 {id, x, y}: `filter->map` as it arrives on /truth/landmarks
 };
 

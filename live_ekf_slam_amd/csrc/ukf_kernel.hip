@@ -294,6 +294,8 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     __shared__ int s_misc[8];                 // k, n_upd, n_ins, capacity, singular
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x, lane = tid & 63;
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
+#define UKF_STAMP(i) do { if (p.prof && tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } while (0)
     int flags = p.flags[b];
     const int M_old = p.M[b];
     const int n = 4 + 2 * M_old, ns = 2 * n + 1;
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     }
     for (int e = tid; e < n * n; e += TPB) sS[e] = Sq[e];
     __syncthreads();
+    UKF_STAMP(0);
 
     // ---- measurements ----
     if (p.sim) {
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
         if (tid == 0) s_misc[0] = kk;
     }
     __syncthreads();
+    UKF_STAMP(1);
     if (s_misc[0] > KCAP) flags |= SLAM_INST_CAPACITY;
     const int k = s_misc[0] < KCAP ? s_misc[0] : KCAP;
     if (p.sim && p.meas_out != nullptr) {
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
         sX4[3 * ns + i] = sn;
     }
     __syncthreads();
+    UKF_STAMP(2);
     const int n_upd = s_misc[1], n_insq = s_misc[2];
 
     const double w0 = (double)kW0;
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
         s_sc[4] = (double)yaw;
     }
     __syncthreads();
+    UKF_STAMP(3);
 
     // ---- landmark updates (ukf.cpp:293-349); K and S never depend on P (sigma points are not redrawn) ----
     const int nfin_ins = (M_old + n_insq <= p.L_max && M_old + n_insq <= LMAX) ? n_insq : ((p.L_max < LMAX ? p.L_max : LMAX) - M_old);
@@ -445,6 +451,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
                 sD1[i] = remainder(z1 - 0.0, kTwoPi);   // z_est(1) stays 0 (ukf.cpp:310-314)
             }
             __syncthreads();
+        UKF_STAMP(4);
             if (tid == 0) {  // leader: z_est(0), S (sequential in i), S^-1, innovation
                 double z0 = 0.0;
                 z0 = z0 + w0 * sZ0[0];
@@ -467,6 +474,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
                 s_sc[15] = remainder((double)b_m - 0.0, kTwoPi);
             }
             __syncthreads();
+        UKF_STAMP(5);
             {
                 const double z0 = s_sc[5];
                 double* Ku = sK + (size_t)u * NMAX * 4;
@@ -488,45 +496,51 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
                 }
             }
             __syncthreads();
+        UKF_STAMP(6);
         }
 
-        // ---- P pass: P_pred = sum_i (w_i d_r) d_c + Q, minus the K S K^T terms; 4 x 4 register tiles ----
+        // ---- P pass: P_pred = sum_i (w_i d_r) d_c + Q, minus the K S K^T terms; TR x 4 register tiles (TR = 2 when the
+        //      block has enough threads for twice as many tiles: the pass is instruction-bound, not operand-bound) ----
         {
-            const int nt = (n + 3) / 4;
+            constexpr int TR = (NMAX <= 44 && TPB >= 256) ? 2 : 4;
+            const int ntr = (n + TR - 1) / TR, ntc = (n + 3) / 4;
             unsigned hiacc = 0u;
-            for (int tile = tid; tile < nt * nt; tile += TPB) {
-                const int r0 = 4 * (tile / nt), c0 = 4 * (tile % nt);
-                double acc[4][4];
+            for (int tile = tid; tile < ntr * ntc; tile += TPB) {
+                const int r0 = TR * (tile / ntc), c0 = 4 * (tile % ntc);
+                double acc[TR][4];
                 if (first_pass) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < TR; ++a)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
-                    double xr[4], xc[4];
+                    double xr[TR], xc[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) { xr[a] = r0 + a < n ? s_xp0[r0 + a] : 0.0; xc[a] = c0 + a < n ? s_xp0[c0 + a] : 0.0; }
+                    for (int a = 0; a < TR; ++a) xr[a] = r0 + a < n ? s_xp0[r0 + a] : 0.0;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) xc[a] = c0 + a < n ? s_xp0[c0 + a] : 0.0;
 #pragma unroll 1
                     for (int i = 0; i < ns; ++i) {
                         const double w = i == 0 ? w0 : wi;
-                        double dr[4], dc[4];
+                        double dr[TR], dc[4];
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            dr[a] = r0 + a < n ? xpred_elem(r0 + a, i) - xr[a] : 0.0;
-                            dc[a] = c0 + a < n ? xpred_elem(c0 + a, i) - xc[a] : 0.0;
-                        }
+                        for (int a = 0; a < TR; ++a) dr[a] = r0 + a < n ? xpred_elem(r0 + a, i) - xr[a] : 0.0;
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) {
+                        for (int a = 0; a < 4; ++a) dc[a] = c0 + a < n ? xpred_elem(c0 + a, i) - xc[a] : 0.0;
+#pragma unroll
+                        for (int a = 0; a < TR; ++a) {
                             const double wd = w * dr[a];
 #pragma unroll
                             for (int c = 0; c < 4; ++c) acc[a][c] = acc[a][c] + wd * dc[c];
                         }
                     }
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        if (r0 == c0 && r0 + a < 4) acc[a][a] = acc[a][a] + s_sc[r0 + a];   // + Q (signed diagonal)
+                    for (int a = 0; a < TR; ++a)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (r0 + a == c0 + c && r0 + a < 4) acc[a][c] = acc[a][c] + s_sc[r0 + a];   // + Q (signed diagonal)
                 } else {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < TR; ++a)
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
                             acc[a][c] = (r0 + a < n && c0 + c < n) ? Pout[(size_t)(r0 + a) * n_fin + c0 + c] : 0.0;
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
                 for (int u = 0; u < ug; ++u) {
                     const double* Ku = sK + (size_t)u * NMAX * 4;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
+                    for (int a = 0; a < TR; ++a) {
                         if (r0 + a >= n) continue;
                         const double ks0 = Ku[4 * (r0 + a) + 2], ks1 = Ku[4 * (r0 + a) + 3];
 #pragma unroll
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
                     }
                 }
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < TR; ++a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (r0 + a < n && c0 + c < n) {
@@ -584,6 +598,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
         if (r >= n || c >= n) Pout[e] = (r == c) ? (((r - n) & 1) ? p.W11 : p.W00) : 0.0;
     }
     __syncthreads();
+    UKF_STAMP(7);
 
     // ---- x_t = x_pred (ukf.cpp:289) and bookkeeping ----
     unsigned hx = 0u;
@@ -608,6 +623,10 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
             p.err_sum[b] = p.err_sum[b] + sqrt(ex * ex + ey * ey);
         }
     }
+    UKF_STAMP(8);
+    if (p.prof && tid == 0)
+        for (int i = 0; i < 10; ++i) p.prof[(size_t)b * 16 + i] = tacc[i];
+#undef UKF_STAMP
 }
 
 // Tuning: threads per instance.  At BASELINE's batch of 4096 only 16 instances share a CU, so wide workgroups win
@@ -645,8 +664,8 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
     if (nmax <= 44) {
         switch (env_tpb(1, 128)) {
             case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
-            case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;
+            case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;   // 2 x 4 tiles
+            default: hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;    // measured best
         }
     } else if (nmax <= 104) {
         switch (env_tpb(1, 1024)) {
