@@ -370,7 +370,7 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
             double* El = Elmb + 6 * (size_t)slot_pos[k];   // the same block in (landmark, time) order for the chain kernel
 #pragma unroll
             for (int a = 0; a < 6; ++a) El[a] = E[a];
-            double* W = Wlb + 5 * k;
+            double* W = Wlb + 5 * (size_t)slot_pos[k];   // in (landmark, time) order: the landmark sum below reads contiguously
             W[0] = Jl[0] * Jl[0] + Jl[2] * Jl[2];
             W[1] = Jl[0] * Jl[1] + Jl[2] * Jl[3];
             W[2] = Jl[1] * Jl[1] + Jl[3] * Jl[3];
@@ -383,14 +383,14 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
         for (int k = 0; k < 3; ++k) gpb[3 * i + k] = gg[k];
     }
     __syncthreads();   // Wl of every factor is visible to the block
-    const int32_t* head = p.lm_head + (size_t)b * p.L_max;
-    const int32_t* mnext = p.mnext + (size_t)b * p.N_max * KP;
+    const int32_t* evt_start = p.evt_start + (size_t)b * (p.L_max + 1);
     double* Db = p.D + (size_t)b * p.L_max * 3;
     double* glb = p.gl + (size_t)b * p.L_max * 2;
-    for (int j = tid; j < M; j += TPB) {   // landmark j: chronological sum over its factors
+    for (int j = tid; j < M; j += TPB) {   // landmark j: chronological sum over its factors (contiguous event records)
         double d0 = 0, d1 = 0, d2 = 0, g0 = 0, g1 = 0;
-        for (int k = head[j]; k >= 0; k = mnext[k]) {
-            const double* W = Wlb + 5 * (size_t)k;
+        const int e1 = evt_start[j + 1];
+        for (int e = evt_start[j]; e < e1; ++e) {
+            const double* W = Wlb + 5 * (size_t)e;
             d0 += W[0]; d1 += W[1]; d2 += W[2]; g0 += W[3]; g1 += W[4];
         }
         Db[3 * j] = d0; Db[3 * j + 1] = d1; Db[3 * j + 2] = d2;
@@ -834,11 +834,86 @@ __global__ __launch_bounds__(CTPB) void pgs_chol_kernel(const PgsParams p) {
 #undef PGS_STAMP
 }
 
-// Pose step: H_pp dp = gp - E dl through the chain factor.  One wavefront per instance; chunks of 64 poses are
-// prepared lane-parallel (v = Linv u, Mx = Linv G), the 3-vector recurrence itself runs on lane 0 out of LDS.
-__global__ __launch_bounds__(64) void pgs_backsolve_kernel(const PgsParams p) {
-    __shared__ double s_v[64][3], s_M[64][9], s_z[64][3];
-    const int b = blockIdx.x + p.b_off, lane = threadIdx.x;
+// Pose step: H_pp dp = gp - E dl through the chain factor: forward  z_i = v_i - M_i z_{i-1}  (v = Linv u, M = Linv G),
+// backward  d_i = w_i - N_i d_{i+1}  (w = Linv^T z, N = Linv^T G_{i+1}^T).  Both are affine recurrences in a 3-vector,
+// so they are evaluated as a SCAN instead of 2 x N dependent steps: every thread prepares (v, M) of its poses, then one
+// wavefront composes the maps of 64 contiguous blocks (sequentially inside a block), scans the 64 composites with
+// lane shuffles, and replays its block from the scanned entry value.  ~2 x (N/64 + 6) dependent steps instead of 2 N.
+struct Affine3 { double a[3], B[9]; };   // z -> a + B z
+__device__ __forceinline__ void affine_step(Affine3& f, const double* W) {   // f <- (z -> v - M z) o f, W = {v[3], M[9]}
+    double na[3], nB[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        na[r] = W[r] - ((W[3 + 3 * r] * f.a[0] + W[4 + 3 * r] * f.a[1]) + W[5 + 3 * r] * f.a[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            nB[3 * r + c] = -((W[3 + 3 * r] * f.B[c] + W[4 + 3 * r] * f.B[3 + c]) + W[5 + 3 * r] * f.B[6 + c]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f.a[k] = na[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f.B[k] = nB[k];
+}
+// cur <- cur o prev  (prev is applied first)
+__device__ __forceinline__ void affine_compose(Affine3& cur, const Affine3& prev) {
+    double na[3], nB[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        na[r] = cur.a[r] + ((cur.B[3 * r] * prev.a[0] + cur.B[3 * r + 1] * prev.a[1]) + cur.B[3 * r + 2] * prev.a[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            nB[3 * r + c] = (cur.B[3 * r] * prev.B[c] + cur.B[3 * r + 1] * prev.B[3 + c]) + cur.B[3 * r + 2] * prev.B[6 + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cur.a[k] = na[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cur.B[k] = nB[k];
+}
+// One wavefront: x_i = W_i.v - W_i.M x_{i-1} over i = 0..N-1 (REV: i = N-1..0 with x_N = 0), x written to out[3 i].
+// W [N][12] in HBM/L2 (just written by this workgroup).
+template <bool REV>
+__device__ __forceinline__ void affine_scan_wave(const double* W, double* out, int N, int lane) {
+    const int BL = (N + 63) / 64;
+    const int blk = REV ? 63 - lane : lane;            // block blk covers poses [blk*BL, min(N, (blk+1)*BL))
+    const int lo = blk * BL, hi = (lo + BL) < N ? (lo + BL) : N;
+    Affine3 f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f.a[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f.B[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (lo < N) {
+        if (!REV) { for (int i = lo; i < hi; ++i) affine_step(f, W + 12 * (size_t)i); }
+        else { for (int i = hi - 1; i >= lo; --i) affine_step(f, W + 12 * (size_t)i); }
+    }
+    // inclusive scan in processing order (lane 0 first)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Affine3 pv;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pv.a[k] = __shfl_up(f.a[k], off, 64);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pv.B[k] = __shfl_up(f.B[k], off, 64);
+        if (lane >= off) affine_compose(f, pv);
+    }
+    // entry value of this lane's block = composite of all earlier blocks applied to 0 = their `a`
+    double x0 = __shfl_up(f.a[0], 1, 64), x1 = __shfl_up(f.a[1], 1, 64), x2 = __shfl_up(f.a[2], 1, 64);
+    if (lane == 0) { x0 = 0.0; x1 = 0.0; x2 = 0.0; }
+    if (lo < N) {
+        for (int t = 0; t < hi - lo; ++t) {
+            const int i = REV ? hi - 1 - t : lo + t;
+            const double* w = W + 12 * (size_t)i;
+            const double n0 = w[0] - ((w[3] * x0 + w[4] * x1) + w[5] * x2);
+            const double n1 = w[1] - ((w[6] * x0 + w[7] * x1) + w[8] * x2);
+            const double n2 = w[2] - ((w[9] * x0 + w[10] * x1) + w[11] * x2);
+            x0 = n0; x1 = n1; x2 = n2;
+            out[3 * i] = x0; out[3 * i + 1] = x1; out[3 * i + 2] = x2;
+        }
+    }
+}
+
+constexpr int BTPB = 256;
+__global__ __launch_bounds__(BTPB) void pgs_backsolve_kernel(const PgsParams p) {
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
     const int N = p.N, KP = p.KP;
     const Inst g = inst_view(p, b);
@@ -848,84 +923,55 @@ __global__ __launch_bounds__(64) void pgs_backsolve_kernel(const PgsParams p) {
     const double* Gb = p.G + (size_t)b * p.N_max * 9;
     const double* dlb = p.dl + (size_t)b * p.L_max * 2;
     double* dpb = p.dp + (size_t)b * p.N_max * 3;
-    double z0 = 0.0, z1 = 0.0, z2 = 0.0;
-    for (int base = 0; base < N; base += 64) {   // forward: z_i = Linv_i (u_i - G_i z_{i-1})
-        const int i = base + lane;
-        if (i < N) {
-            double u0 = gpb[3 * i], u1 = gpb[3 * i + 1], u2 = gpb[3 * i + 2];
-            const int kc = g.cnt[i];
-            for (int s = 0; s < kc; ++s) {
-                const size_t k = (size_t)i * KP + s;
-                const int j = g.mlm[k] & (kPgsFirstBit - 1);
-                const double* E = Eb + 6 * k;
-                const double d0 = dlb[2 * j], d1 = dlb[2 * j + 1];
-                u0 -= E[0] * d0 + E[1] * d1; u1 -= E[2] * d0 + E[3] * d1; u2 -= E[4] * d0 + E[5] * d1;
-            }
-            const double* I = Lb + 6 * i;
-            const double* G = Gb + 9 * i;
-            s_v[lane][0] = I[0] * u0;
-            s_v[lane][1] = I[1] * u0 + I[2] * u1;
-            s_v[lane][2] = (I[3] * u0 + I[4] * u1) + I[5] * u2;
+    double* Wb = p.Y + (size_t)b * p.y_stride;    // Y is dead once S has been formed: scratch for the (v, M) records
+    for (int i = tid; i < N; i += BTPB) {          // forward records
+        double u0 = gpb[3 * i], u1 = gpb[3 * i + 1], u2 = gpb[3 * i + 2];
+        const int kc = g.cnt[i];
+        for (int s = 0; s < kc; ++s) {
+            const size_t k = (size_t)i * KP + s;
+            const int j = g.mlm[k] & (kPgsFirstBit - 1);
+            const double* E = Eb + 6 * k;
+            const double d0 = dlb[2 * j], d1 = dlb[2 * j + 1];
+            u0 -= E[0] * d0 + E[1] * d1; u1 -= E[2] * d0 + E[3] * d1; u2 -= E[4] * d0 + E[5] * d1;
+        }
+        const double* I = Lb + 6 * i;
+        const double* G = Gb + 9 * i;      // G_0 = 0
+        double* W = Wb + 12 * (size_t)i;
+        W[0] = I[0] * u0;
+        W[1] = I[1] * u0 + I[2] * u1;
+        W[2] = (I[3] * u0 + I[4] * u1) + I[5] * u2;
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                s_M[lane][cc] = I[0] * G[cc];
-                s_M[lane][3 + cc] = I[1] * G[cc] + I[2] * G[3 + cc];
-                s_M[lane][6 + cc] = (I[3] * G[cc] + I[4] * G[3 + cc]) + I[5] * G[6 + cc];
-            }
+        for (int cc = 0; cc < 3; ++cc) {
+            W[3 + cc] = I[0] * G[cc];
+            W[6 + cc] = I[1] * G[cc] + I[2] * G[3 + cc];
+            W[9 + cc] = (I[3] * G[cc] + I[4] * G[3 + cc]) + I[5] * G[6 + cc];
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (lane == 0) {
-            const int n = (N - base) < 64 ? (N - base) : 64;
-            for (int l = 0; l < n; ++l) {
-                const double a0 = s_v[l][0] - ((s_M[l][0] * z0 + s_M[l][1] * z1) + s_M[l][2] * z2);
-                const double a1 = s_v[l][1] - ((s_M[l][3] * z0 + s_M[l][4] * z1) + s_M[l][5] * z2);
-                const double a2 = s_v[l][2] - ((s_M[l][6] * z0 + s_M[l][7] * z1) + s_M[l][8] * z2);
-                z0 = a0; z1 = a1; z2 = a2;
-                s_z[l][0] = z0; s_z[l][1] = z1; s_z[l][2] = z2;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (i < N) { dpb[3 * i] = s_z[lane][0]; dpb[3 * i + 1] = s_z[lane][1]; dpb[3 * i + 2] = s_z[lane][2]; }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    for (int top = N; top > 0; top -= 64) {      // backward: dp_i = Linv_i^T (z_i - G_{i+1}^T dp_{i+1})
-        const int base = top - 64 < 0 ? 0 : top - 64;
-        const int n = top - base;
-        const int i = base + lane;
-        if (lane < n) {
-            const double* I = Lb + 6 * i;
-            const double zz0 = dpb[3 * i], zz1 = dpb[3 * i + 1], zz2 = dpb[3 * i + 2];
-            s_v[lane][0] = (I[0] * zz0 + I[1] * zz1) + I[3] * zz2;     // Linv^T z
-            s_v[lane][1] = I[2] * zz1 + I[4] * zz2;
-            s_v[lane][2] = I[5] * zz2;
-            if (i + 1 < N) {   // Mx = Linv^T G_{i+1}^T
-                const double* G = Gb + 9 * (i + 1);
+    __syncthreads();
+    if (tid < 64) affine_scan_wave<false>(Wb, dpb, N, tid);      // z into dp
+    __syncthreads();
+    for (int i = tid; i < N; i += BTPB) {          // backward records: w = Linv^T z, Nx = Linv^T G_{i+1}^T
+        const double* I = Lb + 6 * i;
+        const double zz0 = dpb[3 * i], zz1 = dpb[3 * i + 1], zz2 = dpb[3 * i + 2];
+        double* W = Wb + 12 * (size_t)i;
+        W[0] = (I[0] * zz0 + I[1] * zz1) + I[3] * zz2;
+        W[1] = I[2] * zz1 + I[4] * zz2;
+        W[2] = I[5] * zz2;
+        if (i + 1 < N) {
+            const double* G = Gb + 9 * (i + 1);
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {   // column cc of G^T = row cc of G
-                    s_M[lane][cc] = (I[0] * G[3 * cc] + I[1] * G[3 * cc + 1]) + I[3] * G[3 * cc + 2];
-                    s_M[lane][3 + cc] = I[2] * G[3 * cc + 1] + I[4] * G[3 * cc + 2];
-                    s_M[lane][6 + cc] = I[5] * G[3 * cc + 2];
-                }
-            } else {
+            for (int cc = 0; cc < 3; ++cc) {   // column cc of G^T = row cc of G
+                W[3 + cc] = (I[0] * G[3 * cc] + I[1] * G[3 * cc + 1]) + I[3] * G[3 * cc + 2];
+                W[6 + cc] = I[2] * G[3 * cc + 1] + I[4] * G[3 * cc + 2];
+                W[9 + cc] = I[5] * G[3 * cc + 2];
+            }
+        } else {
 #pragma unroll
-                for (int cc = 0; cc < 9; ++cc) s_M[lane][cc] = 0.0;
-            }
+            for (int cc = 0; cc < 9; ++cc) W[3 + cc] = 0.0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (lane == 0) {
-            for (int l = n - 1; l >= 0; --l) {
-                const double a0 = s_v[l][0] - ((s_M[l][0] * d0 + s_M[l][1] * d1) + s_M[l][2] * d2);
-                const double a1 = s_v[l][1] - ((s_M[l][3] * d0 + s_M[l][4] * d1) + s_M[l][5] * d2);
-                const double a2 = s_v[l][2] - ((s_M[l][6] * d0 + s_M[l][7] * d1) + s_M[l][8] * d2);
-                d0 = a0; d1 = a1; d2 = a2;
-                s_z[l][0] = d0; s_z[l][1] = d1; s_z[l][2] = d2;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (lane < n) { dpb[3 * i] = s_z[lane][0]; dpb[3 * i + 1] = s_z[lane][1]; dpb[3 * i + 2] = s_z[lane][2]; }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
+    __syncthreads();
+    if (tid < 64) affine_scan_wave<true>(Wb, dpb, N, tid);       // dp
 }
 
 // linearised cost of the step, retraction, true cost of the candidate, then GTSAM's tryLambda / iterate /
@@ -1120,7 +1166,7 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
         hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(p.b_cnt), dim3(1024), lds, s, p);
         break;
     }
-    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.b_cnt), dim3(64), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.b_cnt), dim3(BTPB), 0, s, p); break;
     default: hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p); break;
     }
     return hipGetLastError();
