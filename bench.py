@@ -131,11 +131,11 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
 
 
 def pgs_traffic(B, L, N):
-    """HBM-side bytes per solve of the SYRK kernel from the committed PMC passes (profiles/r01i_pgs/summary.json: FETCH_SIZE
+    """HBM-side bytes per solve of the SYRK kernel from the committed PMC passes (profiles/r01k_pgs/summary.json: FETCH_SIZE
     + WRITE_SIZE in KiB, raw: the guide's x2 applies to 16 B/lane streams only and this kernel loads 8 B/lane), if the
     profiled workload is the one being run; else null."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01i_pgs", "summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01k_pgs", "summary.json")))
         c = d["bench_line"]["config"]
         if (c["batch_per_gpu"], c["landmarks"], c["poses"]) != (B, L, N):
             return None

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of tools/profile_pgs.sh (bench.py --filter pgs --steps 2 --warmup 1 = 3 solves per
+"""Condense the rocprofv3 outputs of tools/profile_pgs.sh (bench.py --filter pgs --steps 2 --warmup 1 = 4 solves per
 run) into profiles/<tag>/: kernel_stats.csv (copied), summary.json / summary.txt (per-kernel time per solve, PMC sums).
 Usage: summarize_pgs_profile.py gpurun_out/prof_<tag> profiles/<tag>"""
 import csv, glob, json, os, re, shutil, sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
-SOLVES = 3
+SOLVES = 4   # 1 warm-up + 2 timed + 1 per-kernel-timed solve
 res = {"solves_profiled": SOLVES, "kernels": {}}
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
