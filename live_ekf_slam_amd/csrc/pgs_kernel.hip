@@ -21,6 +21,8 @@
 // All per-instance decisions live on the device; the host only polls the number of active instances.
 #include "pgs_kernel.h"
 
+#include <mutex>
+
 #include "slam_math.h"
 #include "slam_rng.h"
 #include "sim_device.h"
@@ -1156,12 +1158,11 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     }
     case 3: {
         const size_t lds = sizeof(double) * (size_t)(p.LD + 16) * 17;   // panel rows x (NB + 1)
-        static bool attr_set = false;
-        if (!attr_set) {   // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB)
-            hipFuncSetAttribute((const void*)pgs_chol_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            hipFuncSetAttribute((const void*)pgs_chol_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            attr_set = true;
-        }
+        static std::once_flag attr_once;   // solve groups launch from several host threads
+        std::call_once(attr_once, []() {   // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB)
+            (void)hipFuncSetAttribute((const void*)pgs_chol_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute((const void*)pgs_chol_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        });
         if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(p.b_cnt), dim3(256), lds, s, p); break; }
         hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(p.b_cnt), dim3(1024), lds, s, p);
         break;
