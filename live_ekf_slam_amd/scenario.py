@@ -23,7 +23,12 @@ def _dist(a, b):
 
 def generate_landmarks(map_type, num_landmarks, rng, bound=DEFAULTS["bound"],
                        min_sep=DEFAULTS["min_landmark_separation"], grid_step=DEFAULTS["grid_step"]):
-    """Landmark map as float64 array [L][2]; id = row.  map_type: 'random' | 'grid' (sim_node.py:167-188)."""
+    """Landmark map as float64 array [L][2]; id = row.  map_type: 'random' | 'grid' | 'demo' | 'igvc1'
+    (sim_node.py:163-199; the two fixed maps are data files, `num_landmarks` is ignored for them and for 'grid')."""
+    if map_type in ("demo", "igvc1"):
+        import json, os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "fixed_maps.json")) as fh:
+            return np.array(json.load(fh)[map_type], dtype=np.float64)
     if map_type in ("random", "rand"):
         pts = []
         while len(pts) < num_landmarks:
@@ -36,7 +41,7 @@ def generate_landmarks(map_type, num_landmarks, rng, bound=DEFAULTS["bound"],
         half = grid_step / 2
         ticks = np.arange(-bound + half, bound, grid_step)
         return np.array([(float(r), float(c)) for r in ticks for c in ticks], dtype=np.float64)
-    raise ValueError(f"unsupported map_type {map_type!r} (random | grid)")
+    raise ValueError(f"unsupported map_type {map_type!r} (random | grid | demo | igvc1)")
 
 
 def generate_full_trajectory(landmarks, num_iterations, rng, x0=(0.0, 0.0, 0.0), **kw):

@@ -89,7 +89,7 @@ def f32(x):
     return float(np.float32(x))
 
 
-def run_scenario(seed, L, T):
+def run_scenario(seed, L, T, map_type="random"):
     _install_stubs()
     sim = _load(REF + "/src/sim_node.py", "ref_sim_node")
     with open(REF + "/config/params.yaml") as f:
@@ -109,8 +109,9 @@ def run_scenario(seed, L, T):
     random.seed(seed)
 
     # --- map (sim_node.py:177-188)
-    sim.generate_landmarks("random")
+    sim.generate_landmarks(map_type)
     draws_map = list(rec.log); rec.log.clear()
+    L = len(sim.landmarks)          # the fixed maps (demo / grid / igvc1) set their own landmark count
     lm = np.array([sim.landmarks[i] for i in range(L)], dtype=np.float64)
 
     # --- trajectory (sim_node.py:63-152). The publish loop ends by itself at t == num_iterations.
@@ -140,7 +141,7 @@ def run_scenario(seed, L, T):
     meas = meas64.astype(np.float32)  # ROS wire: Float32MultiArray
     return dict(map=lm, cmds=cmds, cmds64=cmds64, truth=truth, meas_count=counts, meas=meas, meas64=meas64,
                 draws_map=np.array(draws_map), draws_traj=np.array(draws_traj), draws_step=draws_step,
-                seed=np.int64(seed), L=np.int64(L), T=np.int64(T))
+                seed=np.int64(seed), L=np.int64(L), T=np.int64(T))  # noqa
 
 
 def avg_err_case():
@@ -175,5 +176,10 @@ if __name__ == "__main__":
         np.savez_compressed(path, **out)
         c = out["meas_count"]
         print(path, "mean k %.3f max k %d" % (c.mean(), c.max()), "bytes", os.path.getsize(path))
+    for map_type in ("demo", "grid", "igvc1"):   # fixed maps: map + trajectory + measurement stream, 200 steps
+        out = run_scenario(5, 0, 200, map_type)
+        path = os.path.join(HERE, f"sim_{map_type}_seed5_T200.npz")
+        np.savez_compressed(path, **out)
+        print(path, "L", int(out["L"]), "mean k %.3f" % out["meas_count"].mean(), "bytes", os.path.getsize(path))
     np.savez_compressed(os.path.join(HERE, "avg_err_case.npz"), **avg_err_case())
     print("avg_err_case written")

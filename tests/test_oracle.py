@@ -178,8 +178,13 @@ def test_unknown_id_association(oracle):
 
 # ---- measurement generator vs the reference simulator -----------------------------------------------------------
 def test_sim_matches_reference_fixtures_bit_exact(oracle, golden_files):
-    """get_cmd restatement (libm policy) == imported reference simulator, draw for draw, on every fixture."""
-    for f in golden_files:
+    """get_cmd restatement (libm policy) == imported reference simulator, draw for draw, on every fixture (random maps
+    and the reference's demo / grid / igvc1 maps)."""
+    import glob, os
+    from conftest import GOLDEN
+    fixed = sorted(glob.glob(os.path.join(GOLDEN, "sim_*_seed5_T200.npz")))
+    assert len(fixed) == 3
+    for f in list(golden_files) + fixed:
         g = np.load(f)
         sim = oracle.OracleSim(g["map"], math=oracle.MATH_LIBM)
         for t in range(int(g["T"])):

@@ -30,3 +30,15 @@ def test_command_constraints_and_grid_map():
     assert d.min() >= 0.05 and np.abs(lm).max() <= 10.0
     grid = generate_landmarks("grid", 0, random.Random(0))
     assert grid.shape == (25, 2) and grid[0].tolist() == [-8.0, -8.0] and grid[-1].tolist() == [8.0, 8.0]
+
+
+def test_fixed_and_grid_maps_match_reference():
+    """map_type demo / grid / igvc1 (sim_node.py:163-199): landmark map and the TSP command sequence planned over it,
+    bit for bit against fixtures captured from the imported reference simulator (tests/golden/make_golden.py)."""
+    import os
+    from conftest import GOLDEN
+    for map_type, L in (("demo", 20), ("grid", 25), ("igvc1", 37)):
+        g = np.load(os.path.join(GOLDEN, f"sim_{map_type}_seed5_T200.npz"))
+        lm, cmds = make_scenario(5, 0, 200, map_type=map_type)
+        assert lm.shape == (L, 2) and np.array_equal(lm, g["map"])
+        assert np.array_equal(cmds, g["cmds"])
