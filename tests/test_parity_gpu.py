@@ -64,7 +64,9 @@ def test_device_math_bit_exact(S, oracle):
 
 @pytest.mark.parametrize("fixture,L_max,wpf", [("sim_seed0_L20_T1000.npz", 20, 0), ("sim_seed1_L20_T400.npz", 20, 148),
                                                ("sim_seed2_L50_T1000.npz", 50, 238), ("sim_seed2_L50_T1000.npz", 50, 4),
-                                               ("sim_seed1234_L50_T400.npz", 50, 424), ("sim_seed0_L20_T1000.npz", 50, 4)])
+                                               ("sim_seed1234_L50_T400.npz", 50, 424), ("sim_seed0_L20_T1000.npz", 50, 4),
+                                               ("sim_igvc1_seed5_T200.npz", 37, 0), ("sim_grid_seed5_T200.npz", 25, 0),
+                                               ("sim_demo_seed5_T200.npz", 20, 0)])
 def test_update_on_reference_measurement_stream(S, oracle, monkeypatch, fixture, L_max, wpf):
     """Filter::update fed with the measurement stream the REFERENCE simulator produced (golden fixture), the same
     message for every instance of the batch; x and P checked against the oracle every 20 steps."""
