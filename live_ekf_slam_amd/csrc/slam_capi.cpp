@@ -125,6 +125,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
 
 // one timestep, either filter kind; `sim` = device-side measurement generator
 int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas, const int32_t* d_count, int k_stride) {
+    if (h->predicted) return fail(SLAM_ERR_STATE, "a prediction stage is pending: call slam_update_dev before the next step");
     if (h->kind == SLAM_EKF_SLAM) {
         slam::EkfStepParams p;
         fill_params(h, p, cmd);
@@ -415,6 +416,7 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
     if (T == 0) return SLAM_OK;
+    if (h->predicted) return fail(SLAM_ERR_STATE, "a prediction stage is pending: call slam_update_dev before the next step");
     if (h->kind != SLAM_EKF_SLAM && !h->dump_meas && h->B >= h->ukf_split_min) {
         // UKF: two launches per timestep (LDS-bound eigen-sqrt, then the latency-heavier sigma-point kernel).  The two
         // halves of the batch run on two streams and drift apart, so one half's sqrt overlaps the other's step kernel.

@@ -163,6 +163,10 @@ def test_prediction_and_update_stage_split_equals_fused_update(S):
     assert pub["X"].dtype == np.float32 and pub["X"].size == n_prev * (2 * n_prev + 1)
     with pytest.raises(S.SlamError):
         b.updateStage()                       # no prediction pending
+    b.predictionStage(S.Command(0.1, 0.0))
+    with pytest.raises(S.SlamError):
+        b.update(S.Command(0.1, 0.0), [])     # a full step while a prediction stage is pending
+    b.updateStage()
     e = S.BatchedEKF(2, 5).readParams(); e.init(0, 0, 0)
     with pytest.raises(S.SlamError):
         S._lib.check(S._lib.lib().slam_predict(e.h, (C.c_float * 2)(0.1, 0.0)))   # the EKF has no separate stages
