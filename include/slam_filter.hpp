@@ -152,6 +152,90 @@ private:
     int batch_, L_max_, device_;
 };
 
+// UKFState.msg payload as UKF::publishState fills it (ukf.cpp:60-104)
+struct UKFState {
+    int32_t timestep = 0;
+    float x_v = 0, y_v = 0, yaw_v = 0;
+    int32_t M = 0;
+    std::vector<float> landmarks;  // [id, x, y] * M
+    std::vector<float> P;          // row-major (4+2M)^2
+    std::vector<float> X;          // sigma points of the last prediction stage, column by column (ukf.cpp:92-101)
+};
+
+// Batch of B UKF-SLAM instances behind the reference's UKF interface (filter.h:177-223, ukf.cpp).
+class BatchedUKF : public Filter {
+public:
+    BatchedUKF(int batch, int L_max, int device = 0) : batch_(batch), L_max_(L_max), device_(device) {
+        type = FilterChoice::UKF_SLAM;
+        check(slam_config_default(&cfg_));
+    }
+    ~BatchedUKF() override { if (h_) slam_destroy(h_); }
+    BatchedUKF(const BatchedUKF&) = delete;
+    BatchedUKF& operator=(const BatchedUKF&) = delete;
+    void readParams(const slam_config& config) override {
+        cfg_ = config;
+        if (h_) { slam_destroy(h_); h_ = nullptr; }
+        check(slam_create(&cfg_, SLAM_UKF_SLAM, batch_, L_max_, SLAM_F64, device_, &h_));
+    }
+    void init(float x_0, float y_0, float yaw_0) override { need(); check(slam_init(h_, x_0, y_0, yaw_0)); isInit = true; }
+    void update(Command::ConstPtr cmdMsg, Float32MultiArray::ConstPtr lmMeasMsg) override {   // ukf.cpp:161-195
+        need();
+        const int k = (int)(lmMeasMsg->data.size() / 3);
+        const int ks = k > 0 ? k : 1;
+        std::vector<float> meas((size_t)batch_ * ks * 3, 0.f);
+        std::vector<int32_t> cnt(batch_, k);
+        for (int b = 0; b < batch_; ++b)
+            for (int i = 0; i < 3 * k; ++i) meas[(size_t)b * ks * 3 + i] = lmMeasMsg->data[i];
+        const float cmd[2] = {cmdMsg->fwd, cmdMsg->ang};
+        check(slam_step(h_, cmd, meas.data(), cnt.data(), ks));
+    }
+    // the two public halves of UKF::update (filter.h:187-188); measurements as DEVICE pointers
+    void predictionStage(const Command& cmd) { need(); const float c[2] = {cmd.fwd, cmd.ang}; check(slam_predict(h_, c)); }
+    void updateStage(const float* d_meas, const int32_t* d_meas_count, int k_stride) { need(); check(slam_update_dev(h_, d_meas, d_meas_count, k_stride)); }
+    void setMap(const std::vector<double>& map_xy) { need(); check(slam_set_map(h_, map_xy.data(), (int)(map_xy.size() / 2))); }
+    void updateSim(const Command& cmd) { need(); const float c[2] = {cmd.fwd, cmd.ang}; check(slam_step_sim(h_, c)); }
+    // ukf.cpp:47-53 (x, y, yaw, landmarks...); the reference's fixed-size Vector3d bug is not replicated
+    std::vector<double> getStateVector() override {
+        need();
+        std::vector<double> x(slam_state_dim_max(h_));
+        int32_t M = 0;
+        std::vector<int32_t> ids(L_max_);
+        check(slam_get_state(h_, 0, x.data(), nullptr, &M, ids.data(), nullptr));
+        lm_IDs.assign(ids.begin(), ids.begin() + M);
+        std::vector<double> out = {x[0], x[1], std::remainder(std::atan2(x[3], x[2]), 2 * 3.14159265358979323846)};
+        out.insert(out.end(), x.begin() + 4, x.begin() + 4 + 2 * M);
+        return out;
+    }
+    void publishState() override { last_state = stateMsg(0); }
+    UKFState stateMsg(int instance) {
+        need();
+        const int nmax = slam_state_dim_max(h_);
+        std::vector<double> x(nmax), P((size_t)nmax * nmax), X((size_t)nmax * (2 * nmax + 1));
+        std::vector<int32_t> ids(L_max_);
+        UKFState s;
+        check(slam_get_state(h_, instance, x.data(), P.data(), &s.M, ids.data(), &s.timestep));
+        const int n = 4 + 2 * s.M;
+        s.x_v = (float)x[0]; s.y_v = (float)x[1]; s.yaw_v = (float)std::remainder(std::atan2(x[3], x[2]), 2 * 3.14159265358979323846);
+        for (int i = 0; i < s.M; ++i) { s.landmarks.push_back((float)ids[i]); s.landmarks.push_back((float)x[4 + 2 * i]); s.landmarks.push_back((float)x[5 + 2 * i]); }
+        s.P.resize((size_t)n * n);
+        for (size_t i = 0; i < (size_t)n * n; ++i) s.P[i] = (float)P[i];
+        int32_t rows = 0, cols = 0;
+        check(slam_get_sigma_points(h_, instance, X.data(), &rows, &cols));
+        s.X.resize((size_t)rows * cols);
+        for (size_t i = 0; i < (size_t)rows * cols; ++i) s.X[i] = (float)X[i];
+        return s;
+    }
+    std::vector<double> errorStats() { need(); std::vector<double> e(batch_); check(slam_error_stats(h_, e.data())); return e; }
+    slam_handle* handle() { return h_; }
+    UKFState last_state;
+
+private:
+    void need() const { if (!h_) throw std::runtime_error("readParams() has not been called"); }
+    slam_config cfg_{};
+    slam_handle* h_ = nullptr;
+    int batch_, L_max_, device_;
+};
+
 // NaiveFilter (filter.h:325-369): propagate the commands, ignore the measurements.  The pose graph's default secondary
 // filter (params.yaml:60).
 class NaiveFilter : public Filter {

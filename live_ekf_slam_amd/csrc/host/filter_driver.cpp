@@ -2,7 +2,7 @@
 // FIFO-paired (command, measurement) messages are popped one pair per tick and fed to Filter::update, then
 // publishState().  Here the filter is the batched MI355X engine behind the reference's Filter interface.
 //
-// usage: filter_driver <batch> <L> <steps> [pose_graph]   (synthetic straight-ish trajectory, device-side measurements)
+// usage: filter_driver <batch> <L> <steps> [pose_graph | ukf]   (synthetic straight-ish trajectory, device-side measurements)
 // Prints one line: mean per-instance average position error and the published state size of instance 0.
 #include <cstdio>
 #include <cstdlib>
@@ -39,10 +39,40 @@ static int run_pose_graph(int B, int L, int T) {
     return 0;
 }
 
+// `filter: "ukf_slam"` (localization_node.cpp:36-38): the same iterate() loop with the UKF behind the Filter pointer
+static int run_ukf(int B, int L, int T) {
+    std::unique_ptr<Filter> filter = std::make_unique<BatchedUKF>(B, L);
+    auto* ukf = static_cast<BatchedUKF*>(filter.get());
+    slam_config cfg;
+    check(slam_config_default(&cfg));
+    filter->readParams(cfg);
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-10.0, 10.0);
+    std::vector<double> map(2 * L);
+    for (auto& v : map) v = U(rng);
+    ukf->setMap(map);
+    filter->init(0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+        Command c; c.fwd = 0.1f; c.ang = (t / 40) % 2 ? -0.03f : 0.03f;
+        ukf->updateSim(c);
+        filter->publishState();
+    }
+    auto cmd = std::make_shared<Command>(); cmd->fwd = 0.05f; cmd->ang = 0.01f;
+    filter->update(cmd, std::make_shared<Float32MultiArray>());
+    filter->publishState();
+    const std::vector<double> sv = filter->getStateVector();
+    double mean = 0;
+    for (double e : ukf->errorStats()) mean += e;
+    std::printf("driver ok: ukf batch=%d L=%d steps=%d mean_avg_err=%.6f M0=%d timestep=%d P_len=%zu X_len=%zu sv_len=%zu\n", B, L, T + 1,
+                mean / B, ukf->last_state.M, ukf->last_state.timestep, ukf->last_state.P.size(), ukf->last_state.X.size(), sv.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 256, L = argc > 2 ? atoi(argv[2]) : 20, T = argc > 3 ? atoi(argv[3]) : 100;
     try {
         if (argc > 4 && std::string(argv[4]) == "pose_graph") return run_pose_graph(B, L, T);
+        if (argc > 4 && std::string(argv[4]) == "ukf") return run_ukf(B, L, T);
         std::unique_ptr<Filter> filter = std::make_unique<BatchedEKF>(B, L);   // localization_node.cpp:33-35
         auto* ekf = static_cast<BatchedEKF*>(filter.get());
         slam_config cfg;

@@ -30,3 +30,14 @@ def test_cpp_pose_graph_driver_runs():
     assert m, out.stdout
     poses, solved, M0, res, xlen, conns = map(int, m.groups())
     assert poses == 90 and solved == 1 and res == 1 and M0 == 3 and xlen == 89 and conns == 30
+
+
+def test_cpp_ukf_driver_runs():
+    exe = os.path.join(ROOT, "live_ekf_slam_amd", "filter_driver")
+    out = subprocess.run([exe, "64", "20", "80", "ukf"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"M0=(\d+) timestep=(\d+) P_len=(\d+) X_len=(\d+) sv_len=(\d+)", out.stdout)
+    assert m, out.stdout
+    M0, ts, plen, xlen, svlen = map(int, m.groups())
+    n = 4 + 2 * M0
+    assert ts == 81 and plen == n * n and svlen == 3 + 2 * M0 and xlen > 0
