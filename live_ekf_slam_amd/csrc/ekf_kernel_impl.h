@@ -801,74 +801,106 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int rs = (VEC * 64) / nf, cs = (VEC * 64) - rs * nf;   // (r, c) step between a lane's vectors
             VT* dst2 = reinterpret_cast<VT*>(Pout);
             const VT* src2 = reinterpret_cast<const VT*>(Pin);
-#pragma unroll 1
-            for (;;) {
-                int ch = 0;
-                if (lane == 0) ch = atomicAdd(&s_chunk, 1);
-                ch = __builtin_amdgcn_readfirstlane(ch);
-                const int q0 = ch * CH + opaque(lane);
-                if (ch * CH >= nvec) break;
-                int r = (VEC * q0) / nf;
-                int c = VEC * q0 - r * nf;
-                double v[UNR][VEC];
-                int rr[UNR], cc[UNR];
+            // One vector: the group's downdates, thin patches, storage rounding, store.  Branch-free per element: every
+            // LDS operand of the VEC elements is read unconditionally (patch reads go to slot 0 when the element is not
+            // thin and are discarded by a select), so the reads of all elements issue back to back instead of one
+            // dependent LDS round trip after another behind per-element branches.
+            auto emit = [&](const int q, const int r0, const int c0, const double (&vin)[VEC]) {
+                int re[VEC], ce[VEC];
+                re[0] = r0; ce[0] = c0;
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {   // issue the loads of UNR vectors first
-                    const int q = q0 + u * 64;
-                    rr[u] = r; cc[u] = c;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[u][e] = 0.0;
-                    if (q < nvec) {
-                        if (vec_load) {
-                            const VT t4 = __builtin_nontemporal_load(src2 + q);
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) v[u][e] = (double)t4[e];
-                        } else {  // other leading dimension (the state grows this step) or fp64 intermediate
-                            int re = r, ce = c;
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) {
-                                if (re < nsrc && ce < nsrc)
-                                    v[u][e] = src_mid ? Pmid[(size_t)re * lds + ce] : (double)Pin[(size_t)re * lds + ce];
-                                ce += 1;
-                                if (ce == nf) { ce = 0; re += 1; }
-                            }
-                        }
-                    }
-                    c += cs; r += rs;
-                    while (c >= nf) { c -= nf; r += 1; }
+                for (int e = 1; e < VEC; ++e) {
+                    const bool wrap = ce[e - 1] + 1 == nf;
+                    ce[e] = wrap ? 0 : ce[e - 1] + 1;
+                    re[e] = wrap ? re[e - 1] + 1 : re[e - 1];
                 }
+                int sr[VEC], sc[VEC];
+                double val[VEC];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int q = q0 + u * 64;
+                for (int e = 0; e < VEC; ++e) { sr[e] = s_slot[re[e]]; sc[e] = s_slot[ce[e]]; val[e] = vin[e]; }
+#pragma unroll
+                for (int w = 0; w < KG; ++w) {
+                    if (w >= nu) break;  // wave-uniform
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const double2 kk = s_K[w * LDP + re[e]];
+                        const double2 hh = s_HP[w * LDP + ce[e]];
+                        val[e] = val[e] - (kk.x * hh.x + kk.y * hh.y);
+                    }
+                }
+                VT outv;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const double pc = s_C[(sc[e] >= 0 ? sc[e] : 0) * LDP + re[e]];
+                    const double pr = s_R[(sr[e] >= 0 ? sr[e] : 0) * LDP + ce[e]];
+                    double o = sc[e] >= 0 ? pc : val[e];
+                    o = sr[e] >= 0 ? pr : o;
+                    if (VEC * q + e >= nn2) o = 0.0;   // don't-care elements pad the last vector
+                    if (!dst_mid) {
+                        const ST stored = (ST)o;         // storage rounding
+                        const unsigned ha = hi_abs((double)stored);
+                        hiacc = hiacc > ha ? hiacc : ha;
+                        outv[e] = stored;
+                    } else if (VEC * q + e < nn2) {
+                        Pmid[(size_t)VEC * q + e] = o;   // fp64 intermediate
+                    }
+                }
+                if (!dst_mid) __builtin_nontemporal_store(outv, dst2 + q);
+            };
+            if (vec_load) {
+                // common case: UNR raw 16-byte vectors in flight per lane, converted to fp64 only when they are used
+                // (a conversion next to its load would make every load wait for the previous one)
+#pragma unroll 1
+                for (;;) {
+                    int ch = 0;
+                    if (lane == 0) ch = atomicAdd(&s_chunk, 1);
+                    ch = __builtin_amdgcn_readfirstlane(ch);
+                    const int q0 = ch * CH + opaque(lane);
+                    if (ch * CH >= nvec) break;
+                    VT raw[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int q = q0 + u * 64;
+                        raw[u] = __builtin_nontemporal_load(src2 + (q < nvec ? q : nvec - 1));
+                    }
+                    int r = (VEC * q0) / nf;
+                    int c = VEC * q0 - r * nf;
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int q = q0 + u * 64;
+                        if (q < nvec) {
+                            double vin[VEC];
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) vin[e] = (double)raw[u][e];
+                            emit(q, r, c, vin);
+                        }
+                        c += cs; r += rs;
+                        while (c >= nf) { c -= nf; r += 1; }
+                    }
+                }
+            } else {
+                // other leading dimension (the state grows this step) or fp64 intermediate: element-wise source reads,
+                // one vector at a time (rare: steps that insert landmarks or hold more than KG detections)
+#pragma unroll 1
+                for (;;) {
+                    int ch = 0;
+                    if (lane == 0) ch = atomicAdd(&s_chunk, 1);
+                    ch = __builtin_amdgcn_readfirstlane(ch);
+                    if (ch * 64 >= nvec) break;
+                    const int q = ch * 64 + opaque(lane);
                     if (q < nvec) {
-                        int re = rr[u], ce = cc[u];
-                        VT outv;
+                        const int r = (VEC * q) / nf, c = VEC * q - r * nf;
+                        double vin[VEC];
+                        int re = r, ce = c;
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) {
-                            double val = v[u][e];
-#pragma unroll
-                            for (int w = 0; w < KG; ++w) {
-                                if (w >= nu) break;  // wave-uniform
-                                const double2 kk = s_K[w * LDP + re];
-                                const double2 hh = s_HP[w * LDP + ce];
-                                val = val - (kk.x * hh.x + kk.y * hh.y);
-                            }
-                            const int sr = s_slot[re], sc = s_slot[ce];
-                            if (sc >= 0) val = s_C[sc * LDP + re];
-                            if (sr >= 0) val = s_R[sr * LDP + ce];
-                            if (VEC * q + e >= nn2) val = 0.0;   // don't-care elements pad the last vector
-                            if (!dst_mid) {
-                                const ST stored = (ST)val;       // storage rounding
-                                const unsigned ha = hi_abs((double)stored);
-                                hiacc = hiacc > ha ? hiacc : ha;
-                                outv[e] = stored;
-                            } else if (VEC * q + e < nn2) {
-                                Pmid[(size_t)VEC * q + e] = val; // fp64 intermediate
-                            }
+                            vin[e] = 0.0;
+                            if (re < nsrc && ce < nsrc)
+                                vin[e] = src_mid ? Pmid[(size_t)re * lds + ce] : (double)Pin[(size_t)re * lds + ce];
                             ce += 1;
                             if (ce == nf) { ce = 0; re += 1; }
                         }
-                        if (!dst_mid) __builtin_nontemporal_store(outv, dst2 + q);
+                        emit(q, r, c, vin);
                     }
                 }
             }
