@@ -79,6 +79,19 @@ __device__ __forceinline__ double block_max(double v, double* s_red, int tid, in
     return r;
 }
 
+// round-robin schedule of the parallel-order Jacobi: indices (p < q) of pair k in round t of a sweep (position 0 fixed)
+__device__ __forceinline__ void rr_pair(int k, int t, int n, int& p, int& q) {
+    const int nm1 = n - 1;
+    int x = k - 1 + t;
+    if (x >= nm1) x -= nm1;
+    const int a = (k == 0) ? 0 : 1 + x;
+    int y = nm1 - k - 1 + t;
+    if (y >= nm1) y -= nm1;
+    const int bq = 1 + y;
+    p = a < bq ? a : bq;
+    q = a < bq ? bq : a;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -91,6 +104,7 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     __shared__ double sVt[NMAX * NMAX];            // V transposed: Vt[p*n + k] = V(k, p)
     __shared__ double s_cs[MMAX], s_sn[MMAX], s_tn[MMAX], s_sd[NMAX];
     __shared__ int s_pp[MMAX], s_qq[MMAX];
+    __shared__ double2 s_csn[MMAX];               // (c, s) of this round's rotations, one 16-byte read per consumer
     __shared__ double s_red[TPB / 64];
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
@@ -163,6 +177,16 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
         }
         desc[u] = d;
     }
+    // Fast rotation phase (every pair-block / diagonal item is some thread's FIRST item): all LDS operands of a thread's
+    // work in a round have addresses that follow from the round-robin schedule alone (rr_pair), so they are issued
+    // together and the round costs ONE LDS round trip instead of three dependent ones per item (rotation parameters ->
+    // indices -> data).  The V row-pairs are mapped so that a thread's rows all belong to one pair: TPB / m threads per
+    // pair, ITV rows each.  Items are independent, so the mapping does not change a single bit.
+    constexpr bool kFast = (MMAX * (MMAX + 1) / 2 <= TPB);
+    constexpr int ITV = kFast ? (NMAX + (TPB / MMAX) - 1) / (TPB / MMAX) : 1;
+    const int tp = TPB / m;                 // threads per pair (V rows)
+    const int iv = tid / tp, subk = tid - iv * tp;
+    const bool vvalid = iv < m;
     bool converged = false;
 #pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -202,8 +226,62 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     s = tt * c;
                 }
                 s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
+                s_csn[k] = make_double2(c, s);
             }
             __syncthreads();
+            if constexpr (kFast) {
+                // ---- V row-pairs of pair iv: operands first ----
+                int vpi, vqi;
+                rr_pair(vvalid ? iv : 0, t, n, vpi, vqi);
+                const double2 vcs = s_csn[vvalid ? iv : 0];
+                double xp[ITV], xq[ITV];
+#pragma unroll
+                for (int u = 0; u < ITV; ++u) {
+                    const int k = subk + tp * u;
+                    const int kk = k < n ? k : 0;
+                    xp[u] = sVt[vpi * n + kk]; xq[u] = sVt[vqi * n + kk];
+                }
+                // ---- the thread's pair-block or diagonal block ----
+                const int d = desc[0];
+                const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
+                if (kind == 0) {
+                    int pi, qi, pj, qj;
+                    rr_pair(i, t, n, pi, qi);
+                    rr_pair(j, t, n, pj, qj);
+                    const double2 csi = s_csn[i], csj = s_csn[j];
+                    auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
+                    const int a00 = idx(pi, pj), a01 = idx(pi, qj), a10 = idx(qi, pj), a11 = idx(qi, qj);
+                    const double b00 = sA[a00], b01 = sA[a01], b10 = sA[a10], b11 = sA[a11];
+                    const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
+                    if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
+                        const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
+                        const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
+                        sA[a00] = t00 * cj - t01 * sj; sA[a01] = t00 * sj + t01 * cj;
+                        sA[a10] = t10 * cj - t11 * sj; sA[a11] = t10 * sj + t11 * cj;
+                    }
+                } else if (kind == 1) {
+                    int pq, qq;
+                    rr_pair(i, t, n, pq, qq);
+                    const int app_i = pq * (pq + 1) / 2 + pq, aqq_i = qq * (qq + 1) / 2 + qq, apq_i = qq * (qq + 1) / 2 + pq;
+                    const double tn = s_tn[i];
+                    const double app = sA[app_i], aqq = sA[aqq_i], apq = sA[apq_i];
+                    sA[app_i] = app - tn * apq;
+                    sA[aqq_i] = aqq + tn * apq;
+                    if (apq != 0.0) sA[apq_i] = 0.0;
+                }
+                // ---- V <- V J ----
+                if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
+                    const double c = vcs.x, sn = vcs.y;
+#pragma unroll
+                    for (int u = 0; u < ITV; ++u) {
+                        const int k = subk + tp * u;
+                        if (k < n) {
+                            sVt[vpi * n + k] = c * xp[u] - sn * xq[u];
+                            sVt[vqi * n + k] = sn * xp[u] + c * xq[u];
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < IT; ++u) {
                 const int d = desc[u];
