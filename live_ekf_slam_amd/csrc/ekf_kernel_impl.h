@@ -473,30 +473,32 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int tg = opaque(tid);
             const ST* srcS = (kWide && src_mid) ? reinterpret_cast<const ST*>(Pmid) : Pin;
             constexpr int GI = (TS * LDP + TPB - 1) / TPB;
-            double rv[GI], cv[GI];
+            // the loaded values stay in their storage type until every load of the lane has been issued: a conversion
+            // next to its load would make each load wait for the previous one
+            auto gather = [&](auto zero, const auto* __restrict__ base) {
+                typedef decltype(zero) LT;
+                LT rv[GI], cv[GI];
 #pragma unroll
-            for (int u = 0; u < GI; ++u) {
-                const int i = tg + TPB * u;
-                rv[u] = 0.0; cv[u] = 0.0;
-                if (i < nT * LDP) {
-                    const int sl = i / LDP, j = i - sl * LDP;
-                    const int t_s = s_T[sl];
-                    if (s_need[sl] == 1 && j < nsrc && t_s < nsrc) {
-                        if (!kWide && src_mid) {
-                            rv[u] = Pmid[(size_t)t_s * lds + j];
-                            cv[u] = Pmid[(size_t)j * lds + t_s];
-                        } else {
-                            rv[u] = (double)srcS[(size_t)t_s * lds + j];   // P[t_s][j]
-                            cv[u] = (double)srcS[(size_t)j * lds + t_s];   // P[j][t_s]
+                for (int u = 0; u < GI; ++u) {
+                    const int i = tg + TPB * u;
+                    rv[u] = (LT)0; cv[u] = (LT)0;
+                    if (i < nT * LDP) {
+                        const int sl = i / LDP, j = i - sl * LDP;
+                        const int t_s = s_T[sl];
+                        if (s_need[sl] == 1 && j < nsrc && t_s < nsrc) {
+                            rv[u] = base[(size_t)t_s * lds + j];   // P[t_s][j]
+                            cv[u] = base[(size_t)j * lds + t_s];   // P[j][t_s]
                         }
                     }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < GI; ++u) {
-                const int i = tg + TPB * u;
-                if (i < nT * LDP && s_need[i / LDP] != 0) { s_R[i] = rv[u]; s_C[i] = cv[u]; }
-            }
+                for (int u = 0; u < GI; ++u) {
+                    const int i = tg + TPB * u;
+                    if (i < nT * LDP && s_need[i / LDP] != 0) { s_R[i] = (double)rv[u]; s_C[i] = (double)cv[u]; }
+                }
+            };
+            if (!kWide && src_mid) gather(0.0, Pmid);
+            else gather((ST)0, srcS);
         }
         __syncthreads();
         if (tid < TS) s_need[tid] = 0;
