@@ -10,8 +10,8 @@ namespace slam {
 struct EkfStepParams {
     // ---- filter state in HBM ----
     // P and x are stored as fp64 (SLAM_F64) or fp32 (SLAM_F32); strides are in ELEMENTS of that type
-    const void* P;      // [B][pstride]  P_t: packed row-major n x n, leading dimension n = 3+2*M[b] (read)
-    void* P_out;        // [B][pstride]  P_t of the next step (written; the two buffers ping-pong)
+    const void* P;      // [B][pstride]  P_t: packed row-major n x n, leading dimension n = 3+2*M[b]; updated IN PLACE
+    void* P_out;        // [B][pstride]  second buffer: target of the steps that change the leading dimension (insertions)
     void* x;            // [B][xstride]  x_t
     double* scratch;    // [B][pstride] fp64, SLAM_F32 only: P between detection groups of one step (NULL for fp64)
     int32_t* M;         // [B]
@@ -33,8 +33,7 @@ struct EkfStepParams {
     // ---- command (Command.msg) ----
     float fwd, ang;
     // multi-step launch (SIM mode only): the kernel runs T consecutive timesteps per instance, step t with command
-    // cmds[2t], cmds[2t+1] and RNG step index step+t, ping-ponging P -> P_out -> P ...; the result is in P_out when T
-    // is odd and in P when T is even.  cmds == NULL: T = 1 with (fwd, ang).
+    // cmds[2t], cmds[2t+1] and RNG step index step+t; the result is always left in P.  cmds == NULL: T = 1 with (fwd, ang).
     const float* cmds;
     int32_t T;
     // ---- filter config after readCommonParams (filter.h:105-121), effective V / W ----

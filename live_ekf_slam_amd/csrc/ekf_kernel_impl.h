@@ -10,11 +10,12 @@
 //    algebra runs on those LDS copies in O(k n) work; the few scalar chains (Jacobian entries, 2x2 inverse,
 //    sincos/atan2) are evaluated by ONE leader lane and broadcast through LDS.  Each update leaves its
 //    K (n x 2) and H P (2 x n) in LDS.
-//  * BULK phase.  P is streamed exactly once: 16-byte-per-lane coalesced loads of the old matrix, the group's
-//    rank-2 downdates applied in detection order from the LDS-resident K / HP, thin rows/cols patched in from
-//    their LDS copies, 16-byte coalesced stores into the OTHER buffer of a ping-pong pair (so a step that grows
-//    the state can change the packed leading dimension without any in-place hazard).  HBM traffic per step is
-//    the algorithmic minimum 2*n^2*8 bytes plus the thin gather (which re-reads lines the stream touches anyway).
+//  * BULK phase.  P is streamed exactly once, IN PLACE: 16-byte-per-lane coalesced loads, the group's rank-2
+//    downdates applied in detection order from the LDS-resident K / HP, thin rows/cols patched in from their LDS
+//    copies, 16-byte coalesced stores to the same addresses (every element is read and rewritten by the same lane).
+//    Only a step that grows the state changes the packed leading dimension and writes into the second buffer.  A step
+//    without any update or insertion writes just the three vehicle rows / columns the prediction changed.  HBM
+//    traffic per step is at most the algorithmic 2*n^2*8 bytes plus the thin gather of newly visible landmarks.
 //    No large register arrays: the kernel runs at high occupancy and has no upper limit on n other than LDS.
 //  More than KG detections in one step are processed in groups (a second pass over P; rare: P(k>4) ~ 0.3 %).
 //
@@ -80,7 +81,7 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
     } while (0)
 
 // The P stream uses PLAIN loads and stores on purpose: in a multi-step launch the matrix a workgroup writes in step t is
-// what it reads in step t+1, and the ~90 MB the resident workgroups ping-pong over stay in the 256 MB Infinity Cache.
+// what it reads in step t+1, and the ~90 MB of the resident workgroups stay in the 256 MB Infinity Cache.
 // Measured at L=50, batch 65536: plain 40.3 M steps/s, non-temporal loads only 39.2 M, non-temporal loads and stores
 // 34.1 M (fp32 storage: 43.3 M plain vs 40.1 M non-temporal).
 // Storage type ST of x and P in HBM: double (SLAM_F64) or float (SLAM_F32; arithmetic stays fp64, values are
@@ -151,11 +152,16 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // ---- prologue: every load that does not depend on another load is issued up front (one HBM round trip) ----
     constexpr int VEC = Vec16<ST>::VEC;
     typedef typename Vec16<ST>::type VT;
-    // T consecutive timesteps per launch: the two P buffers ping-pong, x_t / ids / truth / thin rows stay on chip
+    // T consecutive timesteps per launch: x_t / ids / truth / thin rows stay on chip, P is updated in place
     const int T = MULTI ? p.T : 1;
     ST* const PA = const_cast<ST*>(static_cast<const ST*>(p.P)) + (size_t)b * p.pstride;
     ST* const PB = static_cast<ST*>(p.P_out) + (size_t)b * p.pstride;
-    ST* const Pfinal = (T & 1) ? PB : PA;     // where the host expects P_t after T steps
+    ST* const Pfinal = PA;                    // where the host expects P_t after the launch
+    // The stream updates P IN PLACE (every element is read and rewritten by the same lane; the thin rows / columns it
+    // depends on were copied to LDS before).  Only a step that inserts landmarks changes the packed leading dimension
+    // and therefore writes into the other buffer; Pcur follows the matrix.  Half the ping-pong footprint in the
+    // Infinity Cache, and a step without detections touches nothing but its thin rows and columns.
+    ST* Pcur = PA;
     ST* __restrict__ xb = static_cast<ST*>(p.x) + (size_t)b * p.xstride;
     constexpr bool kWide = sizeof(ST) == 8;   // fp64 storage: intermediate results can live in P_out itself
     int flags = p.flags[b];
@@ -177,12 +183,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     const int ts0 = p.timestep[b];
 
     if (flags & SLAM_INST_INDEX_OOR) {
-        // frozen instance (the reference node died here, filter.h:5): carry the state into the other buffer
-        if (Pfinal != PA) {
-            const int nn = n_init * n_init;
-            for (int i = tid; i < nn; i += TPB) Pfinal[i] = PA[i];
-        }
-        return;
+        return;   // frozen instance (the reference node died here, filter.h:5): the state stays as it is
     }
 
 #pragma unroll
@@ -318,9 +319,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-    const ST* __restrict__ Pin = (t & 1) ? PB : PA;
-    ST* __restrict__ Pout = (t & 1) ? PA : PB;
-    double* __restrict__ Pmid = kWide ? reinterpret_cast<double*>(Pout) : (p.scratch + (size_t)b * p.pstride);
+    const ST* const Pin = Pcur;
     const int pb = t & 1;
     const float* const meas_t = s_meas + pb * 3 * KCAP;
     int* const didx_t = s_didx + pb * KCAP;
@@ -353,6 +352,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     SLAM_STAMP(2);   // association
     int nf = n_old + 2 * n_ins;           // leading dimension of the matrix written this step
     nf = nf < NMAX ? nf : NMAX;
+    ST* const Pout = (nf != n_old) ? (Pcur == PA ? PB : PA) : Pcur;   // in place unless the layout changes
+    double* const Pmid = kWide ? reinterpret_cast<double*>(Pout) : (p.scratch + (size_t)b * p.pstride);
 
     // x_pred of the vehicle (ekf.cpp:56-59) was computed by the pre-step; it is needed before the first group because
     // unknown-id association (ekf.cpp:82-98) projects detections with the PREDICTED pose.  The covariance part of the
@@ -719,9 +720,33 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             }
             if (t + 1 < T) prestep(t + 1);
         }
+        // ---- no update and no insertion in this step (no detection in range, or all dropped): the prediction is the
+        //      only change, and it touches rows / columns 0, 1 and (2,2) only (ekf.cpp:61 with the sparse F_x, F_v).
+        //      P is updated in place, so the rest of the matrix is already where it belongs: write the three vehicle
+        //      rows and columns from their LDS copies and skip the stream. ----
+        const bool skip_stream = first && l1 >= k && nu == 0 && Pout == Pin && !(p.dbg & 16);
+        if (skip_stream) {
+            const int tsk = opaque(tid);
+#pragma unroll 1
+            for (int i = tsk; i < 3 * nf; i += TPB) {
+                const int r = i / nf, c = i - r * nf;
+                const ST sv = (ST)s_R[r * LDP + c];                       // P[r][c], r < 3
+                const unsigned ha = hi_abs((double)sv);
+                hiacc = hiacc > ha ? hiacc : ha;
+                Pout[(size_t)r * nf + c] = sv;
+            }
+#pragma unroll 1
+            for (int i = tsk; i < 3 * (nf - 3); i += TPB) {
+                const int c = i / (nf - 3), r = 3 + (i - c * (nf - 3));
+                const ST sv = (ST)s_C[c * LDP + r];                       // P[r][c], c < 3 <= r
+                const unsigned ha = hi_abs((double)sv);
+                hiacc = hiacc > ha ? hiacc : ha;
+                Pout[(size_t)r * nf + c] = sv;
+            }
+        }
         // ---- BULK (fp64 storage): stream P once.  dst pair q = elements 2q, 2q+1 of the nf-leading-dimension
         //      layout; later groups of the same step update P_out in place. ----
-        if constexpr (kWide) {
+        if constexpr (kWide) if (!skip_stream) {
             const double* src = first ? reinterpret_cast<const double*>(Pin) : reinterpret_cast<const double*>(Pout);
             const int nn2 = nf * nf;
             const int npair = (p.dbg & 1) ? 0 : (nn2 + 1) >> 1;
@@ -795,7 +820,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         //      vector loads from P, vector stores to P_out with storage rounding.  With several groups in one step
         //      the intermediate matrix stays fp64 in the scratch slab (element-wise access), so rounding to float
         //      happens exactly once per step. ----
-        if constexpr (!kWide) {
+        if constexpr (!kWide) if (!skip_stream) {
             const bool src_mid = !first;            // read the previous group's result (fp64 scratch)
             const bool dst_mid = (l1 < k);          // more groups follow: keep fp64
             const int nn2 = nf * nf;
@@ -962,7 +987,14 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
     }
     if ((p.dbg & 32) && p.prof != nullptr && tid == 0 && t < 16) p.prof[(size_t)blockIdx.x * 16 + t] = wall_clock64();
+    Pcur = Pout;
     }   // timestep loop
+
+    if (Pcur != Pfinal) {   // an odd number of layout changes in this launch: bring P_t back to the host's buffer
+        __syncthreads();
+        const int nn = na * na;
+        for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pcur[i];
+    }
 
     finish(T, M, flags);
     SLAM_STAMP(8);   // epilogue

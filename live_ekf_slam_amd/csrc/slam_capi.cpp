@@ -55,7 +55,7 @@ struct slam_handle {
     uint32_t step = 0;
     double range_max, fov_min, fov_max;
     // device buffers
-    void* dP = nullptr; void* dP2 = nullptr;   // dP = current P_t, dP2 = next (ping-pong); fp64 or fp32 elements
+    void* dP = nullptr; void* dP2 = nullptr;   // dP = current P_t; dP2 = second buffer (EKF: layout changes, UKF: ping-pong)
     void* dx = nullptr; int esz = 8;           // x_t; element size of P / x storage
     double* dscratch = nullptr;                // fp32 storage: fp64 slab for P between detection groups
     int32_t* dM = nullptr; int32_t* dids = nullptr;
@@ -142,8 +142,8 @@ int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas
         HIP_TRY(slam::launch_ukf_sqrt(p, h->stream));   // nearestSPD + sqrt (ukf.cpp:106-123,208)
         HIP_TRY(slam::launch_ukf_step(p, h->stream));   // predictionStage + updateStage (ukf.cpp:197-372)
     }
-    std::swap(h->dP, h->dP2);   // the kernel wrote the next P_t into the other buffer
-    h->step += 1;
+    if (h->kind != SLAM_EKF_SLAM) std::swap(h->dP, h->dP2);   // UKF: the kernel wrote the next P_t into the other buffer
+    h->step += 1;                                              // (the EKF kernel updates dP in place)
     return SLAM_OK;
 }
 
@@ -473,7 +473,6 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
         p.cmds = h->dcmds + 2 * (size_t)t0;
         p.T = tc;
         HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
-        if (tc & 1) std::swap(h->dP, h->dP2);
         h->step += (uint32_t)tc;
     }
     return SLAM_OK;
