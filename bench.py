@@ -352,7 +352,10 @@ def main():
                                                                           "true" if spl > 1 else "false"),
                          "kernel_ms": round(kernel_ms, 4), "launches": n_launch, "steps_per_launch": min(spl, K),
                          "algorithmic_bytes_per_launch": launch_bytes,
-                         "algorithmic_bytes_per_step": alg_bytes},
+                         "algorithmic_bytes_per_step": alg_bytes,
+                         "note": "algorithmic = 2(n^2+n)*s per instance-step (SURVEY 8d); steps without an update or "
+                                 "insertion write only their vehicle rows/columns (P is updated in place), so the PMC "
+                                 "traffic (profiles/r01l) is below the algorithmic bytes"},
         }
         if world == 1 and not args.no_cpu_baseline:
             lmc, cmdc = make_scenario(1234, L, 260)
