@@ -124,7 +124,7 @@ def test_sim_step_parity(S, oracle, monkeypatch, L, T, B, wpf):
 
 
 @pytest.mark.parametrize("L,T,B,chunk,dtype,idknown,wide", [
-    (50, 301, 96, 0, "f64", 1, 0),      # the whole run in one launch (odd T: result lands in the other buffer)
+    (50, 301, 96, 0, "f64", 1, 0),      # the whole run in one launch (insertion steps switch buffers, the rest is in place)
     (50, 300, 64, 7, "f64", 1, 1),      # odd chunks + a wide-sensor step inside a chunk (k = 50 > KG: several groups)
     (20, 250, 64, 16, "f64", 0, 0),     # unknown-id association (over-provisioned leading dimension, re-pack)
     (50, 200, 48, 0, "f32", 1, 1),      # fp32 storage: resident thin rows must carry the storage rounding
@@ -132,7 +132,7 @@ def test_sim_step_parity(S, oracle, monkeypatch, L, T, B, wpf):
 ])
 def test_run_sim_multistep_launch_parity(S, oracle, monkeypatch, L, T, B, chunk, dtype, idknown, wide):
     """slam_run_sim runs many timesteps per launch (x_t, ids, true pose and the thin rows/cols of P stay on chip,
-    P ping-pongs between its two buffers): same bits as the oracle, whatever the chunking."""
+    P is updated in place except on insertion steps, which switch buffers): same bits as the oracle, whatever the chunking."""
     from live_ekf_slam_amd.scenario import make_scenario
     monkeypatch.setenv("SLAM_RUN_CHUNK", str(chunk))
     lm, cmds = make_scenario(4321, L, T)
@@ -152,6 +152,32 @@ def test_run_sim_multistep_launch_parity(S, oracle, monkeypatch, L, T, B, chunk,
         assert sg["timestep"] == T or r["flags"][b] != 0
         _assert_state_equal(sg, dict(M=r["M"][b], ids=r["ids"][b, :r["M"][b]], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
     assert r["M"].max() > 3
+    f.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_steps_without_detections_skip_the_stream(S, oracle, dtype):
+    """A blind sensor for 40 steps in the middle of a run: those steps change only what the prediction touches (rows and
+    columns 0, 1 and (2,2) of P, ekf.cpp:61) and the kernel writes just the vehicle rows / columns in place; before and
+    after, the ordinary stream.  Same bits as the oracle, which recomputes the full matrix every step."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, T = 20, 40, 110
+    lm, cmds = make_scenario(777, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1))
+    vis[0] = [1e9, -4.0, 4.0]          # map everything at once
+    vis[35:75] = [1e-6, -1.57, 1.57]   # nothing in range
+    f = S.BatchedEKF(B, L, dtype=S.F32 if dtype == "f32" else S.F64).readParams()
+    f.set_map(lm); f.set_seed(5); f.set_instance_offset(9); f.init(0, 0, 0)
+    t = 0
+    for t1, v in ((1, vis[0]), (35, vis[1]), (75, vis[35]), (T, vis[75])):
+        f.set_vision(*v); f.run_sim(cmds[t:t1]); t = t1
+    mode = oracle.MODE_FAST | (oracle.STORAGE_F32 if dtype == "f32" else 0)
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=5, inst0=9, nthreads=8, mode=mode, vision=vis)
+    assert np.all(r["M"] == L) and np.array_equal(f.landmark_counts(), r["M"])
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.status(), r["flags"])
+    for b in range(B):
+        n = 3 + 2 * L
+        _assert_state_equal(f.get_state(b), dict(M=L, ids=r["ids"][b, :L], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
     f.close()
 
 
