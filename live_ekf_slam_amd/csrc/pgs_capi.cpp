@@ -42,9 +42,10 @@ struct pgs_handle {
     std::vector<hipStream_t> gstreams;
     std::vector<hipEvent_t> gevents;
     int32_t* h_active = nullptr;               // pinned host: per-group active counts
-    bool p_notrim = false;
+    int p_notrim = 0;
     int chol_threads = 0, chol_switch = 256;   // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces; else 256 while > chol_switch instances are active
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
+    int syrk_inst_switch = 160;                  // SLAM_PGS_SYRK_INST_SWITCH: active count from which the instance-resident SYRK runs (SLAM_PGS_SYRK_TILE=1 forces it)
     int syrk_tile = 0, syrk_switch = 1 << 30;    // SLAM_PGS_SYRK_TILE = 32 | 64 forces a variant; SLAM_PGS_SYRK_SWITCH = active count from which
                                              // the 64x64-per-wavefront variant is used (default: never — measured slower at every batch size)
     int last_trials = 0;
@@ -103,10 +104,11 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     h->cfg = *cfg; h->B = batch; h->N_max = N_max; h->L_max = L_max; h->KP = k_per_pose; h->device = device;
     h->LD = round_up(2 * L_max + 1, 64);
     if (const char* e = getenv("SLAM_PGS_MAX_TRIALS")) h->max_trials = atoi(e) > 0 ? atoi(e) : h->max_trials;
-    if (const char* e = getenv("SLAM_PGS_SYRK_TILE")) h->syrk_tile = atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0);
+    if (const char* e = getenv("SLAM_PGS_SYRK_TILE")) h->syrk_tile = atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : (atoi(e) == 1 ? 1 : 0));
+    if (const char* e = getenv("SLAM_PGS_SYRK_INST_SWITCH")) h->syrk_inst_switch = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
     h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
-    h->p_notrim = getenv("SLAM_PGS_NOTRIM") != nullptr;
+    if (const char* e = getenv("SLAM_PGS_NOTRIM")) h->p_notrim = atoi(e) ? atoi(e) : 1;
     if (const char* e = getenv("SLAM_PGS_GROUPS")) h->groups = atoi(e);
     if (const char* e = getenv("SLAM_PGS_CHOL_THREADS")) h->chol_threads = atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0);
     if (const char* e = getenv("SLAM_PGS_CHOL_SWITCH")) h->chol_switch = atoi(e);
@@ -252,10 +254,13 @@ namespace {
 
 // one tryLambda of the instances [p.b_off, p.b_off + p.b_cnt) on `stream`
 int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, hipStream_t stream, int trial_index, bool profile) {
-    p.syrk_notrim = h->p_notrim ? 1 : 0;
+    p.syrk_notrim = h->p_notrim;
     p.chol_threads = h->chol_threads ? h->chol_threads : (active_hint > h->chol_switch ? 256 : 1024);
     // 32x32 wavefront tiles by default; the 64x64 variant (more operand reuse, 4x fewer wavefronts) is kept for tuning
     p.syrk_wave_tile = h->syrk_tile ? h->syrk_tile : (active_hint >= h->syrk_switch ? 64 : 32);
+    // instance-resident accumulators (tile code 1) from syrk_inst_switch active instances; its staging registers are sized for LD <= 448
+    if ((h->syrk_tile == 1 || (!h->syrk_tile && active_hint >= h->syrk_inst_switch)) && p.LD <= 448) p.syrk_wave_tile = 1;
+    else if (p.syrk_wave_tile == 1) p.syrk_wave_tile = 32;
     HIP_TRY(hipMemsetAsync(p.n_active, 0, sizeof(int32_t), stream));
     for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
         if (profile) {

@@ -675,6 +675,136 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
             }
 }
 
+// S_ext with INSTANCE-RESIDENT accumulators (the default from a few dozen active instances): SI_NB workgroups of 16
+// wavefronts per instance hold the whole lower triangle of S_ext in registers (32x32 tiles dealt round-robin, in order
+// of their first non-zero row, to the 16 * SI_NB wavefronts: at most SI_NS tiles = 64 accumulator VGPRs each) and
+// stream Y through double-buffered LDS chunks of SI_ROWS rows, every row of Y read ONCE per workgroup with 16-byte
+// loads that are issued a chunk ahead.  The tile kernel above re-reads Y per tile and leaves the sharing to L2, which
+// it does not get (27 % hit rate, 62 % of the wavefront cycles waiting on misses, profiles/r01m_pgs_cache).
+// LDS row stride = columns + 16 doubles: the four k rows of an MFMA operand (lanes 16 apart) then sit 128 bytes apart
+// in bank space, so the 8-byte fragment reads are conflict-free.  The workgroups of one instance get ids on the same
+// XCD and march through Y in step, so all but the first read L2.
+constexpr int SI_ROWS = 16, SI_NB = 3, SI_NS = 2, SI_TPB = 1024;
+__global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p) {
+    extern __shared__ double s_y[];   // [2][SI_ROWS][ldl]
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int bl = (q / SI_NB) * 8 + xcd, hb = q % SI_NB;
+    if (bl >= p.b_cnt) return;
+    const int b = bl + p.b_off;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int LD = p.LD, m2 = 2 * p.M[b];
+    int ncol = (m2 + 1 + 31) & ~31;               // columns that hold data (incl. the z column), in 32-wide tiles
+    if (ncol > LD) ncol = LD;
+    const int ldl = ncol + 16;
+    const int nt = ncol / 32, ntile = nt * (nt + 1) / 2;
+    if (hb >= ntile) return;                      // small graphs: this workgroup holds no tile
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, cl = lane & 15;
+    const int gw = w * SI_NB + hb;                // wavefront number within the instance
+    const int K3 = 3 * p.N;
+    const int nchunk = (K3 + SI_ROWS - 1) / SI_ROWS;
+    const double* Yb = p.Y + (size_t)b * p.y_stride;
+
+    int rowbase[SI_NS], colbase[SI_NS], c0[SI_NS];
+    bool have[SI_NS];
+    dbl4_t acc[SI_NS][2][2];
+#pragma unroll
+    for (int s = 0; s < SI_NS; ++s) {
+        const int t = gw + 16 * SI_NB * s;
+        have[s] = t < ntile;
+        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (ti * (ti + 1) / 2 > t) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        const int tj = t - ti * (ti + 1) / 2;
+        rowbase[s] = have[s] ? 32 * ti : 0; colbase[s] = have[s] ? 32 * tj : 0;
+        // rows of Y^T are zero before the first detection of their landmark; landmarks are numbered by first detection
+        c0[s] = 0;
+        if (have[s] && rowbase[s] + 31 < m2 && !(p.syrk_notrim & 1)) c0[s] = (3 * p.lm_first[(size_t)b * p.L_max + (rowbase[s] >> 1)]) / SI_ROWS;
+        if (!have[s]) c0[s] = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[s][i][j] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+    }
+
+    // staging: a chunk is SI_ROWS x ncol doubles = SI_ROWS * ncol / 2 16-byte vectors
+    const int vpr = ncol >> 1;                    // vectors per row
+    const int nvec = SI_ROWS * vpr;
+    constexpr int NV = (SI_ROWS * (448 / 2) + SI_TPB - 1) / SI_TPB;   // LD <= 448
+    typedef double dbl2v __attribute__((ext_vector_type(2)));
+    dbl2v stage[NV];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v = tid + SI_TPB * u;
+            const int r = v / vpr, cv = v - r * vpr;
+            const int k = c * SI_ROWS + r;
+            stage[u] = (dbl2v){0.0, 0.0};
+            if (v < nvec && k < K3) stage[u] = *reinterpret_cast<const dbl2v*>(Yb + (size_t)k * LD + 2 * cv);
+        }
+    };
+    auto put = [&](int buf) {
+        double* dst = s_y + (size_t)buf * SI_ROWS * ldl;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v = tid + SI_TPB * u;
+            const int r = v / vpr, cv = v - r * vpr;
+            if (v < nvec) *reinterpret_cast<dbl2v*>(dst + r * ldl + 2 * cv) = stage[u];
+        }
+    };
+    fetch(0);
+    put(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk && !(p.syrk_notrim & 4)) fetch(c + 1);
+        const double* src = s_y + (size_t)(c & 1) * SI_ROWS * ldl + kq * ldl + cl;
+#pragma unroll
+        for (int s = 0; s < SI_NS; ++s) {
+            if (c < c0[s] || (p.syrk_notrim & 2)) continue;               // wave-uniform
+            const double* sa = src + rowbase[s];
+            const double* sb = src + colbase[s];
+#pragma unroll
+            for (int ks = 0; ks < SI_ROWS / 4; ++ks) {
+                const double a0 = sa[ks * 4 * ldl], a1 = sa[ks * 4 * ldl + 16];
+                const double b0 = sb[ks * 4 * ldl], b1 = sb[ks * 4 * ldl + 16];
+                acc[s][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[s][0][0], 0, 0, 0);
+                acc[s][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[s][0][1], 0, 0, 0);
+                acc[s][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[s][1][0], 0, 0, 0);
+                acc[s][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[s][1][1], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunk) put((c + 1) & 1);
+        __syncthreads();
+    }
+    const double lambda = p.lambda[b];
+    const double* Db = p.D + (size_t)b * p.L_max * 3;
+    const double* glb = p.gl + (size_t)b * p.L_max * 2;
+    double* Sb = p.S + (size_t)b * LD * LD;
+#pragma unroll
+    for (int s = 0; s < SI_NS; ++s) {
+        if (!have[s]) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int r = rowbase[s] + 16 * i + kq + 4 * r4;   // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg
+                    const int cc = colbase[s] + 16 * j + cl;
+                    if (r > m2 || cc > r) continue;
+                    double v = -acc[s][i][j][r4];
+                    if (r < m2) {
+                        if (cc == r) v += Db[3 * (r >> 1) + ((r & 1) ? 2 : 0)] + lambda;
+                        else if ((cc >> 1) == (r >> 1)) v += Db[3 * (r >> 1) + 1];
+                    } else if (cc < m2) {
+                        v += glb[cc];
+                    }
+                    Sb[(size_t)r * LD + cc] = v;
+                }
+    }
+}
+
 // Dense blocked Cholesky of S (2M x 2M, lower, in place; the right-hand-side row 2M rides along as one more panel row,
 // which IS the forward substitution) followed by the blocked backward substitution; dl = S^-1 rhs.
 // CTPB threads per instance: 1024 when few instances are active (the factorisation is a chain of short latency-bound
@@ -1147,6 +1277,15 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p); break;
     case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.b_cnt), dim3(64 + p.LD), 0, s, p); break;
     case 2: {
+        if (p.syrk_wave_tile == 1) {   // instance-resident accumulators
+            static std::once_flag attr_once2;
+            std::call_once(attr_once2, []() {
+                (void)hipFuncSetAttribute((const void*)pgs_syrk_inst_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            });
+            const size_t lds = sizeof(double) * 2 * SI_ROWS * (size_t)(p.LD + 16);
+            hipLaunchKernelGGL(pgs_syrk_inst_kernel, dim3(8 * SI_NB * ((p.b_cnt + 7) / 8)), dim3(SI_TPB), lds, s, p);
+            break;
+        }
         if (p.syrk_wave_tile == 64) {
             const int nt = (p.LD + 127) / 128;
             hipLaunchKernelGGL(pgs_syrk_kernel<64>, dim3(8 * (nt * (nt + 1) / 2) * ((p.b_cnt + 7) / 8)), dim3(256), 0, s, p);

@@ -239,3 +239,22 @@ def test_solve_groups_do_not_change_results():
             assert np.array_equal(graphs[b]["landmarks"], out[0][0][b]["landmarks"])
         for key in ("iterations", "trials", "flags", "err_final", "lam"):
             assert np.array_equal(st[key], out[0][1][key])
+
+
+@pytest.mark.parametrize("L,T", [(20, 150), (60, 400)])
+def test_syrk_variants_agree_with_the_oracle(monkeypatch, oracle, L, T):
+    """The Schur complement has two kernels: 64x64 tiles (few active instances) and instance-resident accumulators with
+    Y streamed through LDS (many).  Forced one at a time (SLAM_PGS_SYRK_TILE), both reproduce the oracle's LM path
+    (same iteration and trial counts, _compare) and its result within the usual tolerance."""
+    import live_ekf_slam_amd as S
+    KP, B = 8, 12
+    lm, cmds = make_scenario(21, L, T)
+    cfg = default_config()
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=6, cfg=cfg, nthreads=8)
+    for tile in ("32", "1"):
+        monkeypatch.setenv("SLAM_PGS_SYRK_TILE", tile)
+        pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+        pg.set_map(lm); pg.set_seed(6); pg.init(0.0, 0.0, 0.0)
+        pg.run_sim(cmds); pg.solvePoseGraph()
+        _compare(pg, r, B)
+        pg.close()
