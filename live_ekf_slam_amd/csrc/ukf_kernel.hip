@@ -97,7 +97,9 @@ __device__ __forceinline__ void rr_pair(int k, int t, int n, int& p, int& q) {
 // ------------------------------------------------------------------------------------------------------------------
 // nearestSPD + sqrt
 // ------------------------------------------------------------------------------------------------------------------
-template <int NMAX, int TPB>
+// PROF = true compiles the phase timers in (a separate instantiation, launched only when the debug buffer is attached:
+// as a run-time option they cost the production kernel 20 VGPRs = one wavefront per SIMD of occupancy, -9 % steps/s).
+template <int NMAX, int TPB, bool PROF = false>
 __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     constexpr int MMAX = NMAX / 2;
     __shared__ double sA[NMAX * (NMAX + 1) / 2];   // packed lower triangle: A(r,c), r >= c, at r(r+1)/2 + c
@@ -114,6 +116,11 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     double* __restrict__ Sq = p.sqtP + (size_t)b * p.pstride;
     auto AT = [&](int r, int c) -> double& { return r >= c ? sA[r * (r + 1) / 2 + c] : sA[c * (c + 1) / 2 + r]; };
 
+    // phase timers (debug, SLAM_DEBUG_FLAGS & 4): slots 10..15 of the [B][16] buffer whose slots 0..9 the step kernel fills.
+    // tid 0 stamps right after a barrier, so a delta is one whole barrier-to-barrier phase as wavefront 0 sees it.
+    unsigned long long sacc[PROF ? 6 : 1] = {0}, sprev = 0ull;
+    if constexpr (PROF) sprev = wall_clock64();
+#define SQ_STAMP(i) do { if constexpr (PROF) { if (tid == 0) { const unsigned long long now_ = wall_clock64(); sacc[i] += now_ - sprev; sprev = now_; } } } while (0)
     const float scale_f = (float)(2 * M + 4) / (1 - kW0);   // ukf.cpp:114, evaluated in float
     const double scale = (double)scale_f;
     // Warm start: the eigenvectors of the previous timestep (extended by the identity for landmarks inserted since)
@@ -150,6 +157,7 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
         __syncthreads();
     }
     const int tiny_from = warm ? 0 : 3;
+    SQ_STAMP(0);   // load, symmetrise, warm-start transform
 
     const int nb = m * (m - 1) / 2;
     const int items = nb + m + m * n;
@@ -204,7 +212,9 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     if (!(sweep >= tiny_from && (app + g == app) && (aqq + g == aqq))) live = 1;
                 }
             }
-        if (!__syncthreads_or(live)) { converged = true; break; }
+        const int any_live = __syncthreads_or(live);
+        SQ_STAMP(1);   // convergence check
+        if (!any_live) { converged = true; break; }
 #pragma unroll 1
         for (int t = 0; t < n - 1; ++t) {
             if (tid < m) {  // rotation parameters of this round's pairs (round-robin: position 0 fixed)
@@ -229,6 +239,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                 s_csn[k] = make_double2(c, s);
             }
             __syncthreads();
+            SQ_STAMP(2);   // rotation parameters (22 lanes of wavefront 0) + barrier
+            if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
             if constexpr (kFast) {
                 // ---- V row-pairs of pair iv: operands first ----
                 int vpi, vqi;
@@ -317,6 +329,7 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                 }
             }
             __syncthreads();
+            SQ_STAMP(3);   // rotation phase + barrier
         }
     }
     if (!converged) {
@@ -348,12 +361,20 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
         Sq[(size_t)c * n + r] = acc;
     }
     if (tid == 0) p.n_sq[b] = n;
+    SQ_STAMP(4);   // V^T store, sqrt(D), sqtP = V sqrt(D) V^T
+    if constexpr (PROF) {
+        if (p.prof && tid == 0)
+            for (int i = 0; i < 6; ++i) p.prof[(size_t)b * 16 + 10 + i] = sacc[i];
+    }
+#undef SQ_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // prediction + update
 // ------------------------------------------------------------------------------------------------------------------
-template <int NMAX, int TPB, int KU>
+// PROF: phase timers compiled in (own instantiation, launched only with the debug buffer attached; as a run-time option
+// the ten accumulators cost every variant 22 VGPRs of the production kernel).
+template <int NMAX, int TPB, int KU, bool PROF = false>
 __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     constexpr int LDN = NMAX + 2;
     constexpr int NS = 2 * NMAX + 1;
@@ -372,8 +393,9 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     __shared__ int s_misc[8];                 // k, n_upd, n_ins, capacity, singular
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x, lane = tid & 63;
-    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
-#define UKF_STAMP(i) do { if (p.prof && tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } while (0)
+    unsigned long long tacc[PROF ? 10 : 1] = {0}, tprev = 0ull;
+    if constexpr (PROF) tprev = wall_clock64();
+#define UKF_STAMP(i) do { if constexpr (PROF) { if (tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } } while (0)
     int flags = p.flags[b];
     const int M_old = p.M[b];
     const int n = 4 + 2 * M_old, ns = 2 * n + 1;
@@ -702,8 +724,10 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
         }
     }
     UKF_STAMP(8);
-    if (p.prof && tid == 0)
-        for (int i = 0; i < 10; ++i) p.prof[(size_t)b * 16 + i] = tacc[i];
+    if constexpr (PROF) {
+        if (p.prof && tid == 0)
+            for (int i = 0; i < 10; ++i) p.prof[(size_t)b * 16 + i] = tacc[i];
+    }
 #undef UKF_STAMP
 }
 
@@ -723,13 +747,19 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
         switch (env_tpb(0, 256)) {
             case 128: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 128>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;
             case 64: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 64>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
+            default:
+                if (p.prof) hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, true>), dim3(p.b_cnt), dim3(256), 0, stream, p);
+                else hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p);
+                break;
         }
     } else if (nmax <= 104) {
         switch (env_tpb(0, 1024)) {
             case 512: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 512>), dim3(p.b_cnt), dim3(512), 0, stream, p); break;
             case 256: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024>), dim3(p.b_cnt), dim3(1024), 0, stream, p); break;
+            default:
+                if (p.prof) hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024, true>), dim3(p.b_cnt), dim3(1024), 0, stream, p);
+                else hipLaunchKernelGGL((ukf_sqrt_kernel<104, 1024>), dim3(p.b_cnt), dim3(1024), 0, stream, p);
+                break;
         }
     } else {
         return hipErrorInvalidValue;
@@ -743,13 +773,19 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
         switch (env_tpb(1, 128)) {
             case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
             case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;   // 2 x 4 tiles
-            default: hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;    // measured best
+            default:   // measured best
+                if (p.prof) hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8, true>), dim3(p.b_cnt), dim3(128), 0, stream, p);
+                else hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.b_cnt), dim3(128), 0, stream, p);
+                break;
         }
     } else if (nmax <= 104) {
         switch (env_tpb(1, 1024)) {
             case 256: hipLaunchKernelGGL((ukf_step_kernel<104, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
             case 512: hipLaunchKernelGGL((ukf_step_kernel<104, 512, 8>), dim3(p.b_cnt), dim3(512), 0, stream, p); break;
-            default: hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.b_cnt), dim3(1024), 0, stream, p); break;
+            default:
+                if (p.prof) hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8, true>), dim3(p.b_cnt), dim3(1024), 0, stream, p);
+                else hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.b_cnt), dim3(1024), 0, stream, p);
+                break;
         }
     } else {
         return hipErrorInvalidValue;
