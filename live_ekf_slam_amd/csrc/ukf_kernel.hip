@@ -613,25 +613,72 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
                     for (int a = 0; a < TR; ++a)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
-                    double xr[TR], xc[4];
+                    // X_pred(r, i) is sX4[r][i] for the four pose rows and x_t[r] +- sqtP[i-1 (-n)][r] for the landmark rows
+                    // (ukf.cpp:214-226).  The sigma points are walked in their three uniform ranges (i = 0, 1..n, n+1..2n: the
+                    // same order, the same operations per term as one loop with a case distinction per element), what does not
+                    // depend on i is hoisted, and both candidate operands of an element are read unconditionally and selected,
+                    // so the LDS reads of an iteration (and of the next, unrolled) issue together instead of one dependent
+                    // round trip per element behind per-lane branches.
+                    double xr[TR], xc[4], br[TR], bc[4];
+                    int ir[TR], ic[4];
+                    bool vr[TR], vc[4], pr[TR], pc[4];
 #pragma unroll
-                    for (int a = 0; a < TR; ++a) xr[a] = r0 + a < n ? s_xp0[r0 + a] : 0.0;
+                    for (int a = 0; a < TR; ++a) {
+                        vr[a] = r0 + a < n; ir[a] = vr[a] ? r0 + a : 0; pr[a] = ir[a] < 4;
+                        xr[a] = vr[a] ? s_xp0[ir[a]] : 0.0; br[a] = s_xt[ir[a]];
+                    }
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) xc[a] = c0 + a < n ? s_xp0[c0 + a] : 0.0;
-#pragma unroll 1
-                    for (int i = 0; i < ns; ++i) {
-                        const double w = i == 0 ? w0 : wi;
-                        double dr[TR], dc[4];
-#pragma unroll
-                        for (int a = 0; a < TR; ++a) dr[a] = r0 + a < n ? xpred_elem(r0 + a, i) - xr[a] : 0.0;
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) dc[a] = c0 + a < n ? xpred_elem(c0 + a, i) - xc[a] : 0.0;
+                    for (int a = 0; a < 4; ++a) {
+                        vc[a] = c0 + a < n; ic[a] = vc[a] ? c0 + a : 0; pc[a] = ic[a] < 4;
+                        xc[a] = vc[a] ? s_xp0[ic[a]] : 0.0; bc[a] = s_xt[ic[a]];
+                    }
+                    auto accumulate = [&](const double w, const double (&dr)[TR], const double (&dc)[4]) {
 #pragma unroll
                         for (int a = 0; a < TR; ++a) {
                             const double wd = w * dr[a];
 #pragma unroll
                             for (int c = 0; c < 4; ++c) acc[a][c] = acc[a][c] + wd * dc[c];
                         }
+                    };
+                    {   // i = 0: the mean point
+                        double dr[TR], dc[4];
+#pragma unroll
+                        for (int a = 0; a < TR; ++a) { const double x4 = sX4[(pr[a] ? ir[a] : 0) * ns]; dr[a] = vr[a] ? (pr[a] ? x4 : br[a]) - xr[a] : 0.0; }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) { const double x4 = sX4[(pc[a] ? ic[a] : 0) * ns]; dc[a] = vc[a] ? (pc[a] ? x4 : bc[a]) - xc[a] : 0.0; }
+                        accumulate(w0, dr, dc);
+                    }
+#pragma unroll 2
+                    for (int i = 1; i <= n; ++i) {   // x_t + column i-1 of sqtP
+                        const double* Srow = sS + (size_t)(i - 1) * n;
+                        double dr[TR], dc[4];
+#pragma unroll
+                        for (int a = 0; a < TR; ++a) {
+                            const double x4 = sX4[(pr[a] ? ir[a] : 0) * ns + i], sv = Srow[ir[a]];
+                            dr[a] = vr[a] ? (pr[a] ? x4 : br[a] + sv) - xr[a] : 0.0;
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const double x4 = sX4[(pc[a] ? ic[a] : 0) * ns + i], sv = Srow[ic[a]];
+                            dc[a] = vc[a] ? (pc[a] ? x4 : bc[a] + sv) - xc[a] : 0.0;
+                        }
+                        accumulate(wi, dr, dc);
+                    }
+#pragma unroll 2
+                    for (int i = n + 1; i < ns; ++i) {   // x_t - column i-1-n of sqtP
+                        const double* Srow = sS + (size_t)(i - 1 - n) * n;
+                        double dr[TR], dc[4];
+#pragma unroll
+                        for (int a = 0; a < TR; ++a) {
+                            const double x4 = sX4[(pr[a] ? ir[a] : 0) * ns + i], sv = Srow[ir[a]];
+                            dr[a] = vr[a] ? (pr[a] ? x4 : br[a] - sv) - xr[a] : 0.0;
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const double x4 = sX4[(pc[a] ? ic[a] : 0) * ns + i], sv = Srow[ic[a]];
+                            dc[a] = vc[a] ? (pc[a] ? x4 : bc[a] - sv) - xc[a] : 0.0;
+                        }
+                        accumulate(wi, dr, dc);
                     }
 #pragma unroll
                     for (int a = 0; a < TR; ++a)
