@@ -391,7 +391,22 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
     for (int j = tid; j < M; j += TPB) {   // landmark j: chronological sum over its factors (contiguous event records)
         double d0 = 0, d1 = 0, d2 = 0, g0 = 0, g1 = 0;
         const int e1 = evt_start[j + 1];
-        for (int e = evt_start[j]; e < e1; ++e) {
+        int e = evt_start[j];
+        // The additions stay in chronological order (the oracle's order), the LOADS do not have to wait for them: the
+        // records of a landmark are contiguous, so eight events are fetched at once.  One event per iteration meant one
+        // global round trip per event, serially, for the most observed landmark (the ISA had vmcnt(0) in every iteration).
+        constexpr int UB = 8;
+#pragma unroll 1
+        for (; e + UB <= e1; e += UB) {
+            double w[UB][5];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) w[u][c] = Wlb[5 * (size_t)(e + u) + c];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { d0 += w[u][0]; d1 += w[u][1]; d2 += w[u][2]; g0 += w[u][3]; g1 += w[u][4]; }
+        }
+        for (; e < e1; ++e) {
             const double* W = Wlb + 5 * (size_t)e;
             d0 += W[0]; d1 += W[1]; d2 += W[2]; g0 += W[3]; g1 += W[4];
         }
