@@ -511,11 +511,25 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     };
 
     // ---- weighted mean (ukf.cpp:228-232), sequential in i ----
+    // Same walk as the covariance pass below: the three uniform ranges of i in order (identical terms, identical order),
+    // x_t[r] hoisted, both candidate operands read unconditionally and selected, unrolled so the LDS reads run ahead of
+    // the serial chain of additions instead of one round trip per sigma point.
     for (int r = tid; r < n; r += TPB) {
+        const bool pose = r < 4;
+        const double xt = s_xt[r];
+        const double* X4 = sX4 + (pose ? r : 0) * ns;
         double acc = 0.0;
-        acc = acc + w0 * xpred_elem(r, 0);
-#pragma unroll 1
-        for (int i = 1; i < ns; ++i) acc = acc + wi * xpred_elem(r, i);
+        acc = acc + w0 * (pose ? X4[0] : xt);
+#pragma unroll 4
+        for (int i = 1; i <= n; ++i) {
+            const double x4 = X4[i], sv = sS[(i - 1) * n + r];
+            acc = acc + wi * (pose ? x4 : xt + sv);
+        }
+#pragma unroll 4
+        for (int i = n + 1; i < ns; ++i) {
+            const double x4 = X4[i], sv = sS[(i - 1 - n) * n + r];
+            acc = acc + wi * (pose ? x4 : xt - sv);
+        }
         s_xp0[r] = acc;
         s_xp[r] = acc;
     }
