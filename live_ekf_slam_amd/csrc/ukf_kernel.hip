@@ -129,10 +129,33 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     const int age = p.v_age[b], n_v = p.n_sq[b];
     const bool warm = age >= 0 && age < kWarmMaxAge && n_v > 0 && n_v <= n;
     double* Vs = p.Vt_store + (size_t)b * p.pstride;   // V0^T on entry; scratch for T once V0 sits in LDS; V^T on exit
-    for (int e = tid; e < n * n; e += TPB) {
-        const int r = e / n, c = e - r * n;
-        if (c <= r) sA[r * (r + 1) / 2 + c] = (0.5 * (Pb[(size_t)r * n + c] + Pb[(size_t)c * n + r])) * scale;
-        sVt[e] = (warm && r < n_v && c < n_v) ? Vs[(size_t)r * n_v + c] : ((r == c) ? 1.0 : 0.0);   // row r = eigenvector r
+    {   // the global loads of four elements are issued before the first value is used (a quarter of the memory round trips
+        // of one element at a time: the ISA had vmcnt(0) after each pair of loads).  Four, not all eight: the whole batch
+        // made this prologue the register peak of the kernel (100 VGPRs) and cost the 44/256 variant its fifth wavefront.
+        constexpr int NE = (NMAX * NMAX + TPB - 1) / TPB, NB4 = 4;
+#pragma unroll 1
+        for (int u0 = 0; u0 < NE; u0 += NB4) {
+            double pa[NB4], pb[NB4], pv[NB4];
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) {
+                const int e = tid + TPB * (u0 + u);
+                const bool in = e < n * n;
+                const int r = in ? e / n : 0, c = in ? e - r * n : 0;
+                const bool lower = in && c <= r, wv = in && warm && r < n_v && c < n_v;
+                pa[u] = lower ? Pb[(size_t)r * n + c] : 0.0;
+                pb[u] = lower ? Pb[(size_t)c * n + r] : 0.0;
+                pv[u] = wv ? Vs[(size_t)r * n_v + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) {
+                const int e = tid + TPB * (u0 + u);
+                if (e < n * n) {
+                    const int r = e / n, c = e - r * n;
+                    if (c <= r) sA[r * (r + 1) / 2 + c] = (0.5 * (pa[u] + pb[u])) * scale;
+                    sVt[e] = (warm && r < n_v && c < n_v) ? pv[u] : ((r == c) ? 1.0 : 0.0);   // row r = eigenvector r
+                }
+            }
+        }
     }
     __syncthreads();
     if (warm) {
@@ -151,7 +174,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
             while ((r + 1) * (r + 2) / 2 <= e) ++r;
             const int c = e - r * (r + 1) / 2;
             double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc = acc + sVt[r * n + k] * Vs[(size_t)k * n + c];
+#pragma unroll 11
+            for (int k = 0; k < n; ++k) acc = acc + sVt[r * n + k] * Vs[(size_t)k * n + c];   // T comes back from L2: many loads in flight, sums in order
             sA[e] = acc;
         }
         __syncthreads();
