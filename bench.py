@@ -71,7 +71,8 @@ def ukf_flops_per_step(n, sweeps, k):
 
 
 def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
-    """Secondary line: UKF-SLAM steps/s (BASELINE configs[2]: batch 4096, L=20).  Compute-bound (fp64 VALU / LDS)."""
+    """Secondary line: UKF-SLAM steps/s (BASELINE configs[2]: batch 4096, L=20).  Priced against the fp64 vector peak; by the
+    counters (profiles/r01n_ukf/pmc_summary.txt) the sqrt kernel is VALU-issue bound, the step kernel barrier/latency bound."""
     import live_ekf_slam_amd as S
     from live_ekf_slam_amd.scenario import make_scenario
     L, B, K, W, PRE = args.landmarks, args.batch, args.steps, args.warmup, min(args.preroll, 20)
@@ -113,7 +114,7 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
                        "parity": "bit-exact vs CPU oracle (tests/test_parity_ukf_gpu.py)"},
             "roofline": {"bound": "fp64-valu", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
                          "frac": round(flops / (step_ms * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
-                         "note": "algorithmic FLOPs (warm-started Jacobi: transform + 4 rotating sweeps) / step time of both kernels; LDS-bandwidth-bound, see DESIGN.md"}}
+                         "note": "algorithmic FLOPs (warm-started Jacobi: transform + 4 rotating sweeps) / step time of both kernels; sqrt kernel VALU-issue bound (69 % VALU utilisation, mostly index arithmetic), step kernel barrier/latency bound (profiles/r01n_ukf/pmc_summary.txt)"}}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         Tc = min(T, 131)
