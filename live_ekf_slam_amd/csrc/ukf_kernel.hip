@@ -5,8 +5,10 @@
 //                   SelfAdjointEigenSolver and MatrixFunctions sqrt; here: cyclic Jacobi in PARALLEL (round-robin)
 //                   ORDER entirely in LDS — A packed lower-triangular (exact symmetry by construction), V^T full —
 //                   n/2 disjoint rotations per round, every pair-block B' = R_i^T B R_j and every V row-pair an
-//                   independent work item.  This O(n^3 * sweeps) fp64 phase dominates the UKF; it is LDS / fp64-VALU
-//                   bound, not HBM bound.
+//                   independent work item.  This O(n^3 * sweeps) fp64 phase dominates the UKF (70 % of its GPU time); it
+//                   is not HBM bound but VALU-ISSUE bound: 69 % VALU utilisation, most of it index arithmetic and selects
+//                   around ~70 fp64 operations per wavefront-round (counters: profiles/r01n_ukf/pmc_summary.txt,
+//                   DESIGN.md §4.2 and §7 item 3).
 //  ukf_step_kernel  sigma points through the motion model, weighted mean and covariance (sequential in the sigma
 //                   index exactly like the reference's accumulation loops), all landmark updates (the reference never
 //                   redraws sigma points, so K and S of every update are independent of P), insertions, and ONE
