@@ -61,6 +61,31 @@ def test_ukf_sim_step_parity(S, oracle, L, T, B):
     f.close()
 
 
+@pytest.mark.parametrize("code,L,T,B", [
+    (1280256, 20, 70, 16),   # sqrt 128 threads (generic rotation path), step 256 threads (2 x 4 covariance tiles)
+    (640064, 20, 70, 12),    # one wavefront per instance in both kernels
+    (5120512, 50, 50, 8),    # n = 104: sqrt 512, step 512 (217 VGPRs, no spill; the 1024-thread default spills 69)
+    (2560256, 50, 50, 6),    # n = 104: sqrt 256 (256 VGPRs), step 256
+])
+def test_ukf_thread_count_variants_bit_exact(S, oracle, monkeypatch, code, L, T, B):
+    """The tuning variants behind SLAM_UKF_TPB = <sqrt threads> * 10000 + <step threads> are separate instantiations of the
+    same templates (other tile shapes, other item-to-thread maps, other register budgets): every one must give the
+    oracle's bits.  A wide first step maps all L landmarks, so the L = 50 cases run at the full state size n = 104."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    monkeypatch.setenv("SLAM_UKF_TPB", str(code))
+    lm, cmds = make_scenario(77, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]
+    f = S.BatchedUKF(B, L).readParams(); f.set_map(lm); f.set_seed(3); f.set_instance_offset(11); f.init(0, 0, 0)
+    f.set_vision(*vis[0]); f.run_sim(cmds[:1]); f.set_vision(*vis[1]); f.run_sim(cmds[1:])
+    r = oracle.run_ukf_batch(lm, cmds, B, L, seed=3, inst0=11, nthreads=8, vision=vis)
+    assert np.all(r["M"] == L) and np.array_equal(f.landmark_counts(), r["M"])
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.status(), r["flags"])
+    for b in range(B):
+        n = 4 + 2 * L
+        _eq(f.get_state(b), dict(M=L, ids=r["ids"][b, :L], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    f.close()
+
+
 def test_ukf_many_detections_and_config_switches(S, oracle):
     """k = 20 detections at once (> the 8 updates held per pass), non-zero noise means, double-trig switch, V/W quirk off."""
     from live_ekf_slam_amd.scenario import make_scenario
