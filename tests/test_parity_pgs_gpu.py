@@ -243,16 +243,20 @@ def test_solve_groups_do_not_change_results():
 
 @pytest.mark.parametrize("L,T", [(20, 150), (60, 400)])
 def test_syrk_variants_agree_with_the_oracle(monkeypatch, oracle, L, T):
-    """The Schur complement has two kernels: 64x64 tiles (few active instances) and instance-resident accumulators with
-    Y streamed through LDS (many).  Forced one at a time (SLAM_PGS_SYRK_TILE), both reproduce the oracle's LM path
-    (same iteration and trial counts, _compare) and its result within the usual tolerance."""
+    """The Schur complement has tile kernels (few active instances) and one with instance-resident accumulators and Y
+    streamed through LDS (many); the Cholesky has a 1024- and a 256-thread build.  Forced in combinations
+    (SLAM_PGS_SYRK_TILE, SLAM_PGS_CHOL_THREADS), all reproduce the oracle's LM path (same iteration and trial counts,
+    _compare) and its result within the usual tolerance."""
     import live_ekf_slam_amd as S
     KP, B = 8, 12
     lm, cmds = make_scenario(21, L, T)
     cfg = default_config()
     r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=6, cfg=cfg, nthreads=8)
-    for tile in ("32", "1"):
+    # SYRK: 32x32 tiles / 64x64 tiles / instance-resident accumulators; Cholesky: 1024 or 256 threads per instance (the
+    # 256-thread one is otherwise chosen only above 256 active instances, i.e. by no other test)
+    for tile, chol in (("32", "1024"), ("1", "1024"), ("64", "256"), ("1", "256")):
         monkeypatch.setenv("SLAM_PGS_SYRK_TILE", tile)
+        monkeypatch.setenv("SLAM_PGS_CHOL_THREADS", chol)
         pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
         pg.set_map(lm); pg.set_seed(6); pg.init(0.0, 0.0, 0.0)
         pg.run_sim(cmds); pg.solvePoseGraph()
