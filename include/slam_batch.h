@@ -157,6 +157,16 @@ int slam_state_dim_max(const slam_handle* h);
 /* Algorithmic HBM bytes of the last step summed over instances: sum_b 2*(n_b^2+n_b)*sizeof(storage)
  * (SURVEY.md §8d).  Computed on the device from the per-instance M; synchronises. */
 int slam_algorithmic_bytes(slam_handle* h, double* bytes);
+/* Workload statistics: instance-steps by the number of detections in their message (out[k] for k = 0..6, out[7] for
+ * k >= 7), accumulated by the EKF step kernel since slam_create or the last reset (ekf.cpp:65 `num_landmarks`).  The cost
+ * of EKF::update grows with k (one rank-2 downdate of P per detection, ekf.cpp:140), so a throughput figure is only
+ * meaningful together with this histogram.  Synchronises. */
+int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset);
+/* Build introspection: 1 if the library holds the EKF step-kernel tuning variant `variant` (code PIPE*1000 + W*100 + KG*10 +
+ * UNR, selected per handle by the environment variable SLAM_WAVES_PER_FILTER) for landmark capacity L_max and storage
+ * dtype; 0 = the default, always present.  Release builds hold the defaults only; asking a handle for a variant the build
+ * lacks makes its steps fail with SLAM_ERR_HIP. */
+int slam_variant_available(int L_max, int dtype, int variant);
 /* Diagnostics: evaluate the device's elementary functions on host arrays a[n], b[n]; out[8*n] =
  * {sin a, cos a, atan2(a,b), remainder(a,2pi), sqrt|a|, a/b, (double)(float)a, u53 noise} per element.
  * Used by the parity tests to prove the device math is bit-identical to the host's. */

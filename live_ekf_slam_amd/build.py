@@ -11,8 +11,18 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslam_hip.so")
-SOURCES = ["ekf_inst_103_238.hip", "ekf_inst_103_248.hip", "ekf_inst_103_424.hip", "ekf_inst_103_434.hip", "ekf_inst_103_444.hip", "ekf_inst_203_444.hip", "ekf_inst_103_444_f32.hip", "ekf_inst_103_448.hip", "ekf_inst_103_842.hip", "ekf_inst_43_148.hip", "ekf_inst_43_224.hip", "ekf_inst_43_124.hip", "ekf_inst_43_244.hip", "ekf_inst_43_244_f32.hip", "ekf_inst_43_248.hip", "ekf_inst_43_444.hip", "ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp"]
-HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h", "capi_internal.h", "../../include/slam_batch.h", "../../include/slam_pgs.h"]
+SOURCES = ["ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp"]
+HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h",
+           "capi_internal.h", "../../include/slam_batch.h", "../../include/slam_pgs.h"]
+# Instantiations of the EKF step kernel: (NMAX, W, KG, UNR, f32 storage, PIPE); variant code = PIPE*1000 + W*100 + KG*10 + UNR
+# (ekf_kernel.h).  The release library holds the defaults only (they must match SLAM_DEF_* in ekf_kernel.hip); the sweep
+# set is for tuning sessions: SLAM_SWEEP=1 python -m live_ekf_slam_amd.build --force
+EKF_DEFAULT_VARIANTS = [(43, 2, 4, 4, 0, 1), (43, 1, 2, 4, 0, 1), (103, 4, 4, 4, 0, 1), (203, 4, 4, 4, 0, 1),
+                        (43, 2, 4, 4, 1, 1), (103, 4, 4, 4, 1, 1)]
+EKF_SWEEP_VARIANTS = [(103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
+                      (103, 2, 4, 4, 0, 1), (103, 8, 4, 2, 0, 1), (103, 8, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1), (103, 4, 2, 4, 0, 1),
+                      (103, 4, 4, 4, 1, 0), (103, 4, 4, 8, 1, 1), (103, 4, 4, 2, 1, 1), (103, 2, 4, 4, 1, 1), (103, 8, 4, 2, 1, 1),
+                      (43, 2, 4, 4, 0, 0), (43, 1, 2, 4, 0, 0), (43, 4, 4, 4, 0, 1), (43, 1, 4, 8, 0, 1), (43, 2, 4, 8, 0, 1), (43, 2, 2, 4, 0, 1)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-function", "-x", "hip"]
 
@@ -29,22 +39,35 @@ def build_extension(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs, procs = [], []
-    for src in SOURCES:  # one hipcc per translation unit, all in parallel (the kernel variants dominate)
-        obj = os.path.join(CSRC, src + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-            print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
-    failed = []
-    for src, pr in procs:
+    extra = ["-DSLAM_ABLATE"] if os.environ.get("SLAM_ABLATE") else []   # timing experiments only (WRONG results)
+    jobs = [(src, os.path.join(CSRC, src + ".o"), []) for src in SOURCES]
+    variants = list(EKF_DEFAULT_VARIANTS) + (EKF_SWEEP_VARIANTS if os.environ.get("SLAM_SWEEP") else [])
+    for (nmax, w, kg, unr, f32, pipe) in variants:
+        tag = f"ekf_inst_{nmax}_{pipe}{w}{kg}{unr}{'_f32' if f32 else ''}"
+        jobs.append((tag, os.path.join(CSRC, tag + ".o"),
+                     [f"-DV_NMAX={nmax}", f"-DV_W={w}", f"-DV_KG={kg}", f"-DV_UNR={unr}", f"-DV_F32={f32}", f"-DV_PIPE={pipe}"]))
+    for f in os.listdir(CSRC):   # objects of variants that are no longer part of the build
+        if f.startswith("ekf_inst_") and f.endswith(".o") and os.path.join(CSRC, f) not in [j[1] for j in jobs]:
+            os.remove(os.path.join(CSRC, f))
+    objs, failed = [], []
+    maxpar = int(os.environ.get("SLAM_BUILD_JOBS", "8"))   # one hipcc per translation unit, in parallel
+    pending, running = list(jobs), []
+    while pending or running:
+        while pending and len(running) < maxpar:
+            name, obj, defs = pending.pop(0)
+            src = os.path.join(CSRC, name if not defs else "ekf_inst.hip")
+            cmd = [hipcc] + FLAGS + extra + defs + ["-c", src, "-o", obj]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                print(" ".join(cmd), flush=True)
+            running.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            objs.append(obj)
+        name, pr = running.pop(0)
         out, _ = pr.communicate()
         if verbose or pr.returncode != 0:
             sys.stderr.write(out)
         if pr.returncode != 0:
-            failed.append(src)
+            failed.append(name)
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -10,7 +10,7 @@ namespace slam {
 struct EkfStepParams {
     // ---- filter state in HBM ----
     // P and x are stored as fp64 (SLAM_F64) or fp32 (SLAM_F32); strides are in ELEMENTS of that type
-    const void* P;      // [B][pstride]  P_t: packed row-major n x n, leading dimension n = 3+2*M[b]; updated IN PLACE
+    const void* P;      // [B][pstride]  P_t: row-major n x n with leading dimension ekf_ld(n), n = 3+2*M[b]; updated IN PLACE
     void* P_out;        // [B][pstride]  second buffer: target of the steps that change the leading dimension (insertions)
     void* x;            // [B][xstride]  x_t
     double* scratch;    // [B][pstride] fp64, SLAM_F32 only: P between detection groups of one step (NULL for fp64)
@@ -49,17 +49,48 @@ struct EkfStepParams {
     // ---- geometry ----
     int32_t B, L_max, pstride, xstride;
     int32_t sim;  // 1 = SIM mode, 0 = EXT mode
-    unsigned long long* prof;  // optional [B][16] per-block phase cycles of the last launch (dbg & 4), NULL otherwise
-    int32_t dbg;  // timing experiments only (env SLAM_DEBUG_FLAGS): 1 = skip bulk stream, 2 = skip detections, 4 = phase timers
+    unsigned long long* khist; // [8] instance-steps by detections in their message (k = 0..6, >= 7), accumulated over
+                               // launches (one atomicAdd per bin and workgroup at the end of a launch); may be NULL
+    unsigned long long* prof;  // optional [B][PROF_SLOTS] per-block stamps of the last launch (dbg & 4 | 32), NULL otherwise
+    int32_t dbg;  // SLAM_DEBUG_FLAGS: 4 = phase cycle counters, 32 = wall-clock stamp + detection count per timestep of a
+                  // multi-step launch; 1 / 2 / 16 (ablations, WRONG results) only in a -DSLAM_ABLATE build
 };
+
+// Leading dimension (in elements) of the row-major covariance of an instance with state size n: every row starts on a
+// 16-byte boundary (2 doubles / 4 floats), so one lane's 16-byte vector never straddles two rows and the bulk stream
+// can hand a lane the same column group in several consecutive rows (its (H P) operands are then read once per strip
+// instead of once per element).  The pad elements (columns n .. ld-1) are kept at zero.
+__host__ __device__ constexpr int ekf_ld(int n, int elem_bytes) {
+    return elem_bytes == 8 ? ((n + 1) & ~1) : ((n + 3) & ~3);
+}
+
+static constexpr int kEkfProfSlots = 128;   // per-block slots of EkfStepParams::prof
 
 // Largest landmark capacity of the instantiated variants (n = 3+2L <= 203; the limit is LDS, not registers).
 // fp32 storage is instantiated up to 50 landmarks.
 static constexpr int kEkfMaxLandmarks = 100;
 static constexpr int kEkfMaxLandmarksF32 = 50;
 
-// waves_per_filter: 0 = let the library pick; 2, 4 or 8 otherwise.
-hipError_t launch_ekf_step(const EkfStepParams& p, int waves_per_filter, int f32_storage, hipStream_t stream);
+// Tuning variants of the step kernel.  Every instantiation unit (ekf_inst.hip compiled with -DV_NMAX=.. -DV_W=.. -DV_KG=..
+// -DV_UNR=.. -DV_F32=.. -DV_PIPE=.., see build.py) registers its launcher at load time; launch_ekf_step picks one by size
+// class (smallest NMAX that fits), storage type and variant code = PIPE*1000 + W*100 + KG*10 + UNR:
+//   W    wavefronts per filter instance (workgroup = 64*W threads)
+//   KG   detections per group (updates applied in one pass over P)
+//   UNR  rows per strip of the bulk stream = 16-byte vectors in flight per lane
+//   PIPE 1 = the stream loads the next chunk while it updates and stores the current one
+// The release library holds the defaults only; `SLAM_SWEEP=1 python -m live_ekf_slam_amd.build` adds the sweep set.
+struct EkfVariant {
+    int nmax, code, f32;
+    hipError_t (*launch)(const EkfStepParams&, hipStream_t);
+    EkfVariant* next;
+};
+void register_ekf_variant(EkfVariant* v);
+
+// 1 if this build holds that variant for the size class of L_max (codes as above; 0 = the default, always present)
+int ekf_variant_available(int L_max, int f32_storage, int variant);
+
+// variant: 0 = the library's default for the size class and batch; otherwise a variant code (or just W).
+hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage, hipStream_t stream);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)
 hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, int elem_bytes, double* out, hipStream_t stream);

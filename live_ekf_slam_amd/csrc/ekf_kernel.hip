@@ -7,67 +7,64 @@
 #include "slam_math.h"
 #include "slam_rng.h"
 
+// default variant codes (PIPE*1000 + W*100 + KG*10 + UNR); build.py instantiates exactly these in the release library
+#ifndef SLAM_DEF_43
+#define SLAM_DEF_43 1244
+#endif
+#ifndef SLAM_DEF_43_LARGE
+#define SLAM_DEF_43_LARGE 1124
+#endif
+#ifndef SLAM_DEF_103
+#define SLAM_DEF_103 1444
+#endif
+
 namespace slam {
 
-template <int NMAX, int W, int KG, int UNR, class ST>
-hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream);
-extern template hipError_t launch_variant<103, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4, 3, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 2, 3, 8, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 2, 4, 8, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 8, 4, 2, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4, 4, 8, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4, 2, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 2, 4, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 1, 4, 8, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 2, 4, 8, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 2, 2, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 1, 2, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<103, 4, 4, 4, float>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<203, 4, 4, 4, double>(const EkfStepParams&, hipStream_t);
-extern template hipError_t launch_variant<43, 2, 4, 4, float>(const EkfStepParams&, hipStream_t);
+// ---- variant registry (filled by the static initialisers of the ekf_inst.hip instantiation units) ----
+namespace {
+EkfVariant* g_variants = nullptr;
+const EkfVariant* find_variant(int nmax_class, int f32, int code) {
+    for (const EkfVariant* v = g_variants; v; v = v->next)
+        if (v->nmax == nmax_class && v->f32 == f32 && v->code == code) return v;
+    return nullptr;
+}
+}  // namespace
+void register_ekf_variant(EkfVariant* v) {
+    v->next = g_variants;
+    g_variants = v;
+}
 
-// NMAX only sizes the LDS arrays (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103).  `wpf` selects a tuning
-// variant: 0 = default, W (wavefronts per filter) or the 3-digit code W*100 + KG*10 + UNR.
-hipError_t launch_ekf_step(const EkfStepParams& p, int wpf, int f32_storage, hipStream_t stream) {
-    const int nmax = 3 + 2 * p.L_max;
-    if (f32_storage) {  // fp32 storage of x and P (BASELINE configs[3]); one tuning variant per size class
-        if (nmax <= 43) return launch_variant<43, 2, 4, 4, float>(p, stream);
-        if (nmax <= 103) return launch_variant<103, 4, 4, 4, float>(p, stream);
-        return hipErrorInvalidValue;
+// Default variant code per size class (chosen by sweeps on the GPU, tools/gpu_sweep.py).  NMAX only sizes the LDS arrays
+// (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103, L_max <= 100 -> n <= 203).
+static int default_code(int nmax_class, int f32, int B) {
+    if (nmax_class == 43) {
+        // large batches: one wavefront per filter and groups of 2 detections (smallest footprint, most filters
+        // resident per CU) win by ~10 %; small batches are latency-bound and prefer two wavefronts per filter
+        if (!f32 && B >= 16384) return SLAM_DEF_43_LARGE;
+        return SLAM_DEF_43;
     }
-    if (nmax <= 43) {
-        switch (wpf) {
-            case 244: return launch_variant<43, 2, 4, 4, double>(p, stream);
-            case 444: return launch_variant<43, 4, 4, 4, double>(p, stream);
-            case 148: return launch_variant<43, 1, 4, 8, double>(p, stream);
-            case 248: return launch_variant<43, 2, 4, 8, double>(p, stream);
-            case 224: return launch_variant<43, 2, 2, 4, double>(p, stream);
-            case 124: return launch_variant<43, 1, 2, 4, double>(p, stream);
-            case 4: return launch_variant<43, 4, 4, 4, double>(p, stream);
-            case 1: return launch_variant<43, 1, 4, 8, double>(p, stream);
-            // large batches: one wavefront per filter and groups of 2 detections (smallest footprint, most filters
-            // resident per CU) win by ~10 %; small batches are latency-bound and prefer two wavefronts per filter
-            default: return p.B >= 16384 ? launch_variant<43, 1, 2, 4, double>(p, stream) : launch_variant<43, 2, 4, 4, double>(p, stream);
-        }
+    return SLAM_DEF_103;
+}
+
+static const EkfVariant* pick_variant(int L_max, int B, int variant, int f32_storage) {
+    const int nmax = 3 + 2 * L_max;
+    const int cls = nmax <= 43 ? 43 : (nmax <= 103 ? 103 : (nmax <= 203 ? 203 : -1));
+    if (cls < 0) return nullptr;
+    if (variant <= 0) return find_variant(cls, f32_storage, default_code(cls, f32_storage, B));
+    const EkfVariant* v = find_variant(cls, f32_storage, variant);
+    if (!v && variant < 10) {   // just W: any registered variant of that width
+        for (const EkfVariant* q = g_variants; q && !v; q = q->next)
+            if (q->nmax == cls && q->f32 == f32_storage && (q->code / 100) % 10 == variant) v = q;
     }
-    if (nmax <= 103) {
-        switch (wpf) {
-            case 444: return launch_variant<103, 4, 4, 4, double>(p, stream);
-            case 434: return launch_variant<103, 4, 3, 4, double>(p, stream);
-            case 238: return launch_variant<103, 2, 3, 8, double>(p, stream);
-            case 248: return launch_variant<103, 2, 4, 8, double>(p, stream);
-            case 842: return launch_variant<103, 8, 4, 2, double>(p, stream);
-            case 448: return launch_variant<103, 4, 4, 8, double>(p, stream);
-            case 424: return launch_variant<103, 4, 2, 4, double>(p, stream);
-            case 8: return launch_variant<103, 8, 4, 2, double>(p, stream);
-            case 2: return launch_variant<103, 2, 4, 8, double>(p, stream);
-            default: return launch_variant<103, 4, 4, 4, double>(p, stream);
-        }
-    }
-    if (nmax <= 203) return launch_variant<203, 4, 4, 4, double>(p, stream);   // L_max <= 100: only the LDS arrays grow
-    return hipErrorInvalidValue;
+    return v;   // NULL: asked for a variant this build does not contain -> the caller fails loudly
+}
+
+int ekf_variant_available(int L_max, int f32_storage, int variant) { return pick_variant(L_max, 1, variant, f32_storage) != nullptr; }
+
+hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage, hipStream_t stream) {
+    const EkfVariant* v = pick_variant(p.L_max, p.B, variant, f32_storage);
+    if (!v) return hipErrorInvalidConfiguration;
+    return v->launch(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -91,8 +88,9 @@ __global__ void ekf_init_kernel(const EkfInitParams p) {
     if (b >= p.B) return;
     ST* P = static_cast<ST*>(p.P) + (size_t)b * p.pstride;
     ST* x = static_cast<ST*>(p.x) + (size_t)b * p.xstride;
-    for (int i = 0; i < 9; ++i) P[i] = (ST)0;
-    P[0] = (ST)(0.01 * 0.01); P[4] = (ST)(0.01 * 0.01); P[8] = (ST)(0.005 * 0.005);   // ekf.cpp:11-14
+    constexpr int ld = ekf_ld(3, (int)sizeof(ST));   // rows start on 16-byte boundaries (ekf_kernel.h)
+    for (int i = 0; i < 3 * ld; ++i) P[i] = (ST)0;
+    P[0] = (ST)(0.01 * 0.01); P[ld + 1] = (ST)(0.01 * 0.01); P[2 * ld + 2] = (ST)(0.005 * 0.005);   // ekf.cpp:11-14
     x[0] = (ST)p.x0; x[1] = (ST)p.y0; x[2] = (ST)p.yaw0;                             // ekf.cpp:31 (float arguments)
     p.M[b] = 0; p.flags[b] = 0; p.timestep[b] = 0;
     p.truth[3 * (size_t)b] = p.tx; p.truth[3 * (size_t)b + 1] = p.ty; p.truth[3 * (size_t)b + 2] = p.tyaw;

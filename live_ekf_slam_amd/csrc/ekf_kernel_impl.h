@@ -45,6 +45,17 @@ struct EkfGeom {
     static constexpr int UNR = UNR_;                     // register pairs in flight per lane in the bulk stream
 };
 
+// (H P) of an update is kept de-interleaved by (column mod VEC): entry c lives at (c % VEC) * HS + c / VEC, so the VEC
+// operands a lane of the bulk stream needs for its 16-byte vector of columns are VEC conflict-free reads of consecutive
+// 16-byte entries across the lanes.  HS is the smallest stride >= ceil(LDP / VEC) that staggers the VEC sub-arrays
+// over the 64 LDS banks (stride-1 accesses in c, as the thin phase makes them, then stay conflict-free too).
+template <int VEC>
+constexpr int hp_substride(int ldp) {
+    int hs = (ldp + VEC - 1) / VEC;
+    while ((hs % 16) != (16 / VEC)) ++hs;
+    return hs;
+}
+
 // PartialPivLU inverse of a 2x2 (MatrixXd::inverse(), ekf.cpp:135); same sequence as the oracle's inv2x2_lu.
 __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
     const bool sw = fabs(S[2]) > fabs(S[0]);
@@ -70,12 +81,21 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
     return ok;
 }
 
+// Ablation switches (bit 1: no bulk stream, bit 2: no updates / insertions, bit 16: never skip the stream) produce WRONG
+// filter state; they exist for timing experiments only and are compiled in by -DSLAM_ABLATE (tools/gpu_ablate.py builds
+// its own library).  The release library ignores them; only the timer bits (4, 32) of SLAM_DEBUG_FLAGS stay.
+#ifdef SLAM_ABLATE
+#define SLAM_DBG(x) (x)
+#else
+#define SLAM_DBG(x) 0
+#endif
+
 // phase timers (debug only): thread 0 stores the shader-clock delta since the previous stamp to prof[block][i]
 #define SLAM_STAMP(i)                                                                    \
     do {                                                                                 \
         if (prof_on && tid == 0) {                                                       \
             const unsigned long long now_ = __builtin_readcyclecounter();                \
-            p.prof[(size_t)blockIdx.x * 16 + (i)] = now_ - tprev;                         \
+            p.prof[(size_t)blockIdx.x * kEkfProfSlots + (i)] = now_ - tprev;                         \
             tprev = now_;                                                                \
         }                                                                                \
     } while (0)
@@ -111,7 +131,7 @@ __device__ __forceinline__ unsigned hi_abs(double v) {
 
 // MULTI = false: one timestep per launch (slam_step / slam_step_dev / slam_step_sim); MULTI = true: p.T timesteps per
 // launch with the per-instance state resident on chip (slam_run_sim).  Same code, the loop is compiled out for T = 1.
-template <int NMAX, int W, int KG_, int UNR_, class ST, bool MULTI>
+template <int NMAX, int W, int KG_, int UNR_, class ST, int PIPE, bool MULTI>
 __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(const EkfStepParams p) {
     using G = EkfGeom<NMAX, W, KG_, UNR_>;
     constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, TS = G::TS, UNR = G::UNR;
@@ -121,7 +141,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ double s_R[TS * LDP];      // thin rows   R[s][c] = P[T_s][c]
     __shared__ double s_C[TS * LDP];      // thin cols   C[s][r] = P[r][T_s]
     __shared__ double2 s_K[KG * LDP];     // per update of the group: K[r][0..1]
-    __shared__ double2 s_HP[KG * LDP];    // per update of the group: (H P)[0..1][c]
+    constexpr int VEC = Vec16<ST>::VEC;   // elements of the storage type per 16-byte vector
+    constexpr int HS = hp_substride<VEC>(LDP), HPW = VEC * HS;
+    __shared__ double2 s_HP[KG * HPW];    // per update of the group: (H P)[0..1][c] at hpi(c) (de-interleaved by c % VEC)
     __shared__ double s_sc[16];           // scalars computed by the leader lane (H entries, nu, S^-1, G_x ...)
     __shared__ float s_meas[2 * 3 * KCAP];   // [step parity][detection][id, range, bearing]
     __shared__ int s_ids[LMAX > 0 ? LMAX : 1];
@@ -137,6 +159,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ int s_misc[8];             // -, -, freeze, capacity (unknown ids), l1, nT, singular-S
     __shared__ double s_keep[4 + 2 * 64]; // values that live across the timesteps of one launch: true pose, error
                                           // sum, map entries of ids 0..63 (kept out of registers on purpose)
+    __shared__ int s_kh[8];               // instance-steps of this launch by detection count
+    __shared__ double s_tprev[3];         // true pose before the pre-step advanced it (what a freezing instance keeps)
 
     // row 2 / col 2 of P_t (predict operands) live in the K buffer, which is idle until the first update
     double* const s_r2 = reinterpret_cast<double*>(s_K);
@@ -150,8 +174,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     const bool prof_on = (p.dbg & 4) && p.prof != nullptr;
     unsigned long long tprev = prof_on ? __builtin_readcyclecounter() : 0ull;
     // ---- prologue: every load that does not depend on another load is issued up front (one HBM round trip) ----
-    constexpr int VEC = Vec16<ST>::VEC;
     typedef typename Vec16<ST>::type VT;
+    constexpr int ESZ = (int)sizeof(ST);
+    auto hpi = [](int c) -> int { return (c & (VEC - 1)) * HS + (c / VEC); };
     // T consecutive timesteps per launch: x_t / ids / truth / thin rows stay on chip, P is updated in place
     const int T = MULTI ? p.T : 1;
     ST* const PA = const_cast<ST*>(static_cast<const ST*>(p.P)) + (size_t)b * p.pstride;
@@ -207,9 +232,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         s_T[tid] = tid < 3 ? tid : -1;
         s_need[tid] = (signed char)(tid < 3 ? 1 : 0);
     }
+    if (tid < 8) s_kh[tid] = 0;
 
     // state -> HBM at the end of the launch (or when the instance freezes): x_t lives in s_xt
-    auto finish = [&](int steps_done, int Mf, int fl) {
+    // `pre`: the instance freezes in its PRE-step state (x, P, timestep, error sum and the true pose alike)
+    auto finish = [&](int steps_done, int Mf, int fl, bool pre) {
         const int nfin = 3 + 2 * Mf;
         for (int i = tid; i < nfin; i += TPB) xb[i] = (ST)s_xt[i];
         if (Mf != M_init) {
@@ -221,6 +248,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             p.timestep[b] = ts0 + steps_done;
             if (p.sim) p.err_sum[b] = s_keep[3];
         }
+        if (p.sim && tid < 3) p.truth[3 * (size_t)b + tid] = pre ? s_tprev[tid] : s_keep[tid];
+        if (p.khist != nullptr && tid < 8 && s_kh[tid] != 0) atomicAdd(&p.khist[tid], (unsigned long long)s_kh[tid]);
     };
 
     int M = M_init;
@@ -243,8 +272,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         int kraw;
         if (p.sim) {
             double tx = s_keep[0], ty = s_keep[1], tth = s_keep[2];
-            kraw = sim_wave<KCAP>(p, b, lane, fwd_n, ang_n, p.step + (uint32_t)tn, tx, ty, tth, s_keep[4 + lane],
-                                  s_keep[4 + 64 + lane], meas);
+            if (lane == 0) { s_tprev[0] = tx; s_tprev[1] = ty; s_tprev[2] = tth; }
+            kraw = sim_wave<KCAP, false>(p, b, lane, fwd_n, ang_n, p.step + (uint32_t)tn, tx, ty, tth, s_keep[4 + lane],
+                                         s_keep[4 + 64 + lane], meas);   // the true pose goes to HBM in finish()
             if (lane == 0) { s_keep[0] = tx; s_keep[1] = ty; s_keep[2] = tth; }
         } else {
             kraw = nx[0];   // EXT mode: the message was fetched by the prologue
@@ -328,16 +358,17 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // pre-step state of a freezing instance into the buffer the host reads next
     auto freeze = [&]() {
         if (Pfinal != Pin) {
-            const int nn = n_old * n_old;
+            const int nn = n_old * ekf_ld(n_old, ESZ);
             for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pin[i];
         }
-        finish(t, M_old, flags | SLAM_INST_INDEX_OOR);
+        finish(t, M_old, flags | SLAM_INST_INDEX_OOR, true);
     };
     if (tid < 8) s_misc[tid] = 0;
     __syncthreads();   // the pre-step results of this timestep are visible
     const int kraw = s_next[4 * pb];
     if (kraw > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than one wavefront associates
     const int k = kraw < KCAP ? kraw : KCAP;
+    if (tid == 0) s_kh[k < 7 ? k : 7] += 1;
     if (p.sim && p.meas_out != nullptr && t == T - 1) {
         for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB)
             p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = meas_t[i];
@@ -370,8 +401,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         // matrix written by the previous group's bulk pass (leading dimension nf).  Intermediate results between
         // groups stay in fp64: for fp32 storage they live in a per-instance fp64 scratch slab, so storage rounding
         // happens exactly once per step (when the last group writes P_out).
-        const int lds = first ? n_old : nf;   // leading dimension of the source
-        const int nsrc = first ? n_old : na;  // rows/cols of the source that hold data
+        const int ldd = ekf_ld(nf, ESZ);                       // leading dimension of the matrix this step writes
+        const int lds = first ? ekf_ld(n_old, ESZ) : ldd;      // leading dimension of the source
+        const int nsrc = first ? n_old : na;                   // rows/cols of the source that hold data
 
         // ---- form the group: thread 0 decides, everybody reads.  Thin rows/cols of landmarks that are detected
         //      again stay where they are (their LDS copy IS the current P row); the others give their slot up. ----
@@ -560,7 +592,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         for (int l = l0; l < l1; ++l) {
             const int td = opaque(tid);   // keeps per-lane index arithmetic from being hoisted out of the loops
             const int idx = didx_t[l];
-            if (idx < 0 || (p.dbg & 2)) continue;  // dropped (capacity)
+            if (idx < 0 || SLAM_DBG(p.dbg & 2)) continue;  // dropped (capacity)
             const float r_m = meas_t[3 * l + 1], b_m = meas_t[3 * l + 2];
             const int ii = 3 + 2 * idx;
             if (idx < M) {
@@ -578,7 +610,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     s_sc[8] = (double)nu0f; s_sc[9] = (double)nu1f;
                 }
                 __syncthreads();
-                double2* __restrict__ HPu = s_HP + nu * LDP;
+                double2* __restrict__ HPu = s_HP + nu * HPW;   // entry c at hpi(c)
                 double2* __restrict__ Ku = s_K + nu * LDP;
                 double2 pht[(LDP + TPB - 1) / TPB];
                 {
@@ -600,7 +632,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             ph.x = ((q0 * h00 + q1 * h01) + qi * h03) + qj * h04;
                             ph.y = (((q0 * h10 + q1 * h11) + q2 * h12) + qi * h13) + qj * h14;
                         }
-                        if (c < LDP) HPu[c] = hp;
+                        if (c < LDP) HPu[hpi(c)] = hp;
                         pht[u] = ph;
                     }
                 }
@@ -608,7 +640,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 if (tid == 0) {  // leader: S = (H P) H^T + W and its PartialPivLU inverse (ekf.cpp:133-135)
                     const double h00 = s_sc[0], h01 = s_sc[1], h03 = s_sc[2], h04 = s_sc[3];
                     const double h10 = s_sc[4], h11 = s_sc[5], h12 = -1.0, h13 = s_sc[6], h14 = s_sc[7];
-                    const double2 g0 = HPu[0], g1 = HPu[1], g2 = HPu[2], gi = HPu[ii], gj = HPu[ii + 1];
+                    const double2 g0 = HPu[hpi(0)], g1 = HPu[hpi(1)], g2 = HPu[hpi(2)], gi = HPu[hpi(ii)], gj = HPu[hpi(ii + 1)];
                     double S[4], Si[4];
                     S[0] = ((g0.x * h00 + g1.x * h01) + gi.x * h03) + gj.x * h04;
                     S[1] = (((g0.x * h10 + g1.x * h11) + g2.x * h12) + gi.x * h13) + gj.x * h14;
@@ -644,7 +676,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     const int sl = i / LDP, j = i - sl * LDP;
                     const int t_s = s_T[sl];
                     if (j < na && (unsigned)t_s < (unsigned)na) {
-                        const double2 kt = Ku[t_s], hj = HPu[j], kj = Ku[j], ht = HPu[t_s];
+                        const double2 kt = Ku[t_s], hj = HPu[hpi(j)], kj = Ku[j], ht = HPu[hpi(t_s)];
                         s_R[i] = s_R[i] - (kt.x * hj.x + kt.y * hj.y);   // P[t_s][j]
                         s_C[i] = s_C[i] - (kj.x * ht.x + kj.y * ht.y);   // P[j][t_s]
                     }
@@ -724,7 +756,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         //      only change, and it touches rows / columns 0, 1 and (2,2) only (ekf.cpp:61 with the sparse F_x, F_v).
         //      P is updated in place, so the rest of the matrix is already where it belongs: write the three vehicle
         //      rows and columns from their LDS copies and skip the stream. ----
-        const bool skip_stream = first && l1 >= k && nu == 0 && Pout == Pin && !(p.dbg & 16);
+        const bool skip_stream = first && l1 >= k && nu == 0 && Pout == Pin && !SLAM_DBG(p.dbg & 16);
         if (skip_stream) {
             const int tsk = opaque(tid);
 #pragma unroll 1
@@ -733,7 +765,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 const ST sv = (ST)s_R[r * LDP + c];                       // P[r][c], r < 3
                 const unsigned ha = hi_abs((double)sv);
                 hiacc = hiacc > ha ? hiacc : ha;
-                Pout[(size_t)r * nf + c] = sv;
+                Pout[(size_t)r * ldd + c] = sv;
             }
 #pragma unroll 1
             for (int i = tsk; i < 3 * (nf - 3); i += TPB) {
@@ -741,197 +773,228 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 const ST sv = (ST)s_C[c * LDP + r];                       // P[r][c], c < 3 <= r
                 const unsigned ha = hi_abs((double)sv);
                 hiacc = hiacc > ha ? hiacc : ha;
-                Pout[(size_t)r * nf + c] = sv;
+                Pout[(size_t)r * ldd + c] = sv;
             }
         }
-        // ---- BULK (fp64 storage): stream P once.  dst pair q = elements 2q, 2q+1 of the nf-leading-dimension
-        //      layout; later groups of the same step update P_out in place. ----
-        if constexpr (kWide) if (!skip_stream) {
-            const double* src = first ? reinterpret_cast<const double*>(Pin) : reinterpret_cast<const double*>(Pout);
-            const int nn2 = nf * nf;
-            const int npair = (p.dbg & 1) ? 0 : (nn2 + 1) >> 1;
-            const bool same_layout = (lds == nf);
-            constexpr int CH = 64 * UNR;                      // pairs per chunk: UNR coalesced 1 KiB rows of a wave
-            const int rs = 128 / nf, cs = 128 - rs * nf;      // (r, c) step between a lane's consecutive pairs
-            dbl2_t* dst2 = reinterpret_cast<dbl2_t*>(Pout);
-            const dbl2_t* src2 = reinterpret_cast<const dbl2_t*>(src);
+        // ---- BULK: stream P once, in strips of R = UNR consecutive rows.  Work item `it` = (strip s, vector column j): the
+        //      lane owns the 16-byte vectors (R*s + i, VEC*j .. VEC*j + VEC-1), i < R.  Its (H P) operands (VEC per update)
+        //      are read once per strip and re-used for the R rows; K[r] (one 16-byte read per row and update) is the
+        //      same address for every lane of the strip (LDS broadcast): (VEC + R) operand reads per R*VEC elements and
+        //      update instead of two per element.  64 consecutive items form a chunk; chunks are handed to wavefronts
+        //      dynamically.  Every vector is read and rewritten by the same lane, so the update is in place unless the
+        //      step changes the leading dimension (insertions), which writes the other buffer.
+        //      Thin patches.  The thin copies in LDS undergo, element for element, the same operations in the same order
+        //      as the stream applies (the downdates), EXCEPT where the prediction touched them (rows / columns 0, 1 and
+        //      the (2,2) element) and where a landmark is new.  So the common pass (same layout, single group) patches
+        //      only those from LDS (FAST); passes that insert landmarks or belong to a multi-group step patch every thin
+        //      row / column (general), like the thin phase assumes. ----
+        constexpr int R = UNR;
+        auto stream_pass = [&](auto fast_tag, const ST* __restrict__ srcb) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const int nv = ldd / VEC;                       // vectors per row
+            const int nstrip = (nf + R - 1) / R;
+            const int nitem = SLAM_DBG(p.dbg & 1) ? 0 : nstrip * nv;
+            const float inv_nv = 1.0f / (float)nv;
+            const VT* __restrict__ src2 = reinterpret_cast<const VT*>(srcb);
+            VT* __restrict__ dst2 = reinterpret_cast<VT*>(Pout);
+            const int lsv = lds / VEC;
+            auto next_chunk = [&]() -> int {
+                int ch = 0;
+                if (lane == 0) ch = atomicAdd(&s_chunk, 1);
+                return __builtin_amdgcn_readfirstlane(ch);
+            };
+            // item -> (strip, vector column) without an integer division: (it + 0.5) / nv is at least 0.5 / nv away from
+            // an integer and the float product is off by < 1e-5 at these magnitudes.
+            // FAST passes are branch-free: items beyond the end are clamped to the last item and rows beyond the last row
+            // of the last strip to the last row, so those lanes redo a neighbour's work and store the same bits to the same
+            // addresses (within one wave-instruction, after all loads of the chunk).  With every load and store issued
+            // unconditionally the compiler can count them, so its s_waitcnt for the loads of a chunk leaves the stores and
+            // the prefetch of the next chunk in flight (a store behind a divergent branch forces vmcnt(0) instead).
+            auto decode = [&](int ch, int& it, int& sidx, int& j) {
+                it = ch * 64 + opaque(lane);
+                if (FAST) it = it < nitem ? it : nitem - 1;
+                sidx = (int)(((float)it + 0.5f) * inv_nv);
+                j = it - sidx * nv;
+            };
+            // the loads of one chunk: R 16-byte vectors per lane, issued back to back
+            auto issue = [&](int ch, VT (&raw)[R]) {
+                int it, sidx, j;
+                decode(ch, it, sidx, j);
+                const int r0 = sidx * R;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int r = r0 + i;
+                    if constexpr (FAST) {
+                        raw[i] = src2[(r < nf ? r : nf - 1) * nv + j];
+                    } else {
+                        const bool ok = it < nitem && r < nsrc && j < lsv;
+                        VT z;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
+                        raw[i] = ok ? src2[r * lsv + j] : z;
+                    }
+                }
+            };
+            // downdates, patches, storage rounding and the stores of one chunk
+            auto process = [&](int ch, const VT (&raw)[R]) {
+                int it, sidx, j;
+                decode(ch, it, sidx, j);
+                const bool act = FAST || it < nitem;
+                const int r0 = sidx * R, c0 = j * VEC;
+                int rr[R];   // row of vector i (FAST: clamped to the last row)
+#pragma unroll
+                for (int i = 0; i < R; ++i) rr[i] = (FAST && r0 + i >= nf) ? nf - 1 : r0 + i;
+                double val[R][VEC];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        val[i][e] = (double)raw[i][e];
+                        if (!FAST && !(rr[i] < nsrc && c0 + e < nsrc)) val[i][e] = 0.0;   // nothing there yet
+                    }
+#pragma unroll
+                for (int w = 0; w < KG; ++w) {
+                    if (w >= nu) break;  // wave-uniform
+                    double2 hp[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) hp[e] = s_HP[w * HPW + e * HS + j];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const double2 kk = s_K[w * LDP + rr[i]];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) val[i][e] = val[i][e] - (kk.x * hp[e].x + kk.y * hp[e].y);
+                    }
+                }
+                if constexpr (FAST) {
+                    if (j == 0) {   // columns 0, 1 (the prediction changed them)
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            val[i][0] = s_C[rr[i]];
+                            val[i][1] = s_C[LDP + rr[i]];
+                        }
+                    }
+                    if (sidx == 0) {   // rows 0, 1
+                        static_assert(R >= 2, "rows 0 and 1 must share a strip");
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            val[0][e] = s_R[c0 + e];
+                            val[1][e] = s_R[LDP + c0 + e];
+                        }
+                    }
+                    if (sidx == 2 / R && c0 <= 2 && 2 < c0 + VEC) {   // (2,2)
+                        const double p22 = s_R[2 * LDP + 2];
+#pragma unroll
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e)
+                                if (rr[i] == 2 && c0 + e == 2) val[i][e] = p22;
+                    }
+                } else {
+                    int sc[VEC], sr[R];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) sc[e] = s_slot[c0 + e];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) sr[i] = s_slot[rr[i]];
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            if (sc[e] >= 0) val[i][e] = s_C[sc[e] * LDP + rr[i]];
+                            if (sr[i] >= 0) val[i][e] = s_R[sr[i] * LDP + c0 + e];
+                            if (c0 + e >= nf) val[i][e] = 0.0;   // pad columns stay zero
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    VT o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const ST stored = (ST)val[i][e];   // storage rounding (identity for fp64)
+                        const unsigned ha = hi_abs((double)stored);
+                        hiacc = ((FAST || (act && rr[i] < nf)) && hiacc < ha) ? ha : hiacc;
+                        o[e] = stored;
+                    }
+                    if (FAST || (act && rr[i] < nf)) dst2[rr[i] * nv + j] = o;
+                }
+            };
+            if constexpr (PIPE && FAST) {
+                // Software pipeline over two register sets: the loads of the next chunk are in flight while this one is
+                // updated and stored.  A chunk index beyond the end loads (clamped) the last item and is never processed.
+                VT bufA[R], bufB[R];
+                int ca = next_chunk();
+                issue(ca, bufA);
+#pragma unroll 1
+                while (ca * 64 < nitem) {
+                    const int cb = next_chunk();
+                    issue(cb, bufB);
+                    process(ca, bufA);
+                    if (cb * 64 >= nitem) break;
+                    ca = next_chunk();
+                    issue(ca, bufA);
+                    process(cb, bufB);
+                }
+            } else {
+#pragma unroll 1
+                for (;;) {
+                    const int ch = next_chunk();
+                    if (ch * 64 >= nitem) break;
+                    VT raw[R];
+                    issue(ch, raw);
+                    process(ch, raw);
+                }
+            }
+        };
+        // fp32 storage with more than KG detections in one step (rare): the matrix between the groups stays fp64 in the
+        // per-instance scratch slab so that storage rounding happens exactly once per step.  Element-wise, one vector
+        // of one row per lane, every thin row / column patched.
+        auto mid_pass = [&](bool src_mid, bool dst_mid) {
+            const int nv = ldd / VEC;
+            const int nitem = SLAM_DBG(p.dbg & 1) ? 0 : nf * nv;
 #pragma unroll 1
             for (;;) {
                 int ch = 0;
                 if (lane == 0) ch = atomicAdd(&s_chunk, 1);
                 ch = __builtin_amdgcn_readfirstlane(ch);
-                const int q0 = ch * CH + opaque(lane);
-                if (ch * CH >= npair) break;
-                int r = (2 * q0) / nf;
-                int c = 2 * q0 - r * nf;
-                double2 v[UNR];
-                int rr[UNR], cc[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {   // issue the loads of UNR pairs first
-                    const int q = q0 + u * 64;
-                    rr[u] = r; cc[u] = c;
-                    v[u] = make_double2(0.0, 0.0);
-                    if (q < npair) {
-                        if (same_layout) {
-                            const dbl2_t t2 = src2[q];
-                            v[u] = make_double2(t2.x, t2.y);
-                        } else {  // re-lay-out from leading dimension lds to nf (steps that grow the state)
-                            int c1 = c + 1, r1 = r;
-                            if (c1 == nf) { c1 = 0; r1 = r + 1; }
-                            if (r < nsrc && c < nsrc) v[u].x = src[(size_t)r * lds + c];
-                            if (r1 < nsrc && c1 < nsrc) v[u].y = src[(size_t)r1 * lds + c1];
-                        }
-                    }
-                    c += cs; r += rs;
-                    if (c >= nf) { c -= nf; r += 1; }
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int q = q0 + u * 64;
-                    if (q < npair) {
-                        const int r0 = rr[u], c0 = cc[u];
-                        int c1 = c0 + 1, r1 = r0;
-                        if (c1 == nf) { c1 = 0; r1 = r0 + 1; }
-                        double vx = v[u].x, vy = v[u].y;
-#pragma unroll
-                        for (int w = 0; w < KG; ++w) {
-                            if (w >= nu) break;  // wave-uniform
-                            const double2 k0 = s_K[w * LDP + r0], k1 = s_K[w * LDP + r1];
-                            const double2 h0 = s_HP[w * LDP + c0], h1 = s_HP[w * LDP + c1];
-                            vx = vx - (k0.x * h0.x + k0.y * h0.y);
-                            vy = vy - (k1.x * h1.x + k1.y * h1.y);
-                        }
-                        const int sr = s_slot[r0], sr1 = s_slot[r1], sc = s_slot[c0], sc1 = s_slot[c1];
-                        if (sc >= 0) vx = s_C[sc * LDP + r0];
-                        if (sr >= 0) vx = s_R[sr * LDP + c0];
-                        if (sc1 >= 0) vy = s_C[sc1 * LDP + r1];
-                        if (sr1 >= 0) vy = s_R[sr1 * LDP + c1];
-                        if (2 * q + 1 >= nn2) vy = 0.0;   // odd n*n: one don't-care element pads the last pair
-                        const unsigned h0a = hi_abs(vx), h1a = hi_abs(vy);
-                        hiacc = hiacc > h0a ? hiacc : h0a;
-                        hiacc = hiacc > h1a ? hiacc : h1a;
-                        dbl2_t o; o.x = vx; o.y = vy;
-                        dst2[q] = o;
-                    }
-                }
-            }
-        }
-        // ---- BULK (fp32 storage): a lane's 16-byte vector q holds elements 4q .. 4q+3.  Common case (one group):
-        //      vector loads from P, vector stores to P_out with storage rounding.  With several groups in one step
-        //      the intermediate matrix stays fp64 in the scratch slab (element-wise access), so rounding to float
-        //      happens exactly once per step. ----
-        if constexpr (!kWide) if (!skip_stream) {
-            const bool src_mid = !first;            // read the previous group's result (fp64 scratch)
-            const bool dst_mid = (l1 < k);          // more groups follow: keep fp64
-            const int nn2 = nf * nf;
-            const int nvec = (p.dbg & 1) ? 0 : (nn2 + VEC - 1) / VEC;
-            const bool vec_load = !src_mid && (lds == nf);
-            constexpr int CH = 64 * UNR;
-            const int rs = (VEC * 64) / nf, cs = (VEC * 64) - rs * nf;   // (r, c) step between a lane's vectors
-            VT* dst2 = reinterpret_cast<VT*>(Pout);
-            const VT* src2 = reinterpret_cast<const VT*>(Pin);
-            // One vector: the group's downdates, thin patches, storage rounding, store.  Branch-free per element: every
-            // LDS operand of the VEC elements is read unconditionally (patch reads go to slot 0 when the element is not
-            // thin and are discarded by a select), so the reads of all elements issue back to back instead of one
-            // dependent LDS round trip after another behind per-element branches.
-            auto emit = [&](const int q, const int r0, const int c0, const double (&vin)[VEC]) {
-                int re[VEC], ce[VEC];
-                re[0] = r0; ce[0] = c0;
-#pragma unroll
-                for (int e = 1; e < VEC; ++e) {
-                    const bool wrap = ce[e - 1] + 1 == nf;
-                    ce[e] = wrap ? 0 : ce[e - 1] + 1;
-                    re[e] = wrap ? re[e - 1] + 1 : re[e - 1];
-                }
-                int sr[VEC], sc[VEC];
-                double val[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) { sr[e] = s_slot[re[e]]; sc[e] = s_slot[ce[e]]; val[e] = vin[e]; }
-#pragma unroll
-                for (int w = 0; w < KG; ++w) {
-                    if (w >= nu) break;  // wave-uniform
+                if (ch * 64 >= nitem) break;
+                const int it = ch * 64 + opaque(lane);
+                if (it < nitem) {
+                    const int r = it / nv, c0 = (it - r * nv) * VEC;
+                    const int srw = s_slot[r];
+                    VT o;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        const double2 kk = s_K[w * LDP + re[e]];
-                        const double2 hh = s_HP[w * LDP + ce[e]];
-                        val[e] = val[e] - (kk.x * hh.x + kk.y * hh.y);
-                    }
-                }
-                VT outv;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const double pc = s_C[(sc[e] >= 0 ? sc[e] : 0) * LDP + re[e]];
-                    const double pr = s_R[(sr[e] >= 0 ? sr[e] : 0) * LDP + ce[e]];
-                    double o = sc[e] >= 0 ? pc : val[e];
-                    o = sr[e] >= 0 ? pr : o;
-                    if (VEC * q + e >= nn2) o = 0.0;   // don't-care elements pad the last vector
-                    if (!dst_mid) {
-                        const ST stored = (ST)o;         // storage rounding
-                        const unsigned ha = hi_abs((double)stored);
-                        hiacc = hiacc > ha ? hiacc : ha;
-                        outv[e] = stored;
-                    } else if (VEC * q + e < nn2) {
-                        Pmid[(size_t)VEC * q + e] = o;   // fp64 intermediate
-                    }
-                }
-                if (!dst_mid) dst2[q] = outv;
-            };
-            if (vec_load) {
-                // common case: UNR raw 16-byte vectors in flight per lane, converted to fp64 only when they are used
-                // (a conversion next to its load would make every load wait for the previous one)
-#pragma unroll 1
-                for (;;) {
-                    int ch = 0;
-                    if (lane == 0) ch = atomicAdd(&s_chunk, 1);
-                    ch = __builtin_amdgcn_readfirstlane(ch);
-                    const int q0 = ch * CH + opaque(lane);
-                    if (ch * CH >= nvec) break;
-                    VT raw[UNR];
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const int q = q0 + u * 64;
-                        raw[u] = src2[q < nvec ? q : nvec - 1];
-                    }
-                    int r = (VEC * q0) / nf;
-                    int c = VEC * q0 - r * nf;
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const int q = q0 + u * 64;
-                        if (q < nvec) {
-                            double vin[VEC];
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) vin[e] = (double)raw[u][e];
-                            emit(q, r, c, vin);
+                        const int c = c0 + e;
+                        double v = 0.0;
+                        if (r < nsrc && c < nsrc) v = src_mid ? Pmid[(size_t)r * lds + c] : (double)Pin[(size_t)r * lds + c];
+                        for (int w = 0; w < nu; ++w) {
+                            const double2 kk = s_K[w * LDP + r], hh = s_HP[w * HPW + hpi(c)];
+                            v = v - (kk.x * hh.x + kk.y * hh.y);
                         }
-                        c += cs; r += rs;
-                        while (c >= nf) { c -= nf; r += 1; }
+                        const int scl = s_slot[c];
+                        if (scl >= 0) v = s_C[scl * LDP + r];
+                        if (srw >= 0) v = s_R[srw * LDP + c];
+                        if (c >= nf) v = 0.0;
+                        if (dst_mid) {
+                            Pmid[(size_t)r * ldd + c] = v;
+                        } else {
+                            const ST stored = (ST)v;
+                            const unsigned ha = hi_abs((double)stored);
+                            hiacc = hiacc > ha ? hiacc : ha;
+                            o[e] = stored;
+                        }
                     }
+                    if (!dst_mid) reinterpret_cast<VT*>(Pout)[it] = o;
                 }
+            }
+        };
+        if (!skip_stream) {
+            const bool more = l1 < k;   // further groups of this step follow
+            if (kWide || (first && !more)) {
+                const ST* srcb = first ? Pin : Pout;
+                if (first && !more && nf == n_old) stream_pass(std::true_type{}, srcb);
+                else stream_pass(std::false_type{}, srcb);
             } else {
-                // other leading dimension (the state grows this step) or fp64 intermediate: element-wise source reads,
-                // one vector at a time (rare: steps that insert landmarks or hold more than KG detections)
-#pragma unroll 1
-                for (;;) {
-                    int ch = 0;
-                    if (lane == 0) ch = atomicAdd(&s_chunk, 1);
-                    ch = __builtin_amdgcn_readfirstlane(ch);
-                    if (ch * 64 >= nvec) break;
-                    const int q = ch * 64 + opaque(lane);
-                    if (q < nvec) {
-                        const int r = (VEC * q) / nf, c = VEC * q - r * nf;
-                        double vin[VEC];
-                        int re = r, ce = c;
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            vin[e] = 0.0;
-                            if (re < nsrc && ce < nsrc)
-                                vin[e] = src_mid ? Pmid[(size_t)re * lds + ce] : (double)Pin[(size_t)re * lds + ce];
-                            ce += 1;
-                            if (ce == nf) { ce = 0; re += 1; }
-                        }
-                        emit(q, r, c, vin);
-                    }
-                }
+                mid_pass(!first, more);
             }
         }
         l0 = l1;
@@ -967,46 +1030,50 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if (nonfinite) flags |= SLAM_INST_NONFINITE;
 
     if (na != nf) {
-        // fewer insertions than provisioned (unknown-id mode over-estimates): re-pack from leading dimension nf to
-        // na in place.  Rows move towards lower addresses, so go row by row with a barrier in between.
+        // fewer insertions than provisioned (unknown-id mode over-estimates): re-pack from the leading dimension of nf
+        // to the one of na in place.  Rows move towards lower addresses, so go row by row with a barrier in between.
+        const int ldf = ekf_ld(nf, ESZ), lda = ekf_ld(na, ESZ);
 #pragma unroll 1
-        for (int r = 1; r < na; ++r) {
+        for (int r = 0; r < na; ++r) {
             ST tmp[(LDP + TPB - 1) / TPB];
 #pragma unroll
             for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
                 const int c = te + TPB * u;
-                tmp[u] = c < na ? Pout[(size_t)r * nf + c] : (ST)0;
+                tmp[u] = c < na ? Pout[(size_t)r * ldf + c] : (ST)0;   // pad columns: zero
             }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
                 const int c = te + TPB * u;
-                if (c < na) Pout[(size_t)r * na + c] = tmp[u];
+                if (c < lda) Pout[(size_t)r * lda + c] = tmp[u];
             }
             __syncthreads();
         }
     }
-    if ((p.dbg & 32) && p.prof != nullptr && tid == 0 && t < 16) p.prof[(size_t)blockIdx.x * 16 + t] = wall_clock64();
+    // per-timestep stamp of a multi-step launch: 100 MHz wall clock << 4 | detections of this instance-step
+    if ((p.dbg & 32) && p.prof != nullptr && tid == 0 && t < kEkfProfSlots)
+        p.prof[(size_t)blockIdx.x * kEkfProfSlots + t] = (wall_clock64() << 4) | (unsigned long long)(k < 15 ? k : 15);
     Pcur = Pout;
     }   // timestep loop
 
     if (Pcur != Pfinal) {   // an odd number of layout changes in this launch: bring P_t back to the host's buffer
         __syncthreads();
-        const int nn = na * na;
+        const int nn = na * ekf_ld(na, ESZ);
         for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pcur[i];
     }
 
-    finish(T, M, flags);
+    finish(T, M, flags, false);
     SLAM_STAMP(8);   // epilogue
 }
 
-template <int NMAX, int W, int KG_, int UNR_, class ST>
+template <int NMAX, int W, int KG_, int UNR_, class ST, int PIPE>
 hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream) {
     if (p.cmds != nullptr && p.T > 1)
-        hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST, true>), dim3(p.B), dim3(64 * W), 0, stream, p);
+        hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST, PIPE, true>), dim3(p.B), dim3(64 * W), 0, stream, p);
     else   // a single step takes (fwd, ang); the host sets them to the first command of the chunk
-        hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST, false>), dim3(p.B), dim3(64 * W), 0, stream, p);
+        hipLaunchKernelGGL((ekf_step_kernel<NMAX, W, KG_, UNR_, ST, PIPE, false>), dim3(p.B), dim3(64 * W), 0, stream, p);
     return hipGetLastError();
 }
+
 
 }  // namespace slam

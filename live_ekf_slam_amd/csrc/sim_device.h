@@ -12,8 +12,8 @@ namespace slam {
 // advanced in place; lmx, lmy: prefetched map entry of id = lane.
 // Writes the [id, range, bearing] float32 triplets of the visible landmarks (ascending id) to s_meas and returns
 // their count (wave-uniform; triplets beyond KCAP are not stored, the caller caps and flags); lane 0 stores the new
-// truth pose.
-template <int KCAP, class P>
+// truth pose unless STORE_TRUTH is false (the EKF kernel writes it when it knows whether the instance froze).
+template <int KCAP, bool STORE_TRUTH = true, class P>
 __device__ __forceinline__ int sim_wave(const P& p, int b, int lane, float fwd, float ang, uint32_t step, double& tx,
                                         double& ty, double& tth, double lmx, double lmy, float* s_meas) {
     const uint64_t inst = (uint64_t)(p.inst0 + b);
@@ -57,7 +57,7 @@ __device__ __forceinline__ int sim_wave(const P& p, int b, int lane, float fwd, 
         }
         count += __popcll(mask);
     }
-    if (lane == 0) {
+    if (STORE_TRUTH && lane == 0) {
         p.truth[3 * (size_t)b] = tx;
         p.truth[3 * (size_t)b + 1] = ty;
         p.truth[3 * (size_t)b + 2] = tth;

@@ -44,7 +44,7 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct slam_handle {
     slam_config cfg;
     int kind, B, L_max, dtype, device;
-    int n_max, pstride, xstride;
+    int n_max, ld_max, pstride, xstride;
     int waves_per_filter = 0;
     int dbg = 0;
     hipStream_t stream = nullptr;
@@ -61,7 +61,19 @@ struct slam_handle {
     int32_t* dM = nullptr; int32_t* dids = nullptr;
     int32_t* dflags = nullptr; int32_t* dts = nullptr; double* dtruth = nullptr; double* derr = nullptr;
     double* dmap = nullptr; int L = 0;
-    float* dmeas = nullptr; int32_t* dcount = nullptr; int k_stride = 0;   // staging / last-measurement dump
+    float* dmeas = nullptr; int32_t* dcount = nullptr; int k_stride = 0;   // last-measurement dump (slam_get_last_meas)
+    // slam_step (host measurements): two pinned staging buffers + two device buffers, filled on a copy stream while the
+    // previous step's kernel runs; no stream synchronisation per step
+    struct Stage {
+        float* hmeas = nullptr; int32_t* hcount = nullptr;     // pinned host
+        float* dmeas = nullptr; int32_t* dcount = nullptr;     // device
+        size_t cap = 0;                                        // floats in hmeas / dmeas
+        hipEvent_t copied = nullptr, used = nullptr;
+        bool in_use = false;
+    } stage[2];
+    hipStream_t copy_stream = nullptr;
+    uint32_t stage_next = 0;
+    unsigned long long* dkhist = nullptr;                      // [8] instance-steps by detection count
     double* dscalar = nullptr;
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
@@ -100,6 +112,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
     p.dbg = h->dbg;
     p.prof = (h->dbg & (4 | 32)) ? h->dprof : nullptr;
+    p.khist = h->dkhist;
 }
 
 void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2]) {
@@ -256,13 +269,19 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     h->esz = dtype == SLAM_F32 ? 4 : 8;
     h->base = (kind == SLAM_EKF_SLAM) ? 3 : 4;
     h->n_max = h->base + 2 * L_max;
-    h->pstride = round_up(h->n_max * h->n_max + 4, 64);   // per-filter slab: 256/512-byte aligned, room for vector tails
+    // per-filter slab: n_max rows of the padded leading dimension (EKF: slam::ekf_ld, rows start on 16-byte boundaries;
+    // the UKF packs n x n with n even), 256/512-byte aligned
+    h->ld_max = kind == SLAM_EKF_SLAM ? slam::ekf_ld(h->n_max, h->esz) : h->n_max;
+    h->pstride = round_up(h->n_max * h->ld_max + 4, 64);
     h->xstride = round_up(h->n_max + 1, 2);
     h->range_max = cfg->range_max; h->fov_min = cfg->fov_min; h->fov_max = cfg->fov_max;
     const char* env = getenv("SLAM_WAVES_PER_FILTER");
     if (env) h->waves_per_filter = atoi(env);
-    env = getenv("SLAM_DEBUG_FLAGS");
-    if (env) h->dbg = atoi(env);
+    env = getenv("SLAM_DEBUG_FLAGS");   // 4 / 32: phase and per-step timers.  The ablation bits (1, 2, 16: WRONG results) are
+    if (env) h->dbg = atoi(env);        // compiled out of the release kernels (-DSLAM_ABLATE builds only)
+#ifndef SLAM_ABLATE
+    h->dbg &= (4 | 32);
+#endif
     env = getenv("SLAM_UKF_SPLIT_MIN");   // batch size from which UKF run_sim splits the batch over two streams
     if (env) h->ukf_split_min = atoi(env);
     env = getenv("SLAM_RUN_CHUNK");   // timesteps per launch of slam_run_sim (1 = one launch per step)
@@ -282,7 +301,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMalloc(&h->dtruth, sizeof(double) * B * 3),
         hipMalloc(&h->derr, sizeof(double) * B),
         hipMalloc(&h->dscalar, sizeof(double) * 4),
-        hipMalloc(&h->dprof, sizeof(unsigned long long) * 16 * B),
+        (h->dbg & (4 | 32)) ? hipMalloc(&h->dprof, sizeof(unsigned long long) * slam::kEkfProfSlots * B) : hipSuccess,
+        hipMalloc(&h->dkhist, sizeof(unsigned long long) * 8),
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dsq, sizeof(double) * B * h->pstride) : hipSuccess,
         h->esz == 4 ? hipMalloc(&h->dscratch, sizeof(double) * B * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
@@ -295,11 +315,26 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
             slam_destroy(h);
             return fail(SLAM_ERR_HIP, "hipMalloc -> %s", hipGetErrorString(ee));
         }
-    HIP_TRY(hipMemsetAsync(h->dP, 0, (size_t)h->esz * B * h->pstride, h->stream));
-    HIP_TRY(hipMemsetAsync(h->dP2, 0, (size_t)h->esz * B * h->pstride, h->stream));
-    HIP_TRY(hipMemsetAsync(h->dx, 0, (size_t)h->esz * B * h->xstride, h->stream));
-    HIP_TRY(hipMemsetAsync(h->dids, 0, sizeof(int32_t) * B * L_max, h->stream));
-    HIP_TRY(hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * 16 * B, h->stream));
+    // every buffer a getter can read before slam_init is zeroed (M = 0, flags = 0, timestep = 0, ...)
+    hipError_t zs[] = {
+        hipMemsetAsync(h->dP, 0, (size_t)h->esz * B * h->pstride, h->stream),
+        hipMemsetAsync(h->dP2, 0, (size_t)h->esz * B * h->pstride, h->stream),
+        hipMemsetAsync(h->dx, 0, (size_t)h->esz * B * h->xstride, h->stream),
+        hipMemsetAsync(h->dids, 0, sizeof(int32_t) * B * L_max, h->stream),
+        hipMemsetAsync(h->dM, 0, sizeof(int32_t) * B, h->stream),
+        hipMemsetAsync(h->dflags, 0, sizeof(int32_t) * B, h->stream),
+        hipMemsetAsync(h->dts, 0, sizeof(int32_t) * B, h->stream),
+        hipMemsetAsync(h->dtruth, 0, sizeof(double) * B * 3, h->stream),
+        hipMemsetAsync(h->derr, 0, sizeof(double) * B, h->stream),
+        hipMemsetAsync(h->dkhist, 0, sizeof(unsigned long long) * 8, h->stream),
+        h->dnsq ? hipMemsetAsync(h->dnsq, 0, sizeof(int32_t) * B, h->stream) : hipSuccess,
+        h->dprof ? hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * slam::kEkfProfSlots * B, h->stream) : hipSuccess,
+    };
+    for (hipError_t ee : zs)
+        if (ee != hipSuccess) {
+            slam_destroy(h);
+            return fail(SLAM_ERR_HIP, "hipMemsetAsync -> %s", hipGetErrorString(ee));
+        }
     *out = h;
     return SLAM_OK;
 }
@@ -309,7 +344,16 @@ int slam_destroy(slam_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); hipEventDestroy(h->aux_ev[0]); hipEventDestroy(h->aux_ev[1]); }
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage};
+    if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    for (auto& s : h->stage) {
+        if (s.hmeas) hipHostFree(s.hmeas);
+        if (s.hcount) hipHostFree(s.hcount);
+        if (s.dmeas) hipFree(s.dmeas);
+        if (s.dcount) hipFree(s.dcount);
+        if (s.copied) hipEventDestroy(s.copied);
+        if (s.used) hipEventDestroy(s.used);
+    }
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage, h->dkhist};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -392,15 +436,50 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
     if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
-    int rc = ensure_meas_buffers(h, k_stride);
+    // The caller's buffers may be reused right after return (ekf.cpp:64 copies the message), so the message is packed
+    // into one of two PINNED staging buffers (only max_b count[b] detections per instance travel), copied on a separate
+    // stream while the previous step's kernel is still running, and the kernel waits for the copy by event.  The host
+    // blocks only when it gets two steps ahead of the GPU.
+    slam_handle::Stage& s = h->stage[h->stage_next & 1];
+    h->stage_next += 1;
+    const size_t B = (size_t)h->B;
+    int kmax = 1;
+    for (size_t b = 0; b < B; ++b) kmax = count[b] > kmax ? count[b] : kmax;
+    kmax = kmax < k_stride ? kmax : k_stride;
+    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!s.copied) {
+        HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.used, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&s.hcount, sizeof(int32_t) * B, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.dcount, sizeof(int32_t) * B));
+    }
+    if (s.in_use) HIP_TRY(hipEventSynchronize(s.used));   // the kernel of two steps ago has consumed this buffer
+    const size_t need = (size_t)3 * kmax * B;
+    if (s.cap < need) {
+        if (s.hmeas) hipHostFree(s.hmeas);
+        if (s.dmeas) hipFree(s.dmeas);
+        s.hmeas = nullptr; s.dmeas = nullptr; s.cap = 0;
+        const size_t cap = (size_t)3 * (kmax < 8 && k_stride >= 8 ? 8 : kmax) * B;
+        HIP_TRY(hipHostMalloc((void**)&s.hmeas, sizeof(float) * cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.dmeas, sizeof(float) * cap));
+        s.cap = cap;
+    }
+    memcpy(s.hcount, count, sizeof(int32_t) * B);
+    if (kmax == k_stride) {
+        memcpy(s.hmeas, meas, sizeof(float) * need);
+    } else {
+        for (size_t b = 0; b < B; ++b)
+            memcpy(s.hmeas + (size_t)3 * kmax * b, meas + (size_t)3 * k_stride * b, sizeof(float) * 3 * kmax);
+    }
+    HIP_TRY(hipMemcpyAsync(s.dcount, s.hcount, sizeof(int32_t) * B, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipMemcpyAsync(s.dmeas, s.hmeas, sizeof(float) * need, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipEventRecord(s.copied, h->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, s.copied, 0));
+    int rc = launch_step(h, cmd, 0, s.dmeas, s.dcount, kmax);
     if (rc) return rc;
-    // pack to the staging stride
-    HIP_TRY(hipMemcpy2DAsync(h->dmeas, sizeof(float) * 3 * h->k_stride, meas, sizeof(float) * 3 * k_stride,
-                             sizeof(float) * 3 * k_stride, h->B, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->dcount, count, sizeof(int32_t) * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
-    // host buffers may be reused by the caller right after return (ekf.cpp:64 copies the message)
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return launch_step(h, cmd, 0, h->dmeas, h->dcount, h->k_stride);
+    HIP_TRY(hipEventRecord(s.used, h->stream));
+    s.in_use = true;
+    return SLAM_OK;
 }
 
 int slam_step_sim(slam_handle* h, const float cmd[2]) {
@@ -523,10 +602,12 @@ int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_count,
 int slam_get_sigma_points(slam_handle* h, int inst, double* X, int32_t* rows, int32_t* cols) {
     if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
     if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "sigma points exist for the UKF kinds only");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, h->dnsq + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
+    n = n < 0 ? 0 : (n > h->n_max ? h->n_max : n);
     if (rows) *rows = n;
     if (cols) *cols = n > 0 ? 2 * n + 1 : 0;
     if (!X || n <= 0) return SLAM_OK;
@@ -556,15 +637,22 @@ static int fetch_elems(slam_handle* h, double* dst, const void* dbase, size_t el
 
 int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, int32_t* ids, int32_t* ts) {
     if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     int32_t m = 0;
     HIP_TRY(hipMemcpy(&m, h->dM + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
+    m = m < 0 ? 0 : (m > h->L_max ? h->L_max : m);   // never index past the caller's n_max-sized buffers
     const int n = h->base + 2 * m;
     if (M) *M = m;
     int rc;
     if (x && (rc = fetch_elems(h, x, h->dx, (size_t)inst * h->xstride, n))) return rc;
-    if (P && (rc = fetch_elems(h, P, h->dP, (size_t)inst * h->pstride, (size_t)n * n))) return rc;
+    if (P) {   // rows of the device matrix are ld elements apart (pad columns beyond n); the caller gets packed n x n
+        const int ld = h->kind == SLAM_EKF_SLAM ? slam::ekf_ld(n, h->esz) : n;
+        std::vector<double> tmp((size_t)n * ld);
+        if ((rc = fetch_elems(h, tmp.data(), h->dP, (size_t)inst * h->pstride, (size_t)n * ld))) return rc;
+        for (int r = 0; r < n; ++r) memcpy(P + (size_t)r * n, tmp.data() + (size_t)r * ld, sizeof(double) * n);
+    }
     if (ids && m > 0) HIP_TRY(hipMemcpy(ids, h->dids + (size_t)inst * h->L_max, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
     if (ts) HIP_TRY(hipMemcpy(ts, h->dts + inst, sizeof(int32_t), hipMemcpyDeviceToHost));
     return SLAM_OK;
@@ -617,6 +705,7 @@ int slam_get_last_meas(slam_handle* h, float* meas, int32_t* count, int k_stride
 
 int slam_error_stats(slam_handle* h, double* avg) {
     if (!h || !avg) return fail(SLAM_ERR_ARG, "bad argument");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     std::vector<int32_t> ts(h->B);
     int rc = copy_out(h, avg, h->derr, sizeof(double) * (size_t)h->B);
     if (rc) return rc;
@@ -635,8 +724,21 @@ int slam_sync(slam_handle* h) {
 int slam_batch(const slam_handle* h) { return h ? h->B : 0; }
 int slam_state_dim_max(const slam_handle* h) { return h ? h->n_max : 0; }
 
+int slam_variant_available(int L_max, int dtype, int variant) { return slam::ekf_variant_available(L_max, dtype == SLAM_F32, variant); }
+
+int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset) {
+    if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram element size");
+    HIP_TRY(hipMemcpy(out, h->dkhist, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->dkhist, 0, sizeof(uint64_t) * 8));
+    return SLAM_OK;
+}
+
 int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
     if (!h || !bytes) return fail(SLAM_ERR_ARG, "bad argument");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->dscalar, 0, sizeof(double), h->stream));
     HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->base, h->esz, h->dscalar, h->stream));
@@ -651,11 +753,13 @@ int slam_debug_read_prof(slam_handle* h, unsigned long long out[16]) {
     if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    std::vector<unsigned long long> buf((size_t)16 * h->B);
+    if (!h->dprof) return fail(SLAM_ERR_STATE, "SLAM_DEBUG_FLAGS has no timer bit (4 / 32) set");
+    const size_t S = h->kind == SLAM_EKF_SLAM ? slam::kEkfProfSlots : 16;   // the UKF kernels use 16 slots per block
+    std::vector<unsigned long long> buf(S * h->B);
     HIP_TRY(hipMemcpy(buf.data(), h->dprof, sizeof(unsigned long long) * buf.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; ++i) out[i] = 0;
     for (int b = 0; b < h->B; ++b)
-        for (int i = 0; i < 16; ++i) out[i] += buf[(size_t)16 * b + i];
+        for (int i = 0; i < 16; ++i) out[i] += buf[S * b + i];
     return SLAM_OK;
 }
 
@@ -664,7 +768,9 @@ int slam_debug_read_prof_raw(slam_handle* h, unsigned long long* out) {
     if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(out, h->dprof, sizeof(unsigned long long) * 16 * (size_t)h->B, hipMemcpyDeviceToHost));
+    if (!h->dprof) return fail(SLAM_ERR_STATE, "SLAM_DEBUG_FLAGS has no timer bit (4 / 32) set");
+    const size_t S = h->kind == SLAM_EKF_SLAM ? slam::kEkfProfSlots : 16;   // out: [B][S]
+    HIP_TRY(hipMemcpy(out, h->dprof, sizeof(unsigned long long) * S * (size_t)h->B, hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 

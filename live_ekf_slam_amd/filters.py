@@ -196,6 +196,12 @@ class BatchedFilter:
     def algorithmic_bytes(self):
         self._need(); v = C.c_double(0); _lib.check(_lib.lib().slam_algorithmic_bytes(self.h, C.byref(v))); return v.value
 
+    def k_histogram(self, reset=False):
+        """Instance-steps by detections per message (k = 0..6, >= 7) since creation / the last reset (EKF kernel)."""
+        self._need(); out = np.zeros(8, dtype=np.uint64)
+        _lib.check(_lib.lib().slam_k_histogram(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(bool(reset))))
+        return out
+
     def sync(self):
         self._need(); _lib.check(_lib.lib().slam_sync(self.h))
 

@@ -456,10 +456,14 @@ double orc_run_ekf_batch(const slam_config* cfg, int L_max, int math, int mode, 
                 int k = 0;
                 double truth[3];
                 if (vision) { sim.cfg.range_max = vision[3 * t]; sim.cfg.fov_min = vision[3 * t + 1]; sim.cfg.fov_max = vision[3 * t + 2]; }
+                const double xv_pre[3] = {sim.xv[0], sim.xv[1], sim.xv[2]};
                 orc_sim_step_philox(&sim, cmds[2 * t], cmds[2 * t + 1], seed, (uint64_t)(inst0 + b), (uint32_t)t, truth, meas.data(), &k);
                 kk += k;
                 const int fl = ekf.update(cmds[2 * t], cmds[2 * t + 1], meas.data(), k);
-                if (fl & SLAM_INST_INDEX_OOR) break;   // frozen: no further truth / error / timestep updates
+                if (fl & SLAM_INST_INDEX_OOR) {   // frozen in the PRE-step state: x, P, timestep, error sum and true pose alike
+                    sim.xv[0] = xv_pre[0]; sim.xv[1] = xv_pre[1]; sim.xv[2] = xv_pre[2];
+                    break;
+                }
                 errsum = errsum + (math == MATH_DET ? step_pos_error<DetMath>(wire_f32(ekf.x_t[0]), wire_f32(ekf.x_t[1]), truth[0], truth[1])
                                                     : step_pos_error<LibmMath>(wire_f32(ekf.x_t[0]), wire_f32(ekf.x_t[1]), truth[0], truth[1]));
             }
