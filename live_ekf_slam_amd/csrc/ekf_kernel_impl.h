@@ -51,8 +51,8 @@ struct EkfGeom {
 // over the 64 LDS banks (stride-1 accesses in c, as the thin phase makes them, then stay conflict-free too).
 template <int VEC>
 constexpr int hp_substride(int ldp) {
-    int hs = (ldp + VEC - 1) / VEC;
-    while ((hs % 16) != (16 / VEC)) ++hs;
+    int hs = (ldp + VEC - 1) / VEC;   // sub-array e starts e * hs entries = e * hs * 4 banks further: (64 / VEC)-bank steps
+    while ((hs % 16) != (16 / VEC) && (hs % 16) != 16 - (16 / VEC)) ++hs;
     return hs;
 }
 
@@ -160,12 +160,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ double s_keep[4 + 2 * 64]; // values that live across the timesteps of one launch: true pose, error
                                           // sum, map entries of ids 0..63 (kept out of registers on purpose)
     __shared__ int s_kh[8];               // instance-steps of this launch by detection count
+    __shared__ int s_wend[KG];            // fp32 storage: a timestep ends after this update of the open group (P is rounded there)
     __shared__ double s_tprev[3];         // true pose before the pre-step advanced it (what a freezing instance keeps)
 
-    // row 2 / col 2 of P_t (predict operands) live in the K buffer, which is idle until the first update
-    double* const s_r2 = reinterpret_cast<double*>(s_K);
-    double* const s_c2 = s_r2 + LDP;
-    static_assert(KG >= 1, "need one K slot for the predict operands");
+    // row 2 / col 2 of P_t as they were BEFORE the prediction (its operands).  Not in the K buffer: with deferred groups
+    // the K / (H P) slots hold pending updates across timesteps.
+    __shared__ double s_r2[LDP];
+    __shared__ double s_c2[LDP];
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         s_need[tid] = (signed char)(tid < 3 ? 1 : 0);
     }
     if (tid < 8) s_kh[tid] = 0;
+    if (tid < KG) s_wend[tid] = 0;
 
     // state -> HBM at the end of the launch (or when the instance freezes): x_t lives in s_xt
     // `pre`: the instance freezes in its PRE-step state (x, P, timestep, error sum and the true pose alike)
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 
     int M = M_init;
     int na = n_init;     // active dimension
+    int nu = 0;          // updates of the open group: K / (H P) slots 0 .. nu-1 are pending, P in HBM does not have them yet
     unsigned hiacc = 0u; // non-finite detector (max of |hi word|)
 
     // Everything of timestep tn that does not depend on P, executed by ONE wavefront: the measurement generator
@@ -334,6 +337,260 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
     };
 
+    struct PassArgs {
+        const ST* src; ST* dst; double* mid;
+        int nf, ldd, lds, nsrc, nu;   // state size / leading dimension written, leading dimension / valid size of the source, updates
+    };
+    // ---- BULK: stream P once, in strips of R = UNR consecutive rows.  Work item `it` = (strip s, vector column j): the
+    //      lane owns the 16-byte vectors (R*s + i, VEC*j .. VEC*j + VEC-1), i < R.  Its (H P) operands (VEC per update)
+    //      are read once per strip and re-used for the R rows; K[r] (one 16-byte read per row and update) is the
+    //      same address for every lane of the strip (LDS broadcast): (VEC + R) operand reads per R*VEC elements and
+    //      update instead of two per element.  64 consecutive items form a chunk; chunks are handed to wavefronts
+    //      dynamically.  Every vector is read and rewritten by the same lane, so the update is in place unless the
+    //      step changes the leading dimension (insertions), which writes the other buffer.
+    //      Thin patches.  The thin copies in LDS undergo, element for element, the same operations in the same order
+    //      as the stream applies (the downdates), EXCEPT where the prediction touched them (rows / columns 0, 1 and
+    //      the (2,2) element) and where a landmark is new.  So the common pass (same layout, single group) patches
+    //      only those from LDS (FAST); passes that insert landmarks or belong to a multi-group step patch every thin
+    //      row / column (general), like the thin phase assumes. ----
+    constexpr int R = UNR;
+    auto stream_pass = [&](auto fast_tag, const PassArgs& pa) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const ST* __restrict__ srcb = pa.src;
+        const int nf = pa.nf, ldd = pa.ldd, lds = pa.lds, nsrc = pa.nsrc, nu = pa.nu;
+        const int nv = ldd / VEC;                       // vectors per row
+        const int nstrip = (nf + R - 1) / R;
+        const int nitem = SLAM_DBG(p.dbg & 1) ? 0 : nstrip * nv;
+        const float inv_nv = 1.0f / (float)nv;
+        const VT* __restrict__ src2 = reinterpret_cast<const VT*>(srcb);
+        VT* __restrict__ dst2 = reinterpret_cast<VT*>(pa.dst);
+        const int lsv = lds / VEC;
+        auto next_chunk = [&]() -> int {
+            int ch = 0;
+            if (lane == 0) ch = atomicAdd(&s_chunk, 1);
+            return __builtin_amdgcn_readfirstlane(ch);
+        };
+        // item -> (strip, vector column) without an integer division: (it + 0.5) / nv is at least 0.5 / nv away from
+        // an integer and the float product is off by < 1e-5 at these magnitudes.
+        // FAST passes are branch-free: items beyond the end are clamped to the last item and rows beyond the last row
+        // of the last strip to the last row, so those lanes redo a neighbour's work and store the same bits to the same
+        // addresses (within one wave-instruction, after all loads of the chunk).  With every load and store issued
+        // unconditionally the compiler can count them, so its s_waitcnt for the loads of a chunk leaves the stores and
+        // the prefetch of the next chunk in flight (a store behind a divergent branch forces vmcnt(0) instead).
+        auto decode = [&](int ch, int& it, int& sidx, int& j) {
+            it = ch * 64 + opaque(lane);
+            if (FAST) it = it < nitem ? it : nitem - 1;
+            sidx = (int)(((float)it + 0.5f) * inv_nv);
+            j = it - sidx * nv;
+        };
+        // the loads of one chunk: R 16-byte vectors per lane, issued back to back
+        auto issue = [&](int ch, VT (&raw)[R]) {
+            int it, sidx, j;
+            decode(ch, it, sidx, j);
+            const int r0 = sidx * R;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = r0 + i;
+                if constexpr (FAST) {
+                    raw[i] = src2[(r < nf ? r : nf - 1) * nv + j];
+                } else {
+                    const bool ok = it < nitem && r < nsrc && j < lsv;
+                    VT z;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
+                    raw[i] = ok ? src2[r * lsv + j] : z;
+                }
+            }
+        };
+        // downdates, patches, storage rounding and the stores of one chunk
+        auto process = [&](int ch, const VT (&raw)[R]) {
+            int it, sidx, j;
+            decode(ch, it, sidx, j);
+            const bool act = FAST || it < nitem;
+            const int r0 = sidx * R, c0 = j * VEC;
+            int rr[R];   // row of vector i (FAST: clamped to the last row)
+#pragma unroll
+            for (int i = 0; i < R; ++i) rr[i] = (FAST && r0 + i >= nf) ? nf - 1 : r0 + i;
+            double val[R][VEC];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    val[i][e] = (double)raw[i][e];
+                    if (!FAST && !(rr[i] < nsrc && c0 + e < nsrc)) val[i][e] = 0.0;   // nothing there yet
+                }
+#pragma unroll
+            for (int w = 0; w < KG; ++w) {
+                if (w >= nu) break;  // wave-uniform
+                double2 hp[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) hp[e] = s_HP[w * HPW + e * HS + j];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const double2 kk = s_K[w * LDP + rr[i]];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) val[i][e] = val[i][e] - (kk.x * hp[e].x + kk.y * hp[e].y);
+                }
+                if constexpr (!kWide) {
+                    // fp32 storage rounds P at the end of every timestep; a group that spans several timesteps rounds
+                    // where they end (wave-uniform flag per update)
+                    if (s_wend[w]) {
+#pragma unroll
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) val[i][e] = (double)(ST)val[i][e];
+                    }
+                }
+            }
+            if constexpr (FAST) {
+                if (j == 0) {   // columns 0, 1 (the prediction changed them)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        val[i][0] = s_C[rr[i]];
+                        val[i][1] = s_C[LDP + rr[i]];
+                    }
+                }
+                if (sidx == 0) {   // rows 0, 1
+                    static_assert(R >= 2, "rows 0 and 1 must share a strip");
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        val[0][e] = s_R[c0 + e];
+                        val[1][e] = s_R[LDP + c0 + e];
+                    }
+                }
+                if (sidx == 2 / R && c0 <= 2 && 2 < c0 + VEC) {   // (2,2)
+                    const double p22 = s_R[2 * LDP + 2];
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            if (rr[i] == 2 && c0 + e == 2) val[i][e] = p22;
+                }
+            } else {
+                int sc[VEC], sr[R];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sc[e] = s_slot[c0 + e];
+#pragma unroll
+                for (int i = 0; i < R; ++i) sr[i] = s_slot[rr[i]];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if (sc[e] >= 0) val[i][e] = s_C[sc[e] * LDP + rr[i]];
+                        if (sr[i] >= 0) val[i][e] = s_R[sr[i] * LDP + c0 + e];
+                        if (c0 + e >= nf) val[i][e] = 0.0;   // pad columns stay zero
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const ST stored = (ST)val[i][e];   // storage rounding (identity for fp64)
+                    const unsigned ha = hi_abs((double)stored);
+                    hiacc = ((FAST || (act && rr[i] < nf)) && hiacc < ha) ? ha : hiacc;
+                    o[e] = stored;
+                }
+                if (FAST || (act && rr[i] < nf)) dst2[rr[i] * nv + j] = o;
+            }
+        };
+        if constexpr (PIPE && FAST) {
+            // Software pipeline over two register sets: the loads of the next chunk are in flight while this one is
+            // updated and stored.  A chunk index beyond the end loads (clamped) the last item and is never processed.
+            VT bufA[R], bufB[R];
+            int ca = next_chunk();
+            issue(ca, bufA);
+#pragma unroll 1
+            while (ca * 64 < nitem) {
+                const int cb = next_chunk();
+                issue(cb, bufB);
+                process(ca, bufA);
+                if (cb * 64 >= nitem) break;
+                ca = next_chunk();
+                issue(ca, bufA);
+                process(cb, bufB);
+            }
+        } else {
+#pragma unroll 1
+            for (;;) {
+                const int ch = next_chunk();
+                if (ch * 64 >= nitem) break;
+                VT raw[R];
+                issue(ch, raw);
+                process(ch, raw);
+            }
+        }
+    };
+    // fp32 storage with more than KG detections in one step (rare): the matrix between the groups stays fp64 in the
+    // per-instance scratch slab so that storage rounding happens exactly once per step.  Element-wise, one vector
+    // of one row per lane, every thin row / column patched.
+    auto mid_pass = [&](bool src_mid, bool dst_mid, const PassArgs& pa) {
+        const int nf = pa.nf, ldd = pa.ldd, lds = pa.lds, nsrc = pa.nsrc, nu = pa.nu;
+        double* const Pmid = pa.mid;
+        const ST* const Pin = pa.src;
+        ST* const Pout = pa.dst;
+        const int nv = ldd / VEC;
+        const int nitem = SLAM_DBG(p.dbg & 1) ? 0 : nf * nv;
+#pragma unroll 1
+        for (;;) {
+            int ch = 0;
+            if (lane == 0) ch = atomicAdd(&s_chunk, 1);
+            ch = __builtin_amdgcn_readfirstlane(ch);
+            if (ch * 64 >= nitem) break;
+            const int it = ch * 64 + opaque(lane);
+            if (it < nitem) {
+                const int r = it / nv, c0 = (it - r * nv) * VEC;
+                const int srw = s_slot[r];
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int c = c0 + e;
+                    double v = 0.0;
+                    if (r < nsrc && c < nsrc) v = src_mid ? Pmid[(size_t)r * lds + c] : (double)Pin[(size_t)r * lds + c];
+                    for (int w = 0; w < nu; ++w) {
+                        const double2 kk = s_K[w * LDP + r], hh = s_HP[w * HPW + hpi(c)];
+                        v = v - (kk.x * hh.x + kk.y * hh.y);
+                    }
+                    const int scl = s_slot[c];
+                    if (scl >= 0) v = s_C[scl * LDP + r];
+                    if (srw >= 0) v = s_R[srw * LDP + c];
+                    if (c >= nf) v = 0.0;
+                    if (dst_mid) {
+                        Pmid[(size_t)r * ldd + c] = v;
+                    } else {
+                        const ST stored = (ST)v;
+                        const unsigned ha = hi_abs((double)stored);
+                        hiacc = hiacc > ha ? hiacc : ha;
+                        o[e] = stored;
+                    }
+                }
+                if (!dst_mid) reinterpret_cast<VT*>(Pout)[it] = o;
+            }
+        }
+    };
+    // The three vehicle rows and columns of P from their LDS copies (what the prediction changes, ekf.cpp:61 with the sparse
+    // F_x, F_v) into a matrix of state size n: all a step without update or insertion has to write.
+    auto write_vehicle = [&](ST* Pbuf, int n) {
+        const int ldn = ekf_ld(n, ESZ);
+        const int tsk = opaque(tid);
+#pragma unroll 1
+        for (int i = tsk; i < 3 * n; i += TPB) {
+            const int r = i / n, c = i - r * n;
+            const ST sv = (ST)s_R[r * LDP + c];                       // P[r][c], r < 3
+            const unsigned ha = hi_abs((double)sv);
+            hiacc = hiacc > ha ? hiacc : ha;
+            Pbuf[(size_t)r * ldn + c] = sv;
+        }
+#pragma unroll 1
+        for (int i = tsk; i < 3 * (n - 3); i += TPB) {
+            const int c = i / (n - 3), r = 3 + (i - c * (n - 3));
+            const ST sv = (ST)s_C[c * LDP + r];                       // P[r][c], c < 3 <= r
+            const unsigned ha = hi_abs((double)sv);
+            hiacc = hiacc > ha ? hiacc : ha;
+            Pbuf[(size_t)r * ldn + c] = sv;
+        }
+    };
+
     if (!p.sim) {   // EXT mode (single step): fetch the message
         int kk = p.meas_count_in[b];
         kk = kk < p.k_stride_in ? kk : p.k_stride_in;
@@ -347,6 +604,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if (tid < 64) prestep(0);
     SLAM_STAMP(1);   // measurements, association, motion scalars of the first step
 
+    // a freezing instance leaves both loops and writes its PRE-step state below (the reference node died at that step)
+    int frz_at = -1, frz_M = 0, frz_n = 0;
+    const ST* frz_P = nullptr;
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
     const ST* const Pin = Pcur;
@@ -355,14 +615,6 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     int* const didx_t = s_didx + pb * KCAP;
     const int M_old = M;
     const int n_old = na;
-    // pre-step state of a freezing instance into the buffer the host reads next
-    auto freeze = [&]() {
-        if (Pfinal != Pin) {
-            const int nn = n_old * ekf_ld(n_old, ESZ);
-            for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pin[i];
-        }
-        finish(t, M_old, flags | SLAM_INST_INDEX_OOR, true);
-    };
     if (tid < 8) s_misc[tid] = 0;
     __syncthreads();   // the pre-step results of this timestep are visible
     const int kraw = s_next[4 * pb];
@@ -375,10 +627,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         if (tid == 0) p.meas_count_out[b] = k;
     }
     const int n_ins = p.id_known ? s_next[4 * pb + 1] : k;  // insertions this step (upper bound k for unknown ids)
-    if (p.id_known && s_next[4 * pb + 2]) {  // freeze in the pre-step state
-        freeze();
-        return;
-    }
+    const bool frz_top = p.id_known && s_next[4 * pb + 2];  // freeze in the pre-step state (after the pending group is flushed)
     if (p.id_known && s_next[4 * pb + 3]) flags |= SLAM_INST_CAPACITY;
     SLAM_STAMP(2);   // association
     int nf = n_old + 2 * n_ins;           // leading dimension of the matrix written this step
@@ -414,8 +663,19 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             int want[KG], nw = 0;
 #pragma unroll
             for (int w = 0; w < KG; ++w) want[w] = -1;
+            // Pre-flush: the open group (nu pending updates of earlier timesteps) is streamed into P BEFORE this step if the
+            // step cannot join it: it inserts landmarks (layout change), its updates do not fit into the free slots, it
+            // needs a thin row / column from HBM (which must then be current), or the instance freezes.
+            int fb = 0, lim = KG;
+            if (first && nu > 0) {
+                int kupd = 0;
+                for (int l = 0; l < k; ++l) kupd += (didx_t[l] >= 0 && didx_t[l] < M_g) ? 1 : 0;
+                fb = (frz_top || n_ins > 0 || nu + kupd > KG) ? 1 : 0;
+                lim = fb ? KG : KG - nu;
+            }
+            int needg = 0;
 #pragma unroll 1
-            while (l1 < k && l1 - l0 < KG) {
+            while (l1 < k && l1 - l0 < lim) {
                 int idx;
                 if (p.id_known) {
                     idx = didx_t[l1];
@@ -480,6 +740,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     s_slot[ii] = (signed char)(3 + 2 * j); s_slot[ii + 1] = (signed char)(4 + 2 * j);
                     const signed char nd = (signed char)(ii < nsrc ? 1 : 2);   // known landmark: gather, new one: zeros
                     s_need[3 + 2 * j] = nd; s_need[4 + 2 * j] = nd;
+                    needg |= (nd == 1) ? 1 : 0;
                 }
             }
             int nT = 3;
@@ -490,14 +751,35 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             s_misc[4] = l1;
             s_misc[5] = nT;      // high-water mark: slots [3, nT) may contain free pairs (s_T < 0)
             s_misc[2] = frz;
+            s_misc[7] = (first && nu > 0 && (fb || needg)) ? 1 : 0;
         }
         __syncthreads();
         const int l1 = s_misc[4], nT = s_misc[5];
         SLAM_STAMP(3);   // x_pred + group formation
+        if (first && s_misc[7]) {
+            // ---- pre-flush: stream the open group into P in place (layout of the previous step); the patches of rows /
+            //      columns 0, 1 and (2,2) come from the thin copies, which hold the END of the previous step (this step's
+            //      prediction has not touched them yet) ----
+            PassArgs pa;
+            pa.src = Pin; pa.dst = const_cast<ST*>(Pin); pa.mid = nullptr;
+            pa.nf = n_old; pa.ldd = lds; pa.lds = lds; pa.nsrc = n_old; pa.nu = nu;
+            stream_pass(std::true_type{}, pa);
+            nu = 0;
+            __syncthreads();   // P in HBM is current (the gather below reads it); every wave is done with s_chunk / s_wend
+            if (tid == 0) s_chunk = 0;
+            if (tid < KG) s_wend[tid] = 0;
+        }
+        if (first && frz_top) {   // duplicate new id (ekf.cpp:115 would index out of range): freeze in the pre-step state
+            // rows / columns the deferred predictions changed (at the first step of a launch P in HBM is current and the
+            // thin copies have not been gathered yet)
+            if (!s_misc[7] && t > 0) write_vehicle(const_cast<ST*>(Pin), n_old);
+            frz_at = t; frz_M = M_old; frz_n = n_old; frz_P = Pin;
+            break;   // one exit for freezing instances, after the timestep loop
+        }
         if (s_misc[2]) {
             // unknown-id quirk: the reference throws.  Freeze in the pre-step state.
-            freeze();
-            return;
+            frz_at = t; frz_M = M_old; frz_n = n_old; frz_P = Pin;
+            break;
         }
         if (s_misc[3]) flags |= SLAM_INST_CAPACITY;
 
@@ -587,7 +869,6 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 
         SLAM_STAMP(5);   // predict
         // ---- detections of the group in message order ----
-        int nu = 0;  // updates recorded for the bulk pass
 #pragma unroll 1
         for (int l = l0; l < l1; ++l) {
             const int td = opaque(tid);   // keeps per-lane index arithmetic from being hoisted out of the loops
@@ -752,256 +1033,38 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             }
             if (t + 1 < T) prestep(t + 1);
         }
-        // ---- no update and no insertion in this step (no detection in range, or all dropped): the prediction is the
-        //      only change, and it touches rows / columns 0, 1 and (2,2) only (ekf.cpp:61 with the sparse F_x, F_v).
-        //      P is updated in place, so the rest of the matrix is already where it belongs: write the three vehicle
-        //      rows and columns from their LDS copies and skip the stream. ----
-        const bool skip_stream = first && l1 >= k && nu == 0 && Pout == Pin && !SLAM_DBG(p.dbg & 16);
-        if (skip_stream) {
-            const int tsk = opaque(tid);
-#pragma unroll 1
-            for (int i = tsk; i < 3 * nf; i += TPB) {
-                const int r = i / nf, c = i - r * nf;
-                const ST sv = (ST)s_R[r * LDP + c];                       // P[r][c], r < 3
-                const unsigned ha = hi_abs((double)sv);
-                hiacc = hiacc > ha ? hiacc : ha;
-                Pout[(size_t)r * ldd + c] = sv;
-            }
-#pragma unroll 1
-            for (int i = tsk; i < 3 * (nf - 3); i += TPB) {
-                const int c = i / (nf - 3), r = 3 + (i - c * (nf - 3));
-                const ST sv = (ST)s_C[c * LDP + r];                       // P[r][c], c < 3 <= r
-                const unsigned ha = hi_abs((double)sv);
-                hiacc = hiacc > ha ? hiacc : ha;
-                Pout[(size_t)r * ldd + c] = sv;
-            }
-        }
-        // ---- BULK: stream P once, in strips of R = UNR consecutive rows.  Work item `it` = (strip s, vector column j): the
-        //      lane owns the 16-byte vectors (R*s + i, VEC*j .. VEC*j + VEC-1), i < R.  Its (H P) operands (VEC per update)
-        //      are read once per strip and re-used for the R rows; K[r] (one 16-byte read per row and update) is the
-        //      same address for every lane of the strip (LDS broadcast): (VEC + R) operand reads per R*VEC elements and
-        //      update instead of two per element.  64 consecutive items form a chunk; chunks are handed to wavefronts
-        //      dynamically.  Every vector is read and rewritten by the same lane, so the update is in place unless the
-        //      step changes the leading dimension (insertions), which writes the other buffer.
-        //      Thin patches.  The thin copies in LDS undergo, element for element, the same operations in the same order
-        //      as the stream applies (the downdates), EXCEPT where the prediction touched them (rows / columns 0, 1 and
-        //      the (2,2) element) and where a landmark is new.  So the common pass (same layout, single group) patches
-        //      only those from LDS (FAST); passes that insert landmarks or belong to a multi-group step patch every thin
-        //      row / column (general), like the thin phase assumes. ----
-        constexpr int R = UNR;
-        auto stream_pass = [&](auto fast_tag, const ST* __restrict__ srcb) {
-            constexpr bool FAST = decltype(fast_tag)::value;
-            const int nv = ldd / VEC;                       // vectors per row
-            const int nstrip = (nf + R - 1) / R;
-            const int nitem = SLAM_DBG(p.dbg & 1) ? 0 : nstrip * nv;
-            const float inv_nv = 1.0f / (float)nv;
-            const VT* __restrict__ src2 = reinterpret_cast<const VT*>(srcb);
-            VT* __restrict__ dst2 = reinterpret_cast<VT*>(Pout);
-            const int lsv = lds / VEC;
-            auto next_chunk = [&]() -> int {
-                int ch = 0;
-                if (lane == 0) ch = atomicAdd(&s_chunk, 1);
-                return __builtin_amdgcn_readfirstlane(ch);
-            };
-            // item -> (strip, vector column) without an integer division: (it + 0.5) / nv is at least 0.5 / nv away from
-            // an integer and the float product is off by < 1e-5 at these magnitudes.
-            // FAST passes are branch-free: items beyond the end are clamped to the last item and rows beyond the last row
-            // of the last strip to the last row, so those lanes redo a neighbour's work and store the same bits to the same
-            // addresses (within one wave-instruction, after all loads of the chunk).  With every load and store issued
-            // unconditionally the compiler can count them, so its s_waitcnt for the loads of a chunk leaves the stores and
-            // the prefetch of the next chunk in flight (a store behind a divergent branch forces vmcnt(0) instead).
-            auto decode = [&](int ch, int& it, int& sidx, int& j) {
-                it = ch * 64 + opaque(lane);
-                if (FAST) it = it < nitem ? it : nitem - 1;
-                sidx = (int)(((float)it + 0.5f) * inv_nv);
-                j = it - sidx * nv;
-            };
-            // the loads of one chunk: R 16-byte vectors per lane, issued back to back
-            auto issue = [&](int ch, VT (&raw)[R]) {
-                int it, sidx, j;
-                decode(ch, it, sidx, j);
-                const int r0 = sidx * R;
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int r = r0 + i;
-                    if constexpr (FAST) {
-                        raw[i] = src2[(r < nf ? r : nf - 1) * nv + j];
-                    } else {
-                        const bool ok = it < nitem && r < nsrc && j < lsv;
-                        VT z;
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) z[e] = (ST)0;
-                        raw[i] = ok ? src2[r * lsv + j] : z;
-                    }
-                }
-            };
-            // downdates, patches, storage rounding and the stores of one chunk
-            auto process = [&](int ch, const VT (&raw)[R]) {
-                int it, sidx, j;
-                decode(ch, it, sidx, j);
-                const bool act = FAST || it < nitem;
-                const int r0 = sidx * R, c0 = j * VEC;
-                int rr[R];   // row of vector i (FAST: clamped to the last row)
-#pragma unroll
-                for (int i = 0; i < R; ++i) rr[i] = (FAST && r0 + i >= nf) ? nf - 1 : r0 + i;
-                double val[R][VEC];
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        val[i][e] = (double)raw[i][e];
-                        if (!FAST && !(rr[i] < nsrc && c0 + e < nsrc)) val[i][e] = 0.0;   // nothing there yet
-                    }
-#pragma unroll
-                for (int w = 0; w < KG; ++w) {
-                    if (w >= nu) break;  // wave-uniform
-                    double2 hp[VEC];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) hp[e] = s_HP[w * HPW + e * HS + j];
-#pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        const double2 kk = s_K[w * LDP + rr[i]];
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) val[i][e] = val[i][e] - (kk.x * hp[e].x + kk.y * hp[e].y);
-                    }
-                }
-                if constexpr (FAST) {
-                    if (j == 0) {   // columns 0, 1 (the prediction changed them)
-#pragma unroll
-                        for (int i = 0; i < R; ++i) {
-                            val[i][0] = s_C[rr[i]];
-                            val[i][1] = s_C[LDP + rr[i]];
-                        }
-                    }
-                    if (sidx == 0) {   // rows 0, 1
-                        static_assert(R >= 2, "rows 0 and 1 must share a strip");
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            val[0][e] = s_R[c0 + e];
-                            val[1][e] = s_R[LDP + c0 + e];
-                        }
-                    }
-                    if (sidx == 2 / R && c0 <= 2 && 2 < c0 + VEC) {   // (2,2)
-                        const double p22 = s_R[2 * LDP + 2];
-#pragma unroll
-                        for (int i = 0; i < R; ++i)
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e)
-                                if (rr[i] == 2 && c0 + e == 2) val[i][e] = p22;
-                    }
-                } else {
-                    int sc[VEC], sr[R];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) sc[e] = s_slot[c0 + e];
-#pragma unroll
-                    for (int i = 0; i < R; ++i) sr[i] = s_slot[rr[i]];
-#pragma unroll
-                    for (int i = 0; i < R; ++i)
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            if (sc[e] >= 0) val[i][e] = s_C[sc[e] * LDP + rr[i]];
-                            if (sr[i] >= 0) val[i][e] = s_R[sr[i] * LDP + c0 + e];
-                            if (c0 + e >= nf) val[i][e] = 0.0;   // pad columns stay zero
-                        }
-                }
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    VT o;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const ST stored = (ST)val[i][e];   // storage rounding (identity for fp64)
-                        const unsigned ha = hi_abs((double)stored);
-                        hiacc = ((FAST || (act && rr[i] < nf)) && hiacc < ha) ? ha : hiacc;
-                        o[e] = stored;
-                    }
-                    if (FAST || (act && rr[i] < nf)) dst2[rr[i] * nv + j] = o;
-                }
-            };
-            if constexpr (PIPE && FAST) {
-                // Software pipeline over two register sets: the loads of the next chunk are in flight while this one is
-                // updated and stored.  A chunk index beyond the end loads (clamped) the last item and is never processed.
-                VT bufA[R], bufB[R];
-                int ca = next_chunk();
-                issue(ca, bufA);
-#pragma unroll 1
-                while (ca * 64 < nitem) {
-                    const int cb = next_chunk();
-                    issue(cb, bufB);
-                    process(ca, bufA);
-                    if (cb * 64 >= nitem) break;
-                    ca = next_chunk();
-                    issue(ca, bufA);
-                    process(cb, bufB);
-                }
+        // ---- what goes to HBM now.  Updates are DEFERRED: the group (K, H P of up to KG updates) stays open across
+        //      timesteps and P is streamed once per group instead of once per step; the thin rows / columns in LDS are
+        //      always current, so nothing on the critical path needs P itself.  The stream runs now if the group cannot
+        //      stay open: more groups of this step follow, the step changed the layout (insertions), unknown-id
+        //      association (every detection is its own group), or the launch ends.  (A pending group is flushed at the
+        //      START of a step that needs HBM to be current: see the pre-flush above.) ----
+        const bool more = l1 < k;   // further groups of this step follow
+        const bool pass_now = more || !first || nf != n_old || !p.id_known || t + 1 >= T || SLAM_DBG(p.dbg & 16);
+        if (pass_now) {
+            PassArgs pa;
+            pa.src = first ? Pin : Pout; pa.dst = Pout; pa.mid = Pmid;
+            pa.nf = nf; pa.ldd = ldd; pa.lds = lds; pa.nsrc = nsrc; pa.nu = nu;
+            if (first && !more && nf == n_old) {
+                if (nu == 0 && !SLAM_DBG(p.dbg & 16)) write_vehicle(Pout, nf);   // nothing pending: only the prediction's rows / columns
+                else stream_pass(std::true_type{}, pa);
+            } else if (kWide || (first && !more)) {
+                stream_pass(std::false_type{}, pa);
             } else {
-#pragma unroll 1
-                for (;;) {
-                    const int ch = next_chunk();
-                    if (ch * 64 >= nitem) break;
-                    VT raw[R];
-                    issue(ch, raw);
-                    process(ch, raw);
-                }
+                pa.src = Pin;
+                mid_pass(!first, more, pa);
             }
-        };
-        // fp32 storage with more than KG detections in one step (rare): the matrix between the groups stays fp64 in the
-        // per-instance scratch slab so that storage rounding happens exactly once per step.  Element-wise, one vector
-        // of one row per lane, every thin row / column patched.
-        auto mid_pass = [&](bool src_mid, bool dst_mid) {
-            const int nv = ldd / VEC;
-            const int nitem = SLAM_DBG(p.dbg & 1) ? 0 : nf * nv;
-#pragma unroll 1
-            for (;;) {
-                int ch = 0;
-                if (lane == 0) ch = atomicAdd(&s_chunk, 1);
-                ch = __builtin_amdgcn_readfirstlane(ch);
-                if (ch * 64 >= nitem) break;
-                const int it = ch * 64 + opaque(lane);
-                if (it < nitem) {
-                    const int r = it / nv, c0 = (it - r * nv) * VEC;
-                    const int srw = s_slot[r];
-                    VT o;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int c = c0 + e;
-                        double v = 0.0;
-                        if (r < nsrc && c < nsrc) v = src_mid ? Pmid[(size_t)r * lds + c] : (double)Pin[(size_t)r * lds + c];
-                        for (int w = 0; w < nu; ++w) {
-                            const double2 kk = s_K[w * LDP + r], hh = s_HP[w * HPW + hpi(c)];
-                            v = v - (kk.x * hh.x + kk.y * hh.y);
-                        }
-                        const int scl = s_slot[c];
-                        if (scl >= 0) v = s_C[scl * LDP + r];
-                        if (srw >= 0) v = s_R[srw * LDP + c];
-                        if (c >= nf) v = 0.0;
-                        if (dst_mid) {
-                            Pmid[(size_t)r * ldd + c] = v;
-                        } else {
-                            const ST stored = (ST)v;
-                            const unsigned ha = hi_abs((double)stored);
-                            hiacc = hiacc > ha ? hiacc : ha;
-                            o[e] = stored;
-                        }
-                    }
-                    if (!dst_mid) reinterpret_cast<VT*>(Pout)[it] = o;
-                }
-            }
-        };
-        if (!skip_stream) {
-            const bool more = l1 < k;   // further groups of this step follow
-            if (kWide || (first && !more)) {
-                const ST* srcb = first ? Pin : Pout;
-                if (first && !more && nf == n_old) stream_pass(std::true_type{}, srcb);
-                else stream_pass(std::false_type{}, srcb);
-            } else {
-                mid_pass(!first, more);
-            }
+            nu = 0;
+        } else if (!kWide && nu > 0 && tid == 0) {
+            s_wend[nu - 1] = 1;   // fp32 storage: P is rounded where this timestep ends
         }
         l0 = l1;
         first = false;
     }
+    if (frz_at >= 0) break;
     __syncthreads();
     SLAM_STAMP(7);   // bulk stream
+    if (nu == 0 && tid < KG) s_wend[tid] = 0;
 
     // ------------------------------------------------------------------------------------------------------
     // x_t = x_pred (ekf.cpp:176) and bookkeeping.  P_t = P_pred was written by the bulk stream.
@@ -1056,6 +1119,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     Pcur = Pout;
     }   // timestep loop
 
+    if (frz_at >= 0) {   // pre-step state of the frozen instance into the buffer the host reads next
+        __syncthreads();
+        if (Pfinal != frz_P) {
+            const int nn = frz_n * ekf_ld(frz_n, ESZ);
+            for (int i = tid; i < nn; i += TPB) Pfinal[i] = frz_P[i];
+        }
+        finish(frz_at, frz_M, flags | SLAM_INST_INDEX_OOR, true);
+        return;
+    }
     if (Pcur != Pfinal) {   // an odd number of layout changes in this launch: bring P_t back to the host's buffer
         __syncthreads();
         const int nn = na * ekf_ld(na, ESZ);
