@@ -124,6 +124,9 @@ int slam_step_sim(slam_handle* h, const float cmd[2]);
 /* T consecutive slam_step_sim calls; cmds = [T][2] float32 host array (precomputed trajectory,
  * sim_node.py:142-152). */
 int slam_run_sim(slam_handle* h, const float* cmds, int T);
+/* Timesteps one kernel launch of slam_run_sim carries (EKF): 0 = the whole call (default; also the environment variable
+ * SLAM_RUN_CHUNK at slam_create), 1 = one launch per timestep.  Results do not depend on it. */
+int slam_set_run_chunk(slam_handle* h, int steps_per_launch);
 /* UKF only: the two public halves of UKF::update, predictionStage(cmd) and updateStage(meas) (filter.h:187-188,
  * ukf.cpp:197-291).  x_t / P_t change when the update stage finishes, exactly as in the reference; the pair gives
  * bit-identical results to slam_step_dev.  d_meas / d_meas_count are DEVICE pointers (k_stride 0 = empty message). */
@@ -162,6 +165,10 @@ int slam_algorithmic_bytes(slam_handle* h, double* bytes);
  * of EKF::update grows with k (one rank-2 downdate of P per detection, ekf.cpp:140), so a throughput figure is only
  * meaningful together with this histogram.  Synchronises. */
 int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset);
+/* Diagnostics: flag 32 = every workgroup of the EKF multi-step kernel stamps the wall clock and its detection count per
+ * timestep (read back by the profiling tools / bench.py's per-k table), flag 4 = per-phase cycle counters; 0 = off (default;
+ * the environment variable SLAM_DEBUG_FLAGS sets the initial value). */
+int slam_set_debug_flags(slam_handle* h, int flags);
 /* Build introspection: 1 if the library holds the EKF step-kernel tuning variant `variant` (code PIPE*1000 + W*100 + KG*10 +
  * UNR, selected per handle by the environment variable SLAM_WAVES_PER_FILTER) for landmark capacity L_max and storage
  * dtype; 0 = the default, always present.  Release builds hold the defaults only; asking a handle for a variant the build

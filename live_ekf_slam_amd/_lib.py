@@ -51,6 +51,8 @@ SIGNATURES = {
     "slam_batch": (C.c_int, [_H]),
     "slam_state_dim_max": (C.c_int, [_H]),
     "slam_algorithmic_bytes": (C.c_int, [_H, _dp]),
+    "slam_set_run_chunk": (C.c_int, [_H, C.c_int]),
+    "slam_set_debug_flags": (C.c_int, [_H, C.c_int]),
     "slam_variant_available": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "slam_k_histogram": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
     "slam_math_probe": (C.c_int, [_dp, _dp, _dp, C.c_int, C.c_int]),

@@ -724,6 +724,30 @@ int slam_sync(slam_handle* h) {
 int slam_batch(const slam_handle* h) { return h ? h->B : 0; }
 int slam_state_dim_max(const slam_handle* h) { return h ? h->n_max : 0; }
 
+int slam_set_run_chunk(slam_handle* h, int steps_per_launch) {
+    if (!h || steps_per_launch < 0) return fail(SLAM_ERR_ARG, "bad argument");
+    h->run_chunk = steps_per_launch;
+    return SLAM_OK;
+}
+
+// Per-timestep stamps of the EKF multi-step kernel (flag 32) / phase cycle counters (flag 4) for subsequent launches; 0 = off.
+// The ablation bits are honoured by -DSLAM_ABLATE builds only.
+int slam_set_debug_flags(slam_handle* h, int flags) {
+    if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+#ifndef SLAM_ABLATE
+    flags &= (4 | 32);
+#endif
+    if ((flags & (4 | 32)) && !h->dprof) {
+        const size_t bytes = sizeof(unsigned long long) * slam::kEkfProfSlots * (size_t)h->B;
+        HIP_TRY(hipMalloc(&h->dprof, bytes));
+        HIP_TRY(hipMemset(h->dprof, 0, bytes));
+    }
+    h->dbg = flags;
+    return SLAM_OK;
+}
+
 int slam_variant_available(int L_max, int dtype, int variant) { return slam::ekf_variant_available(L_max, dtype == SLAM_F32, variant); }
 
 int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset) {

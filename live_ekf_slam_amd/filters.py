@@ -196,6 +196,24 @@ class BatchedFilter:
     def algorithmic_bytes(self):
         self._need(); v = C.c_double(0); _lib.check(_lib.lib().slam_algorithmic_bytes(self.h, C.byref(v))); return v.value
 
+    def set_run_chunk(self, steps_per_launch):
+        """Timesteps per kernel launch of run_sim (0 = the whole call)."""
+        self._need(); _lib.check(_lib.lib().slam_set_run_chunk(self.h, int(steps_per_launch)))
+
+    def set_debug_flags(self, flags):
+        self._need(); _lib.check(_lib.lib().slam_set_debug_flags(self.h, int(flags)))
+
+    def step_stamps(self, steps):
+        """(wall-clock ticks at 100 MHz, detections) of every workgroup at the end of each of the first `steps` (<= 128)
+        timesteps of the LAST multi-step launch (needs set_debug_flags(32) before that launch): two [batch][steps] arrays."""
+        self._need()
+        L = _lib.lib()
+        L.slam_debug_read_prof_raw.argtypes = [C.c_void_p, C.c_void_p]
+        L.slam_debug_read_prof_raw.restype = C.c_int
+        buf = np.zeros((self.batch, 128), dtype=np.uint64)
+        _lib.check(L.slam_debug_read_prof_raw(self.h, buf.ctypes.data_as(C.c_void_p)))
+        return (buf[:, :steps] >> np.uint64(4)).astype(np.int64), (buf[:, :steps] & np.uint64(15)).astype(np.int64)
+
     def k_histogram(self, reset=False):
         """Instance-steps by detections per message (k = 0..6, >= 7) since creation / the last reset (EKF kernel)."""
         self._need(); out = np.zeros(8, dtype=np.uint64)

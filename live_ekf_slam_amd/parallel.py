@@ -49,3 +49,56 @@ def reduce_summary(local_err, dist=None, device=None):
     mean = acc[0] / acc[2]
     var = max(acc[1] / acc[2] - mean * mean, 0.0)
     return mean, var ** 0.5, int(acc[2])
+
+
+class ShardedRun:
+    """The N>1 path of bench.py, factored out so that the world-size-2 gloo test drives exactly this code with a CPU
+    engine (tests/test_distributed_cpu.py): shard plan, barrier-bracketed timing with the MAX over ranks, and the one
+    collective of the run (error statistics, after the timed region).
+
+    `engine` protocol (BatchedEKF satisfies it): run_sim(cmds) enqueues timesteps, sync() waits for them,
+    error_stats() -> per-instance average position error of the local shard."""
+
+    def __init__(self, dist=None, device=None):
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.device = device
+
+    def plan(self, batch, scaling):
+        """(first global instance, local instances, global instances).  strong: `batch` is the GLOBAL batch, split
+        contiguously (BASELINE configs[3]: 65536 -> 8192 per GPU at 8 GPUs); weak: `batch` instances on every rank."""
+        if scaling == "strong":
+            start, n = shard_range(batch, self.rank, self.world)
+            return start, n, int(batch)
+        if scaling == "weak":
+            return self.rank * int(batch), int(batch), int(batch) * self.world
+        raise ValueError("scaling must be 'strong' or 'weak'")
+
+    def barrier(self, engine):
+        engine.sync()
+        if self.dist:
+            self.dist.barrier()
+            engine.sync()
+
+    def timed(self, engine, fn):
+        """Seconds of fn() bracketed by engine sync + barrier on both sides, MAX over ranks."""
+        import time
+        self.barrier(engine)
+        t0 = time.perf_counter()
+        fn()
+        self.barrier(engine)
+        wall = time.perf_counter() - t0
+        if self.dist:
+            import torch
+            tw = torch.tensor([wall], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+            self.dist.all_reduce(tw, op=self.dist.ReduceOp.MAX)
+            wall = float(tw.item())
+        return wall
+
+    def error_statistics(self, engine):
+        """(global per-instance errors, mean, std, count): the end-of-run gather + reduce (RCCL on the GPU box)."""
+        err = engine.error_stats()
+        allerr = gather_error_stats(err, self.dist, self.device)
+        mean, std, n = reduce_summary(err, self.dist, self.device)
+        return allerr, mean, std, n

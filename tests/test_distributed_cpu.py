@@ -1,5 +1,6 @@
-"""world_size-2 gloo test of the N>1 path: shard ranges, global-instance-keyed noise streams and the
-end-of-run error-statistics gather.  The per-rank compute is done by the CPU oracle here (no GPU)."""
+"""world_size-2 gloo tests of the N>1 path: they drive parallel.ShardedRun, the code bench.py runs under torch.distributed
+(shard plan for strong / weak scaling, global-instance-keyed noise streams, barrier-bracketed timing with the MAX over
+ranks, the end-of-run error-statistics gather), with the CPU oracle as the per-rank engine (no GPU here)."""
 import os
 import socket
 
@@ -24,36 +25,80 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, B, q):
+class OracleEngine:
+    """CPU stand-in for BatchedEKF behind the engine protocol of parallel.ShardedRun (run_sim / sync / error_stats): the
+    per-rank compute is the oracle, everything around it (shard plan, barrier-bracketed timing with MAX over ranks, the
+    end-of-run gather and reduce) is the code bench.py runs on the GPUs."""
+
+    def __init__(self, lm, L, first, n, seed):
+        self.lm, self.L, self.first, self.n, self.seed = lm, L, first, n, seed
+        self.cmds = np.zeros((0, 2), np.float32)
+        self.result = None
+
+    def run_sim(self, cmds):
+        self.cmds = np.concatenate([self.cmds, np.asarray(cmds, np.float32).reshape(-1, 2)])
+        self.result = None
+
+    def sync(self):
+        if self.result is None and len(self.cmds):
+            from oracle import oracle as O
+            self.result = O.run_ekf_batch(self.lm, self.cmds, self.n, self.L, seed=self.seed, inst0=self.first, nthreads=1, want_P=False)
+
+    def error_stats(self):
+        self.sync()
+        return self.result["avg_err"]
+
+
+def _worker(rank, world, port, B, scaling, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import oracle as O
+    from live_ekf_slam_amd.parallel import ShardedRun
     lm, cmds = make_scenario(1234, 20, 120)
-    start, n = shard_range(B, rank, world)
-    r = O.run_ekf_batch(lm, cmds, n, 20, seed=9, inst0=start, nthreads=1, want_P=False)
-    allerr = gather_error_stats(r["avg_err"], dist)
-    summ = reduce_summary(r["avg_err"], dist)
+    run = ShardedRun(dist)
+    first, n, total = run.plan(B, scaling)
+    eng = OracleEngine(lm, 20, first, n, seed=9)
+    eng.run_sim(cmds[:100])                                   # "pre-roll + warm-up"
+    wall = run.timed(eng, lambda: eng.run_sim(cmds[100:]))    # the timed window: barriers both sides, MAX over ranks
+    allerr, mean, std, cnt = run.error_statistics(eng)        # the one collective of the run
     if rank == 0:
-        q.put((allerr, summ))
+        q.put((allerr, (mean, std, cnt), total, wall))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_equals_single_process():
-    B = 21  # ragged split 11 + 10
+def _run_two_ranks(B, scaling):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, scaling, q)) for r in range(2)]
     for p in procs:
         p.start()
-    allerr, summ = q.get(timeout=120)
+    out = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return out
+
+
+def test_two_rank_strong_shard_equals_single_process():
+    """bench.py's default for --gpus N: the GLOBAL batch split contiguously (ragged here: 11 + 10)."""
+    B = 21
+    allerr, summ, total, wall = _run_two_ranks(B, "strong")
     from oracle import oracle as O
     lm, cmds = make_scenario(1234, 20, 120)
     ref = O.run_ekf_batch(lm, cmds, B, 20, seed=9, inst0=0, nthreads=2, want_P=False)
+    assert total == B and wall > 0
     assert np.array_equal(allerr, ref["avg_err"])            # identical regardless of the sharding
     assert summ[2] == B and abs(summ[0] - ref["avg_err"].mean()) < 1e-15
     assert abs(summ[1] - ref["avg_err"].std()) < 1e-12
+
+
+def test_two_rank_weak_scaling_covers_disjoint_global_instances():
+    """--scaling weak: B instances on every rank, global ids rank*B ..: the gathered vector equals one 2B-instance run."""
+    B = 6
+    allerr, summ, total, wall = _run_two_ranks(B, "weak")
+    from oracle import oracle as O
+    lm, cmds = make_scenario(1234, 20, 120)
+    ref = O.run_ekf_batch(lm, cmds, 2 * B, 20, seed=9, inst0=0, nthreads=2, want_P=False)
+    assert total == 2 * B and summ[2] == 2 * B
+    assert np.array_equal(allerr, ref["avg_err"])
