@@ -8,7 +8,9 @@ import os
 from .config import SlamConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libslam_hip.so")
+# SLAM_HIP_LIB: another build of the same library, for A/B tuning sessions (tools/gpu_ab.sh); the product path is the
+# in-tree libslam_hip.so next to this file
+LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(HERE, "libslam_hip.so")
 _lib = None
 
 _dp = C.POINTER(C.c_double)

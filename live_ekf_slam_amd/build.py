@@ -40,6 +40,7 @@ def build_extension(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DSLAM_ABLATE"] if os.environ.get("SLAM_ABLATE") else []   # timing experiments only (WRONG results)
+    extra += os.environ.get("SLAM_EXTRA_FLAGS", "").split()               # A/B tuning builds (tools/gpu_ab.sh)
     jobs = [(src, os.path.join(CSRC, src + ".o"), []) for src in SOURCES]
     variants = list(EKF_DEFAULT_VARIANTS) + (EKF_SWEEP_VARIANTS if os.environ.get("SLAM_SWEEP") else [])
     for (nmax, w, kg, unr, f32, pipe) in variants:

@@ -90,12 +90,16 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
 #define SLAM_DBG(x) 0
 #endif
 
+#ifndef SLAM_PRIO_THIN
+#define SLAM_PRIO_THIN 2
+#endif
+
 // phase timers (debug only): thread 0 stores the shader-clock delta since the previous stamp to prof[block][i]
 #define SLAM_STAMP(i)                                                                    \
     do {                                                                                 \
         if (prof_on && tid == 0) {                                                       \
             const unsigned long long now_ = __builtin_readcyclecounter();                \
-            p.prof[(size_t)blockIdx.x * kEkfProfSlots + (i)] = now_ - tprev;                         \
+            p.prof[(size_t)blockIdx.x * kEkfProfSlots + (i)] += now_ - tprev;   /* summed over the steps of the launch */                         \
             tprev = now_;                                                                \
         }                                                                                \
     } while (0)
@@ -123,6 +127,13 @@ template <> struct Vec16<float> {
 __device__ __forceinline__ int opaque(int v) {
     asm volatile("" : "+v"(v));
     return v;
+}
+
+// value of `v` in lane `l` as a wave-uniform double (two v_readlane_b32)
+__device__ __forceinline__ double rdlane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ unsigned hi_abs(double v) {
@@ -163,17 +174,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ int s_wend[KG];            // fp32 storage: a timestep ends after this update of the open group (P is rounded there)
     __shared__ double s_tprev[3];         // true pose before the pre-step advanced it (what a freezing instance keeps)
 
-    // row 2 / col 2 of P_t as they were BEFORE the prediction (its operands).  Not in the K buffer: with deferred groups
-    // the K / (H P) slots hold pending updates across timesteps.
-    __shared__ double s_r2[LDP];
-    __shared__ double s_c2[LDP];
-
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
     const bool prof_on = (p.dbg & 4) && p.prof != nullptr;
     unsigned long long tprev = prof_on ? __builtin_readcyclecounter() : 0ull;
+    if (prof_on && tid < 16) p.prof[(size_t)blockIdx.x * kEkfProfSlots + tid] = 0ull;
     // ---- prologue: every load that does not depend on another load is issued up front (one HBM round trip) ----
     typedef typename Vec16<ST>::type VT;
     constexpr int ESZ = (int)sizeof(ST);
@@ -616,6 +623,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     const int M_old = M;
     const int n_old = na;
     if (tid < 8) s_misc[tid] = 0;
+    __builtin_amdgcn_s_setprio(SLAM_PRIO_THIN);   // the thin phases are dependent chains: let them issue ahead of other workgroups' streams
     __syncthreads();   // the pre-step results of this timestep are visible
     const int kraw = s_next[4 * pb];
     if (kraw > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than one wavefront associates
@@ -657,7 +665,85 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         // ---- form the group: thread 0 decides, everybody reads.  Thin rows/cols of landmarks that are detected
         //      again stay where they are (their LDS copy IS the current P row); the others give their slot up. ----
         __syncthreads();
-        if (tid == 0) {
+        if (p.id_known) {
+            // Known ids: the landmark of every detection is known from the pre-step (didx), so the whole formation is
+            // lane-parallel in wavefront 0: lane l <-> detection l0 + l of the group AND thin slot pair l; votes via
+            // ballot, a handful of LDS round trips instead of a serial chain of them on the critical path of every step.
+            if (tid < 64) {
+                const int M_g = M;
+                int fb = 0, lim = KG;
+                if (first && nu > 0) {   // pre-flush decision (see the serial path below for the rules)
+                    const bool isupd = lane < k && didx_t[lane] >= 0 && didx_t[lane] < M_g;
+                    const int kupd = __popcll(__ballot(isupd));
+                    fb = (frz_top || n_ins > 0 || nu + kupd > KG) ? 1 : 0;
+                    lim = fb ? KG : KG - nu;
+                }
+                const int l1 = (k - l0 < lim) ? k : l0 + lim;
+                const int ng = l1 - l0;                                   // detections of this group (<= KG)
+                const int idx = (lane < ng) ? didx_t[l0 + lane] : -1;
+                const int myii = idx >= 0 ? 3 + 2 * idx : -1;             // wanted state index of detection lane
+                const int cur = (lane < KG) ? s_T[3 + 2 * lane] : -1;     // landmark in slot pair lane
+                bool dupl = false, has = false, keep = false;
+#pragma unroll
+                for (int w = 0; w < KG; ++w) {
+                    const int ii_w = __shfl(myii, w), cur_w = __shfl(cur, w);
+                    dupl = dupl || (w < lane && ii_w == myii);            // an earlier detection wants the same landmark
+                    has = has || (cur_w >= 0 && cur_w == myii);           // my landmark already has a slot
+                    keep = keep || (ii_w >= 0 && ii_w == cur);            // somebody wants the landmark in my slot
+                }
+                const bool wantv = myii >= 0 && !dupl;
+                const bool release = lane < KG && cur >= 0 && !keep;
+                if (release) {   // the pending updates (or the last pass) produce this row / column in HBM bit for bit
+                    s_slot[cur] = (signed char)-1; s_slot[cur + 1] = (signed char)-1;
+                    s_T[3 + 2 * lane] = -1; s_T[4 + 2 * lane] = -1;
+                }
+                const bool freeslot = lane < KG && (cur < 0 || !keep);
+                const unsigned long long fmask = __ballot(freeslot);
+                const bool needs = wantv && !has;
+                const unsigned long long nmask = __ballot(needs);
+                int rank = __popcll(nmask & ((1ull << lane) - 1ull));
+                int j = 0;                                                 // the rank-th free pair
+                {
+                    unsigned long long fm = fmask;
+#pragma unroll
+                    for (int w = 0; w < KG; ++w) {
+                        const int lowest = __ffsll((long long)fm) - 1;
+                        if (w == rank) j = lowest;
+                        fm &= fm - 1ull;
+                    }
+                }
+                bool gath = false;
+                if (needs) {
+                    s_T[3 + 2 * j] = myii; s_T[4 + 2 * j] = myii + 1;
+                    s_slot[myii] = (signed char)(3 + 2 * j); s_slot[myii + 1] = (signed char)(4 + 2 * j);
+                    const signed char nd = (signed char)(myii < nsrc ? 1 : 2);   // known landmark: gather, new one: zeros
+                    s_need[3 + 2 * j] = nd; s_need[4 + 2 * j] = nd;
+                    gath = nd == 1;
+                }
+                const int needg = __ballot(gath) != 0ull ? 1 : 0;
+                // occupied pairs after release + assignment: kept ones and newly taken ones
+                unsigned long long occ = __ballot(lane < KG && cur >= 0 && keep);
+                const unsigned long long taken = __ballot(needs);
+                {   // OR in the pairs the needing lanes took
+                    unsigned long long fm = fmask;
+                    const int ntake = __popcll(taken);
+#pragma unroll
+                    for (int w = 0; w < KG; ++w) {
+                        const int lowest = __ffsll((long long)fm) - 1;
+                        if (w < ntake && lowest >= 0) occ |= 1ull << lowest;
+                        fm &= fm - 1ull;
+                    }
+                }
+                if (lane == 0) {
+                    const int top = 63 - __clzll((long long)(occ | 0ull));   // highest occupied pair, -1 if none
+                    s_chunk = 0;
+                    s_misc[4] = l1;
+                    s_misc[5] = occ ? 5 + 2 * top : 3;   // high-water mark: slots [3, nT) may contain free pairs (s_T < 0)
+                    s_misc[2] = 0;
+                    s_misc[7] = (first && nu > 0 && (fb || needg)) ? 1 : 0;
+                }
+            }
+        } else if (tid == 0) {
             int l1 = l0, na_g = na, M_g = M;
             int frz = 0;
             int want[KG], nw = 0;
@@ -763,11 +849,14 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             PassArgs pa;
             pa.src = Pin; pa.dst = const_cast<ST*>(Pin); pa.mid = nullptr;
             pa.nf = n_old; pa.ldd = lds; pa.lds = lds; pa.nsrc = n_old; pa.nu = nu;
+            __builtin_amdgcn_s_setprio(0);
             stream_pass(std::true_type{}, pa);
+            __builtin_amdgcn_s_setprio(SLAM_PRIO_THIN);
             nu = 0;
             __syncthreads();   // P in HBM is current (the gather below reads it); every wave is done with s_chunk / s_wend
             if (tid == 0) s_chunk = 0;
             if (tid < KG) s_wend[tid] = 0;
+            SLAM_STAMP(9);   // pre-flush pass
         }
         if (first && frz_top) {   // duplicate new id (ekf.cpp:115 would index out of range): freeze in the pre-step state
             // rows / columns the deferred predictions changed (at the first step of a launch P in HBM is current and the
@@ -820,20 +909,22 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         __syncthreads();
         if (tid < TS) s_need[tid] = 0;
         SLAM_STAMP(4);   // thin gather
-        // ---- prediction stage on the thin copies (first group only), ekf.cpp:41-61 ----
+        // ---- prediction stage on the thin copies (first group only), ekf.cpp:41-61.  The operands are row 2 / column 2 of
+        //      P_t as they are BEFORE the prediction; of those only P[2][0..2] and P[0..2][2] change, all of them owned by the
+        //      thread of thin slot 2, which keeps its new values in registers until everybody has read the old ones (one
+        //      barrier, no copies of the operand row / column). ----
         if (first) {
             const int tp = opaque(tid);
             const double* const ps = s_ps + 10 * pb;   // F_x(0,2), F_x(1,2), F_v V F_v^T from the pre-step
-#pragma unroll 1
-            for (int i = tp; i < LDP; i += TPB) { s_r2[i] = s_R[2 * LDP + i]; s_c2[i] = s_C[2 * LDP + i]; }
-            __syncthreads();
+            const double* const r2o = s_R + 2 * LDP;   // P_t[2][.]
+            const double* const c2o = s_C + 2 * LDP;   // P_t[.][2]
             const double fa = ps[3], fb = ps[4];
-            const double p22 = s_r2[2];
+            const double p22 = r2o[2];
             auto predicted = [&](double t, int r, int cc) -> double {
                 const double f_r = r == 0 ? fa : fb;
-                if (r < 2) t = t + f_r * s_r2[cc];                 // rows 0,1 of F_x * P
+                if (r < 2) t = t + f_r * r2o[cc];                  // rows 0,1 of F_x * P
                 if (cc < 2) {                                      // cols 0,1 of (F_x P) F_x^T
-                    double a2 = s_c2[r];
+                    double a2 = c2o[r];
                     if (r < 2) a2 = a2 + f_r * p22;
                     t = t + a2 * (cc == 0 ? fa : fb);
                 }
@@ -851,20 +942,27 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 }
             }
             // ... and entries 0,1 (+ the (2,2) element) of every other thin row / col
+            double n_r0 = 0.0, n_r1 = 0.0, n_c0 = 0.0, n_c1 = 0.0, n_22 = 0.0;
             if (tp >= 2 && tp < nT) {
                 const int t_s = s_T[tp];
                 if ((unsigned)t_s < (unsigned)na) {
-                    s_R[tp * LDP + 0] = predicted(s_R[tp * LDP + 0], t_s, 0);
-                    s_R[tp * LDP + 1] = predicted(s_R[tp * LDP + 1], t_s, 1);
-                    s_C[tp * LDP + 0] = predicted(s_C[tp * LDP + 0], 0, t_s);
-                    s_C[tp * LDP + 1] = predicted(s_C[tp * LDP + 1], 1, t_s);
-                    if (t_s == 2) {
-                        s_R[2 * LDP + 2] = predicted(s_R[2 * LDP + 2], 2, 2);
-                        s_C[2 * LDP + 2] = predicted(s_C[2 * LDP + 2], 2, 2);
+                    n_r0 = predicted(s_R[tp * LDP + 0], t_s, 0);
+                    n_r1 = predicted(s_R[tp * LDP + 1], t_s, 1);
+                    n_c0 = predicted(s_C[tp * LDP + 0], 0, t_s);
+                    n_c1 = predicted(s_C[tp * LDP + 1], 1, t_s);
+                    if (tp == 2) {
+                        n_22 = predicted(p22, 2, 2);
+                    } else {
+                        s_R[tp * LDP + 0] = n_r0; s_R[tp * LDP + 1] = n_r1;
+                        s_C[tp * LDP + 0] = n_c0; s_C[tp * LDP + 1] = n_c1;
                     }
                 }
             }
             __syncthreads();
+            if (tp == 2) {   // slot 2 is state index 2 for the whole launch
+                s_R[2 * LDP + 0] = n_r0; s_R[2 * LDP + 1] = n_r1; s_R[2 * LDP + 2] = n_22;
+                s_C[2 * LDP + 0] = n_c0; s_C[2 * LDP + 1] = n_c1; s_C[2 * LDP + 2] = n_22;
+            }
         }
 
         SLAM_STAMP(5);   // predict
@@ -878,25 +976,58 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int ii = 3 + 2 * idx;
             if (idx < M) {
                 // ---------------- landmark update, ekf.cpp:110-140 ----------------
+                // Three barriers per update.  Everything that is a scalar chain in the reference (Jacobian entries with their
+                // float truncations, the innovation, S and its PartialPivLU inverse) is evaluated by wavefront 0 WITHOUT a
+                // barrier in between: the eight quotients of H on eight lanes at once, atan2 beside them (independent
+                // chains in one instruction stream), the five columns of H P that S needs on five lanes, the results passed
+                // between lanes as wave-uniform values (v_readlane).  The other wavefronts join for the O(n) parts.
                 const int si = s_slot[ii];
-                if (tid == 0) {  // leader: Jacobian entries and innovation (all the float truncations live here)
+                if (tid < 64) {
                     const double dx = s_xt[ii] - s_xp[0], dy = s_xt[ii + 1] - s_xp[1];
                     const float dist = (float)sqrt(dx * dx + dy * dy);
                     const double dd = (double)dist, d2 = (double)(dist * dist);
-                    s_sc[0] = -dx / dd; s_sc[1] = -dy / dd; s_sc[2] = dx / dd; s_sc[3] = dy / dd;       // H row 0
-                    s_sc[4] = dy / d2; s_sc[5] = -dx / d2; s_sc[6] = -dy / d2; s_sc[7] = dx / d2;       // H row 1 (H12 = -1)
+                    // lane j < 8: H entry j = num_j / den_j, (H row 0: cols 0, 1, i, i+1; row 1: cols 0, 1, i, i+1; H12 = -1)
+                    const int hl = lane & 7;
+                    const bool usey = (hl == 1) || (hl == 3) || (hl == 4) || (hl == 6);
+                    const bool neg = (hl == 0) || (hl == 1) || (hl == 5) || (hl == 6);
+                    double num = usey ? dy : dx;
+                    num = neg ? -num : num;
+                    const double q = num / (hl < 4 ? dd : d2);
                     const float angf = (float)remainder(det_atan2(dy, dx) - s_xp[2], kTwoPi);
                     const float nu0f = r_m - dist - p.w_r;
                     const float nu1f = b_m - angf - p.w_b;
-                    s_sc[8] = (double)nu0f; s_sc[9] = (double)nu1f;
+                    const double h00 = rdlane(q, 0), h01 = rdlane(q, 1), h03 = rdlane(q, 2), h04 = rdlane(q, 3);
+                    const double h10 = rdlane(q, 4), h11 = rdlane(q, 5), h12 = -1.0, h13 = rdlane(q, 6), h14 = rdlane(q, 7);
+                    // the columns 0, 1, 2, i, i+1 of H P (lanes 0..4), same expression as the full pass below
+                    const int cs = lane < 3 ? lane : (lane == 3 ? ii : ii + 1);
+                    const double p0 = s_R[cs], p1 = s_R[LDP + cs], p2 = s_R[2 * LDP + cs], pi = s_R[si * LDP + cs], pj = s_R[(si + 1) * LDP + cs];
+                    const double gx = ((h00 * p0 + h01 * p1) + h03 * pi) + h04 * pj;
+                    const double gy = (((h10 * p0 + h11 * p1) + h12 * p2) + h13 * pi) + h14 * pj;
+                    const double g0x = rdlane(gx, 0), g1x = rdlane(gx, 1), g2x = rdlane(gx, 2), gix = rdlane(gx, 3), gjx = rdlane(gx, 4);
+                    const double g0y = rdlane(gy, 0), g1y = rdlane(gy, 1), g2y = rdlane(gy, 2), giy = rdlane(gy, 3), gjy = rdlane(gy, 4);
+                    double S[4], Si[4];   // S = (H P) H^T + W and its PartialPivLU inverse (ekf.cpp:133-135)
+                    S[0] = ((g0x * h00 + g1x * h01) + gix * h03) + gjx * h04;
+                    S[1] = (((g0x * h10 + g1x * h11) + g2x * h12) + gix * h13) + gjx * h14;
+                    S[2] = ((g0y * h00 + g1y * h01) + giy * h03) + gjy * h04;
+                    S[3] = (((g0y * h10 + g1y * h11) + g2y * h12) + giy * h13) + gjy * h14;
+                    S[0] = S[0] + p.W00;
+                    S[3] = S[3] + p.W11;
+                    const bool okS = inv2x2_lu(S, Si);
+                    if (lane < 8) s_sc[lane] = q;
+                    if (lane == 0) {
+                        if (!okS) s_misc[6] = 1;
+                        s_sc[8] = (double)nu0f; s_sc[9] = (double)nu1f;
+                        s_sc[10] = Si[0]; s_sc[11] = Si[1]; s_sc[12] = Si[2]; s_sc[13] = Si[3];
+                    }
                 }
                 __syncthreads();
                 double2* __restrict__ HPu = s_HP + nu * HPW;   // entry c at hpi(c)
                 double2* __restrict__ Ku = s_K + nu * LDP;
-                double2 pht[(LDP + TPB - 1) / TPB];
-                {
+                {   // every state index: its column of H P, its row of P H^T, K = P H^T S^-1, x_pred += K nu
                     const double h00 = s_sc[0], h01 = s_sc[1], h03 = s_sc[2], h04 = s_sc[3];
                     const double h10 = s_sc[4], h11 = s_sc[5], h12 = -1.0, h13 = s_sc[6], h14 = s_sc[7];
+                    const double si0 = s_sc[10], si1 = s_sc[11], si2 = s_sc[12], si3 = s_sc[13];
+                    const double nu0 = s_sc[8], nu1 = s_sc[9];
                     const double* Ri = s_R + si * LDP;
                     const double* Rj = s_R + (si + 1) * LDP;
                     const double* Ci = s_C + si * LDP;
@@ -904,50 +1035,21 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 #pragma unroll
                     for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
                         const int c = td + TPB * u;
-                        double2 hp = make_double2(0.0, 0.0), ph = make_double2(0.0, 0.0);
+                        double2 hp = make_double2(0.0, 0.0), kk = make_double2(0.0, 0.0);
                         if (c < na) {
                             const double p0 = s_R[c], p1 = s_R[LDP + c], p2 = s_R[2 * LDP + c], pi = Ri[c], pj = Rj[c];
                             hp.x = ((h00 * p0 + h01 * p1) + h03 * pi) + h04 * pj;
                             hp.y = (((h10 * p0 + h11 * p1) + h12 * p2) + h13 * pi) + h14 * pj;
                             const double q0 = s_C[c], q1 = s_C[LDP + c], q2 = s_C[2 * LDP + c], qi = Ci[c], qj = Cj[c];
-                            ph.x = ((q0 * h00 + q1 * h01) + qi * h03) + qj * h04;
-                            ph.y = (((q0 * h10 + q1 * h11) + q2 * h12) + qi * h13) + qj * h14;
+                            const double phx = ((q0 * h00 + q1 * h01) + qi * h03) + qj * h04;
+                            const double phy = (((q0 * h10 + q1 * h11) + q2 * h12) + qi * h13) + qj * h14;
+                            kk.x = phx * si0 + phy * si2;
+                            kk.y = phx * si1 + phy * si3;
+                            double xv = s_xp[c] + (kk.x * nu0 + kk.y * nu1);
+                            if (c == 2) xv = remainder(xv, kTwoPi);
+                            s_xp[c] = xv;
                         }
-                        if (c < LDP) HPu[hpi(c)] = hp;
-                        pht[u] = ph;
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) {  // leader: S = (H P) H^T + W and its PartialPivLU inverse (ekf.cpp:133-135)
-                    const double h00 = s_sc[0], h01 = s_sc[1], h03 = s_sc[2], h04 = s_sc[3];
-                    const double h10 = s_sc[4], h11 = s_sc[5], h12 = -1.0, h13 = s_sc[6], h14 = s_sc[7];
-                    const double2 g0 = HPu[hpi(0)], g1 = HPu[hpi(1)], g2 = HPu[hpi(2)], gi = HPu[hpi(ii)], gj = HPu[hpi(ii + 1)];
-                    double S[4], Si[4];
-                    S[0] = ((g0.x * h00 + g1.x * h01) + gi.x * h03) + gj.x * h04;
-                    S[1] = (((g0.x * h10 + g1.x * h11) + g2.x * h12) + gi.x * h13) + gj.x * h14;
-                    S[2] = ((g0.y * h00 + g1.y * h01) + gi.y * h03) + gj.y * h04;
-                    S[3] = (((g0.y * h10 + g1.y * h11) + g2.y * h12) + gi.y * h13) + gj.y * h14;
-                    S[0] = S[0] + p.W00;
-                    S[3] = S[3] + p.W11;
-                    if (!inv2x2_lu(S, Si)) s_misc[6] = 1;
-                    s_sc[10] = Si[0]; s_sc[11] = Si[1]; s_sc[12] = Si[2]; s_sc[13] = Si[3];
-                }
-                __syncthreads();
-                {
-                    const double si0 = s_sc[10], si1 = s_sc[11], si2 = s_sc[12], si3 = s_sc[13];
-                    const double nu0 = s_sc[8], nu1 = s_sc[9];
-#pragma unroll
-                    for (int u = 0; u < (LDP + TPB - 1) / TPB; ++u) {
-                        const int r = td + TPB * u;
-                        double2 kk = make_double2(0.0, 0.0);
-                        if (r < na) {
-                            kk.x = pht[u].x * si0 + pht[u].y * si2;
-                            kk.y = pht[u].x * si1 + pht[u].y * si3;
-                            double xv = s_xp[r] + (kk.x * nu0 + kk.y * nu1);
-                            if (r == 2) xv = remainder(xv, kTwoPi);
-                            s_xp[r] = xv;
-                        }
-                        if (r < LDP) Ku[r] = kk;
+                        if (c < LDP) { HPu[hpi(c)] = hp; Ku[c] = kk; }
                     }
                 }
                 __syncthreads();
@@ -1042,6 +1144,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         const bool more = l1 < k;   // further groups of this step follow
         const bool pass_now = more || !first || nf != n_old || !p.id_known || t + 1 >= T || SLAM_DBG(p.dbg & 16);
         if (pass_now) {
+            __syncthreads();   // the thin copies are final for this pass (the prediction's late stores of slot 2 included)
+            __builtin_amdgcn_s_setprio(0);
             PassArgs pa;
             pa.src = first ? Pin : Pout; pa.dst = Pout; pa.mid = Pmid;
             pa.nf = nf; pa.ldd = ldd; pa.lds = lds; pa.nsrc = nsrc; pa.nu = nu;
@@ -1117,6 +1221,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if ((p.dbg & 32) && p.prof != nullptr && tid == 0 && t < kEkfProfSlots)
         p.prof[(size_t)blockIdx.x * kEkfProfSlots + t] = (wall_clock64() << 4) | (unsigned long long)(k < 15 ? k : 15);
     Pcur = Pout;
+    SLAM_STAMP(10);   // end of step: x_t = x_pred, flags, stamps
     }   // timestep loop
 
     if (frz_at >= 0) {   // pre-step state of the frozen instance into the buffer the host reads next

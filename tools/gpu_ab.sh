@@ -1,7 +1,9 @@
 #!/bin/bash
-# A/B two builds of libslam_hip.so on the same box: tools/libslam_hip_old.so vs the in-tree one
-cp live_ekf_slam_amd/libslam_hip.so /tmp/new.so
-for rep in 1 2 3; do
-  cp tools/libslam_hip_old.so live_ekf_slam_amd/libslam_hip.so; echo -n "old: "; python tools/gpu_ablate.py 0 2>&1 | tail -1
-  cp /tmp/new.so live_ekf_slam_amd/libslam_hip.so; echo -n "new: "; python tools/gpu_ablate.py 0 2>&1 | tail -1
+# A/B builds of libslam_hip.so on the same box: tools/ab_*.so (built with SLAM_EXTRA_FLAGS=..., copied there) vs each other.
+# usage: tools/gpu_ab.sh f64|f32 variant lib1.so lib2.so ...
+dt=$1; var=$2; shift 2
+for rep in 1 2; do
+  for lib in "$@"; do
+    echo -n "$(basename $lib): "; SLAM_HIP_LIB=$PWD/$lib python tools/gpu_variants.py $dt $var 2>&1 | tail -1
+  done
 done

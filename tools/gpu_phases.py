@@ -1,36 +1,31 @@
 #!/usr/bin/env python3
-"""Per-phase shader-clock breakdown of ONE timestep of the multi-step EKF kernel by detection count (thread-0 timers,
-SLAM_DEBUG_FLAGS=4: every step overwrites the slots, so a launch that ENDS on timestep t leaves the breakdown of t).
-The bench trajectory (seed 1234, L=50) has k = 3 for every instance at t = 44..50, k = 2 at t = 54..61, k = 1 at
-t = 70..87 and k = 0 at t = 96..104."""
+"""Steady-state per-phase shader-clock breakdown of the multi-step EKF kernel (thread-0 timers summed over the timesteps of one
+launch, SLAM_DEBUG_FLAGS=4), bench trajectory, window t = 644 .. 743 (mean k 1.68).
+usage: gpu_phases.py [f64|f32] [variant]"""
 import ctypes as C, os, sys, time
-os.environ["SLAM_DEBUG_FLAGS"] = "4"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import live_ekf_slam_amd as S
 from live_ekf_slam_amd import _lib
 from live_ekf_slam_amd.scenario import make_scenario
-names = ["init loads", "pre-step(0)", "association", "xpred+group", "thin gather", "predict", "detections", "bulk stream", "epilogue"]
+names = {0: "init loads", 1: "pre-step(0)", 2: "wait for pre-step", 3: "group formation", 9: "pre-flush pass", 4: "thin gather", 5: "predict",
+         6: "detections", 7: "pass / end barrier", 10: "end of step", 8: "epilogue"}
 dt = sys.argv[1] if len(sys.argv) > 1 else "f64"
 if len(sys.argv) > 2:
     os.environ["SLAM_WAVES_PER_FILTER"] = sys.argv[2]
-L, B = 50, 65536
-lm, cmds = make_scenario(1234, L, 200)
+L, B, t0, steps = 50, 65536, 644, 100
+lm, cmds = make_scenario(1234, L, t0 + steps + 1)
 f = S.BatchedEKF(B, L, dtype=S.F32 if dt == "f32" else S.F64).readParams(); f.set_map(lm); f.set_seed(2025); f.init(0, 0, 0)
 f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
-f.run_sim(cmds[1:40]); f.sync()
+f.run_sim(cmds[1:t0]); f.sync()
+f.set_debug_flags(4); f.k_histogram(reset=True)
+t1 = time.time(); f.run_sim(cmds[t0:t0 + steps]); f.sync(); el = time.time() - t1
+h = f.k_histogram().astype(float)
 out = (C.c_ulonglong * 16)()
-t = 40
-for k, t_end in ((3, 49), (2, 59), (1, 80), (0, 100)):
-    f.run_sim(cmds[t:t_end - 4]); f.sync()
-    f.k_histogram(reset=True)
-    t0 = time.time(); f.run_sim(cmds[t_end - 4:t_end + 1]); f.sync(); el = time.time() - t0
-    t = t_end + 1
-    h = f.k_histogram()
-    _lib.check(_lib.lib().slam_debug_read_prof(f.h, out))
-    tot = sum(out[2:8])
-    print(f"{dt} step t={t_end} (k={k}; 5-step launch histogram {h[:5].tolist()}, {el / 5 * 1e3:.3f} ms/step): "
-          f"cycles per workgroup-step {tot / B:.0f} (2.4 GHz: {tot / B / 2400:.1f} us)")
-    for i in range(2, 8):
-        print(f"   {names[i]:14s} {out[i] / B:9.0f} cycles  {100.0 * out[i] / tot:5.1f} %")
+_lib.check(_lib.lib().slam_debug_read_prof(f.h, out))
+tot = sum(out[i] for i in names)
+print(f"{dt} {steps} steps from t={t0}: {el / steps * 1e3:.3f} ms/step with timers, mean k {(h * np.arange(8)).sum() / h.sum():.2f}; "
+      f"cycles per workgroup-step {tot / B / steps:.0f}")
+for i, nm in names.items():
+    print(f"   {nm:20s} {out[i] / B / steps:9.0f} cycles per step  {100.0 * out[i] / tot:5.1f} %")
 f.close()
