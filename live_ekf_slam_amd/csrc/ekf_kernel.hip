@@ -111,7 +111,7 @@ __global__ void math_probe_kernel(const double* a, const double* b, double* out,
     out[8 * (size_t)i + 0] = s;
     out[8 * (size_t)i + 1] = c;
     out[8 * (size_t)i + 2] = det_atan2(a[i], b[i]);
-    out[8 * (size_t)i + 3] = remainder(a[i], kTwoPi);
+    out[8 * (size_t)i + 3] = rem2pi(a[i]);   // the device's short-cut for remainder(x, 2 pi); the host compares with libm
     out[8 * (size_t)i + 4] = sqrt(fabs(a[i]));
     out[8 * (size_t)i + 5] = a[i] / b[i];
     out[8 * (size_t)i + 6] = (double)(float)a[i];

@@ -90,6 +90,9 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
 #define SLAM_DBG(x) 0
 #endif
 
+#ifndef SLAM_PASS_MIN
+#define SLAM_PASS_MIN 4   // decoupled loop: the streamers start a pass when this many updates are pending (or on request)
+#endif
 #ifndef SLAM_PRIO_THIN
 #define SLAM_PRIO_THIN 2
 #endif
@@ -171,6 +174,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ double s_keep[4 + 2 * 64]; // values that live across the timesteps of one launch: true pose, error
                                           // sum, map entries of ids 0..63 (kept out of registers on purpose)
     __shared__ int s_kh[8];               // instance-steps of this launch by detection count
+    __shared__ int s_ring[8];             // decoupled loop: published updates, applied updates, flush request, exit, next timestep,
+                                          // flag bits raised by the control wavefront
+    __shared__ int s_pass[4];             // decoupled loop: pass id, first update, number of updates, streamers done
     __shared__ int s_wend[KG];            // fp32 storage: a timestep ends after this update of the open group (P is rounded there)
     __shared__ double s_tprev[3];         // true pose before the pre-step advanced it (what a freezing instance keeps)
 
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 
     const bool prof_on = (p.dbg & 4) && p.prof != nullptr;
     unsigned long long tprev = prof_on ? __builtin_readcyclecounter() : 0ull;
-    if (prof_on && tid < 16) p.prof[(size_t)blockIdx.x * kEkfProfSlots + tid] = 0ull;
+    if (prof_on && tid < 32) p.prof[(size_t)blockIdx.x * kEkfProfSlots + tid] = 0ull;
     // ---- prologue: every load that does not depend on another load is issued up front (one HBM round trip) ----
     typedef typename Vec16<ST>::type VT;
     constexpr int ESZ = (int)sizeof(ST);
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 nx[0] = kraw;
                 ps[0] = x0 + (double)dd * cs;
                 ps[1] = x1 + (double)dd * sn;
-                ps[2] = remainder((th + (double)ang_n) + (double)p.v_th, kTwoPi);
+                ps[2] = rem2pi((th + (double)ang_n) + (double)p.v_th);
                 ps[3] = (double)(-1 * fwd_n) * sn;  // F_x(0,2)
                 ps[4] = (double)fwd_n * cs;         // F_x(1,2)
                 ps[5] = cv * cs; ps[6] = cv * sn; ps[7] = sv * cs; ps[8] = sv * sn;
@@ -344,9 +350,137 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
     };
 
+    // ---- the scalar chain of one landmark update (ekf.cpp:110-135), evaluated by ONE wavefront without a barrier: the eight
+    //      quotients of H on eight lanes at once, atan2 beside them (independent chains in one instruction stream), the five
+    //      columns of H P that S needs on five lanes, results passed between lanes as wave-uniform values (v_readlane).
+    //      H = {H00, H01, H0i, H0i+1, H10, H11, H1i, H1i+1} (H12 = -1), innovation (nu0, nu1), Si = S^-1.  Every lane of the
+    //      wavefront returns the same values.  false: zero pivot in the PartialPivLU of S. ----
+    auto leader_chain = [&](int ii, int si, float r_m, float b_m, double (&H)[8], double& nu0, double& nu1, double (&Si)[4]) -> bool {
+        const double dx = s_xt[ii] - s_xp[0], dy = s_xt[ii + 1] - s_xp[1];
+        const float dist = (float)sqrt(dx * dx + dy * dy);
+        const double dd = (double)dist, d2 = (double)(dist * dist);
+        // lane j < 8: H entry j = num_j / den_j
+        const int hl = lane & 7;
+        const bool usey = (hl == 1) || (hl == 3) || (hl == 4) || (hl == 6);
+        const bool neg = (hl == 0) || (hl == 1) || (hl == 5) || (hl == 6);
+        double num = usey ? dy : dx;
+        num = neg ? -num : num;
+        const double q = num / (hl < 4 ? dd : d2);
+        const float angf = (float)rem2pi(det_atan2(dy, dx) - s_xp[2]);
+        const float nu0f = r_m - dist - p.w_r;     // float arithmetic (ekf.cpp:130-131)
+        const float nu1f = b_m - angf - p.w_b;
+        nu0 = (double)nu0f; nu1 = (double)nu1f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) H[j] = rdlane(q, j);
+        const double h00 = H[0], h01 = H[1], h03 = H[2], h04 = H[3], h10 = H[4], h11 = H[5], h12 = -1.0, h13 = H[6], h14 = H[7];
+        // the columns 0, 1, 2, i, i+1 of H P (lanes 0..4), same expression as the full pass over all columns
+        const int cs = lane < 3 ? lane : (lane == 3 ? ii : ii + 1);
+        const double p0 = s_R[cs], p1 = s_R[LDP + cs], p2 = s_R[2 * LDP + cs], pi = s_R[si * LDP + cs], pj = s_R[(si + 1) * LDP + cs];
+        const double gx = ((h00 * p0 + h01 * p1) + h03 * pi) + h04 * pj;
+        const double gy = (((h10 * p0 + h11 * p1) + h12 * p2) + h13 * pi) + h14 * pj;
+        const double g0x = rdlane(gx, 0), g1x = rdlane(gx, 1), g2x = rdlane(gx, 2), gix = rdlane(gx, 3), gjx = rdlane(gx, 4);
+        const double g0y = rdlane(gy, 0), g1y = rdlane(gy, 1), g2y = rdlane(gy, 2), giy = rdlane(gy, 3), gjy = rdlane(gy, 4);
+        double S[4];   // S = (H P) H^T + W (ekf.cpp:133)
+        S[0] = ((g0x * h00 + g1x * h01) + gix * h03) + gjx * h04;
+        S[1] = (((g0x * h10 + g1x * h11) + g2x * h12) + gix * h13) + gjx * h14;
+        S[2] = ((g0y * h00 + g1y * h01) + giy * h03) + gjy * h04;
+        S[3] = (((g0y * h10 + g1y * h11) + g2y * h12) + giy * h13) + gjy * h14;
+        S[0] = S[0] + p.W00;
+        S[3] = S[3] + p.W11;
+        return inv2x2_lu(S, Si);
+    };
+
+    // ---- group formation for KNOWN ids, lane-parallel in ONE wavefront: lane l <-> detection l0 + l of the group AND thin
+    //      slot pair l.  Landmarks that are detected again keep their slot (their LDS copy IS the current P row / column),
+    //      the others give theirs up, newly wanted ones take the lowest free pairs in detection order (s_need: 1 = gather
+    //      from HBM, 2 = new landmark, starts from zeros).  Returns whether a gather is needed; l1 = end of the group, nT =
+    //      high-water mark of the slots in use.  Same assignment as the serial path for unknown ids below. ----
+    auto form_known = [&](const int* didx_g, int k, int l0, int lim, int nsrc, int& l1_out, int& nT_out) -> int {
+        const int l1 = (k - l0 < lim) ? k : l0 + lim;
+        const int ng = l1 - l0;                                   // detections of this group (<= KG)
+        const int idx = (lane < ng) ? didx_g[l0 + lane] : -1;
+        const int myii = idx >= 0 ? 3 + 2 * idx : -1;             // wanted state index of detection lane
+        const int cur = (lane < KG) ? s_T[3 + 2 * lane] : -1;     // landmark in slot pair lane
+        bool dupl = false, has = false, keep = false;
+#pragma unroll
+        for (int w = 0; w < KG; ++w) {
+            const int ii_w = __shfl(myii, w), cur_w = __shfl(cur, w);
+            dupl = dupl || (w < lane && ii_w == myii);            // an earlier detection wants the same landmark
+            has = has || (cur_w >= 0 && cur_w == myii);           // my landmark already has a slot
+            keep = keep || (ii_w >= 0 && ii_w == cur);            // somebody wants the landmark in my slot
+        }
+        const bool wantv = myii >= 0 && !dupl;
+        const bool release = lane < KG && cur >= 0 && !keep;
+        if (release) {   // the pending updates (or the last pass) produce this row / column in HBM bit for bit
+            s_slot[cur] = (signed char)-1; s_slot[cur + 1] = (signed char)-1;
+            s_T[3 + 2 * lane] = -1; s_T[4 + 2 * lane] = -1;
+        }
+        const bool freeslot = lane < KG && (cur < 0 || !keep);
+        const unsigned long long fmask = __ballot(freeslot);
+        const bool needs = wantv && !has;
+        const unsigned long long nmask = __ballot(needs);
+        const int rank = __popcll(nmask & ((1ull << lane) - 1ull));
+        int j = 0;                                                 // the rank-th free pair
+        {
+            unsigned long long fm = fmask;
+#pragma unroll
+            for (int w = 0; w < KG; ++w) {
+                const int lowest = __ffsll((long long)fm) - 1;
+                if (w == rank) j = lowest;
+                fm &= fm - 1ull;
+            }
+        }
+        bool gath = false;
+        if (needs) {
+            s_T[3 + 2 * j] = myii; s_T[4 + 2 * j] = myii + 1;
+            s_slot[myii] = (signed char)(3 + 2 * j); s_slot[myii + 1] = (signed char)(4 + 2 * j);
+            const signed char nd = (signed char)(myii < nsrc ? 1 : 2);   // known landmark: gather, new one: zeros
+            s_need[3 + 2 * j] = nd; s_need[4 + 2 * j] = nd;
+            gath = nd == 1;
+        }
+        // occupied pairs after release + assignment: the kept ones and the lowest free ones the needing lanes took
+        unsigned long long occ = __ballot(lane < KG && cur >= 0 && keep);
+        {
+            unsigned long long fm = fmask;
+            const int ntake = __popcll(nmask);
+#pragma unroll
+            for (int w = 0; w < KG; ++w) {
+                const int lowest = __ffsll((long long)fm) - 1;
+                if (w < ntake && lowest >= 0) occ |= 1ull << lowest;
+                fm &= fm - 1ull;
+            }
+        }
+        l1_out = l1;
+        nT_out = occ ? 5 + 2 * (63 - __clzll((long long)occ)) : 3;   // slots [3, nT) may contain free pairs (s_T < 0)
+        return __ballot(gath) != 0ull ? 1 : 0;
+    };
+
+    // ---- the thin copies follow a downdate  P -= K (H P):  R[s][j] -= K[T_s] . (H P)[j],  C[s][j] -= K[j] . (H P)[T_s].
+    //      A thread owns state index j (its K[j], (H P)[j] are read once) and walks the slots s0, s0 + sstride, ...; the
+    //      slot operands K[T_s], (H P)[T_s] are the same address for all lanes (LDS broadcast).  One downdate per element,
+    //      same expression as the bulk stream. ----
+    auto thin_downdate = [&](int j0, int jstride, int s0, int sstride, int nTd, int nd, const double2* __restrict__ Ku,
+                             const double2* __restrict__ HPu) {
+#pragma unroll 1
+        for (int j = j0; j < nd; j += jstride) {
+            const double2 kj = Ku[j], hj = HPu[hpi(j)];
+#pragma unroll 2
+            for (int sl = s0; sl < nTd; sl += sstride) {
+                const int t_s = s_T[sl];
+                if ((unsigned)t_s < (unsigned)nd) {   // wave-uniform
+                    const double2 kt = Ku[t_s], ht = HPu[hpi(t_s)];
+                    const int i = sl * LDP + j;
+                    s_R[i] = s_R[i] - (kt.x * hj.x + kt.y * hj.y);   // P[T_s][j]
+                    s_C[i] = s_C[i] - (kj.x * ht.x + kj.y * ht.y);   // P[j][T_s]
+                }
+            }
+        }
+    };
+
     struct PassArgs {
         const ST* src; ST* dst; double* mid;
         int nf, ldd, lds, nsrc, nu;   // state size / leading dimension written, leading dimension / valid size of the source, updates
+        int lo;                       // RING passes (decoupled loop): update w of the pass lives in slot (lo + w) % KG
     };
     // ---- BULK: stream P once, in strips of R = UNR consecutive rows.  Work item `it` = (strip s, vector column j): the
     //      lane owns the 16-byte vectors (R*s + i, VEC*j .. VEC*j + VEC-1), i < R.  Its (H P) operands (VEC per update)
@@ -362,7 +496,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     //      row / column (general), like the thin phase assumes. ----
     constexpr int R = UNR;
     auto stream_pass = [&](auto fast_tag, const PassArgs& pa) {
-        constexpr bool FAST = decltype(fast_tag)::value;
+        // mode 1: FAST (same layout, patches only where the prediction touches); 0: general (every thin row / column
+        // patched, layout may change); 2: RING = FAST without any patch, updates taken from the ring of the decoupled loop
+        constexpr int MODE = decltype(fast_tag)::value;
+        constexpr bool FAST = MODE != 0;
+        constexpr bool RING = MODE == 2;
         const ST* __restrict__ srcb = pa.src;
         const int nf = pa.nf, ldd = pa.ldd, lds = pa.lds, nsrc = pa.nsrc, nu = pa.nu;
         const int nv = ldd / VEC;                       // vectors per row
@@ -429,19 +567,20 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 #pragma unroll
             for (int w = 0; w < KG; ++w) {
                 if (w >= nu) break;  // wave-uniform
+                const int sw = RING ? (pa.lo + w) % KG : w;   // slot of update w
                 double2 hp[VEC];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) hp[e] = s_HP[w * HPW + e * HS + j];
+                for (int e = 0; e < VEC; ++e) hp[e] = s_HP[sw * HPW + e * HS + j];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    const double2 kk = s_K[w * LDP + rr[i]];
+                    const double2 kk = s_K[sw * LDP + rr[i]];
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) val[i][e] = val[i][e] - (kk.x * hp[e].x + kk.y * hp[e].y);
                 }
                 if constexpr (!kWide) {
                     // fp32 storage rounds P at the end of every timestep; a group that spans several timesteps rounds
                     // where they end (wave-uniform flag per update)
-                    if (s_wend[w]) {
+                    if (s_wend[sw]) {
 #pragma unroll
                         for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -449,7 +588,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     }
                 }
             }
-            if constexpr (FAST) {
+            if constexpr (RING) {
+                // no patches: rows / columns 0, 1 and (2,2) of P in HBM are not maintained inside the decoupled loop
+                // (nobody reads them there; they are written from the thin copies when the loop ends)
+            } else if constexpr (FAST) {
                 if (j == 0) {   // columns 0, 1 (the prediction changed them)
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
@@ -638,6 +780,295 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     const bool frz_top = p.id_known && s_next[4 * pb + 2];  // freeze in the pre-step state (after the pending group is flushed)
     if (p.id_known && s_next[4 * pb + 3]) flags |= SLAM_INST_CAPACITY;
     SLAM_STAMP(2);   // association
+
+    // =====================================================================================================================
+    // DECOUPLED STEADY-STATE LOOP.  As long as the steps ahead neither insert landmarks nor freeze, overflow or exceed KG
+    // detections, the workgroup leaves the barrier-synchronised step above: wavefront 0 (CONTROL) runs every thin phase of
+    // consecutive timesteps by itself - pre-step, group formation, prediction, per detection the scalar chain, K / H P, the
+    // state update and the downdate of the thin copies, all wave-synchronous, no workgroup barrier - and publishes each
+    // update's K / H P in a ring of KG slots; the other wavefronts (STREAMERS) apply the published updates to P in passes
+    // of up to KG updates, concurrently.  The thin copies in LDS are always current, so the control wavefront never waits for
+    // P except when a landmark comes into view whose row / column it must gather: then it has the streamers drain the ring
+    // first.  Rows / columns 0, 1 and (2,2) of P in HBM are not maintained inside the loop (a gathered row takes those
+    // entries from the resident vehicle columns); they are written when the loop ends.  Every element of P sees the same
+    // operations in the same order as in the synchronised path, so the results are bit-identical.
+    // =====================================================================================================================
+    if constexpr (MULTI && W >= 2) {
+        auto fastable = [&](int tq) -> bool {   // step tq (its pre-step results are in the parity buffers) can run decoupled
+            const int* nx = s_next + 4 * (tq & 1);
+            return nx[0] <= KG && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
+        };
+        const bool fast_ok = p.id_known && p.sim && t > 0 && t + 1 < T && p.meas_out == nullptr && fastable(t) &&
+                             !SLAM_DBG(p.dbg & (2 | 16 | 64));
+        if (fast_ok) {
+            const int n = na, ldn = ekf_ld(n, ESZ);
+            ST* const Pbuf = Pcur;
+            constexpr int NS = W - 1;                 // streamers
+            if (tid == 0) {
+                s_ring[0] = nu; s_ring[1] = 0; s_ring[2] = 0; s_ring[3] = 0; s_ring[4] = t; s_ring[5] = 0;
+                s_pass[0] = 0; s_pass[1] = 0; s_pass[2] = 0; s_pass[3] = 0;
+            }
+            __syncthreads();
+            auto ld_i = [](int* q) -> int { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+            auto st_i = [](int* q, int v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+            if (tid < 64) {
+                // ------------------------------------------------ CONTROL ------------------------------------------------
+                __builtin_amdgcn_s_setprio(3);
+                int tt = t;
+                int pub = nu;
+                int fl_or = 0;
+                bool first_it = true;
+#pragma unroll 1
+                for (;;) {
+                    const int pq = tt & 1;
+                    const float* const meas_q = s_meas + pq * 3 * KCAP;
+                    const int* const didx_q = s_didx + pq * KCAP;
+                    const int kq = s_next[4 * pq];
+                    if (!first_it && lane == 0) s_kh[kq < 7 ? kq : 7] += 1;
+                    first_it = false;
+                    if (lane < 3) s_xp[lane] = s_ps[10 * pq + lane];
+                    SLAM_STAMP(16);  // loop overhead
+                    int l1q, nTq;
+                    const int needg = form_known(didx_q, kq, 0, KG, n, l1q, nTq);
+                    SLAM_STAMP(17);  // group formation
+                    if (needg) {
+                        // a landmark comes into view: its row / column must come from HBM, which must hold every update
+                        // published so far -> have the streamers drain the ring, then gather
+                        if (lane == 0) st_i(&s_ring[2], 1);
+                        while (ld_i(&s_ring[1]) != pub) __builtin_amdgcn_s_sleep(2);
+                        if (lane == 0) st_i(&s_ring[2], 0);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 1
+                        for (int sl = 3; sl < nTq; ++sl) {
+                            if (s_need[sl] != 1) continue;
+                            const int t_s = s_T[sl];
+#pragma unroll 1
+                            for (int j = lane; j < LDP; j += 64) {
+                                double rv = 0.0, cv = 0.0;
+                                if (j < n) {
+                                    rv = (double)Pbuf[(size_t)t_s * ldn + j];   // P[t_s][j]
+                                    cv = (double)Pbuf[(size_t)j * ldn + t_s];   // P[j][t_s]
+                                }
+                                s_R[sl * LDP + j] = rv;
+                                s_C[sl * LDP + j] = cv;
+                            }
+                            // entries against the vehicle states come from the resident vehicle columns / rows (HBM does not
+                            // have the predictions of the steps since the loop began)
+                            if (lane < 3) {
+                                s_R[sl * LDP + lane] = s_C[lane * LDP + t_s];   // P[t_s][c], c < 3
+                                s_C[sl * LDP + lane] = s_R[lane * LDP + t_s];   // P[r][t_s], r < 3
+                            }
+                        }
+                    }
+                    if (lane < TS) s_need[lane] = 0;
+                    SLAM_STAMP(18);  // flush wait + gather
+                    // ---- prediction on the thin copies (ekf.cpp:41-61), one wavefront: see the synchronised path ----
+                    {
+                        const double* const ps = s_ps + 10 * pq;
+                        const double* const r2o = s_R + 2 * LDP;
+                        const double* const c2o = s_C + 2 * LDP;
+                        const double fa = ps[3], fb = ps[4];
+                        const double p22 = r2o[2];
+                        auto predicted = [&](double tv, int r, int cc) -> double {
+                            const double f_r = r == 0 ? fa : fb;
+                            if (r < 2) tv = tv + f_r * r2o[cc];
+                            if (cc < 2) {
+                                double a2 = c2o[r];
+                                if (r < 2) a2 = a2 + f_r * p22;
+                                tv = tv + a2 * (cc == 0 ? fa : fb);
+                            }
+                            if (r < 2 && cc < 2) tv = tv + ps[5 + 2 * r + cc];
+                            if (r == 2 && cc == 2) tv = tv + p.V11;
+                            return tv;
+                        };
+                        double n_r0 = 0.0, n_r1 = 0.0, n_c0 = 0.0, n_c1 = 0.0, n_22 = 0.0;
+                        const int t_s = (lane >= 2 && lane < nTq) ? s_T[lane] : -1;
+                        const bool thin_l = (unsigned)t_s < (unsigned)n;
+                        if (thin_l) {   // entries 0, 1 (+ (2,2)) of the other thin rows / cols: computed BEFORE rows / cols 0, 1 change
+                            n_r0 = predicted(s_R[lane * LDP + 0], t_s, 0);
+                            n_r1 = predicted(s_R[lane * LDP + 1], t_s, 1);
+                            n_c0 = predicted(s_C[lane * LDP + 0], 0, t_s);
+                            n_c1 = predicted(s_C[lane * LDP + 1], 1, t_s);
+                            if (lane == 2) n_22 = predicted(p22, 2, 2);
+                        }
+#pragma unroll 1
+                        for (int i = lane; i < 2 * LDP; i += 64) {
+                            const int sl = i >= LDP ? 1 : 0, j = i - sl * LDP;
+                            if (j < n) {
+                                s_R[i] = predicted(s_R[i], sl, j);
+                                s_C[i] = predicted(s_C[i], j, sl);
+                            }
+                        }
+                        if (thin_l) {   // late stores: every operand above was read before
+                            s_R[lane * LDP + 0] = n_r0; s_R[lane * LDP + 1] = n_r1;
+                            s_C[lane * LDP + 0] = n_c0; s_C[lane * LDP + 1] = n_c1;
+                            if (lane == 2) { s_R[2 * LDP + 2] = n_22; s_C[2 * LDP + 2] = n_22; }
+                        }
+                    }
+                    SLAM_STAMP(19);  // prediction
+                    // ---- detections in message order (all of them updates: the step inserts nothing) ----
+                    int lastu = -1;
+                    if constexpr (!kWide) {
+                        const bool isupd = lane < kq && didx_q[lane] >= 0;
+                        const unsigned long long um = __ballot(isupd);
+                        lastu = um ? 63 - __clzll((long long)um) : -1;
+                    }
+#pragma unroll 1
+                    for (int l = 0; l < kq; ++l) {
+                        const int idx = didx_q[l];
+                        if (idx < 0) continue;
+                        const float r_m = meas_q[3 * l + 1], b_m = meas_q[3 * l + 2];
+                        const int ii = 3 + 2 * idx;
+                        const int si = s_slot[ii];
+                        double H[8], Si[4], nu0, nu1;
+                        if (!leader_chain(ii, si, r_m, b_m, H, nu0, nu1, Si)) fl_or |= SLAM_INST_S_SINGULAR;
+                        SLAM_STAMP(20);  // scalar chain of the update
+                        while (pub - ld_i(&s_ring[1]) >= KG) __builtin_amdgcn_s_sleep(1);   // a free slot in the ring
+                        SLAM_STAMP(21);  // waiting for a ring slot
+                        const int slot = pub % KG;
+                        double2* __restrict__ HPu = s_HP + slot * HPW;
+                        double2* __restrict__ Ku = s_K + slot * LDP;
+                        {
+                            const double h00 = H[0], h01 = H[1], h03 = H[2], h04 = H[3], h10 = H[4], h11 = H[5], h12 = -1.0, h13 = H[6], h14 = H[7];
+                            const double* Ri = s_R + si * LDP;
+                            const double* Rj = s_R + (si + 1) * LDP;
+                            const double* Ci = s_C + si * LDP;
+                            const double* Cj = s_C + (si + 1) * LDP;
+#pragma unroll
+                            for (int u = 0; u < (LDP + 63) / 64; ++u) {
+                                const int c = lane + 64 * u;
+                                double2 hp = make_double2(0.0, 0.0), kk = make_double2(0.0, 0.0);
+                                if (c < n) {
+                                    const double p0 = s_R[c], p1 = s_R[LDP + c], p2 = s_R[2 * LDP + c], pi = Ri[c], pj = Rj[c];
+                                    hp.x = ((h00 * p0 + h01 * p1) + h03 * pi) + h04 * pj;
+                                    hp.y = (((h10 * p0 + h11 * p1) + h12 * p2) + h13 * pi) + h14 * pj;
+                                    const double q0 = s_C[c], q1 = s_C[LDP + c], q2 = s_C[2 * LDP + c], qi = Ci[c], qj = Cj[c];
+                                    const double phx = ((q0 * h00 + q1 * h01) + qi * h03) + qj * h04;
+                                    const double phy = (((q0 * h10 + q1 * h11) + q2 * h12) + qi * h13) + qj * h14;
+                                    kk.x = phx * Si[0] + phy * Si[2];
+                                    kk.y = phx * Si[1] + phy * Si[3];
+                                    double xv = s_xp[c] + (kk.x * nu0 + kk.y * nu1);
+                                    if (c == 2) xv = rem2pi(xv);
+                                    s_xp[c] = xv;
+                                }
+                                if (c < LDP) { HPu[hpi(c)] = hp; Ku[c] = kk; }
+                            }
+                        }
+                        if (!kWide && lane == 0) s_wend[slot] = (l == lastu) ? 1 : 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // K / H P of the slot are in LDS before it is published
+                        pub += 1;
+                        if (lane == 0) st_i(&s_ring[0], pub);
+                        SLAM_STAMP(22);  // H P, K, x_pred
+                        // thin copies follow the same downdate  P -= K (H P)
+                        thin_downdate(lane, 64, 0, 1, nTq, n, Ku, HPu);
+                    }
+                    SLAM_STAMP(23);  // thin downdates (+ loop)
+                    // ---- end of the step: error statistic, x_t = x_pred (ekf.cpp:176), storage rounding ----
+                    if (lane == 0) {   // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
+                        const double ex = (double)(float)s_xp[0] - s_keep[0], ey = (double)(float)s_xp[1] - s_keep[1];
+                        s_keep[3] = s_keep[3] + sqrt(ex * ex + ey * ey);
+                    }
+#pragma unroll 1
+                    for (int i = lane; i < n; i += 64) {
+                        const ST sv = (ST)s_xp[i];
+                        s_xt[i] = (double)sv;
+                        s_xp[i] = (double)sv;
+                        const unsigned h0 = hi_abs((double)sv);
+                        hiacc = hiacc > h0 ? hiacc : h0;
+                    }
+                    if constexpr (!kWide) {   // resident thin rows / cols carry the storage rounding of every step
+#pragma unroll 1
+                        for (int i = lane; i < nTq * LDP; i += 64) {
+                            s_R[i] = (double)(ST)s_R[i];
+                            s_C[i] = (double)(ST)s_C[i];
+                        }
+                    }
+                    if ((p.dbg & 32) && p.prof != nullptr && lane == 0 && tt < kEkfProfSlots)
+                        p.prof[(size_t)blockIdx.x * kEkfProfSlots + tt] = (wall_clock64() << 4) | (unsigned long long)(kq < 15 ? kq : 15);
+                    tt += 1;
+                    SLAM_STAMP(24);  // end of step
+                    if (tt >= T) break;
+                    prestep(tt);
+                    SLAM_STAMP(25);  // pre-step of the next timestep
+                    if (!fastable(tt) || tt + 1 >= T) break;   // the last step of the launch goes through the synchronised path
+                }
+                if (lane == 0) {
+                    s_ring[4] = tt;
+                    s_ring[5] = fl_or;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    st_i(&s_ring[3], 1);   // exit: the streamers drain the ring and leave
+                }
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                // ------------------------------------------------ STREAMERS ------------------------------------------------
+                __builtin_amdgcn_s_setprio(0);
+                const bool leader = (tid >> 6) == 1;
+                int seen = 0;   // passes this wavefront has taken part in
+#pragma unroll 1
+                for (;;) {
+                    if (leader) {
+                        int app, pend;
+                        bool stop = false;
+#pragma unroll 1
+                        for (;;) {
+                            app = ld_i(&s_ring[1]);
+                            pend = ld_i(&s_ring[0]) - app;
+                            const int fl = ld_i(&s_ring[2]), ex = ld_i(&s_ring[3]);
+                            if (pend > 0 && (pend >= SLAM_PASS_MIN || fl || ex)) break;
+                            if (ex && pend == 0) {   // re-read: an update published just before the exit flag
+                                if (ld_i(&s_ring[0]) - app == 0) { stop = true; break; }
+                                continue;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        int cnt = pend < KG ? pend : KG;
+                        if constexpr (!kWide) {
+                            // fp32 storage rounds P once per timestep: a pass must not end inside a step, or the store would round
+                            // an intermediate result.  Take the longest prefix that ends where a step ends (there is one whenever
+                            // the control wavefront is waiting for a slot, because a step has at most KG updates).
+                            if (!stop) {
+                                while (cnt > 0 && !ld_i(&s_wend[(app + cnt - 1) % KG])) cnt -= 1;
+                                if (cnt == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+                            }
+                        }
+                        if (lane == 0) {
+                            s_pass[1] = app;
+                            s_pass[2] = stop ? -1 : cnt;
+                            s_pass[3] = 0;
+                            s_chunk = 0;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            st_i(&s_pass[0], seen + 1);
+                        }
+                    }
+                    while (ld_i(&s_pass[0]) <= seen) __builtin_amdgcn_s_sleep(1);
+                    seen += 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const int lo = ld_i(&s_pass[1]), cnt = ld_i(&s_pass[2]);
+                    if (cnt < 0) break;
+                    PassArgs pa;
+                    pa.src = Pbuf; pa.dst = Pbuf; pa.mid = nullptr;
+                    pa.nf = n; pa.ldd = ldn; pa.lds = ldn; pa.nsrc = n; pa.nu = cnt; pa.lo = lo;
+                    stream_pass(std::integral_constant<int, 2>{}, pa);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wavefront's stores of the pass have landed
+                    if (lane == 0) atomicAdd(&s_pass[3], 1);
+                    if (leader) {
+                        while (ld_i(&s_pass[3]) < NS) __builtin_amdgcn_s_sleep(1);
+                        if (lane == 0) st_i(&s_ring[1], lo + cnt);   // the ring slots are free, P holds these updates
+                    }
+                }
+            }
+            __syncthreads();
+            // back to the synchronised path: everything published is in P; write what the loop left aside
+            nu = 0;
+            flags |= s_ring[5];
+            const int t_next = s_ring[4];
+            write_vehicle(Pbuf, n);
+            if (tid < KG) s_wend[tid] = 0;
+            if (__syncthreads_or(hiacc >= 0x7ff00000u)) flags |= SLAM_INST_NONFINITE;
+            t = t_next - 1;
+            continue;
+        }
+    }
     int nf = n_old + 2 * n_ins;           // leading dimension of the matrix written this step
     nf = nf < NMAX ? nf : NMAX;
     ST* const Pout = (nf != n_old) ? (Pcur == PA ? PB : PA) : Pcur;   // in place unless the layout changes
@@ -670,75 +1101,19 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             // lane-parallel in wavefront 0: lane l <-> detection l0 + l of the group AND thin slot pair l; votes via
             // ballot, a handful of LDS round trips instead of a serial chain of them on the critical path of every step.
             if (tid < 64) {
-                const int M_g = M;
                 int fb = 0, lim = KG;
                 if (first && nu > 0) {   // pre-flush decision (see the serial path below for the rules)
-                    const bool isupd = lane < k && didx_t[lane] >= 0 && didx_t[lane] < M_g;
+                    const bool isupd = lane < k && didx_t[lane] >= 0 && didx_t[lane] < M;
                     const int kupd = __popcll(__ballot(isupd));
                     fb = (frz_top || n_ins > 0 || nu + kupd > KG) ? 1 : 0;
                     lim = fb ? KG : KG - nu;
                 }
-                const int l1 = (k - l0 < lim) ? k : l0 + lim;
-                const int ng = l1 - l0;                                   // detections of this group (<= KG)
-                const int idx = (lane < ng) ? didx_t[l0 + lane] : -1;
-                const int myii = idx >= 0 ? 3 + 2 * idx : -1;             // wanted state index of detection lane
-                const int cur = (lane < KG) ? s_T[3 + 2 * lane] : -1;     // landmark in slot pair lane
-                bool dupl = false, has = false, keep = false;
-#pragma unroll
-                for (int w = 0; w < KG; ++w) {
-                    const int ii_w = __shfl(myii, w), cur_w = __shfl(cur, w);
-                    dupl = dupl || (w < lane && ii_w == myii);            // an earlier detection wants the same landmark
-                    has = has || (cur_w >= 0 && cur_w == myii);           // my landmark already has a slot
-                    keep = keep || (ii_w >= 0 && ii_w == cur);            // somebody wants the landmark in my slot
-                }
-                const bool wantv = myii >= 0 && !dupl;
-                const bool release = lane < KG && cur >= 0 && !keep;
-                if (release) {   // the pending updates (or the last pass) produce this row / column in HBM bit for bit
-                    s_slot[cur] = (signed char)-1; s_slot[cur + 1] = (signed char)-1;
-                    s_T[3 + 2 * lane] = -1; s_T[4 + 2 * lane] = -1;
-                }
-                const bool freeslot = lane < KG && (cur < 0 || !keep);
-                const unsigned long long fmask = __ballot(freeslot);
-                const bool needs = wantv && !has;
-                const unsigned long long nmask = __ballot(needs);
-                int rank = __popcll(nmask & ((1ull << lane) - 1ull));
-                int j = 0;                                                 // the rank-th free pair
-                {
-                    unsigned long long fm = fmask;
-#pragma unroll
-                    for (int w = 0; w < KG; ++w) {
-                        const int lowest = __ffsll((long long)fm) - 1;
-                        if (w == rank) j = lowest;
-                        fm &= fm - 1ull;
-                    }
-                }
-                bool gath = false;
-                if (needs) {
-                    s_T[3 + 2 * j] = myii; s_T[4 + 2 * j] = myii + 1;
-                    s_slot[myii] = (signed char)(3 + 2 * j); s_slot[myii + 1] = (signed char)(4 + 2 * j);
-                    const signed char nd = (signed char)(myii < nsrc ? 1 : 2);   // known landmark: gather, new one: zeros
-                    s_need[3 + 2 * j] = nd; s_need[4 + 2 * j] = nd;
-                    gath = nd == 1;
-                }
-                const int needg = __ballot(gath) != 0ull ? 1 : 0;
-                // occupied pairs after release + assignment: kept ones and newly taken ones
-                unsigned long long occ = __ballot(lane < KG && cur >= 0 && keep);
-                const unsigned long long taken = __ballot(needs);
-                {   // OR in the pairs the needing lanes took
-                    unsigned long long fm = fmask;
-                    const int ntake = __popcll(taken);
-#pragma unroll
-                    for (int w = 0; w < KG; ++w) {
-                        const int lowest = __ffsll((long long)fm) - 1;
-                        if (w < ntake && lowest >= 0) occ |= 1ull << lowest;
-                        fm &= fm - 1ull;
-                    }
-                }
+                int l1g, nTg;
+                const int needg = form_known(didx_t, k, l0, lim, nsrc, l1g, nTg);
                 if (lane == 0) {
-                    const int top = 63 - __clzll((long long)(occ | 0ull));   // highest occupied pair, -1 if none
                     s_chunk = 0;
-                    s_misc[4] = l1;
-                    s_misc[5] = occ ? 5 + 2 * top : 3;   // high-water mark: slots [3, nT) may contain free pairs (s_T < 0)
+                    s_misc[4] = l1g;
+                    s_misc[5] = nTg;
                     s_misc[2] = 0;
                     s_misc[7] = (first && nu > 0 && (fb || needg)) ? 1 : 0;
                 }
@@ -847,10 +1222,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             //      columns 0, 1 and (2,2) come from the thin copies, which hold the END of the previous step (this step's
             //      prediction has not touched them yet) ----
             PassArgs pa;
+            pa.lo = 0;
             pa.src = Pin; pa.dst = const_cast<ST*>(Pin); pa.mid = nullptr;
             pa.nf = n_old; pa.ldd = lds; pa.lds = lds; pa.nsrc = n_old; pa.nu = nu;
             __builtin_amdgcn_s_setprio(0);
-            stream_pass(std::true_type{}, pa);
+            stream_pass(std::integral_constant<int, 1>{}, pa);
             __builtin_amdgcn_s_setprio(SLAM_PRIO_THIN);
             nu = 0;
             __syncthreads();   // P in HBM is current (the gather below reads it); every wave is done with s_chunk / s_wend
@@ -983,40 +1359,17 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 // between lanes as wave-uniform values (v_readlane).  The other wavefronts join for the O(n) parts.
                 const int si = s_slot[ii];
                 if (tid < 64) {
-                    const double dx = s_xt[ii] - s_xp[0], dy = s_xt[ii + 1] - s_xp[1];
-                    const float dist = (float)sqrt(dx * dx + dy * dy);
-                    const double dd = (double)dist, d2 = (double)(dist * dist);
-                    // lane j < 8: H entry j = num_j / den_j, (H row 0: cols 0, 1, i, i+1; row 1: cols 0, 1, i, i+1; H12 = -1)
-                    const int hl = lane & 7;
-                    const bool usey = (hl == 1) || (hl == 3) || (hl == 4) || (hl == 6);
-                    const bool neg = (hl == 0) || (hl == 1) || (hl == 5) || (hl == 6);
-                    double num = usey ? dy : dx;
-                    num = neg ? -num : num;
-                    const double q = num / (hl < 4 ? dd : d2);
-                    const float angf = (float)remainder(det_atan2(dy, dx) - s_xp[2], kTwoPi);
-                    const float nu0f = r_m - dist - p.w_r;
-                    const float nu1f = b_m - angf - p.w_b;
-                    const double h00 = rdlane(q, 0), h01 = rdlane(q, 1), h03 = rdlane(q, 2), h04 = rdlane(q, 3);
-                    const double h10 = rdlane(q, 4), h11 = rdlane(q, 5), h12 = -1.0, h13 = rdlane(q, 6), h14 = rdlane(q, 7);
-                    // the columns 0, 1, 2, i, i+1 of H P (lanes 0..4), same expression as the full pass below
-                    const int cs = lane < 3 ? lane : (lane == 3 ? ii : ii + 1);
-                    const double p0 = s_R[cs], p1 = s_R[LDP + cs], p2 = s_R[2 * LDP + cs], pi = s_R[si * LDP + cs], pj = s_R[(si + 1) * LDP + cs];
-                    const double gx = ((h00 * p0 + h01 * p1) + h03 * pi) + h04 * pj;
-                    const double gy = (((h10 * p0 + h11 * p1) + h12 * p2) + h13 * pi) + h14 * pj;
-                    const double g0x = rdlane(gx, 0), g1x = rdlane(gx, 1), g2x = rdlane(gx, 2), gix = rdlane(gx, 3), gjx = rdlane(gx, 4);
-                    const double g0y = rdlane(gy, 0), g1y = rdlane(gy, 1), g2y = rdlane(gy, 2), giy = rdlane(gy, 3), gjy = rdlane(gy, 4);
-                    double S[4], Si[4];   // S = (H P) H^T + W and its PartialPivLU inverse (ekf.cpp:133-135)
-                    S[0] = ((g0x * h00 + g1x * h01) + gix * h03) + gjx * h04;
-                    S[1] = (((g0x * h10 + g1x * h11) + g2x * h12) + gix * h13) + gjx * h14;
-                    S[2] = ((g0y * h00 + g1y * h01) + giy * h03) + gjy * h04;
-                    S[3] = (((g0y * h10 + g1y * h11) + g2y * h12) + giy * h13) + gjy * h14;
-                    S[0] = S[0] + p.W00;
-                    S[3] = S[3] + p.W11;
-                    const bool okS = inv2x2_lu(S, Si);
-                    if (lane < 8) s_sc[lane] = q;
+                    double H[8], Si[4], nu0, nu1;
+                    const bool okS = leader_chain(ii, si, r_m, b_m, H, nu0, nu1, Si);
+                    if (lane < 8) {   // broadcast to the other wavefronts through LDS
+                        double hv = H[0];
+#pragma unroll
+                        for (int q = 1; q < 8; ++q) hv = lane == q ? H[q] : hv;
+                        s_sc[lane] = hv;
+                    }
                     if (lane == 0) {
                         if (!okS) s_misc[6] = 1;
-                        s_sc[8] = (double)nu0f; s_sc[9] = (double)nu1f;
+                        s_sc[8] = nu0; s_sc[9] = nu1;
                         s_sc[10] = Si[0]; s_sc[11] = Si[1]; s_sc[12] = Si[2]; s_sc[13] = Si[3];
                     }
                 }
@@ -1046,7 +1399,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             kk.x = phx * si0 + phy * si2;
                             kk.y = phx * si1 + phy * si3;
                             double xv = s_xp[c] + (kk.x * nu0 + kk.y * nu1);
-                            if (c == 2) xv = remainder(xv, kTwoPi);
+                            if (c == 2) xv = rem2pi(xv);
                             s_xp[c] = xv;
                         }
                         if (c < LDP) { HPu[hpi(c)] = hp; Ku[c] = kk; }
@@ -1054,15 +1407,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 }
                 __syncthreads();
                 // thin copies follow the same downdate  P -= K (H P)
-#pragma unroll 1
-                for (int i = td; i < nT * LDP; i += TPB) {
-                    const int sl = i / LDP, j = i - sl * LDP;
-                    const int t_s = s_T[sl];
-                    if (j < na && (unsigned)t_s < (unsigned)na) {
-                        const double2 kt = Ku[t_s], hj = HPu[hpi(j)], kj = Ku[j], ht = HPu[hpi(t_s)];
-                        s_R[i] = s_R[i] - (kt.x * hj.x + kt.y * hj.y);   // P[t_s][j]
-                        s_C[i] = s_C[i] - (kj.x * ht.x + kj.y * ht.y);   // P[j][t_s]
-                    }
+                {
+                    constexpr int JW = TPB < 128 ? TPB : 128;   // threads along a thin row; the others take other slots
+                    thin_downdate(td % JW, JW, td / JW, TPB / JW, nT, na, Ku, HPu);
                 }
                 nu += 1;
                 __syncthreads();
@@ -1147,13 +1494,14 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             __syncthreads();   // the thin copies are final for this pass (the prediction's late stores of slot 2 included)
             __builtin_amdgcn_s_setprio(0);
             PassArgs pa;
+            pa.lo = 0;
             pa.src = first ? Pin : Pout; pa.dst = Pout; pa.mid = Pmid;
             pa.nf = nf; pa.ldd = ldd; pa.lds = lds; pa.nsrc = nsrc; pa.nu = nu;
             if (first && !more && nf == n_old) {
                 if (nu == 0 && !SLAM_DBG(p.dbg & 16)) write_vehicle(Pout, nf);   // nothing pending: only the prediction's rows / columns
-                else stream_pass(std::true_type{}, pa);
+                else stream_pass(std::integral_constant<int, 1>{}, pa);
             } else if (kWide || (first && !more)) {
-                stream_pass(std::false_type{}, pa);
+                stream_pass(std::integral_constant<int, 0>{}, pa);
             } else {
                 pa.src = Pin;
                 mid_pass(!first, more, pa);

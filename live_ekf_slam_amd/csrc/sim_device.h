@@ -41,7 +41,7 @@ __device__ __forceinline__ int sim_wave(const P& p, int b, int lane, float fwd, 
             const double dx = lmx - tx, dy = lmy - ty;
             r = sqrt(dx * dx + dy * dy);
             const double gb = det_atan2(dy, dx);
-            beta = remainder(gb - tth, kTwoPi);
+            beta = rem2pi(gb - tth);
             vis = !(r > p.range_max) && (beta > p.fov_min && beta < p.fov_max);
         }
         const unsigned long long mask = __ballot(vis);

@@ -773,7 +773,7 @@ int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
 
 // debug only (not declared in slam_batch.h): per-block phase cycles of the LAST launch, summed over blocks
 // (SLAM_DEBUG_FLAGS & 4)
-int slam_debug_read_prof(slam_handle* h, unsigned long long out[16]) {
+int slam_debug_read_prof(slam_handle* h, unsigned long long* out) {
     if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -781,9 +781,10 @@ int slam_debug_read_prof(slam_handle* h, unsigned long long out[16]) {
     const size_t S = h->kind == SLAM_EKF_SLAM ? slam::kEkfProfSlots : 16;   // the UKF kernels use 16 slots per block
     std::vector<unsigned long long> buf(S * h->B);
     HIP_TRY(hipMemcpy(buf.data(), h->dprof, sizeof(unsigned long long) * buf.size(), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 16; ++i) out[i] = 0;
+    const int nslot = h->kind == SLAM_EKF_SLAM ? 32 : 16;   // out[32] for the EKF (slots 16.. = decoupled loop), out[16] for the UKF
+    for (int i = 0; i < nslot; ++i) out[i] = 0;
     for (int b = 0; b < h->B; ++b)
-        for (int i = 0; i < 16; ++i) out[i] += buf[S * b + i];
+        for (int i = 0; i < nslot; ++i) out[i] += buf[S * b + i];
     return SLAM_OK;
 }
 

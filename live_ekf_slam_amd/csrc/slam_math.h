@@ -149,4 +149,23 @@ SLAM_HD double det_atan2(double y, double x) {
 // tests/test_parity_gpu.py::test_device_math_bit_exact checks that on the device.
 SLAM_HD double wrap2pi(double x) { return remainder(x, kTwoPi); }
 
+// The same value as remainder(x, 2*pi), bit for bit, in a dozen instructions for |x| <= 4*pi (every wrap of a heading in the
+// filters): the library routine is an iterative reduction (~300 cycles of dependent instructions on the GPU).  IEEE
+// remainder is x - n*y with n = x/y rounded to nearest, ties to even; for |x| <= 2y = 4*pi, n is in {0, +-1, +-2} and every
+// subtraction below is exact (Sterbenz: a - b is exact when b/2 <= a <= 2b), so the result IS the IEEE remainder.  y/2 is
+// exactly fl(pi) and 2y is exact.  Larger or non-finite arguments take the library path.  Checked against the host's libm
+// on the device by tests/test_parity_gpu.py::test_device_math_bit_exact.
+SLAM_HD double rem2pi(double x) {
+    const double y = kTwoPi, hy = kPi;
+    const double ax = fabs(x);
+    if (!(ax <= 2.0 * y)) return remainder(x, y);
+    double r = ax;                      // n = 0: |x| <= y/2 (the tie 0.5 rounds to the even 0)
+    if (ax > hy) {
+        const double d = ax - y;        // exact: y/2 < ax <= 2y
+        r = d;                          // n = 1: |x|/y in (0.5, 1.5)
+        if (d >= hy) r = d - y;         // n = 2: |x|/y in [1.5, 2] (the tie 1.5 rounds to the even 2); exact: y/2 <= d <= y
+    }
+    return signbit(x) ? -r : r;         // remainder(-x) = -remainder(x); a zero result carries the sign of x
+}
+
 }  // namespace slam
