@@ -159,7 +159,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     constexpr int HS = hp_substride<VEC>(LDP), HPW = VEC * HS;
     __shared__ double2 s_HP[KG * HPW];    // per update of the group: (H P)[0..1][c] at hpi(c) (de-interleaved by c % VEC)
     __shared__ double s_sc[16];           // scalars computed by the leader lane (H entries, nu, S^-1, G_x ...)
-    __shared__ float s_meas[2 * 3 * KCAP];   // [step parity][detection][id, range, bearing]
+    // The measurement generator does not depend on the filter, so it may run AHEAD of it: a ring of SD timesteps, slot = t % SD.
+    constexpr int SD = sizeof(ST) == 8 ? 4 : 3;   // (fp32 storage: 3, to stay within 40 KB of LDS = 4 workgroups per CU)
+    __shared__ float s_meas[SD * 3 * KCAP];  // [t % SD][detection][id, range, bearing]
+    __shared__ double s_tru[SD * 6];         // [t % SD] true pose before (0..2) and after (3..5) timestep t
+    __shared__ int s_kraw[SD];               // [t % SD] detections in the message of timestep t (uncapped)
+    __shared__ int s_sim[2];                 // timesteps generated so far (launch-relative), timestep the filter is at
     __shared__ int s_ids[LMAX > 0 ? LMAX : 1];
     __shared__ int s_didx[2 * KCAP];      // [step parity] per detection: landmark number (>= M_old: inserted this
                                           // step), -1 dropped
@@ -178,7 +183,6 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                           // flag bits raised by the control wavefront
     __shared__ int s_pass[4];             // decoupled loop: pass id, first update, number of updates, streamers done
     __shared__ int s_wend[KG];            // fp32 storage: a timestep ends after this update of the open group (P is rounded there)
-    __shared__ double s_tprev[3];         // true pose before the pre-step advanced it (what a freezing instance keeps)
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     }
     if (tid < 8) s_kh[tid] = 0;
     if (tid < KG) s_wend[tid] = 0;
+    if (tid < 2) s_sim[tid] = 0;
 
     // state -> HBM at the end of the launch (or when the instance freezes): x_t lives in s_xt
     // `pre`: the instance freezes in its PRE-step state (x, P, timestep, error sum and the true pose alike)
@@ -263,7 +268,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             p.timestep[b] = ts0 + steps_done;
             if (p.sim) p.err_sum[b] = s_keep[3];
         }
-        if (p.sim && tid < 3) p.truth[3 * (size_t)b + tid] = pre ? s_tprev[tid] : s_keep[tid];
+        // true pose: before the frozen step, or after the last step of the launch (the generator never runs past it)
+        if (p.sim && tid < 3) {
+            const int tq = pre ? steps_done : steps_done - 1;
+            p.truth[3 * (size_t)b + tid] = steps_done == 0 && !pre ? s_keep[tid] : s_tru[(tq % SD) * 6 + (pre ? 0 : 3) + tid];
+        }
         if (p.khist != nullptr && tid < 8 && s_kh[tid] != 0) atomicAdd(&p.khist[tid], (unsigned long long)s_kh[tid]);
     };
 
@@ -277,9 +286,24 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // and the vehicle part of the prediction (ekf.cpp:41-59).  For tn > first step of the launch it runs inside the
     // bulk stream of step tn-1 (the other wavefronts keep streaming), so its latency chain is off the critical path.
     // Reads x_{tn} from s_xp (final x_pred of step tn-1), the current M / s_ids; writes the parity-tn buffers.
+    // simgen(tn): the measurement generator for timestep tn (ONE wavefront) into ring slot tn % SD; advances the true pose.
+    auto simgen = [&](int tn) {
+        const int sq = tn % SD;
+        const float fwd_n = MULTI ? p.cmds[2 * tn] : p.fwd;
+        const float ang_n = MULTI ? p.cmds[2 * tn + 1] : p.ang;
+        double tx = s_keep[0], ty = s_keep[1], tth = s_keep[2];
+        if (lane == 0) { s_tru[sq * 6 + 0] = tx; s_tru[sq * 6 + 1] = ty; s_tru[sq * 6 + 2] = tth; }
+        const int kr = sim_wave<KCAP, false>(p, b, lane, fwd_n, ang_n, p.step + (uint32_t)tn, tx, ty, tth, s_keep[4 + lane],
+                                             s_keep[4 + 64 + lane], s_meas + sq * 3 * KCAP);   // the true pose goes to HBM in finish()
+        if (lane == 0) {
+            s_keep[0] = tx; s_keep[1] = ty; s_keep[2] = tth;
+            s_tru[sq * 6 + 3] = tx; s_tru[sq * 6 + 4] = ty; s_tru[sq * 6 + 5] = tth;
+            s_kraw[sq] = kr;
+        }
+    };
     auto prestep = [&](int tn) {
         const int qb = tn & 1;
-        float* meas = s_meas + qb * 3 * KCAP;
+        float* meas = s_meas + (tn % SD) * 3 * KCAP;
         int* didx = s_didx + qb * KCAP;
         int* nx = s_next + 4 * qb;
         double* ps = s_ps + 10 * qb;
@@ -287,11 +311,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         const float ang_n = MULTI ? p.cmds[2 * tn + 1] : p.ang;
         int kraw;
         if (p.sim) {
-            double tx = s_keep[0], ty = s_keep[1], tth = s_keep[2];
-            if (lane == 0) { s_tprev[0] = tx; s_tprev[1] = ty; s_tprev[2] = tth; }
-            kraw = sim_wave<KCAP, false>(p, b, lane, fwd_n, ang_n, p.step + (uint32_t)tn, tx, ty, tth, s_keep[4 + lane],
-                                         s_keep[4 + 64 + lane], meas);   // the true pose goes to HBM in finish()
-            if (lane == 0) { s_keep[0] = tx; s_keep[1] = ty; s_keep[2] = tth; }
+            if (s_sim[0] <= tn) {   // not generated ahead of time (the decoupled loop's generator wavefront does that)
+                simgen(tn);
+                if (lane == 0) s_sim[0] = tn + 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            kraw = s_kraw[tn % SD];
         } else {
             kraw = nx[0];   // EXT mode: the message was fetched by the prologue
         }
@@ -760,7 +785,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     for (int t = 0; t < T; ++t) {
     const ST* const Pin = Pcur;
     const int pb = t & 1;
-    const float* const meas_t = s_meas + pb * 3 * KCAP;
+    const float* const meas_t = s_meas + (t % SD) * 3 * KCAP;
     int* const didx_t = s_didx + pb * KCAP;
     const int M_old = M;
     const int n_old = na;
@@ -798,12 +823,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int* nx = s_next + 4 * (tq & 1);
             return nx[0] <= KG && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
         };
-        const bool fast_ok = p.id_known && p.sim && t > 0 && t + 1 < T && p.meas_out == nullptr && fastable(t) &&
+        const bool fast_ok = p.id_known && p.sim && p.meas_out == nullptr && fastable(t) &&
                              !SLAM_DBG(p.dbg & (2 | 16 | 64));
         if (fast_ok) {
             const int n = na, ldn = ekf_ld(n, ESZ);
             ST* const Pbuf = Pcur;
             constexpr int NS = W - 1;                 // streamers
+            constexpr bool kGen = W >= 3;             // the last streamer also runs the measurement generator ahead of the filter
             if (tid == 0) {
                 s_ring[0] = nu; s_ring[1] = 0; s_ring[2] = 0; s_ring[3] = 0; s_ring[4] = t; s_ring[5] = 0;
                 s_pass[0] = 0; s_pass[1] = 0; s_pass[2] = 0; s_pass[3] = 0;
@@ -821,9 +847,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
 #pragma unroll 1
                 for (;;) {
                     const int pq = tt & 1;
-                    const float* const meas_q = s_meas + pq * 3 * KCAP;
+                    const float* const meas_q = s_meas + (tt % SD) * 3 * KCAP;
                     const int* const didx_q = s_didx + pq * KCAP;
                     const int kq = s_next[4 * pq];
+                    if (lane == 0) st_i(&s_sim[1], tt);   // ring slots of the timesteps before tt are free for the generator
                     if (!first_it && lane == 0) s_kh[kq < 7 ? kq : 7] += 1;
                     first_it = false;
                     if (lane < 3) s_xp[lane] = s_ps[10 * pq + lane];
@@ -831,7 +858,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     int l1q, nTq;
                     const int needg = form_known(didx_q, kq, 0, KG, n, l1q, nTq);
                     SLAM_STAMP(17);  // group formation
-                    if (needg) {
+                    const bool veh = s_need[0] == 1;   // first step of the launch: the vehicle rows / columns are still in HBM only
+                    if (needg || veh) {
                         // a landmark comes into view: its row / column must come from HBM, which must hold every update
                         // published so far -> have the streamers drain the ring, then gather
                         if (lane == 0) st_i(&s_ring[2], 1);
@@ -839,7 +867,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         if (lane == 0) st_i(&s_ring[2], 0);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll 1
-                        for (int sl = 3; sl < nTq; ++sl) {
+                        for (int sl = 0; sl < nTq; ++sl) {
                             if (s_need[sl] != 1) continue;
                             const int t_s = s_T[sl];
 #pragma unroll 1
@@ -854,7 +882,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             }
                             // entries against the vehicle states come from the resident vehicle columns / rows (HBM does not
                             // have the predictions of the steps since the loop began)
-                            if (lane < 3) {
+                            if (sl >= 3 && lane < 3) {
                                 s_R[sl * LDP + lane] = s_C[lane * LDP + t_s];   // P[t_s][c], c < 3
                                 s_C[sl * LDP + lane] = s_R[lane * LDP + t_s];   // P[r][t_s], r < 3
                             }
@@ -965,7 +993,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     SLAM_STAMP(23);  // thin downdates (+ loop)
                     // ---- end of the step: error statistic, x_t = x_pred (ekf.cpp:176), storage rounding ----
                     if (lane == 0) {   // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
-                        const double ex = (double)(float)s_xp[0] - s_keep[0], ey = (double)(float)s_xp[1] - s_keep[1];
+                        const double* tru = s_tru + (tt % SD) * 6 + 3;   // true pose after this timestep
+                        const double ex = (double)(float)s_xp[0] - tru[0], ey = (double)(float)s_xp[1] - tru[1];
                         s_keep[3] = s_keep[3] + sqrt(ex * ex + ey * ey);
                     }
 #pragma unroll 1
@@ -988,9 +1017,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     tt += 1;
                     SLAM_STAMP(24);  // end of step
                     if (tt >= T) break;
+                    if constexpr (kGen) {   // the measurements of timestep tt come from the generator wavefront
+                        while (ld_i(&s_sim[0]) <= tt) __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
                     prestep(tt);
                     SLAM_STAMP(25);  // pre-step of the next timestep
-                    if (!fastable(tt) || tt + 1 >= T) break;   // the last step of the launch goes through the synchronised path
+                    if (!fastable(tt)) break;   // that step goes through the synchronised path
                 }
                 if (lane == 0) {
                     s_ring[4] = tt;
@@ -1040,7 +1073,20 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             st_i(&s_pass[0], seen + 1);
                         }
                     }
-                    while (ld_i(&s_pass[0]) <= seen) __builtin_amdgcn_s_sleep(1);
+                    while (ld_i(&s_pass[0]) <= seen) {
+                        if constexpr (kGen) {
+                            if ((tid >> 6) == W - 1) {   // between passes: run the measurement generator ahead of the filter
+                                const int ts = ld_i(&s_sim[0]);
+                                if (ts < T && ts < ld_i(&s_sim[1]) + SD && !ld_i(&s_ring[3])) {
+                                    simgen(ts);
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                    if (lane == 0) st_i(&s_sim[0], ts + 1);
+                                    continue;
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                     seen += 1;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const int lo = ld_i(&s_pass[1]), cnt = ld_i(&s_pass[2]);
@@ -1477,7 +1523,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         //      when it is done (chunks are handed out dynamically, so the others simply take more of them) ----
         if (l1 >= k && (tid >> 6) == W - 1) {
             if (p.sim && lane == 0) {  // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
-                const double ex = (double)(float)s_xp[0] - s_keep[0], ey = (double)(float)s_xp[1] - s_keep[1];
+                const double* tru = s_tru + (t % SD) * 6 + 3;   // true pose after this timestep
+                const double ex = (double)(float)s_xp[0] - tru[0], ey = (double)(float)s_xp[1] - tru[1];
                 s_keep[3] = s_keep[3] + sqrt(ex * ex + ey * ey);
             }
             if (t + 1 < T) prestep(t + 1);

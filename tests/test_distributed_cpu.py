@@ -73,7 +73,7 @@ def _run_two_ranks(B, scaling):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, B, scaling, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = q.get(timeout=180)
+    out = q.get(timeout=900)   # the first `import torch` of a cold container can take minutes
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
