@@ -134,6 +134,35 @@ def test_fast_dense_libm_det_agree_on_trajectory(oracle):
         assert np.abs(s["P"] - base["P"]).max() < 1e-10
 
 
+@pytest.mark.parametrize("fixture", ["seed0_L20_T1000.npz", "seed1_L20_T400.npz", "seed2_L50_T1000.npz", "seed1234_L50_T400.npz"])
+def test_ekf_oracle_matches_numpy_transliteration(oracle, fixture):
+    """Long-trajectory pin of the oracle's EKF arithmetic against an INDEPENDENT statement of ekf.cpp:37-179: the dense numpy
+    transliteration tests/golden/make_ekf_traj.py (full F_x P F_x^T, (K H) P, Y p_temp Y^T, numpy's 2x2 inverse, float32
+    casts where the reference declares float), run over the reference simulator's own measurement streams.  Tolerance 1e-10
+    (observed ~1e-13: different association of the dense products).  This removes the single-author risk of the oracle; it
+    does not pin it to the reference binary, which cannot be built here."""
+    g = load_golden("sim_" + fixture)
+    r = load_golden("ekf_traj_" + fixture)
+    L = int(g["L"])
+    for mode, math, tol in ((oracle.MODE_DENSE, oracle.MATH_LIBM, 1e-10), (oracle.MODE_FAST, oracle.MATH_DET, 1e-9)):
+        e = oracle.OracleEKF(L_max=L, math=math, mode=mode); e.init(0, 0, 0)
+        steps = {int(t): i for i, t in enumerate(r["steps"])}
+        worst = 0.0
+        for t in range(int(g["T"])):
+            k = int(g["meas_count"][t])
+            e.update(g["cmds"][t, 0], g["cmds"][t, 1], g["meas"][t, :k])
+            if t + 1 in steps:
+                i = steps[t + 1]
+                so = e.state()
+                n = 3 + 2 * so["M"]
+                assert so["M"] == int(r["M"][i])
+                worst = max(worst, np.abs(so["x"] - r["x"][i, :n]).max(), np.abs(np.diag(so["P"]) - r["diagP"][i, :n]).max())
+        so = e.state()
+        assert np.array_equal(so["ids"], r["ids"])
+        worst = max(worst, np.abs(so["P"] - r["P_final"]).max())
+        assert worst < tol, (mode, math, worst)
+
+
 def test_invariants_on_trajectory(oracle):
     """P symmetric to rounding, PSD, M monotone, yaw wrapped, estimate near truth."""
     g = load_golden("sim_seed0_L20_T1000.npz")

@@ -303,6 +303,49 @@ def test_full_size_properties(S, oracle):
     h.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_run_sim_full_size_one_launch(S, oracle, dtype):
+    """The BENCHMARKED path at its own size: BASELINE batch 65536, L = 50, slam_run_sim carrying K = 60 timesteps in ONE launch
+    (deferred update groups, the decoupled control / streamer loop, the generator wavefront), fp64 and fp32 storage
+    (configs[3]'s dtype): oracle spot checks on six instances bit for bit, shard invariance, determinism, no instance flagged."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, T = 50, 65536, 61
+    lm, cmds = make_scenario(1234, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]
+    dt = S.F32 if dtype == "f32" else S.F64
+    mode = oracle.MODE_FAST | (oracle.STORAGE_F32 if dtype == "f32" else 0)
+
+    def run(batch, offset):
+        f = S.BatchedEKF(batch, L, dtype=dt).readParams(); f.set_map(lm); f.set_seed(2025); f.set_instance_offset(offset); f.init(0, 0, 0)
+        f.set_vision(*vis[0]); f.update_sim(cmds[0]); f.set_vision(*vis[1])
+        f.run_sim(cmds[1:T])                      # ONE multi-step launch, like bench.py's timed region
+        return f
+
+    f = run(B, 0)
+    M = f.landmark_counts(); poses = f.poses(); err = f.error_stats(); flags = f.status(); truth = f.truth()
+    assert np.all(M == L) and np.all(flags == 0)
+    assert np.all(np.isfinite(poses)) and np.all(np.abs(poses[:, 2]) <= np.pi) and 0.0 < err.mean() < 0.3
+    kh = f.k_histogram()
+    assert kh.sum() == B * T and kh[3] > 0 and kh[1] > 0          # the window mixes detection counts
+    picks = [0, 1, 4095, 32768, 36863, 65535]
+    states = {b: f.get_state(b) for b in picks}
+    for b in picks:
+        r = oracle.run_ekf_batch(lm, cmds, 1, L, seed=2025, inst0=b, vision=vis, mode=mode)
+        _assert_state_equal(states[b], dict(M=L, ids=r["ids"][0], x=r["x"][0], P=r["P"][0].reshape(103, 103)))
+        assert err[b] == r["avg_err"][0] and np.array_equal(truth[b], r["truth"][0])
+        assert states[b]["timestep"] == T
+    f.close()
+    g = run(8192, 32768)                          # configs[3]'s per-GPU shard (65536 / 8) at a global offset
+    assert np.array_equal(g.poses(), poses[32768:32768 + 8192]) and np.array_equal(g.error_stats(), err[32768:32768 + 8192])
+    _assert_state_equal(g.get_state(0), states[32768])
+    _assert_state_equal(g.get_state(36863 - 32768), states[36863])
+    g.close()
+    h = run(4096, 0)                              # determinism
+    assert np.array_equal(h.poses(), poses[:4096])
+    _assert_state_equal(h.get_state(1), states[1])
+    h.close()
+
+
 @pytest.mark.parametrize("L,T,B", [(20, 300, 64), (50, 300, 48)])
 def test_fp32_storage_variant(S, oracle, L, T, B):
     """SLAM_F32 (BASELINE configs[3]): x and P live in HBM as float, arithmetic stays fp64; the oracle rounds its
