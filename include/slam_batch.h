@@ -153,6 +153,16 @@ int slam_get_last_meas(slam_handle* h, float* meas, int32_t* meas_count, int k_s
 int slam_error_stats(slam_handle* h, double* per_instance_avg_err);
 int slam_status(slam_handle* h, int32_t* per_instance_flags);       /* [batch] slam_instance_flags */
 
+/* ---- scenario generators (host side; sim_node.py:63-206) ------------------------------------------------------ */
+/* generate_landmarks + generate_full_trajectory of the reference simulator for one scenario seed (the reference seeds
+ * CPython's Mersenne Twister; the same generator is implemented in include/slam_scenario.hpp, so a seed gives the reference's
+ * map and command sequence bit for bit).  map_type: "random" | "grid" | "demo" | "igvc1" (the two fixed maps are read from
+ * fixed_maps_json = live_ekf_slam_amd/data/fixed_maps.json; num_landmarks is ignored for them and for "grid").
+ * Out: map_xy [*num_landmarks_out][2] (may be NULL to query the count; capacity in landmarks), cmds [num_iterations][2] float32
+ * (fwd, ang) = the Command messages of sim_node.py:142-152.  Runs on the host; no GPU needed. */
+int slam_scenario_make(const char* map_type, const char* fixed_maps_json, uint64_t seed, int num_landmarks, int num_iterations,
+                       double* map_xy, int map_capacity, int32_t* num_landmarks_out, float* cmds);
+
 /* ---- misc ------------------------------------------------------------------------------------------------ */
 int slam_sync(slam_handle* h);
 int slam_batch(const slam_handle* h);

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <memory>
+#include <queue>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -52,7 +53,13 @@ public:
     FilterChoice type = FilterChoice::NOT_SET;
     bool isInit = false;
     std::vector<int> lm_IDs;  // of instance 0 (filter.h:70)
+    std::vector<float> map;   // true map as [id, x, y] triplets, for localisation-only filters (filter.h:69)
     virtual ~Filter() = default;
+    // trueMapCallback stores `filter->map = msg->data` (localization_node.cpp:152-156); a batched filter also uploads it
+    virtual void setTrueMap(const std::vector<float>& id_x_y) { map = id_x_y; }
+    // Filter::setupStatePublisher(ros::NodeHandle) (filter.h:65) advertises the state topic; without ROS there is nothing to
+    // advertise: publishState() leaves the message payload in `last_state` of the concrete class instead.
+    virtual void setupStatePublisher() {}
     virtual void readParams(const slam_config& config) = 0;                     // filter.h:59 (YAML::Node there)
     virtual void init(float x_0, float y_0, float yaw_0) = 0;                   // filter.h:60
     virtual void update(Command::ConstPtr cmdMsg, Float32MultiArray::ConstPtr lmMeasMsg) = 0;  // filter.h:61
@@ -175,7 +182,7 @@ public:
     void readParams(const slam_config& config) override {
         cfg_ = config;
         if (h_) { slam_destroy(h_); h_ = nullptr; }
-        check(slam_create(&cfg_, SLAM_UKF_SLAM, batch_, L_max_, SLAM_F64, device_, &h_));
+        check(slam_create(&cfg_, kind_, batch_, L_max_, SLAM_F64, device_, &h_));
     }
     void init(float x_0, float y_0, float yaw_0) override { need(); check(slam_init(h_, x_0, y_0, yaw_0)); isInit = true; }
     void update(Command::ConstPtr cmdMsg, Float32MultiArray::ConstPtr lmMeasMsg) override {   // ukf.cpp:161-195
@@ -228,6 +235,9 @@ public:
     std::vector<double> errorStats() { need(); std::vector<double> e(batch_); check(slam_error_stats(h_, e.data())); return e; }
     slam_handle* handle() { return h_; }
     UKFState last_state;
+
+protected:
+    int kind_ = SLAM_UKF_SLAM;
 
 private:
     void need() const { if (!h_) throw std::runtime_error("readParams() has not been called"); }
@@ -342,6 +352,55 @@ private:
     int batch_, L_max_, kp_, device_;
     std::vector<double> sec_;
     bool have_sec_ = false;
+};
+
+// UKF localisation against the known map (FilterChoice::UKF_LOC, localization_node.cpp:39-41, ukf.cpp:146-154): the state is
+// the vehicle only; every detection updates against the true-map landmark of the same id.
+class BatchedUKFLoc : public BatchedUKF {
+public:
+    explicit BatchedUKFLoc(int batch, int device = 0) : BatchedUKF(batch, 1, device) { type = FilterChoice::UKF_LOC; kind_ = SLAM_UKF_LOC; }
+    void setTrueMap(const std::vector<float>& id_x_y) override {   // rows are sorted by id in the reference's message (sim_node.py:203)
+        map = id_x_y;
+        std::vector<double> xy(2 * (id_x_y.size() / 3));
+        for (size_t i = 0; i < id_x_y.size() / 3; ++i) { xy[2 * i] = id_x_y[3 * i + 1]; xy[2 * i + 1] = id_x_y[3 * i + 2]; }
+        setMap(xy);
+    }
+};
+
+// ROS-free restatement of the node harness (localization_node.cpp): the two FIFO queues the subscriber callbacks fill
+// (:17-18, :142-150), the true-map gate for localisation-only filters (:21, :113-116, :152-156), the secondary filter hook
+// for the pose graph (:24-25, :123-128) and iterate() (:108-140), which a ROS timer calls at 1/dt.  One (command, measurement)
+// pair is consumed per call; a call that finds a queue empty, the filter uninitialised or the map missing returns early.
+struct LocalizationNode {
+    std::unique_ptr<Filter> filter, filter_secondary;        // :24-25
+    std::queue<Command::ConstPtr> cmdQueue;                  // :17
+    std::queue<Float32MultiArray::ConstPtr> lmMeasQueue;     // :18
+    bool loadedTrueMap = false;                              // :21
+    int iterations = 0;
+
+    void initCallback(float x_0, float y_0, float yaw_0) {   // :90-106
+        if (filter->isInit) return;
+        filter->init(x_0, y_0, yaw_0);
+        if (filter->filter_to_compare != FilterChoice::NOT_SET) filter_secondary->init(x_0, y_0, yaw_0);
+    }
+    void cmdCallback(const Command::ConstPtr& msg) { cmdQueue.push(msg); }                    // :142-145
+    void lmMeasCallback(const Float32MultiArray::ConstPtr& msg) { lmMeasQueue.push(msg); }    // :147-150
+    void trueMapCallback(const Float32MultiArray::ConstPtr& msg) { filter->setTrueMap(msg->data); loadedTrueMap = true; }   // :152-156
+    bool iterate() {                                         // :108-140
+        if (!filter->isInit || cmdQueue.empty() || lmMeasQueue.empty()) return false;        // :109-112
+        if (filter->type == FilterChoice::UKF_LOC && !loadedTrueMap) return false;           // :113-116
+        Command::ConstPtr cmdMsg = cmdQueue.front(); cmdQueue.pop();                         // :118-119
+        Float32MultiArray::ConstPtr lmMeasMsg = lmMeasQueue.front(); lmMeasQueue.pop();      // :120-121
+        if (filter->filter_to_compare != FilterChoice::NOT_SET) {                            // :124-128
+            filter_secondary->update(cmdMsg, lmMeasMsg);
+            filter->updateNaiveVehPoseEstimate(filter_secondary->getStateVector(), filter_secondary->lm_IDs);
+        }
+        filter->update(cmdMsg, lmMeasMsg);                                                   // :131
+        if (filter->filter_to_compare != FilterChoice::NOT_SET) filter_secondary->publishState();   // :135-139
+        else filter->publishState();
+        iterations += 1;
+        return true;
+    }
 };
 
 }  // namespace slam_amd

@@ -53,6 +53,7 @@ SIGNATURES = {
     "slam_batch": (C.c_int, [_H]),
     "slam_state_dim_max": (C.c_int, [_H]),
     "slam_algorithmic_bytes": (C.c_int, [_H, _dp]),
+    "slam_scenario_make": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_int, _dp, C.c_int, _ip, _fp]),
     "slam_set_run_chunk": (C.c_int, [_H, C.c_int]),
     "slam_set_debug_flags": (C.c_int, [_H, C.c_int]),
     "slam_variant_available": (C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -92,3 +92,20 @@ def make_scenario(seed, num_landmarks, num_iterations, map_type="random", **kw):
     cmds = generate_full_trajectory(lm, num_iterations, rng,
                                     **{k: v for k, v in kw.items() if k not in ("min_sep", "grid_step")})
     return lm, cmds.astype(np.float32)
+
+
+def make_scenario_native(seed, num_landmarks, num_iterations, map_type="random"):
+    """The same scenario from the C++ generators of the host library (include/slam_scenario.hpp through the C ABI
+    slam_scenario_make): what a C++ host uses; bit-identical to make_scenario (tests/test_scenario.py)."""
+    import ctypes as C
+    import os
+    from . import _lib
+    L = _lib.lib()
+    fixed = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "fixed_maps.json").encode()
+    n = C.c_int32(0)
+    _lib.check(L.slam_scenario_make(map_type.encode(), fixed, int(seed), int(num_landmarks), 0, None, 0, C.byref(n), None))
+    lm = np.zeros((n.value, 2)); cmds = np.zeros((int(num_iterations), 2), dtype=np.float32)
+    _lib.check(L.slam_scenario_make(map_type.encode(), fixed, int(seed), int(num_landmarks), int(num_iterations),
+                                    lm.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n),
+                                    cmds.ctypes.data_as(C.POINTER(C.c_float))))
+    return lm, cmds

@@ -42,3 +42,23 @@ def test_fixed_and_grid_maps_match_reference():
         lm, cmds = make_scenario(5, 0, 200, map_type=map_type)
         assert lm.shape == (L, 2) and np.array_equal(lm, g["map"])
         assert np.array_equal(cmds, g["cmds"])
+
+
+def test_cpp_generators_match_reference_fixtures(golden_files):
+    """generate_landmarks / generate_full_trajectory as host C++ (include/slam_scenario.hpp, exported as
+    slam_scenario_make): map and float32 command sequence bit for bit against the fixtures captured from the imported reference
+    simulator, for the random maps of every golden seed and for the grid / demo / igvc1 maps.  Host code: no GPU needed."""
+    import os
+    from conftest import GOLDEN
+    from live_ekf_slam_amd.scenario import make_scenario_native
+    for f in golden_files:
+        g = np.load(f)
+        lm, cmds = make_scenario_native(int(g["seed"]), int(g["L"]), int(g["T"]))
+        assert np.array_equal(lm, g["map"]) and np.array_equal(cmds, g["cmds"])
+    for map_type, L in (("demo", 20), ("grid", 25), ("igvc1", 37)):
+        g = np.load(os.path.join(GOLDEN, f"sim_{map_type}_seed5_T200.npz"))
+        lm, cmds = make_scenario_native(5, 0, 200, map_type=map_type)
+        assert lm.shape == (L, 2) and np.array_equal(lm, g["map"]) and np.array_equal(cmds, g["cmds"])
+    lm, cmds = make_scenario_native(1234, 50, 800)       # the bench scenario
+    lm2, cmds2 = make_scenario(1234, 50, 800)
+    assert np.array_equal(lm, lm2) and np.array_equal(cmds, cmds2)
