@@ -121,6 +121,10 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
  * instance's true pose with its own noise stream and produces its measurements, then the filter consumes
  * them in the same kernel.  Also accumulates the position error of plotting_node.py:209-212. */
 int slam_step_sim(slam_handle* h, const float cmd[2]);
+/* EKF: consecutive slam_step_sim calls are queued on the host and run as one multi-step launch of up to n timesteps (default
+ * 16, environment variable SLAM_LAZY_STEPS; 0 = one launch per call); every other entry point runs what is queued first, so
+ * the results seen through the API do not change (a multi-step launch gives the same bits as single steps), only the speed. */
+int slam_set_lazy_steps(slam_handle* h, int n);
 /* T consecutive slam_step_sim calls; cmds = [T][2] float32 host array (precomputed trajectory,
  * sim_node.py:142-152). */
 int slam_run_sim(slam_handle* h, const float* cmds, int T);

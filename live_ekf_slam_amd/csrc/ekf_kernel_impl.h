@@ -775,7 +775,26 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     }
     __syncthreads();
     SLAM_STAMP(0);   // initial loads
+    // The vehicle rows / columns of P are needed by every launch: the wavefronts that do not run the pre-step fetch them
+    // meanwhile (a single-wavefront workgroup does it first), so the first group formation finds them resident.
+    auto pregather = [&](int i0, int istride) {
+        const int ldi = ekf_ld(n_init, ESZ);
+#pragma unroll 1
+        for (int i = i0; i < 3 * LDP; i += istride) {
+            const int sl = i / LDP, j = i - sl * LDP;
+            double rv = 0.0, cv = 0.0;
+            if (j < n_init) {
+                rv = (double)PA[(size_t)sl * ldi + j];   // P[sl][j]
+                cv = (double)PA[(size_t)j * ldi + sl];   // P[j][sl]
+            }
+            s_R[i] = rv;
+            s_C[i] = cv;
+        }
+    };
+    if (W == 1) pregather(tid, TPB);
+    else if (tid >= 64) pregather(tid - 64, TPB - 64);
     if (tid < 64) prestep(0);
+    if (tid >= TPB - 3) s_need[tid - (TPB - 3)] = 0;   // slots 0..2 are resident (visible after the barrier at the top of the step)
     SLAM_STAMP(1);   // measurements, association, motion scalars of the first step
 
     // a freezing instance leaves both loops and writes its PRE-step state below (the reference node died at that step)

@@ -74,6 +74,12 @@ struct slam_handle {
     hipStream_t copy_stream = nullptr;
     uint32_t stage_next = 0;
     unsigned long long* dkhist = nullptr;                      // [8] instance-steps by detection count
+    // slam_step_sim (EKF): the commands of consecutive calls are queued on the host and run as ONE multi-step launch when the
+    // queue is full or anything else touches the handle (every other entry point flushes first).  The kernels are asynchronous
+    // anyway, and a multi-step launch gives the same bits as single steps, so only the speed changes (one launch per call
+    // re-reads x, ids and the thin rows / columns of P and cannot keep update groups open across timesteps).
+    std::vector<float> lazy_cmds;
+    int lazy_max = 16;                                         // 0 / 1 = off (SLAM_LAZY_STEPS, slam_set_lazy_steps)
     double* dscalar = nullptr;
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
@@ -189,6 +195,14 @@ bool parse_scalar(const char* line, const char* key, double* out) {
 
 }  // namespace
 
+static int run_sim_now(slam_handle* h, const float* cmds, int T);
+static int flush_lazy(slam_handle* h);
+#define FLUSH(h)                        \
+    do {                                \
+        const int frc_ = flush_lazy(h); \
+        if (frc_) return frc_;          \
+    } while (0)
+
 extern "C" {
 
 int slam_internal_fail(int code, const char* fmt, ...) {
@@ -284,6 +298,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
 #endif
     env = getenv("SLAM_UKF_SPLIT_MIN");   // batch size from which UKF run_sim splits the batch over two streams
     if (env) h->ukf_split_min = atoi(env);
+    env = getenv("SLAM_LAZY_STEPS");   // slam_step_sim calls queued per multi-step launch (0 = one launch per call)
+    if (env) h->lazy_max = atoi(env);
     env = getenv("SLAM_RUN_CHUNK");   // timesteps per launch of slam_run_sim (1 = one launch per step)
     if (env) h->run_chunk = atoi(env);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -341,6 +357,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
 
 int slam_destroy(slam_handle* h) {
     if (!h) return SLAM_OK;
+    flush_lazy(h);
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); hipEventDestroy(h->aux_ev[0]); hipEventDestroy(h->aux_ev[1]); }
@@ -363,22 +380,25 @@ int slam_destroy(slam_handle* h) {
 
 int slam_set_stream(slam_handle* h, void* s) {
     if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    FLUSH(h);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)s;
     h->own_stream = false;
     return SLAM_OK;
 }
-int slam_set_instance_offset(slam_handle* h, int64_t v) { if (!h) return fail(SLAM_ERR_ARG, "NULL handle"); h->inst0 = v; return SLAM_OK; }
-int slam_set_seed(slam_handle* h, uint64_t s) { if (!h) return fail(SLAM_ERR_ARG, "NULL handle"); h->seed = s; return SLAM_OK; }
+int slam_set_instance_offset(slam_handle* h, int64_t v) { if (!h) return fail(SLAM_ERR_ARG, "NULL handle"); FLUSH(h); h->inst0 = v; return SLAM_OK; }
+int slam_set_seed(slam_handle* h, uint64_t s) { if (!h) return fail(SLAM_ERR_ARG, "NULL handle"); FLUSH(h); h->seed = s; return SLAM_OK; }
 int slam_set_vision(slam_handle* h, double range_max, double fov_min, double fov_max) {
     if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    FLUSH(h);
     h->range_max = range_max; h->fov_min = fov_min; h->fov_max = fov_max;
     return SLAM_OK;
 }
 
 int slam_init(slam_handle* h, float x0, float y0, float yaw0) {
     if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     if (h->kind == SLAM_EKF_SLAM) {
         slam::EkfInitParams p;
@@ -407,6 +427,7 @@ int slam_init(slam_handle* h, float x0, float y0, float yaw0) {
 
 int slam_set_map(slam_handle* h, const double* map_xy, int L) {
     if (!h || !map_xy || L <= 0) return fail(SLAM_ERR_ARG, "bad map");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     if (h->dmap) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(h->dmap); h->dmap = nullptr; }
     HIP_TRY(hipMalloc(&h->dmap, sizeof(double) * 2 * (size_t)L));
@@ -425,6 +446,7 @@ int slam_set_map(slam_handle* h, const double* map_xy, int L) {
 
 int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_count, int k_stride) {
     if (!h || !cmd || !d_meas || !d_count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
     HIP_TRY(hipSetDevice(h->device));
@@ -433,6 +455,7 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
 
 int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* count, int k_stride) {
     if (!h || !cmd || !meas || !count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
     if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
@@ -450,7 +473,7 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
     if (!s.copied) {
         HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.used, hipEventDisableTiming));
-        HIP_TRY(hipHostMalloc((void**)&s.hcount, sizeof(int32_t) * B, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&s.hcount, sizeof(int32_t) * B, hipHostMallocNonCoherent));   // CPU-cached pinned memory: fast to fill
         HIP_TRY(hipMalloc(&s.dcount, sizeof(int32_t) * B));
     }
     if (s.in_use) HIP_TRY(hipEventSynchronize(s.used));   // the kernel of two steps ago has consumed this buffer
@@ -460,7 +483,7 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
         if (s.dmeas) hipFree(s.dmeas);
         s.hmeas = nullptr; s.dmeas = nullptr; s.cap = 0;
         const size_t cap = (size_t)3 * (kmax < 8 && k_stride >= 8 ? 8 : kmax) * B;
-        HIP_TRY(hipHostMalloc((void**)&s.hmeas, sizeof(float) * cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&s.hmeas, sizeof(float) * cap, hipHostMallocNonCoherent));
         HIP_TRY(hipMalloc(&s.dmeas, sizeof(float) * cap));
         s.cap = cap;
     }
@@ -486,14 +509,33 @@ int slam_step_sim(slam_handle* h, const float cmd[2]) {
     if (!h || !cmd) return fail(SLAM_ERR_ARG, "bad argument");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
+    if (h->kind == SLAM_EKF_SLAM && h->lazy_max > 1 && !h->dump_meas && h->run_chunk != 1) {
+        h->lazy_cmds.push_back(cmd[0]); h->lazy_cmds.push_back(cmd[1]);
+        return (int)(h->lazy_cmds.size() / 2) >= h->lazy_max ? flush_lazy(h) : SLAM_OK;
+    }
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     return launch_step(h, cmd, 1, nullptr, nullptr, 0);
+}
+
+int slam_set_lazy_steps(slam_handle* h, int n) {
+    if (!h || n < 0) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
+    h->lazy_max = n;
+    return SLAM_OK;
 }
 
 int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     if (!h || !cmds || T < 0) return fail(SLAM_ERR_ARG, "bad argument");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
+    FLUSH(h);
+    return run_sim_now(h, cmds, T);
+}
+
+}  // extern "C"
+
+static int run_sim_now(slam_handle* h, const float* cmds, int T) {
     if (T == 0) return SLAM_OK;
     if (h->predicted) return fail(SLAM_ERR_STATE, "a prediction stage is pending: call slam_update_dev before the next step");
     if (h->kind != SLAM_EKF_SLAM && !h->dump_meas && h->B >= h->ukf_split_min) {
@@ -528,8 +570,9 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     }
     if (h->kind != SLAM_EKF_SLAM || h->dump_meas || h->run_chunk == 1) {
         // one launch (pair) per timestep
+        HIP_TRY(hipSetDevice(h->device));
         for (int t = 0; t < T; ++t) {
-            int rc = slam_step_sim(h, cmds + 2 * (size_t)t);
+            int rc = launch_step(h, cmds + 2 * (size_t)t, 1, nullptr, nullptr, 0);
             if (rc) return rc;
         }
         return SLAM_OK;
@@ -557,6 +600,15 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
     return SLAM_OK;
 }
 
+static int flush_lazy(slam_handle* h) {
+    if (h->lazy_cmds.empty()) return SLAM_OK;
+    std::vector<float> c;
+    c.swap(h->lazy_cmds);
+    return run_sim_now(h, c.data(), (int)(c.size() / 2));
+}
+
+extern "C" {
+
 // UKF::predictionStage / UKF::updateStage (filter.h:187-188, ukf.cpp:197-291) as two calls.  predictionStage only
 // writes members that updateStage consumes (sqtP, X, X_pred, x_pred, P_pred); x_t / P_t change when updateStage
 // finishes (ukf.cpp:289-290).  So the split is: predict = nearestSPD + sqrt (the kernel that dominates the step) with
@@ -564,6 +616,7 @@ int slam_run_sim(slam_handle* h, const float* cmds, int T) {
 // bit-identical to slam_step_dev.
 int slam_predict(slam_handle* h, const float cmd[2]) {
     if (!h || !cmd) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "EKF has no separate prediction stage: EKF::update does both (ekf.cpp:37-179); use slam_step");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (h->predicted) return fail(SLAM_ERR_STATE, "slam_predict called twice without slam_update_dev");
@@ -577,6 +630,7 @@ int slam_predict(slam_handle* h, const float cmd[2]) {
 }
 int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_count, int k_stride) {
     if (!h || k_stride < 0 || (k_stride > 0 && (!d_meas || !d_count))) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "EKF has no separate update stage (ekf.cpp:37-179); use slam_step");
     if (!h->predicted) return fail(SLAM_ERR_STATE, "slam_update_dev needs a preceding slam_predict");
     HIP_TRY(hipSetDevice(h->device));
@@ -601,6 +655,7 @@ int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_count,
 // X = [x, x + sqtP(:,i), x - sqtP(:,i)] (ukf.cpp:214-219) around the x_t that step started from.
 int slam_get_sigma_points(slam_handle* h, int inst, double* X, int32_t* rows, int32_t* cols) {
     if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
+    FLUSH(h);
     if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "sigma points exist for the UKF kinds only");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
@@ -637,6 +692,7 @@ static int fetch_elems(slam_handle* h, double* dst, const void* dbase, size_t el
 
 int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, int32_t* ids, int32_t* ts) {
     if (!h || inst < 0 || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
+    FLUSH(h);
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -660,6 +716,7 @@ int slam_get_state(slam_handle* h, int inst, double* x, double* P, int32_t* M, i
 
 int slam_get_poses(slam_handle* h, double* poses) {
     if (!h || !poses) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->esz == 8) {
@@ -674,6 +731,7 @@ int slam_get_poses(slam_handle* h, double* poses) {
 
 static int copy_out(slam_handle* h, void* dst, const void* src, size_t bytes) {
     if (!h || !dst) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
@@ -685,6 +743,7 @@ int slam_status(slam_handle* h, int32_t* f) { return copy_out(h, f, h ? h->dflag
 
 int slam_get_last_meas(slam_handle* h, float* meas, int32_t* count, int k_stride) {
     if (!h || !meas || !count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     if (!h->dump_meas || h->k_stride < k_stride) {
         // enable the dump for subsequent slam_step_sim calls; nothing recorded yet for past steps
@@ -717,6 +776,7 @@ int slam_error_stats(slam_handle* h, double* avg) {
 
 int slam_sync(slam_handle* h) {
     if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAM_OK;
@@ -726,6 +786,7 @@ int slam_state_dim_max(const slam_handle* h) { return h ? h->n_max : 0; }
 
 int slam_set_run_chunk(slam_handle* h, int steps_per_launch) {
     if (!h || steps_per_launch < 0) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     h->run_chunk = steps_per_launch;
     return SLAM_OK;
 }
@@ -734,6 +795,7 @@ int slam_set_run_chunk(slam_handle* h, int steps_per_launch) {
 // The ablation bits are honoured by -DSLAM_ABLATE builds only.
 int slam_set_debug_flags(slam_handle* h, int flags) {
     if (!h) return fail(SLAM_ERR_ARG, "NULL handle");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
 #ifndef SLAM_ABLATE
@@ -752,6 +814,7 @@ int slam_variant_available(int L_max, int dtype, int variant) { return slam::ekf
 
 int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset) {
     if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram element size");
@@ -763,6 +826,7 @@ int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset) {
 int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
     if (!h || !bytes) return fail(SLAM_ERR_ARG, "bad argument");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->dscalar, 0, sizeof(double), h->stream));
     HIP_TRY(slam::launch_algorithmic_bytes(h->dM, h->B, h->base, h->esz, h->dscalar, h->stream));
@@ -775,6 +839,7 @@ int slam_algorithmic_bytes(slam_handle* h, double* bytes) {
 // (SLAM_DEBUG_FLAGS & 4)
 int slam_debug_read_prof(slam_handle* h, unsigned long long* out) {
     if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (!h->dprof) return fail(SLAM_ERR_STATE, "SLAM_DEBUG_FLAGS has no timer bit (4 / 32) set");
@@ -791,6 +856,7 @@ int slam_debug_read_prof(slam_handle* h, unsigned long long* out) {
 // debug only: the raw [B][16] buffer
 int slam_debug_read_prof_raw(slam_handle* h, unsigned long long* out) {
     if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (!h->dprof) return fail(SLAM_ERR_STATE, "SLAM_DEBUG_FLAGS has no timer bit (4 / 32) set");

@@ -8,27 +8,54 @@ import numpy as np
 import live_ekf_slam_amd as S
 from live_ekf_slam_amd.scenario import make_scenario
 
-L, B, K, KS = 50, 65536, 8, 8
-lm, cmds = make_scenario(1234, L, 64)
-f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.init(0, 0, 0)
-f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
-f.run_sim(cmds[1:20]); f.sync()
-# record K steps of generated measurements (the generator's own output, so ids / ranges are consistent with the state)
+L, B, K, KS = 50, 65536, 40, 8
+lm, cmds = make_scenario(1234, L, 400)
+def fresh():
+    g = S.BatchedEKF(B, L).readParams(); g.set_map(lm); g.init(0, 0, 0)
+    g.set_vision(1e9, -4.0, 4.0); g.update_sim(cmds[0]); g.set_vision(3.0, -1.57, 1.57)
+    g.run_sim(cmds[1:20]); g.sync()
+    return g
+# record K steps of generated measurements on a throw-away filter (the measurement dump switches the multi-step paths off)
+frec = fresh()
 rec = []
 for t in range(20, 20 + K):
-    f.update_sim(cmds[t]); rec.append(f.last_meas(KS))
-f.sync()
+    frec.update_sim(cmds[t]); rec.append(frec.last_meas(KS))
+frec.close()
+f = fresh()
 hip = C.CDLL("libamdhip64.so")
 def run(label, fn):
     f.sync(); t0 = time.perf_counter()
     for i in range(K): fn(i)
     f.sync(); dt = time.perf_counter() - t0
     print(f"{label:34s} {dt / K * 1e3:7.3f} ms/step  {B * K / dt / 1e6:6.2f} M steps/s")
-run("slam_step_sim (device generator)", lambda i: f.update_sim(cmds[28 + i]))
-run("slam_step (host buffers, H2D/step)", lambda i: f.update(cmds[36 + i], rec[i][0], rec[i][1]))
+from live_ekf_slam_amd import _lib
+Lc = _lib.lib()
+fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)); ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+cm = [np.ascontiguousarray(c, dtype=np.float32) for c in cmds]
+run("slam_step_sim (device generator)", lambda i: _lib.check(Lc.slam_step_sim(f.h, fp(cm[60 + i]))))
+run("slam_step (host buffers, H2D/step)", lambda i: _lib.check(Lc.slam_step(f.h, fp(cm[100 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)))
 dm, dc = C.c_void_p(), C.c_void_p()
 hip.hipMalloc(C.byref(dm), B * KS * 12); hip.hipMalloc(C.byref(dc), B * 4)
 hip.hipMemcpy(dm, rec[0][0].ctypes.data_as(C.c_void_p), B * KS * 12, 1); hip.hipMemcpy(dc, rec[0][1].ctypes.data_as(C.c_void_p), B * 4, 1)
-run("slam_step_dev (resident buffers)", lambda i: f.update_dev(cmds[44 + i], dm.value, dc.value, KS))
-print(f"copied per step: {B * KS * 12 / 1e6:.1f} MB measurements + {B * 4 / 1e6:.2f} MB counts (pageable host memory)")
+dms, dcs = [], []
+for i in range(K):   # every step's message resident on the device: the GPU time of the host-measurement step without any copy
+    a_, b_ = C.c_void_p(), C.c_void_p()
+    hip.hipMalloc(C.byref(a_), B * KS * 12); hip.hipMalloc(C.byref(b_), B * 4)
+    hip.hipMemcpy(a_, rec[i][0].ctypes.data_as(C.c_void_p), B * KS * 12, 1); hip.hipMemcpy(b_, rec[i][1].ctypes.data_as(C.c_void_p), B * 4, 1)
+    dms.append(a_); dcs.append(b_)
+g2 = fresh()
+import time as _t
+def run2(label, fn, flt):
+    flt.sync(); t0 = _t.perf_counter(); hostt = 0.0
+    for i in range(K):
+        h0 = _t.perf_counter(); fn(i); hostt += _t.perf_counter() - h0
+    flt.sync(); dt = _t.perf_counter() - t0
+    print(f"{label:34s} {dt / K * 1e3:7.3f} ms/step  {B * K / dt / 1e6:6.2f} M steps/s   (host time inside the calls {hostt / K * 1e3:.3f} ms/step)")
+run2("slam_step_dev (each step's own msg)", lambda i: _lib.check(Lc.slam_step_dev(g2.h, fp(cm[20 + i]), dms[i], dcs[i], KS)), g2)
+g3 = fresh()
+run2("slam_step (host buffers) again", lambda i: _lib.check(Lc.slam_step(g3.h, fp(cm[20 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)), g3)
+run("slam_step_dev (one msg repeated)", lambda i: _lib.check(Lc.slam_step_dev(f.h, fp(cm[140 + i]), dm, dc, KS)))
+kmax = max(int(r[1].max()) for r in rec)
+print(f"caller buffers per step: {B * KS * 12 / 1e6:.1f} MB measurements (stride {KS}) + {B * 4 / 1e6:.2f} MB counts in pageable host memory; "
+      f"slam_step packs them to stride max(count) = {kmax} into pinned staging and copies on its own stream")
 f.close()
