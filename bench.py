@@ -412,8 +412,9 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev):
         if os.path.exists(pmc):
             try:
                 d = json.load(open(pmc))
-                if d.get("batch") == B and d.get("landmarks") == L and d.get("dtype", "f64") == args.dtype:
-                    traffic = d.get("hbm_bytes_per_step") * K / n_launch   # L2<->fabric bytes (rocprofv3 PMC)
+                per_step = d.get("hbm_bytes_per_step_by_steps", {}).get(str(K))
+                if d.get("batch") == B and d.get("landmarks") == L and d.get("dtype", "f64") == args.dtype and per_step and n_launch == 1:
+                    traffic = per_step * K             # L2<->fabric bytes of the K-step launch (rocprofv3 PMC, this K)
             except Exception:
                 traffic = None
         cfg = {"workload": f"EKF-SLAM fused sim+update step, L={L} random landmarks (n={n_state}), global batch={B_global} "
