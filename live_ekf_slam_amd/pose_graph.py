@@ -65,7 +65,27 @@ class BatchedPoseGraph:
         if isinstance(config, SlamConfig):
             self.cfg = config.copy()
         elif isinstance(config, str):
+            # a params.yaml path: the common keys through the C reader, plus the three keys PoseGraph::readParams itself takes
+            # from the file (pose_graph.cpp:28-47): num_iterations, pose_graph.implementation, .solve_graph_every_iteration
             _lib.check(L.slam_config_load(C.byref(self.cfg), config.encode()))
+            section = None
+            with open(config) as fh:
+                for line in fh:
+                    body = line.split("#", 1)[0].rstrip()
+                    if not body.strip():
+                        continue
+                    if not body[0].isspace():
+                        section = body.split(":", 1)[0].strip()
+                    key, _, val = body.strip().partition(":")
+                    val = val.strip().strip('"').strip("'")
+                    if not val:
+                        continue
+                    if section == "num_iterations" and key == "num_iterations":
+                        self.num_iterations_total = int(val)
+                    elif section == "pose_graph" and key == "implementation" and val != "gtsam":   # pose_graph.cpp:31-40
+                        raise _lib.SlamError("pose_graph.implementation must be gtsam (the reference's sesync/custom are incomplete)")
+                    elif section == "pose_graph" and key == "solve_graph_every_iteration":
+                        self.solve_graph_every_iteration = val.lower() == "true"
         elif isinstance(config, dict):
             pg = config.get("pose_graph", {})
             if pg.get("implementation", "gtsam") != "gtsam":   # pose_graph.cpp:31-40: sesync / custom throw
