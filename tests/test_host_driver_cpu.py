@@ -14,5 +14,5 @@ def test_driver_builds_and_fails_loudly_without_gpu():
     assert os.path.exists(exe)
     if torch.cuda.is_available():
         return
-    out = subprocess.run([exe, "4", "20", "3"], capture_output=True, text=True, timeout=60)
+    out = subprocess.run([exe, "run", "ekf", "4", "20", "3"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "driver failed" in out.stderr
