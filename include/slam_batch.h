@@ -111,8 +111,10 @@ int slam_set_map(slam_handle* h, const double* map_xy, int L);
 /* ---- Filter::update (ekf.cpp:37-179, ukf.cpp:161-195; called from iterate localization_node.cpp:131) ------ */
 /* One timestep for all instances.  cmd = {fwd, ang} (Command.msg:3-5), shared by the batch.
  * meas: [batch][k_stride][3] float32 {id, range, bearing} (Float32MultiArray layout of sim_node.py:245-249,
- * padded to k_stride detections per instance); meas_count: [batch].  HOST pointers (copied to the device
- * asynchronously, mirroring `lm_meas = lmMeasMsg->data`, ekf.cpp:64). */
+ * padded to k_stride detections per instance); meas_count: [batch].  HOST pointers: the message is copied before the call
+ * returns (mirroring `lm_meas = lmMeasMsg->data`, ekf.cpp:64), so the caller may reuse its buffers at once.  EKF: like
+ * slam_step_sim, consecutive calls are queued (up to slam_set_lazy_steps timesteps, messages of at most 4 detections per
+ * instance) and run as one multi-step launch; every other entry point runs what is queued first. */
 int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* meas_count, int k_stride);
 /* Same, with DEVICE pointers (no copy). */
 int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_meas_count,

@@ -24,15 +24,15 @@ struct EkfStepParams {
     const double* map;  // [L][2]
     int32_t L;
     // ---- measurements ----
-    const float* meas_in;         // EXT mode: [B][k_stride_in][3]
-    const int32_t* meas_count_in; // EXT mode: [B]
+    const float* meas_in;         // EXT mode: [T][B][k_stride_in][3] (one timestep per launch: T = 1)
+    const int32_t* meas_count_in; // EXT mode: [T][B]
     int32_t k_stride_in;
     float* meas_out;              // SIM mode, optional dump: [B][k_stride_out][3]
     int32_t* meas_count_out;      // SIM mode, optional: [B]
     int32_t k_stride_out;
     // ---- command (Command.msg) ----
     float fwd, ang;
-    // multi-step launch (SIM mode only): the kernel runs T consecutive timesteps per instance, step t with command
+    // multi-step launch: the kernel runs T consecutive timesteps per instance, step t with command
     // cmds[2t], cmds[2t+1] and RNG step index step+t; the result is always left in P.  cmds == NULL: T = 1 with (fwd, ang).
     const float* cmds;
     int32_t T;

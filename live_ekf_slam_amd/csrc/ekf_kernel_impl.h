@@ -289,6 +289,18 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     // simgen(tn): the measurement generator for timestep tn (ONE wavefront) into ring slot tn % SD; advances the true pose.
     auto simgen = [&](int tn) {
         const int sq = tn % SD;
+        if (!p.sim) {
+            // EXT mode: the message of timestep tn comes from the caller's queue in device memory,
+            // meas_in[tn][b][k_stride][3] / meas_count_in[tn][b] (one timestep per launch: tn = 0)
+            int kk = p.meas_count_in[(size_t)tn * p.B + b];
+            kk = kk < p.k_stride_in ? kk : p.k_stride_in;
+            kk = kk < 0 ? 0 : kk;
+            const int kc = kk < KCAP ? kk : KCAP;
+            const float* src = p.meas_in + ((size_t)tn * p.B + b) * p.k_stride_in * 3;
+            for (int i = lane; i < 3 * kc; i += 64) s_meas[sq * 3 * KCAP + i] = src[i];
+            if (lane == 0) s_kraw[sq] = kk;
+            return;
+        }
         const float fwd_n = MULTI ? p.cmds[2 * tn] : p.fwd;
         const float ang_n = MULTI ? p.cmds[2 * tn + 1] : p.ang;
         double tx = s_keep[0], ty = s_keep[1], tth = s_keep[2];
@@ -309,18 +321,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         double* ps = s_ps + 10 * qb;
         const float fwd_n = MULTI ? p.cmds[2 * tn] : p.fwd;
         const float ang_n = MULTI ? p.cmds[2 * tn + 1] : p.ang;
-        int kraw;
-        if (p.sim) {
-            if (s_sim[0] <= tn) {   // not generated ahead of time (the decoupled loop's generator wavefront does that)
-                simgen(tn);
-                if (lane == 0) s_sim[0] = tn + 1;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            kraw = s_kraw[tn % SD];
-        } else {
-            kraw = nx[0];   // EXT mode: the message was fetched by the prologue
+        if (s_sim[0] <= tn) {   // not produced ahead of time (the decoupled loop's generator wavefront does that)
+            simgen(tn);
+            if (lane == 0) s_sim[0] = tn + 1;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int kraw = s_kraw[tn % SD];
         {   // x_pred of the vehicle (ekf.cpp:56-59) and the scalars of F_x, F_v V F_v^T (ekf.cpp:41-55)
             const double x0 = (double)(ST)s_xp[0], x1 = (double)(ST)s_xp[1], th = (double)(ST)s_xp[2];
             double sn, cs;
@@ -765,14 +771,6 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
     };
 
-    if (!p.sim) {   // EXT mode (single step): fetch the message
-        int kk = p.meas_count_in[b];
-        kk = kk < p.k_stride_in ? kk : p.k_stride_in;
-        kk = kk < 0 ? 0 : kk;
-        const int kc = kk < KCAP ? kk : KCAP;
-        for (int i = tid; i < 3 * kc; i += TPB) s_meas[i] = p.meas_in[(size_t)b * p.k_stride_in * 3 + i];
-        if (tid == 0) s_next[0] = kk;
-    }
     __syncthreads();
     SLAM_STAMP(0);   // initial loads
     // The vehicle rows / columns of P are needed by every launch: the wavefronts that do not run the pre-step fetch them
@@ -842,7 +840,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int* nx = s_next + 4 * (tq & 1);
             return nx[0] <= KG && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
         };
-        const bool fast_ok = p.id_known && p.sim && p.meas_out == nullptr && fastable(t) &&
+        const bool fast_ok = p.id_known && p.meas_out == nullptr && fastable(t) &&
                              !SLAM_DBG(p.dbg & (2 | 16 | 64));
         if (fast_ok) {
             const int n = na, ldn = ekf_ld(n, ESZ);
@@ -1011,7 +1009,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     }
                     SLAM_STAMP(23);  // thin downdates (+ loop)
                     // ---- end of the step: error statistic, x_t = x_pred (ekf.cpp:176), storage rounding ----
-                    if (lane == 0) {   // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
+                    if (p.sim && lane == 0) {   // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
                         const double* tru = s_tru + (tt % SD) * 6 + 3;   // true pose after this timestep
                         const double ex = (double)(float)s_xp[0] - tru[0], ey = (double)(float)s_xp[1] - tru[1];
                         s_keep[3] = s_keep[3] + sqrt(ex * ex + ey * ey);

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -38,6 +39,19 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// fn(begin, end) over [0, n) on a few host threads (packing 65 536 per-instance messages is ~1 ms on one core)
+template <class F>
+void host_parallel(size_t n, F fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = n < 8192 ? 1 : (hw >= 8 ? 4 : (hw >= 2 ? 2 : 1));
+    if (nt == 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t i = 1; i < nt; ++i) th.emplace_back(fn, i * per, (i + 1) * per < n ? (i + 1) * per : n);
+    fn((size_t)0, per < n ? per : n);
+    for (auto& t : th) t.join();
+}
 
 }  // namespace
 
@@ -80,6 +94,18 @@ struct slam_handle {
     // re-reads x, ids and the thin rows / columns of P and cannot keep update groups open across timesteps).
     std::vector<float> lazy_cmds;
     int lazy_max = 16;                                         // 0 / 1 = off (SLAM_LAZY_STEPS, slam_set_lazy_steps)
+    // slam_step (EKF, HOST measurements): the same queueing.  Each call packs its message (stride kExtQ detections per
+    // instance; a message with more goes through the immediate path) and its command into one of two pinned queues of up to
+    // lazy_max timesteps; a flush copies the queue on the copy stream and runs ONE multi-step launch that takes the message of
+    // timestep t from the device-side queue instead of the generator.
+    struct ExtQueue {
+        float* hmeas = nullptr; int32_t* hcount = nullptr; float* hcmds = nullptr;   // pinned: [cap][B][kExtQ][3], [cap][B], [cap][2]
+        float* dmeas = nullptr; int32_t* dcount = nullptr;                           // device
+        int cap = 0, n = 0;
+        hipEvent_t copied = nullptr, used = nullptr;
+        bool in_use = false;
+    } extq[2];
+    int extq_cur = 0;
     double* dscalar = nullptr;
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
@@ -197,6 +223,8 @@ bool parse_scalar(const char* line, const char* key, double* out) {
 
 static int run_sim_now(slam_handle* h, const float* cmds, int T);
 static int flush_lazy(slam_handle* h);
+static int flush_ext(slam_handle* h);
+static constexpr int kExtQ = 4;   // detections per instance a queued slam_step message can hold
 #define FLUSH(h)                        \
     do {                                \
         const int frc_ = flush_lazy(h); \
@@ -362,6 +390,10 @@ int slam_destroy(slam_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); hipEventDestroy(h->aux_ev[0]); hipEventDestroy(h->aux_ev[1]); }
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    for (auto& q : h->extq) {
+        if (q.hmeas) { hipHostFree(q.hmeas); hipHostFree(q.hcount); hipHostFree(q.hcmds); hipFree(q.dmeas); hipFree(q.dcount); }
+        if (q.copied) { hipEventDestroy(q.copied); hipEventDestroy(q.used); }
+    }
     for (auto& s : h->stage) {
         if (s.hmeas) hipHostFree(s.hmeas);
         if (s.hcount) hipHostFree(s.hcount);
@@ -455,9 +487,44 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
 
 int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* count, int k_stride) {
     if (!h || !cmd || !meas || !count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
-    FLUSH(h);
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->kind == SLAM_EKF_SLAM && h->lazy_max > 1 && h->run_chunk != 1) {
+        const size_t B = (size_t)h->B;
+        int kmax = 0;
+        for (size_t b = 0; b < B; ++b) kmax = count[b] > kmax ? count[b] : kmax;   // 65 536 ints: ~20 us
+        kmax = kmax < k_stride ? kmax : k_stride;
+        if (kmax <= kExtQ) {
+            if (!h->lazy_cmds.empty()) FLUSH(h);   // generator steps queued before this one run first
+            slam_handle::ExtQueue& q = h->extq[h->extq_cur];
+            if (q.cap < h->lazy_max) {
+                if (q.n > 0) FLUSH(h);
+                if (q.in_use) { HIP_TRY(hipEventSynchronize(q.used)); q.in_use = false; }
+                if (q.hmeas) { hipHostFree(q.hmeas); hipHostFree(q.hcount); hipHostFree(q.hcmds); hipFree(q.dmeas); hipFree(q.dcount); }
+                q.cap = h->lazy_max;
+                HIP_TRY(hipHostMalloc((void**)&q.hmeas, sizeof(float) * 3 * kExtQ * B * q.cap, hipHostMallocNonCoherent));
+                HIP_TRY(hipHostMalloc((void**)&q.hcount, sizeof(int32_t) * B * q.cap, hipHostMallocNonCoherent));
+                HIP_TRY(hipHostMalloc((void**)&q.hcmds, sizeof(float) * 2 * q.cap, hipHostMallocNonCoherent));
+                HIP_TRY(hipMalloc(&q.dmeas, sizeof(float) * 3 * kExtQ * B * q.cap));
+                HIP_TRY(hipMalloc(&q.dcount, sizeof(int32_t) * B * q.cap));
+                if (!q.copied) {
+                    HIP_TRY(hipEventCreateWithFlags(&q.copied, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&q.used, hipEventDisableTiming));
+                }
+            }
+            if (q.n == 0 && q.in_use) { HIP_TRY(hipEventSynchronize(q.used)); q.in_use = false; }   // the launch that read this queue is done
+            float* dst = q.hmeas + (size_t)q.n * B * kExtQ * 3;
+            const int kc = k_stride < kExtQ ? k_stride : kExtQ;
+            host_parallel(B, [&](size_t b0, size_t b1) {
+                for (size_t b = b0; b < b1; ++b) memcpy(dst + b * kExtQ * 3, meas + b * (size_t)k_stride * 3, sizeof(float) * 3 * kc);
+            });
+            memcpy(q.hcount + (size_t)q.n * B, count, sizeof(int32_t) * B);
+            q.hcmds[2 * q.n] = cmd[0]; q.hcmds[2 * q.n + 1] = cmd[1];
+            q.n += 1;
+            return q.n >= h->lazy_max ? flush_ext(h) : SLAM_OK;
+        }
+    }
+    FLUSH(h);
     if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
     // The caller's buffers may be reused right after return (ekf.cpp:64 copies the message), so the message is packed
     // into one of two PINNED staging buffers (only max_b count[b] detections per instance travel), copied on a separate
@@ -510,6 +577,7 @@ int slam_step_sim(slam_handle* h, const float cmd[2]) {
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
     if (h->kind == SLAM_EKF_SLAM && h->lazy_max > 1 && !h->dump_meas && h->run_chunk != 1) {
+        if (h->extq[h->extq_cur].n > 0) FLUSH(h);   // host-measurement steps queued before this one run first
         h->lazy_cmds.push_back(cmd[0]); h->lazy_cmds.push_back(cmd[1]);
         return (int)(h->lazy_cmds.size() / 2) >= h->lazy_max ? flush_lazy(h) : SLAM_OK;
     }
@@ -600,11 +668,46 @@ static int run_sim_now(slam_handle* h, const float* cmds, int T) {
     return SLAM_OK;
 }
 
+static int flush_ext(slam_handle* h) {
+    slam_handle::ExtQueue& q = h->extq[h->extq_cur];
+    if (q.n == 0) return SLAM_OK;
+    const int T = q.n;
+    const size_t B = (size_t)h->B;
+    q.n = 0;
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMemcpyAsync(q.dcount, q.hcount, sizeof(int32_t) * B * T, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipMemcpyAsync(q.dmeas, q.hmeas, sizeof(float) * 3 * kExtQ * B * T, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipEventRecord(q.copied, h->copy_stream));
+    if (h->cmds_cap < T) {
+        if (h->dcmds) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(h->dcmds); h->dcmds = nullptr; }
+        HIP_TRY(hipMalloc(&h->dcmds, sizeof(float) * 2 * (size_t)T));
+        h->cmds_cap = T;
+    }
+    HIP_TRY(hipMemcpyAsync(h->dcmds, q.hcmds, sizeof(float) * 2 * (size_t)T, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, q.copied, 0));
+    slam::EkfStepParams p;
+    fill_params(h, p, q.hcmds);
+    p.sim = 0;
+    p.meas_in = q.dmeas; p.meas_count_in = q.dcount; p.k_stride_in = kExtQ;
+    p.cmds = h->dcmds;
+    p.T = T;
+    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
+    h->step += (uint32_t)T;
+    HIP_TRY(hipEventRecord(q.used, h->stream));
+    q.in_use = true;
+    h->extq_cur ^= 1;
+    return SLAM_OK;
+}
+
 static int flush_lazy(slam_handle* h) {
-    if (h->lazy_cmds.empty()) return SLAM_OK;
-    std::vector<float> c;
-    c.swap(h->lazy_cmds);
-    return run_sim_now(h, c.data(), (int)(c.size() / 2));
+    if (!h->lazy_cmds.empty()) {
+        std::vector<float> c;
+        c.swap(h->lazy_cmds);
+        const int rc = run_sim_now(h, c.data(), (int)(c.size() / 2));
+        if (rc) return rc;
+    }
+    return flush_ext(h);
 }
 
 extern "C" {

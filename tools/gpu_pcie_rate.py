@@ -33,7 +33,6 @@ Lc = _lib.lib()
 fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)); ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
 cm = [np.ascontiguousarray(c, dtype=np.float32) for c in cmds]
 run("slam_step_sim (device generator)", lambda i: _lib.check(Lc.slam_step_sim(f.h, fp(cm[60 + i]))))
-run("slam_step (host buffers, H2D/step)", lambda i: _lib.check(Lc.slam_step(f.h, fp(cm[100 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)))
 dm, dc = C.c_void_p(), C.c_void_p()
 hip.hipMalloc(C.byref(dm), B * KS * 12); hip.hipMalloc(C.byref(dc), B * 4)
 hip.hipMemcpy(dm, rec[0][0].ctypes.data_as(C.c_void_p), B * KS * 12, 1); hip.hipMemcpy(dc, rec[0][1].ctypes.data_as(C.c_void_p), B * 4, 1)
@@ -53,7 +52,7 @@ def run2(label, fn, flt):
     print(f"{label:34s} {dt / K * 1e3:7.3f} ms/step  {B * K / dt / 1e6:6.2f} M steps/s   (host time inside the calls {hostt / K * 1e3:.3f} ms/step)")
 run2("slam_step_dev (each step's own msg)", lambda i: _lib.check(Lc.slam_step_dev(g2.h, fp(cm[20 + i]), dms[i], dcs[i], KS)), g2)
 g3 = fresh()
-run2("slam_step (host buffers) again", lambda i: _lib.check(Lc.slam_step(g3.h, fp(cm[20 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)), g3)
+run2("slam_step (host buffers, queued)", lambda i: _lib.check(Lc.slam_step(g3.h, fp(cm[20 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)), g3)
 run("slam_step_dev (one msg repeated)", lambda i: _lib.check(Lc.slam_step_dev(f.h, fp(cm[140 + i]), dm, dc, KS)))
 kmax = max(int(r[1].max()) for r in rec)
 print(f"caller buffers per step: {B * KS * 12 / 1e6:.1f} MB measurements (stride {KS}) + {B * 4 / 1e6:.2f} MB counts in pageable host memory; "
