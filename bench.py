@@ -269,11 +269,20 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    # BENCH_SHARE_GPU=1 (testing only): every rank uses GPU 0 and the collectives run over gloo, so that the N > 1 control flow
+    # (shard plan, barriers, gather) can be exercised on a one-GPU box; the figures of such a run mean nothing.
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    args.coll_device = None if share else dev   # where the tensors of the collectives live
 
     if args.waves_per_filter:
         os.environ["SLAM_WAVES_PER_FILTER"] = str(args.waves_per_filter)
@@ -325,7 +334,7 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev):
     vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]
     spl = args.steps_per_launch if args.steps_per_launch > 0 else max(K, 1)
 
-    run = ShardedRun(dist if world > 1 else None, dev)
+    run = ShardedRun(dist if world > 1 else None, args.coll_device)
     first, B, B_global = run.plan(args.batch, args.scaling)
     f = S.BatchedEKF(B, L, device=local_rank, dtype=S.F32 if args.dtype == "f32" else S.F64).readParams()
     stream = torch.cuda.Stream(device=dev)

@@ -111,6 +111,7 @@ struct slam_handle {
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
     double* dxprev = nullptr;                         // UKF: x_t the last sigma points were drawn around
     double* dvt = nullptr; int32_t* dvage = nullptr;  // UKF: V^T of the last eigen-decomposition + warm-start age
+    uint4* drot = nullptr;                            // UKF (n <= 44): Jacobi schedule table of the fast sqrt kernel
     hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[2] = {nullptr, nullptr};   // UKF run_sim: second half of the batch
     int ukf_split_min = 1024;                                                        // batch size from which it is used
     bool predicted = false; float pred_cmd[2] = {0.f, 0.f};   // UKF: slam_predict done, slam_update_dev pending
@@ -165,6 +166,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
     p.b_off = 0; p.b_cnt = h->B;
     p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
+    p.rot_tab = h->drot;
     p.prof = (h->dbg & 4) ? h->dprof : nullptr;
 }
 
@@ -353,6 +355,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dxprev, sizeof(double) * B * h->xstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvt, sizeof(double) * B * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvage, sizeof(int32_t) * B) : hipSuccess,
+        (kind != SLAM_EKF_SLAM && h->n_max <= 44) ? hipMalloc(&h->drot, sizeof(uint4) * slam::kUkfRotTabEntries) : hipSuccess,
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -373,6 +376,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMemsetAsync(h->dkhist, 0, sizeof(unsigned long long) * 8, h->stream),
         h->dnsq ? hipMemsetAsync(h->dnsq, 0, sizeof(int32_t) * B, h->stream) : hipSuccess,
         h->dprof ? hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * slam::kEkfProfSlots * B, h->stream) : hipSuccess,
+        h->drot ? slam::launch_ukf_rot_table(h->drot, h->stream) : hipSuccess,
     };
     for (hipError_t ee : zs)
         if (ee != hipSuccess) {
@@ -402,7 +406,7 @@ int slam_destroy(slam_handle* h) {
         if (s.copied) hipEventDestroy(s.copied);
         if (s.used) hipEventDestroy(s.used);
     }
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage, h->dkhist};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage, h->dkhist, h->drot};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);

@@ -47,7 +47,16 @@ struct UkfStepParams {
     int32_t loc;          // 1 = FilterChoice::UKF_LOC: every detection updates against the known map (ukf.cpp:146-154)
     unsigned long long* prof;   // optional [B][16] phase timers of the step kernel (debug), NULL otherwise
     const float* mapf;    // [L][3] float32 {id, x, y}: `filter->map` as it arrives on /truth/landmarks
+    // Jacobi schedule table of the fast sqrt kernel (<44, 256>): [n / 2][round t < 43][thread 256] x 16 bytes, the LDS byte
+    // offsets of every operand a thread touches in round t at state size n (built once by launch_ukf_rot_table); NULL = the
+    // kernel derives them from the round-robin schedule itself, as the other variants do
+    const uint4* rot_tab;
 };
+
+// Schedule table for ukf_sqrt_kernel<44, 256>: kUkfRotTabEntries uint4 entries (4 MB); see UkfStepParams::rot_tab.
+static constexpr int kUkfRotRounds = 43, kUkfRotThreads = 256, kUkfRotSizes = 23;   // n = 0, 2, ..., 44
+static constexpr size_t kUkfRotTabEntries = (size_t)kUkfRotSizes * kUkfRotRounds * kUkfRotThreads;
+hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream);
 
 static constexpr int kUkfMaxLandmarks = 50;   // n = 4 + 2L <= 104
 

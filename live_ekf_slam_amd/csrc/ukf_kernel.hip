@@ -97,6 +97,57 @@ __device__ __forceinline__ void rr_pair(int k, int t, int n, int& p, int& q) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
+// Jacobi schedule table.  In the fast rotation phase a thread's work is fixed (pair-block (i, j) or diagonal block i, and a
+// few V^T rows of pair iv); what changes from round to round is only WHICH matrix rows / columns its pairs hold (the
+// round-robin schedule).  Deriving the operand addresses from the schedule costs ~100 integer instructions per thread and
+// round against ~60 fp64 operations (the kernel is VALU-issue bound); they depend on (n, t, thread) only, so they are
+// tabulated once: entry = {a00 | a01 << 16, a10 | a11 << 16, vp | vq << 16, p | q << 16} as LDS byte offsets (pair-block:
+// the four elements; diagonal block: A_pp, A_qq, A_qp; V^T rows p, q of the thread's pair) and, for thread k < n / 2, the
+// indices (p, q) of pair k for the parameter phase.  One 16-byte load per thread and round, issued before the parameter
+// phase.  Same addresses, same arithmetic: not a bit changes.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void ukf_rot_table_kernel(uint4* tab) {
+    const int n = 2 * blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    uint4 e = make_uint4(0u, 0u, 0u, 0u);
+    if (n >= 4 && t < n - 1) {
+        const int m = n / 2, nb = m * (m - 1) / 2;
+        auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
+        if (tid < nb) {            // pair-block (i, j), i > j: same decoding as the kernel's desc[]
+            int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)tid)) * 0.5f);
+            while (i * (i - 1) / 2 > tid) --i;
+            while ((i + 1) * i / 2 <= tid) ++i;
+            const int j = tid - i * (i - 1) / 2;
+            int pi, qi, pj, qj;
+            rr_pair(i, t, n, pi, qi);
+            rr_pair(j, t, n, pj, qj);
+            e.x = (unsigned)(8 * idx(pi, pj)) | ((unsigned)(8 * idx(pi, qj)) << 16);
+            e.y = (unsigned)(8 * idx(qi, pj)) | ((unsigned)(8 * idx(qi, qj)) << 16);
+        } else if (tid < nb + m) { // diagonal block of pair i
+            int pq, qq;
+            rr_pair(tid - nb, t, n, pq, qq);
+            e.x = (unsigned)(8 * (pq * (pq + 1) / 2 + pq)) | ((unsigned)(8 * (qq * (qq + 1) / 2 + qq)) << 16);
+            e.y = (unsigned)(8 * (qq * (qq + 1) / 2 + pq));
+        }
+        const int tp = kUkfRotThreads / m, iv = tid / tp;   // V^T rows of pair iv
+        if (iv < m) {
+            int vp, vq;
+            rr_pair(iv, t, n, vp, vq);
+            e.z = (unsigned)(8 * vp * n) | ((unsigned)(8 * vq * n) << 16);
+        }
+        if (tid < m) {             // parameter phase: pair k = tid
+            int pp, qq;
+            rr_pair(tid, t, n, pp, qq);
+            e.w = (unsigned)pp | ((unsigned)qq << 16);
+        }
+    }
+    tab[((size_t)blockIdx.y * kUkfRotRounds + t) * kUkfRotThreads + tid] = e;
+}
+hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream) {
+    hipLaunchKernelGGL(ukf_rot_table_kernel, dim3(kUkfRotRounds, kUkfRotSizes), dim3(kUkfRotThreads), 0, stream, tab);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // nearestSPD + sqrt
 // ------------------------------------------------------------------------------------------------------------------
 // PROF = true compiles the phase timers in (a separate instantiation, launched only when the debug buffer is attached:
@@ -221,6 +272,9 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     const int tp = TPB / m;                 // threads per pair (V rows)
     const int iv = tid / tp, subk = tid - iv * tp;
     const bool vvalid = iv < m;
+    // schedule table (see ukf_rot_table_kernel): this thread's column of the table for state size n, or NULL
+    constexpr bool kTab = kFast && NMAX == 44 && TPB == kUkfRotThreads;
+    const uint4* const tabn = kTab ? p.rot_tab + (size_t)(n / 2) * kUkfRotRounds * kUkfRotThreads + tid : nullptr;   // the launcher checks rot_tab
     bool converged = false;
 #pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -243,12 +297,19 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
         if (!any_live) { converged = true; break; }
 #pragma unroll 1
         for (int t = 0; t < n - 1; ++t) {
+            uint4 te = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (kTab) te = tabn[(size_t)t * kUkfRotThreads];   // in flight during the parameter phase
             if (tid < m) {  // rotation parameters of this round's pairs (round-robin: position 0 fixed)
                 const int k = tid;
-                const int a = (k == 0) ? 0 : 1 + ((k - 1 + t) % (n - 1));
-                const int k2 = n - 1 - k;
-                const int bq = 1 + ((k2 - 1 + t) % (n - 1));
-                const int pidx = a < bq ? a : bq, qidx = a < bq ? bq : a;
+                int pidx, qidx;
+                if constexpr (kTab) {
+                    pidx = (int)(te.w & 0xffffu); qidx = (int)(te.w >> 16);
+                } else {
+                    const int a = (k == 0) ? 0 : 1 + ((k - 1 + t) % (n - 1));
+                    const int k2 = n - 1 - k;
+                    const int bq = 1 + ((k2 - 1 + t) % (n - 1));
+                    pidx = a < bq ? a : bq; qidx = a < bq ? bq : a;
+                }
                 const double app = AT(pidx, pidx), aqq = AT(qidx, qidx), apq = AT(qidx, pidx);
                 double c = 1.0, s = 0.0, tt = 0.0;
                 // small-element rule (classical Jacobi): after three sweeps an off-diagonal element that cannot change
@@ -267,7 +328,58 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
             __syncthreads();
             SQ_STAMP(2);   // rotation parameters (22 lanes of wavefront 0) + barrier
             if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
-            if constexpr (kFast) {
+            if constexpr (kTab) {
+                // ---- the same round with every operand address taken from the schedule table ----
+                char* const sAb = reinterpret_cast<char*>(sA);
+                char* const sVb = reinterpret_cast<char*>(sVt);
+                const unsigned vpo = te.z & 0xffffu, vqo = te.z >> 16;
+                const double2 vcs = s_csn[vvalid ? iv : 0];
+                double xp[ITV], xq[ITV];
+#pragma unroll
+                for (int u = 0; u < ITV; ++u) {
+                    const int k = subk + tp * u;
+                    const int kk = k < n ? k : 0;
+                    xp[u] = *reinterpret_cast<const double*>(sVb + vpo + 8 * kk);
+                    xq[u] = *reinterpret_cast<const double*>(sVb + vqo + 8 * kk);
+                }
+                const int d = desc[0];
+                const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
+                if (kind == 0) {
+                    const double2 csi = s_csn[i], csj = s_csn[j];
+                    double* const e00 = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
+                    double* const e01 = reinterpret_cast<double*>(sAb + (te.x >> 16));
+                    double* const e10 = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
+                    double* const e11 = reinterpret_cast<double*>(sAb + (te.y >> 16));
+                    const double b00 = *e00, b01 = *e01, b10 = *e10, b11 = *e11;
+                    const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
+                    if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
+                        const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
+                        const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
+                        *e00 = t00 * cj - t01 * sj; *e01 = t00 * sj + t01 * cj;
+                        *e10 = t10 * cj - t11 * sj; *e11 = t10 * sj + t11 * cj;
+                    }
+                } else if (kind == 1) {
+                    double* const epp = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
+                    double* const eqq = reinterpret_cast<double*>(sAb + (te.x >> 16));
+                    double* const epq = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
+                    const double tn = s_tn[i];
+                    const double app = *epp, aqq = *eqq, apq = *epq;
+                    *epp = app - tn * apq;
+                    *eqq = aqq + tn * apq;
+                    if (apq != 0.0) *epq = 0.0;
+                }
+                if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
+                    const double c = vcs.x, sn = vcs.y;
+#pragma unroll
+                    for (int u = 0; u < ITV; ++u) {
+                        const int k = subk + tp * u;
+                        if (k < n) {
+                            *reinterpret_cast<double*>(sVb + vpo + 8 * k) = c * xp[u] - sn * xq[u];
+                            *reinterpret_cast<double*>(sVb + vqo + 8 * k) = sn * xp[u] + c * xq[u];
+                        }
+                    }
+                }
+            } else if constexpr (kFast) {
                 // ---- V row-pairs of pair iv: operands first ----
                 int vpi, vqi;
                 rr_pair(vvalid ? iv : 0, t, n, vpi, vqi);
@@ -860,6 +972,7 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
             case 128: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 128>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;
             case 64: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 64>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
             default:
+                if (p.rot_tab == nullptr) return hipErrorInvalidValue;   // <44, 256> takes its operand addresses from the schedule table
                 if (p.prof) hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, true>), dim3(p.b_cnt), dim3(256), 0, stream, p);
                 else hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p);
                 break;
