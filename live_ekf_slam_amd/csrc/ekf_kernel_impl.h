@@ -936,13 +936,24 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             n_c1 = predicted(s_C[lane * LDP + 1], 1, t_s);
                             if (lane == 2) n_22 = predicted(p22, 2, 2);
                         }
-#pragma unroll 1
-                        for (int i = lane; i < 2 * LDP; i += 64) {
-                            const int sl = i >= LDP ? 1 : 0, j = i - sl * LDP;
-                            if (j < n) {
-                                s_R[i] = predicted(s_R[i], sl, j);
-                                s_C[i] = predicted(s_C[i], j, sl);
+                        // rows / cols 0, 1 at state index j >= 2 take one term each (what `predicted` reduces to there):
+                        // P[0][j] += F02 P[2][j], P[1][j] += F12 P[2][j], P[j][0] += P[j][2] F02, P[j][1] += P[j][2] F12
+#pragma unroll
+                        for (int u = 0; u < (LDP + 63) / 64; ++u) {
+                            const int j = lane + 64 * u;
+                            if (j >= 2 && j < n) {
+                                const double r2 = r2o[j], c2 = c2o[j];
+                                s_R[j] = s_R[j] + fa * r2;
+                                s_R[LDP + j] = s_R[LDP + j] + fb * r2;
+                                s_C[j] = s_C[j] + c2 * fa;
+                                s_C[LDP + j] = s_C[LDP + j] + c2 * fb;
                             }
+                        }
+                        if (lane < 2) {   // the 2 x 2 corner (all terms)
+                            const int j = lane;
+                            const double v00 = predicted(s_R[j], 0, j), v10 = predicted(s_R[LDP + j], 1, j);
+                            const double w00 = predicted(s_C[j], j, 0), w10 = predicted(s_C[LDP + j], j, 1);
+                            s_R[j] = v00; s_R[LDP + j] = v10; s_C[j] = w00; s_C[LDP + j] = w10;
                         }
                         if (thin_l) {   // late stores: every operand above was read before
                             s_R[lane * LDP + 0] = n_r0; s_R[lane * LDP + 1] = n_r1;
