@@ -179,8 +179,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ double s_keep[4 + 2 * 64]; // values that live across the timesteps of one launch: true pose, error
                                           // sum, map entries of ids 0..63 (kept out of registers on purpose)
     __shared__ int s_kh[8];               // instance-steps of this launch by detection count
-    __shared__ int s_ring[8];             // decoupled loop: published updates, applied updates, flush request, exit, next timestep,
-                                          // flag bits raised by the control wavefront
+    __shared__ int s_ring[8];             // decoupled loop: published updates, applied updates, (unused), exit, next timestep,
+                                          // flag bits raised by the control wavefront, hold (no new pass), pass in flight
     __shared__ int s_pass[4];             // decoupled loop: pass id, first update, number of updates, streamers done
     __shared__ int s_wend[KG];            // fp32 storage: a timestep ends after this update of the open group (P is rounded there)
 
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             constexpr int NS = W - 1;                 // streamers
             constexpr bool kGen = W >= 3;             // the last streamer also runs the measurement generator ahead of the filter
             if (tid == 0) {
-                s_ring[0] = nu; s_ring[1] = 0; s_ring[2] = 0; s_ring[3] = 0; s_ring[4] = t; s_ring[5] = 0;
+                s_ring[0] = nu; s_ring[1] = 0; s_ring[2] = 0; s_ring[3] = 0; s_ring[4] = t; s_ring[5] = 0; s_ring[6] = 0; s_ring[7] = 0;
                 s_pass[0] = 0; s_pass[1] = 0; s_pass[2] = 0; s_pass[3] = 0;
             }
             __syncthreads();
@@ -877,12 +877,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     SLAM_STAMP(17);  // group formation
                     const bool veh = s_need[0] == 1;   // first step of the launch: the vehicle rows / columns are still in HBM only
                     if (needg || veh) {
-                        // a landmark comes into view: its row / column must come from HBM, which must hold every update
-                        // published so far -> have the streamers drain the ring, then gather
-                        if (lane == 0) st_i(&s_ring[2], 1);
-                        while (ld_i(&s_ring[1]) != pub) __builtin_amdgcn_s_sleep(2);
-                        if (lane == 0) st_i(&s_ring[2], 0);
+                        // A landmark comes into view: its row / column comes from HBM, which holds the updates the streamers
+                        // have applied so far (`app`); the ones still pending are in the ring slots, so the gathered copy is
+                        // brought up to date here, with the operations the stream will apply to P.  Only a pass in flight
+                        // must end first (P is half-updated meanwhile), and no new one may start during the gather.
+                        if (lane == 0) st_i(&s_ring[6], 1);                          // hold
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        while (ld_i(&s_ring[7])) __builtin_amdgcn_s_sleep(1);        // pass in flight
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int app = ld_i(&s_ring[1]);
 #pragma unroll 1
                         for (int sl = 0; sl < nTq; ++sl) {
                             if (s_need[sl] != 1) continue;
@@ -893,6 +896,18 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                 if (j < n) {
                                     rv = (double)Pbuf[(size_t)t_s * ldn + j];   // P[t_s][j]
                                     cv = (double)Pbuf[(size_t)j * ldn + t_s];   // P[j][t_s]
+#pragma unroll 1
+                                    for (int u = app; u < pub; ++u) {
+                                        const int us = u % KG;
+                                        const double2* Ku = s_K + us * LDP;
+                                        const double2* HPu = s_HP + us * HPW;
+                                        const double2 kt = Ku[t_s], ht = HPu[hpi(t_s)], kj = Ku[j], hj = HPu[hpi(j)];
+                                        rv = rv - (kt.x * hj.x + kt.y * hj.y);
+                                        cv = cv - (kj.x * ht.x + kj.y * ht.y);
+                                        if constexpr (!kWide) {
+                                            if (s_wend[us]) { rv = (double)(ST)rv; cv = (double)(ST)cv; }   // end of a timestep: storage rounding
+                                        }
+                                    }
                                 }
                                 s_R[sl * LDP + j] = rv;
                                 s_C[sl * LDP + j] = cv;
@@ -904,6 +919,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                 s_C[sl * LDP + lane] = s_R[lane * LDP + t_s];   // P[r][t_s], r < 3
                             }
                         }
+                        if (lane == 0) st_i(&s_ring[6], 0);
                     }
                     if (lane < TS) s_need[lane] = 0;
                     SLAM_STAMP(18);  // flush wait + gather
@@ -1074,8 +1090,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         for (;;) {
                             app = ld_i(&s_ring[1]);
                             pend = ld_i(&s_ring[0]) - app;
-                            const int fl = ld_i(&s_ring[2]), ex = ld_i(&s_ring[3]);
-                            if (pend > 0 && (pend >= SLAM_PASS_MIN || fl || ex)) break;
+                            const int ex = ld_i(&s_ring[3]);
+                            if (pend > 0 && (pend >= SLAM_PASS_MIN || ex) && !ld_i(&s_ring[6])) break;
                             if (ex && pend == 0) {   // re-read: an update published just before the exit flag
                                 if (ld_i(&s_ring[0]) - app == 0) { stop = true; break; }
                                 continue;
@@ -1090,6 +1106,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             if (!stop) {
                                 while (cnt > 0 && !ld_i(&s_wend[(app + cnt - 1) % KG])) cnt -= 1;
                                 if (cnt == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+                            }
+                        }
+                        if (!stop) {   // claim the pass; back off if the control wavefront is gathering (it waits for a claimed pass)
+                            if (lane == 0) st_i(&s_ring[7], 1);
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            if (ld_i(&s_ring[6])) {
+                                if (lane == 0) st_i(&s_ring[7], 0);
+                                __builtin_amdgcn_s_sleep(1);
+                                continue;
                             }
                         }
                         if (lane == 0) {
@@ -1127,7 +1152,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     if (lane == 0) atomicAdd(&s_pass[3], 1);
                     if (leader) {
                         while (ld_i(&s_pass[3]) < NS) __builtin_amdgcn_s_sleep(1);
-                        if (lane == 0) st_i(&s_ring[1], lo + cnt);   // the ring slots are free, P holds these updates
+                        if (lane == 0) {
+                            st_i(&s_ring[1], lo + cnt);   // the ring slots are free, P holds these updates
+                            st_i(&s_ring[7], 0);
+                        }
                     }
                 }
             }
