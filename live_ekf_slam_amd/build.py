@@ -43,6 +43,9 @@ def build_extension(force=False, verbose=False):
     extra = ["-DSLAM_ABLATE"] if os.environ.get("SLAM_ABLATE") else []   # timing experiments only (WRONG results)
     extra += os.environ.get("SLAM_EXTRA_FLAGS", "").split()               # A/B tuning builds (tools/gpu_ab.sh)
     jobs = [(src, os.path.join(CSRC, src + ".o"), []) for src in SOURCES]
+    # per-file code generation options: the UKF step kernel keeps its MFMA accumulators in VGPRs (the compiler's default put them
+    # in AGPRs and copied all of them in and out around every k-block of the covariance contraction)
+    per_file = {"ukf_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     variants = list(EKF_DEFAULT_VARIANTS) + (EKF_SWEEP_VARIANTS if os.environ.get("SLAM_SWEEP") else [])
     for (nmax, w, kg, unr, f32, pipe) in variants:
         tag = f"ekf_inst_{nmax}_{pipe}{w}{kg}{unr}{'_f32' if f32 else ''}"
@@ -58,7 +61,7 @@ def build_extension(force=False, verbose=False):
         while pending and len(running) < maxpar:
             name, obj, defs = pending.pop(0)
             src = os.path.join(CSRC, name if not defs else "ekf_inst.hip")
-            cmd = [hipcc] + FLAGS + extra + defs + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + extra + per_file.get(name, []) + defs + ["-c", src, "-o", obj]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 print(" ".join(cmd), flush=True)

@@ -26,6 +26,8 @@
 #include "slam_math.h"
 #include "slam_rng.h"
 
+typedef double dbl4_t __attribute__((ext_vector_type(4)));   // C/D of v_mfma_f64_16x16x4_f64
+
 namespace slam {
 
 namespace {
@@ -776,99 +778,115 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
         UKF_STAMP(6);
         }
 
-        // ---- P pass: P_pred = sum_i (w_i d_r) d_c + Q, minus the K S K^T terms; TR x 4 register tiles (TR = 2 when the
-        //      block has enough threads for twice as many tiles: the pass is instruction-bound, not operand-bound) ----
-        {
-            constexpr int TR = (NMAX <= 44 && TPB >= 256) ? 2 : 4;
+        // ---- P pass: P_pred = sum_i (w_i d_r) d_c + Q (ukf.cpp:235-240), minus the K S K^T terms of this group's updates.
+        //      First pass: the n x (2n+1) x n contraction runs on the matrix pipe.  v_mfma_f64_16x16x4_f64 computes, for every
+        //      output element, the chain acc = fma(a_k, b_k, acc) over its four k in ascending order (tools/ubench_mfma_f64.hip
+        //      checks that bit for bit), so chaining the instruction over k-blocks 0, 1, ... IS the reference's sequential sum over
+        //      the sigma points with each term fused - which is what the oracle evaluates (std::fma).  A operand = w_i d_r(i)
+        //      (rounded product, Eigen's `Wts(i) * d` first), B operand = d_c(i); a wavefront owns a row of 16 x 16 tiles, builds
+        //      the d operands of every 16-row block once per k-block and feeds all tiles of its row from them.  Padding rows /
+        //      sigma points give zero operands (fma(0, 0, acc) = acc).
+        if (first_pass) {
+            constexpr int NT = (NMAX + 15) / 16;
+            const int nt = (n + 15) >> 4;
+            const int wv = tid >> 6, kq = lane >> 4, cl = lane & 15;
+            const int nks = (ns + 3) >> 2;
+            unsigned hiacc = 0u;
+            // per 16-row block t: this lane's state row, its x_t and x_pred entries
+            int rr[NT];
+            bool vr[NT], pr[NT];
+            double bt[NT], xm[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int row = 16 * t + cl;
+                vr[t] = row < n; rr[t] = vr[t] ? row : 0; pr[t] = rr[t] < 4;
+                bt[t] = s_xt[rr[t]]; xm[t] = vr[t] ? s_xp0[rr[t]] : 0.0;
+            }
+#pragma unroll 1
+            for (int tr = wv; tr < nt; tr += TPB / 64) {
+                dbl4_t acc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = dbl4_t{0.0, 0.0, 0.0, 0.0};
+                // operands of k-block ks: d[t] for every 16-row block t, a = w * d[tr]
+                auto operands = [&](int ks, double (&d)[NT], double& a) {
+                    const int k = 4 * ks + kq;                      // sigma point of this lane's operands
+                    const bool vk = k < ns;
+                    const int kc = vk ? k : 0;
+                    const bool plus = kc <= n;                      // 1..n: x_t + column k-1 of sqtP; n+1..2n: x_t - column k-1-n
+                    int kk = plus ? kc - 1 : kc - 1 - n;
+                    kk = kk < 0 ? 0 : kk;
+                    const double* Srow = sS + (size_t)kk * n;
+                    const double w = kc == 0 ? w0 : wi;
+                    // branch-free: both candidate operands are read unconditionally and selected (blocks beyond the state size
+                    // read row 0 and yield zeros), so the LDS reads of a k-block issue together
+                    double x4[NT], sv[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        x4[t] = sX4[(pr[t] ? rr[t] : 0) * ns + kc]; sv[t] = Srow[rr[t]];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {   // (the asm keeps the compiler from sinking the loads into per-lane branches)
+                        asm volatile("" : "+v"(x4[t]), "+v"(sv[t]));
+                        const double lp = bt[t] + sv[t], lm = bt[t] - sv[t];
+                        const double lv = kc == 0 ? bt[t] : (plus ? lp : lm);
+                        const double dv = (pr[t] ? x4[t] : lv) - xm[t];
+                        d[t] = (vr[t] && vk) ? dv : 0.0;
+                    }
+                    double av = d[0];
+#pragma unroll
+                    for (int t = 1; t < NT; ++t) av = (t == tr) ? d[t] : av;
+                    a = w * av;
+                };
+                // software pipeline: the operands of k-block ks + 1 are formed while the matrix pipe works on k-block ks
+                double dc[NT], ac;
+                operands(0, dc, ac);
+#pragma unroll 1
+                for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac, dc[t], acc[t], 0, 0, 0);
+                    double dn[NT], an;
+                    operands(ks + 1 < nks ? ks + 1 : ks, dn, an);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) dc[t] = dn[t];
+                    ac = an;
+                }
+                UKF_STAMP(9);   // contraction of this tile row
+                // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, column = lane & 15
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t >= nt) continue;
+                    const int c = 16 * t + cl;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * tr + kq + 4 * i;
+                        if (r >= n || c >= n) continue;
+                        double v = acc[t][i];
+                        if (r == c && r < 4) v = v + s_sc[r];   // + Q (signed diagonal)
+#pragma unroll 1
+                        for (int u = 0; u < ug; ++u) {
+                            const double* Ku = sK + (size_t)u * NMAX * 4;
+                            v = v - (Ku[4 * r + 2] * Ku[4 * c + 0] + Ku[4 * r + 3] * Ku[4 * c + 1]);
+                        }
+                        Pout[(size_t)r * n_fin + c] = v;
+                        const unsigned h = (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu;
+                        hiacc = hiacc > h ? hiacc : h;
+                    }
+                }
+            }
+            if (__syncthreads_or(hiacc >= 0x7ff00000u)) flags |= SLAM_INST_NONFINITE;
+        } else {
+            // later passes (more than KU updates in one step): P comes back from HBM, 4 x 4 register tiles
+            constexpr int TR = 4;
             const int ntr = (n + TR - 1) / TR, ntc = (n + 3) / 4;
             unsigned hiacc = 0u;
             for (int tile = tid; tile < ntr * ntc; tile += TPB) {
                 const int r0 = TR * (tile / ntc), c0 = 4 * (tile % ntc);
                 double acc[TR][4];
-                if (first_pass) {
 #pragma unroll
-                    for (int a = 0; a < TR; ++a)
+                for (int a = 0; a < TR; ++a)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
-                    // X_pred(r, i) is sX4[r][i] for the four pose rows and x_t[r] +- sqtP[i-1 (-n)][r] for the landmark rows
-                    // (ukf.cpp:214-226).  The sigma points are walked in their three uniform ranges (i = 0, 1..n, n+1..2n: the
-                    // same order, the same operations per term as one loop with a case distinction per element), what does not
-                    // depend on i is hoisted, and both candidate operands of an element are read unconditionally and selected,
-                    // so the LDS reads of an iteration (and of the next, unrolled) issue together instead of one dependent
-                    // round trip per element behind per-lane branches.
-                    double xr[TR], xc[4], br[TR], bc[4];
-                    int ir[TR], ic[4];
-                    bool vr[TR], vc[4], pr[TR], pc[4];
-#pragma unroll
-                    for (int a = 0; a < TR; ++a) {
-                        vr[a] = r0 + a < n; ir[a] = vr[a] ? r0 + a : 0; pr[a] = ir[a] < 4;
-                        xr[a] = vr[a] ? s_xp0[ir[a]] : 0.0; br[a] = s_xt[ir[a]];
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        vc[a] = c0 + a < n; ic[a] = vc[a] ? c0 + a : 0; pc[a] = ic[a] < 4;
-                        xc[a] = vc[a] ? s_xp0[ic[a]] : 0.0; bc[a] = s_xt[ic[a]];
-                    }
-                    auto accumulate = [&](const double w, const double (&dr)[TR], const double (&dc)[4]) {
-#pragma unroll
-                        for (int a = 0; a < TR; ++a) {
-                            const double wd = w * dr[a];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[a][c] = acc[a][c] + wd * dc[c];
-                        }
-                    };
-                    {   // i = 0: the mean point
-                        double dr[TR], dc[4];
-#pragma unroll
-                        for (int a = 0; a < TR; ++a) { const double x4 = sX4[(pr[a] ? ir[a] : 0) * ns]; dr[a] = vr[a] ? (pr[a] ? x4 : br[a]) - xr[a] : 0.0; }
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) { const double x4 = sX4[(pc[a] ? ic[a] : 0) * ns]; dc[a] = vc[a] ? (pc[a] ? x4 : bc[a]) - xc[a] : 0.0; }
-                        accumulate(w0, dr, dc);
-                    }
-#pragma unroll 2
-                    for (int i = 1; i <= n; ++i) {   // x_t + column i-1 of sqtP
-                        const double* Srow = sS + (size_t)(i - 1) * n;
-                        double dr[TR], dc[4];
-#pragma unroll
-                        for (int a = 0; a < TR; ++a) {
-                            const double x4 = sX4[(pr[a] ? ir[a] : 0) * ns + i], sv = Srow[ir[a]];
-                            dr[a] = vr[a] ? (pr[a] ? x4 : br[a] + sv) - xr[a] : 0.0;
-                        }
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const double x4 = sX4[(pc[a] ? ic[a] : 0) * ns + i], sv = Srow[ic[a]];
-                            dc[a] = vc[a] ? (pc[a] ? x4 : bc[a] + sv) - xc[a] : 0.0;
-                        }
-                        accumulate(wi, dr, dc);
-                    }
-#pragma unroll 2
-                    for (int i = n + 1; i < ns; ++i) {   // x_t - column i-1-n of sqtP
-                        const double* Srow = sS + (size_t)(i - 1 - n) * n;
-                        double dr[TR], dc[4];
-#pragma unroll
-                        for (int a = 0; a < TR; ++a) {
-                            const double x4 = sX4[(pr[a] ? ir[a] : 0) * ns + i], sv = Srow[ir[a]];
-                            dr[a] = vr[a] ? (pr[a] ? x4 : br[a] - sv) - xr[a] : 0.0;
-                        }
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const double x4 = sX4[(pc[a] ? ic[a] : 0) * ns + i], sv = Srow[ic[a]];
-                            dc[a] = vc[a] ? (pc[a] ? x4 : bc[a] - sv) - xc[a] : 0.0;
-                        }
-                        accumulate(wi, dr, dc);
-                    }
-#pragma unroll
-                    for (int a = 0; a < TR; ++a)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (r0 + a == c0 + c && r0 + a < 4) acc[a][c] = acc[a][c] + s_sc[r0 + a];   // + Q (signed diagonal)
-                } else {
-#pragma unroll
-                    for (int a = 0; a < TR; ++a)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[a][c] = (r0 + a < n && c0 + c < n) ? Pout[(size_t)(r0 + a) * n_fin + c0 + c] : 0.0;
-                }
+                    for (int c = 0; c < 4; ++c)
+                        acc[a][c] = (r0 + a < n && c0 + c < n) ? Pout[(size_t)(r0 + a) * n_fin + c0 + c] : 0.0;
 #pragma unroll 1
                 for (int u = 0; u < ug; ++u) {
                     const double* Ku = sK + (size_t)u * NMAX * 4;
@@ -997,7 +1015,8 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
     if (nmax <= 44) {
         switch (env_tpb(1, 128)) {
             case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
-            case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;   // 2 x 4 tiles
+            case 256: hipLaunchKernelGGL((ukf_step_kernel<44, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
+            case 192: hipLaunchKernelGGL((ukf_step_kernel<44, 192, 8>), dim3(p.b_cnt), dim3(192), 0, stream, p); break;   // one wavefront per tile row of the covariance
             default:   // measured best
                 if (p.prof) hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8, true>), dim3(p.b_cnt), dim3(128), 0, stream, p);
                 else hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.b_cnt), dim3(128), 0, stream, p);

@@ -249,7 +249,10 @@ struct Ukf {
         for (int r = 0; r < nn; ++r)
             for (int c = 0; c < nn; ++c) {
                 double acc = 0.0;
-                for (int i = 0; i < ns; ++i) acc = acc + (wt(i, nn) * D[(size_t)r * ns + i]) * D[(size_t)c * ns + i];
+                // each term fused: acc = fma(w_i d_r, d_c, acc).  The reference leaves the contraction of `P += (w d) d^T` to Eigen and
+                // the compiler (ukf.cpp:235-238); the device evaluates it with v_mfma_f64_16x16x4_f64, whose result is this
+                // chain in ascending i, bit for bit (tools/ubench_mfma_f64.hip).
+                for (int i = 0; i < ns; ++i) acc = std::fma(wt(i, nn) * D[(size_t)r * ns + i], D[(size_t)c * ns + i], acc);
                 P_pred[(size_t)r * nn + c] = acc;
             }
         // + Q (ukf.cpp:182-186, 240): signed diagonal from the yaw of x_t

@@ -19,10 +19,11 @@ names = ["prologue loads", "measurements", "assoc+sigma rows0-3", "weighted mean
 def show(tag):
     out = (C.c_ulonglong * 16)()
     _lib.lib().slam_debug_read_prof(f.h, out)
-    tot = sum(out[:9])
+    tot = sum(out[:10])
     print(f"{tag} L={L} B={B}: mean us per block-step {tot / B / 100:.1f}")
     for i, nm in enumerate(names):
         print(f"   {nm:22s} {out[i] / B / 100:8.1f} us  {100.0 * out[i] / tot:5.1f} %")
+    print(f"   {'(of the P pass: MFMA contraction)':22s} {out[9] / B / 100:8.1f} us")
     return out
 show("step 59")
 for t in range(60, 60 + extra):
@@ -30,5 +31,5 @@ for t in range(60, 60 + extra):
     out = (C.c_ulonglong * 16)(); _lib.lib().slam_debug_read_prof(f.h, out)
     meas, cnt = f.last_meas(8) if hasattr(f, "last_meas") else (None, np.zeros(1))
     upd = (out[4] + out[5] + out[6]) / B / 100
-    print(f"step {t}: total {sum(out[:9]) / B / 100:6.1f} us, update phases {upd:6.1f} us (sensing {out[4] / B / 100:.1f}, leader S {out[5] / B / 100:.1f}, C,K,x {out[6] / B / 100:.1f}), P pass {out[7] / B / 100:.1f}, mean detections {float(np.mean(cnt)):.2f}")
+    print(f"step {t}: total {sum(out[:10]) / B / 100:6.1f} us, update phases {upd:6.1f} us (sensing {out[4] / B / 100:.1f}, leader S {out[5] / B / 100:.1f}, C,K,x {out[6] / B / 100:.1f}), P pass {(out[7] + out[9]) / B / 100:.1f} (contraction {out[9] / B / 100:.1f}), mean detections {float(np.mean(cnt)):.2f}")
 f.close()
