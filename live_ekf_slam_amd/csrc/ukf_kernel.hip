@@ -278,6 +278,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     constexpr bool kTab = kFast && NMAX == 44 && TPB == kUkfRotThreads;
     const uint4* const tabn = kTab ? p.rot_tab + (size_t)(n / 2) * kUkfRotRounds * kUkfRotThreads + tid : nullptr;   // the launcher checks rot_tab
     bool converged = false;
+    uint4 te_next = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (kTab) te_next = tabn[0];
 #pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: every off-diagonal element is exactly zero OR would only be zeroed by the small-element rule
@@ -299,8 +301,10 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
         if (!any_live) { converged = true; break; }
 #pragma unroll 1
         for (int t = 0; t < n - 1; ++t) {
-            uint4 te = make_uint4(0u, 0u, 0u, 0u);
-            if constexpr (kTab) te = tabn[(size_t)t * kUkfRotThreads];   // in flight during the parameter phase
+            // the table entry of this round was requested a round ago (the parameter lanes need it at once: waiting for it
+            // here put an L2 round trip at the head of every round); the next round's is requested now
+            const uint4 te = te_next;
+            if constexpr (kTab) te_next = tabn[(size_t)(t + 1 < n - 1 ? t + 1 : 0) * kUkfRotThreads];
             if (tid < m) {  // rotation parameters of this round's pairs (round-robin: position 0 fixed)
                 const int k = tid;
                 int pidx, qidx;
