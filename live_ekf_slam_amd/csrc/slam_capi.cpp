@@ -93,6 +93,8 @@ struct slam_handle {
     // anyway, and a multi-step launch gives the same bits as single steps, so only the speed changes (one launch per call
     // re-reads x, ids and the thin rows / columns of P and cannot keep update groups open across timesteps).
     std::vector<float> lazy_cmds;
+    int eager_init = 2;                                        // first idle-GPU launch size (SLAM_EAGER_FLUSH, 0 = off)
+    int eager_target = 2;                                      // queued steps an idle GPU is given at once (doubles per such launch)
     int lazy_max = 16;                                         // 0 / 1 = off (SLAM_LAZY_STEPS, slam_set_lazy_steps)
     // slam_step (EKF, HOST measurements): the same queueing.  Each call packs its message (stride kExtQ detections per
     // instance; a message with more goes through the immediate path) and its command into one of two pinned queues of up to
@@ -226,6 +228,22 @@ bool parse_scalar(const char* line, const char* key, double* out) {
 static int run_sim_now(slam_handle* h, const float* cmds, int T);
 static int flush_lazy(slam_handle* h);
 static int flush_ext(slam_handle* h);
+// The queues exist to give the GPU long multi-step launches while the caller keeps calling once per tick; when the GPU has
+// nothing to do, waiting for the queue to fill only delays the work (a run of K calls paid one whole queue of packing with
+// the GPU idle before the first launch).  So a queued step is launched at once if the compute stream is idle.
+// Launching every single queued step would waste the multi-step kernel (2.4 vs 1.5 ms per step), so the idle-GPU launch
+// needs `eager_target` queued steps, and the target doubles with every such launch (2, 4, 8, ... up to the queue length):
+// the pipeline fills geometrically instead of after one whole queue.  SLAM_EAGER_FLUSH=0 switches it off.  Only slam_step
+// does this (its caller spends ~1 ms per call delivering a message); slam_step_sim calls cost microseconds, so its queue is
+// full long before the first launch would have finished.
+static bool eager_flush(slam_handle* h, int queued) {
+    if (h->eager_target <= 0 || queued < h->eager_target) return false;
+    const hipError_t e = hipStreamQuery(h->stream);
+    (void)hipGetLastError();   // hipErrorNotReady is an answer, not an error
+    if (e != hipSuccess) return false;
+    h->eager_target = 2 * queued < h->lazy_max ? 2 * queued : h->lazy_max;
+    return true;
+}
 static constexpr int kExtQ = 4;   // detections per instance a queued slam_step message can hold
 #define FLUSH(h)                        \
     do {                                \
@@ -330,6 +348,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (env) h->ukf_split_min = atoi(env);
     env = getenv("SLAM_LAZY_STEPS");   // slam_step_sim calls queued per multi-step launch (0 = one launch per call)
     if (env) h->lazy_max = atoi(env);
+    env = getenv("SLAM_EAGER_FLUSH");   // queued steps from which an idle GPU is given work before the queue is full (0 = never)
+    if (env) h->eager_init = h->eager_target = atoi(env);
     env = getenv("SLAM_RUN_CHUNK");   // timesteps per launch of slam_run_sim (1 = one launch per step)
     if (env) h->run_chunk = atoi(env);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -525,7 +545,7 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
             memcpy(q.hcount + (size_t)q.n * B, count, sizeof(int32_t) * B);
             q.hcmds[2 * q.n] = cmd[0]; q.hcmds[2 * q.n + 1] = cmd[1];
             q.n += 1;
-            return q.n >= h->lazy_max ? flush_ext(h) : SLAM_OK;
+            return (q.n >= h->lazy_max || eager_flush(h, q.n)) ? flush_ext(h) : SLAM_OK;
         }
     }
     FLUSH(h);
@@ -886,6 +906,7 @@ int slam_sync(slam_handle* h) {
     FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->eager_target = h->eager_init;   // the pipeline is drained: the next burst of calls fills it from small launches again
     return SLAM_OK;
 }
 int slam_batch(const slam_handle* h) { return h ? h->B : 0; }

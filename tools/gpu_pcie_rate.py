@@ -8,7 +8,7 @@ import numpy as np
 import live_ekf_slam_amd as S
 from live_ekf_slam_amd.scenario import make_scenario
 
-L, B, K, KS = 50, 65536, 40, 8
+L, B, K, KS = 50, 65536, int(os.environ.get('PCIE_K', '40')), 8
 lm, cmds = make_scenario(1234, L, 400)
 def fresh():
     g = S.BatchedEKF(B, L).readParams(); g.set_map(lm); g.init(0, 0, 0)
@@ -51,8 +51,23 @@ def run2(label, fn, flt):
     flt.sync(); dt = _t.perf_counter() - t0
     print(f"{label:34s} {dt / K * 1e3:7.3f} ms/step  {B * K / dt / 1e6:6.2f} M steps/s   (host time inside the calls {hostt / K * 1e3:.3f} ms/step)")
 run2("slam_step_dev (each step's own msg)", lambda i: _lib.check(Lc.slam_step_dev(g2.h, fp(cm[20 + i]), dms[i], dcs[i], KS)), g2)
+if os.environ.get("SLAM_EAGER_FLUSH") == "0":   # packing cost alone: 15 calls that only fill the queue
+    gp = fresh(); t0 = _t.perf_counter()
+    for i in range(15): _lib.check(Lc.slam_step(gp.h, fp(cm[20 + i]), fp(rec[i][0]), ip(rec[i][1]), KS))
+    print(f"slam_step host packing alone: {(_t.perf_counter() - t0) / 15 * 1e3:.3f} ms per call"); gp.close()
 g3 = fresh()
-run2("slam_step (host buffers, queued)", lambda i: _lib.check(Lc.slam_step(g3.h, fp(cm[20 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)), g3)
+# two untimed calls + sync first: each of the two message queues pins ~50 MB of host memory on first use (several ms, once per handle)
+for i in range(2): _lib.check(Lc.slam_step(g3.h, fp(cm[20 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)); g3.sync()
+K0 = K; K = K - 2
+run2("slam_step (host buffers, queued)", lambda i: _lib.check(Lc.slam_step(g3.h, fp(cm[22 + i]), fp(rec[2 + i][0]), ip(rec[2 + i][1]), KS)), g3)
+K = K0
+g4 = fresh()
+g4.sync(); t0 = time.perf_counter(); g4.run_sim(cmds[20:20 + K]); g4.sync(); dt = time.perf_counter() - t0
+print(f"{'run_sim over the same timesteps':34s} {dt / K * 1e3:7.3f} ms/step  {B * K / dt / 1e6:6.2f} M steps/s   (one launch, device generator)")
+g4.close()
+g5 = fresh()
+run2("slam_step_sim over the same steps", lambda i: _lib.check(Lc.slam_step_sim(g5.h, fp(cm[20 + i]))), g5)
+g5.close()
 run("slam_step_dev (one msg repeated)", lambda i: _lib.check(Lc.slam_step_dev(f.h, fp(cm[140 + i]), dm, dc, KS)))
 kmax = max(int(r[1].max()) for r in rec)
 print(f"caller buffers per step: {B * KS * 12 / 1e6:.1f} MB measurements (stride {KS}) + {B * 4 / 1e6:.2f} MB counts in pageable host memory; "
