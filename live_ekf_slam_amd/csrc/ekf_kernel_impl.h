@@ -1050,10 +1050,22 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         hiacc = hiacc > h0 ? hiacc : h0;
                     }
                     if constexpr (!kWide) {   // resident thin rows / cols carry the storage rounding of every step
+                        // four elements of each per trip: the reads of a trip issue together (one at a time this loop was a dozen
+                        // dependent LDS round trips per step)
+                        const int nel = nTq * LDP;
 #pragma unroll 1
-                        for (int i = lane; i < nTq * LDP; i += 64) {
-                            s_R[i] = (double)(ST)s_R[i];
-                            s_C[i] = (double)(ST)s_C[i];
+                        for (int i0 = lane; i0 < nel; i0 += 256) {
+                            double rv[4], cv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int i = i0 + 64 * u < nel ? i0 + 64 * u : i0;
+                                rv[u] = s_R[i]; cv[u] = s_C[i];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int i = i0 + 64 * u;
+                                if (i < nel) { s_R[i] = (double)(ST)rv[u]; s_C[i] = (double)(ST)cv[u]; }
+                            }
                         }
                     }
                     if ((p.dbg & 32) && p.prof != nullptr && lane == 0 && tt < kEkfProfSlots)
