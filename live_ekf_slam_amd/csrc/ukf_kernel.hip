@@ -323,10 +323,18 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                 const double g = 100.0 * fabs(apq);
                 const bool tiny = sweep >= tiny_from && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq));
                 if (apq != 0.0 && !tiny) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + tt * tt);
-                    s = tt * c;
+                    // t = tan(theta) of the rotation that annihilates a_pq: the smaller root of t^2 + 2 tau t - 1 = 0 with
+                    // tau = (a_qq - a_pp) / (2 a_pq), written without tau so that the dependent chain is sqrt, div, sqrt instead
+                    // of div, sqrt, div, sqrt, div: with d = a_qq - a_pp, h = hypot(d, 2 a_pq), w = |d| + h:
+                    // t = 2 a_pq / (+-w) (sign of d), c = 1 / sqrt(1 + t^2) = sqrt(w / (2 h)), s = t c.
+                    const double d = aqq - app, b2 = 2.0 * apq;
+                    const double h = sqrt(fma(d, d, b2 * b2));
+                    if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
+                        const double w = fabs(d) + h;
+                        tt = b2 / (d >= 0.0 ? w : -w);
+                        c = sqrt(w / (2.0 * h));
+                        s = tt * c;
+                    }
                 }
                 s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
                 s_csn[k] = make_double2(c, s);
@@ -359,10 +367,10 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const double b00 = *e00, b01 = *e01, b10 = *e10, b11 = *e11;
                     const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
                     if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
-                        const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
-                        const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
-                        *e00 = t00 * cj - t01 * sj; *e01 = t00 * sj + t01 * cj;
-                        *e10 = t10 * cj - t11 * sj; *e11 = t10 * sj + t11 * cj;
+                        const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
+                        const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
+                        *e00 = fma(t00, cj, -(t01 * sj)); *e01 = fma(t00, sj, t01 * cj);
+                        *e10 = fma(t10, cj, -(t11 * sj)); *e11 = fma(t10, sj, t11 * cj);
                     }
                 } else if (kind == 1) {
                     double* const epp = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
@@ -370,8 +378,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     double* const epq = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
                     const double tn = s_tn[i];
                     const double app = *epp, aqq = *eqq, apq = *epq;
-                    *epp = app - tn * apq;
-                    *eqq = aqq + tn * apq;
+                    *epp = fma(-tn, apq, app);
+                    *eqq = fma(tn, apq, aqq);
                     if (apq != 0.0) *epq = 0.0;
                 }
                 if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
@@ -380,8 +388,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     for (int u = 0; u < ITV; ++u) {
                         const int k = subk + tp * u;
                         if (k < n) {
-                            *reinterpret_cast<double*>(sVb + vpo + 8 * k) = c * xp[u] - sn * xq[u];
-                            *reinterpret_cast<double*>(sVb + vqo + 8 * k) = sn * xp[u] + c * xq[u];
+                            *reinterpret_cast<double*>(sVb + vpo + 8 * k) = fma(c, xp[u], -(sn * xq[u]));
+                            *reinterpret_cast<double*>(sVb + vqo + 8 * k) = fma(sn, xp[u], c * xq[u]);
                         }
                     }
                 }
@@ -410,10 +418,10 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const double b00 = sA[a00], b01 = sA[a01], b10 = sA[a10], b11 = sA[a11];
                     const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
                     if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
-                        const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
-                        const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
-                        sA[a00] = t00 * cj - t01 * sj; sA[a01] = t00 * sj + t01 * cj;
-                        sA[a10] = t10 * cj - t11 * sj; sA[a11] = t10 * sj + t11 * cj;
+                        const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
+                        const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
+                        sA[a00] = fma(t00, cj, -(t01 * sj)); sA[a01] = fma(t00, sj, t01 * cj);
+                        sA[a10] = fma(t10, cj, -(t11 * sj)); sA[a11] = fma(t10, sj, t11 * cj);
                     }
                 } else if (kind == 1) {
                     int pq, qq;
@@ -421,8 +429,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const int app_i = pq * (pq + 1) / 2 + pq, aqq_i = qq * (qq + 1) / 2 + qq, apq_i = qq * (qq + 1) / 2 + pq;
                     const double tn = s_tn[i];
                     const double app = sA[app_i], aqq = sA[aqq_i], apq = sA[apq_i];
-                    sA[app_i] = app - tn * apq;
-                    sA[aqq_i] = aqq + tn * apq;
+                    sA[app_i] = fma(-tn, apq, app);
+                    sA[aqq_i] = fma(tn, apq, aqq);
                     if (apq != 0.0) sA[apq_i] = 0.0;
                 }
                 // ---- V <- V J ----
@@ -432,8 +440,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     for (int u = 0; u < ITV; ++u) {
                         const int k = subk + tp * u;
                         if (k < n) {
-                            sVt[vpi * n + k] = c * xp[u] - sn * xq[u];
-                            sVt[vqi * n + k] = sn * xp[u] + c * xq[u];
+                            sVt[vpi * n + k] = fma(c, xp[u], -(sn * xq[u]));
+                            sVt[vqi * n + k] = fma(sn, xp[u], c * xq[u]);
                         }
                     }
                 }
@@ -451,15 +459,15 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const double ci = s_cs[i], cj = s_cs[j];
                     double& e00 = AT(pi, pj); double& e01 = AT(pi, qj); double& e10 = AT(qi, pj); double& e11 = AT(qi, qj);
                     const double b00 = e00, b01 = e01, b10 = e10, b11 = e11;
-                    const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
-                    const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
-                    e00 = t00 * cj - t01 * sj; e01 = t00 * sj + t01 * cj;
-                    e10 = t10 * cj - t11 * sj; e11 = t10 * sj + t11 * cj;
+                    const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
+                    const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
+                    e00 = fma(t00, cj, -(t01 * sj)); e01 = fma(t00, sj, t01 * cj);
+                    e10 = fma(t10, cj, -(t11 * sj)); e11 = fma(t10, sj, t11 * cj);
                 } else if (kind == 1) {
                     const int pq = s_pp[i], qq = s_qq[i];
                     const double app = AT(pq, pq), aqq = AT(qq, qq), apq = AT(qq, pq);
-                    AT(pq, pq) = app - s_tn[i] * apq;
-                    AT(qq, qq) = aqq + s_tn[i] * apq;
+                    AT(pq, pq) = fma(-s_tn[i], apq, app);
+                    AT(qq, qq) = fma(s_tn[i], apq, aqq);
                     if (apq != 0.0) AT(qq, pq) = 0.0;
                 } else {
                     const int k = jk;
@@ -468,8 +476,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const int pq = s_pp[i], qq = s_qq[i];
                     const double c = s_cs[i];
                     const double vp = sVt[pq * n + k], vq = sVt[qq * n + k];
-                    sVt[pq * n + k] = c * vp - s * vq;
-                    sVt[qq * n + k] = s * vp + c * vq;
+                    sVt[pq * n + k] = fma(c, vp, -(s * vq));
+                    sVt[qq * n + k] = fma(s, vp, c * vq);
                 }
             }
             __syncthreads();

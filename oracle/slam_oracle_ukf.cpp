@@ -66,10 +66,18 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
                 const bool tiny = sweep >= tiny_from && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq));
                 zr[k] = tiny ? 1 : 0;
                 if (apq != 0.0 && !tiny) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + tt * tt);
-                    s = tt * c;
+                    // t = tan(theta): the smaller root of t^2 + 2 tau t - 1 = 0, tau = (a_qq - a_pp) / (2 a_pq), in the form
+                    // d = a_qq - a_pp, h = hypot(d, 2 a_pq), w = |d| + h: t = 2 a_pq / (+-w), c = sqrt(w / (2 h)), s = t c
+                    // (three dependent sqrt / div instead of five; the device's critical path per round).  Products that feed
+                    // an addition are fused (std::fma) here and in the rotations below, as the kernel evaluates them.
+                    const double d = aqq - app, b2 = 2.0 * apq;
+                    const double h = sqrt(std::fma(d, d, b2 * b2));
+                    if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
+                        const double w = fabs(d) + h;
+                        tt = b2 / (d >= 0.0 ? w : -w);
+                        c = sqrt(w / (2.0 * h));
+                        s = tt * c;
+                    }
                 }
                 cs[k] = c; sn[k] = s; tn[k] = tt;
             }
@@ -82,10 +90,10 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
                     const double cj = cs[j], sj = sn[j];
                     const double b00 = A[(size_t)pi * n + pj], b01 = A[(size_t)pi * n + qj];
                     const double b10 = A[(size_t)qi * n + pj], b11 = A[(size_t)qi * n + qj];
-                    const double t00 = ci * b00 - si * b10, t01 = ci * b01 - si * b11;
-                    const double t10 = si * b00 + ci * b10, t11 = si * b01 + ci * b11;
-                    const double r00 = t00 * cj - t01 * sj, r01 = t00 * sj + t01 * cj;
-                    const double r10 = t10 * cj - t11 * sj, r11 = t10 * sj + t11 * cj;
+                    const double t00 = std::fma(ci, b00, -(si * b10)), t01 = std::fma(ci, b01, -(si * b11));
+                    const double t10 = std::fma(si, b00, ci * b10), t11 = std::fma(si, b01, ci * b11);
+                    const double r00 = std::fma(t00, cj, -(t01 * sj)), r01 = std::fma(t00, sj, t01 * cj);
+                    const double r10 = std::fma(t10, cj, -(t11 * sj)), r11 = std::fma(t10, sj, t11 * cj);
                     A[(size_t)pi * n + pj] = r00; A[(size_t)pj * n + pi] = r00;
                     A[(size_t)pi * n + qj] = r01; A[(size_t)qj * n + pi] = r01;
                     A[(size_t)qi * n + pj] = r10; A[(size_t)pj * n + qi] = r10;
@@ -95,8 +103,8 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
             for (int i = 0; i < m; ++i) {  // diagonal blocks
                 const int p = pp[i], q = qq[i];
                 const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q], apq = A[(size_t)q * n + p];
-                A[(size_t)p * n + p] = app - tn[i] * apq;
-                A[(size_t)q * n + q] = aqq + tn[i] * apq;
+                A[(size_t)p * n + p] = std::fma(-tn[i], apq, app);
+                A[(size_t)q * n + q] = std::fma(tn[i], apq, aqq);
                 if (apq != 0.0) { A[(size_t)q * n + p] = 0.0; A[(size_t)p * n + q] = 0.0; }   // rotated away, or tiny (zr[i])
             }
             for (int i = 0; i < m; ++i) {  // V <- V J
@@ -104,8 +112,8 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
                 const double c = cs[i], s = sn[i];
                 for (int k = 0; k < n; ++k) {
                     const double vp = V[(size_t)k * n + p], vq = V[(size_t)k * n + q];
-                    V[(size_t)k * n + p] = c * vp - s * vq;
-                    V[(size_t)k * n + q] = s * vp + c * vq;
+                    V[(size_t)k * n + p] = std::fma(c, vp, -(s * vq));
+                    V[(size_t)k * n + q] = std::fma(s, vp, c * vq);
                 }
             }
         }
