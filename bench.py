@@ -92,6 +92,7 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
         f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
         f.run_sim(cmds[1:1 + PRE + W])
         sync_all()
+        f.k_histogram(reset=True); f.sweep_stats(reset=True)   # workload counters of the timed window only
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
@@ -104,17 +105,21 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     M = f.landmark_counts(); n = 4 + 2 * int(round(M.mean()))
-    flops = ukf_flops_per_step(n, 4, 1.24 if L <= 20 else 1.7) * B   # 4 rotating sweeps with the warm start (oracle: 5 incl. the zero-only one)
+    kh = f.k_histogram().astype(np.float64); sw = f.sweep_stats().astype(np.float64)
+    k_mean = float((kh * np.arange(8)).sum() / max(kh.sum(), 1.0))       # detections per instance-step, counted by the step kernel
+    sweeps_mean = float(sw[0] / max(sw[1], 1.0))                          # rotating Jacobi sweeps per decomposition, counted by the sqrt kernel
+    flops = ukf_flops_per_step(n, sweeps_mean, k_mean) * B
     step_ms = ev0.elapsed_time(ev1) / K
     line = {"metric": "UKF predict-update steps/sec (secondary; BASELINE configs[2] shape)", "value": round(B * world * K / wall, 1),
             "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"UKF-SLAM fused sim+update step, L={L} (n={n}, {2 * n + 1} sigma points), batch={B}, steady state",
+                       "mean_detections_per_step": round(k_mean, 3), "mean_jacobi_sweeps": round(sweeps_mean, 3),
                        "instances_flagged": int((f.status() != 0).sum()), "avg_position_error_m": round(float(f.error_stats().mean()), 5),
-                       "parity": "bit-exact vs CPU oracle (tests/test_parity_ukf_gpu.py)"},
+                       "parity": "bit-exact vs the CPU oracle (tests/test_parity_ukf_gpu.py); the oracle's eigen-decomposition is pinned to LAPACK at 1e-12 and to a numpy transliteration of ukf.cpp, not to the reference binary (Eigen/ROS absent)"},
             "roofline": {"bound": "fp64-valu", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
                          "frac": round(flops / (step_ms * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
-                         "note": "algorithmic FLOPs (warm-started Jacobi: transform + 4 rotating sweeps) / step time of both kernels; sqrt kernel VALU-issue bound (69 % VALU utilisation, mostly index arithmetic), step kernel barrier/latency bound (profiles/r01n_ukf/pmc_summary.txt)"}}
+                         "note": "algorithmic FLOPs (warm-start transform + the counted Jacobi sweeps + sqtP + weighted covariance on v_mfma_f64_16x16x4_f64 + the counted updates) / step time of both kernels; sqrt kernel VALU-issue bound (69 % VALU utilisation, profiles/r01n_ukf/pmc_summary.txt)"}}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         Tc = min(T, 131)

@@ -177,10 +177,14 @@ int slam_state_dim_max(const slam_handle* h);
  * (SURVEY.md §8d).  Computed on the device from the per-instance M; synchronises. */
 int slam_algorithmic_bytes(slam_handle* h, double* bytes);
 /* Workload statistics: instance-steps by the number of detections in their message (out[k] for k = 0..6, out[7] for
- * k >= 7), accumulated by the EKF step kernel since slam_create or the last reset (ekf.cpp:65 `num_landmarks`).  The cost
+ * k >= 7), accumulated by the EKF / UKF step kernels since slam_create or the last reset (ekf.cpp:65 `num_landmarks`).  The cost
  * of EKF::update grows with k (one rank-2 downdate of P per detection, ekf.cpp:140), so a throughput figure is only
  * meaningful together with this histogram.  Synchronises. */
 int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset);
+/* UKF handles: out[0] = Jacobi sweeps that rotated at least one pair, out[1] = eigen-decompositions (instance-steps), summed
+ * by the square-root kernel since slam_create or the last reset: out[0] / out[1] is the mean number of sweeps the
+ * `nearestSPD` + `.sqrt()` of ukf.cpp:106-123,208 took, which sets the arithmetic of a UKF step.  Synchronises. */
+int slam_ukf_sweep_stats(slam_handle* h, uint64_t out[2], int reset);
 /* Diagnostics: flag 32 = every workgroup of the EKF multi-step kernel stamps the wall clock and its detection count per
  * timestep (read back by the profiling tools / bench.py's per-k table), flag 4 = per-phase cycle counters; 0 = off (default;
  * the environment variable SLAM_DEBUG_FLAGS sets the initial value). */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "slam_set_debug_flags": (C.c_int, [_H, C.c_int]),
     "slam_variant_available": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "slam_k_histogram": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
+    "slam_ukf_sweep_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
     "slam_math_probe": (C.c_int, [_dp, _dp, _dp, C.c_int, C.c_int]),
     # include/slam_pgs.h
     "pgs_create": (C.c_int, [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),

@@ -169,6 +169,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.b_off = 0; p.b_cnt = h->B;
     p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
     p.rot_tab = h->drot;
+    p.khist = h->dkhist;
     p.prof = (h->dbg & 4) ? h->dprof : nullptr;
 }
 
@@ -368,7 +369,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMalloc(&h->derr, sizeof(double) * B),
         hipMalloc(&h->dscalar, sizeof(double) * 4),
         (h->dbg & (4 | 32)) ? hipMalloc(&h->dprof, sizeof(unsigned long long) * slam::kEkfProfSlots * B) : hipSuccess,
-        hipMalloc(&h->dkhist, sizeof(unsigned long long) * 8),
+        hipMalloc(&h->dkhist, sizeof(unsigned long long) * 16),
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dsq, sizeof(double) * B * h->pstride) : hipSuccess,
         h->esz == 4 ? hipMalloc(&h->dscratch, sizeof(double) * B * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
@@ -393,7 +394,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMemsetAsync(h->dts, 0, sizeof(int32_t) * B, h->stream),
         hipMemsetAsync(h->dtruth, 0, sizeof(double) * B * 3, h->stream),
         hipMemsetAsync(h->derr, 0, sizeof(double) * B, h->stream),
-        hipMemsetAsync(h->dkhist, 0, sizeof(unsigned long long) * 8, h->stream),
+        hipMemsetAsync(h->dkhist, 0, sizeof(unsigned long long) * 16, h->stream),
         h->dnsq ? hipMemsetAsync(h->dnsq, 0, sizeof(int32_t) * B, h->stream) : hipSuccess,
         h->dprof ? hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * slam::kEkfProfSlots * B, h->stream) : hipSuccess,
         h->drot ? slam::launch_ukf_rot_table(h->drot, h->stream) : hipSuccess,
@@ -944,10 +945,21 @@ int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset) {
     if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
     FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->kind == SLAM_EKF_SLAM ? hipStreamSynchronize(h->stream) : hipDeviceSynchronize());
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram element size");
     HIP_TRY(hipMemcpy(out, h->dkhist, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(h->dkhist, 0, sizeof(uint64_t) * 8));
+    return SLAM_OK;
+}
+
+int slam_ukf_sweep_stats(slam_handle* h, uint64_t out[2], int reset) {
+    if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    if (h->kind == SLAM_EKF_SLAM) return fail(SLAM_ERR_STATE, "UKF handles only");
+    FLUSH(h);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());   // the UKF splits large batches over two streams
+    HIP_TRY(hipMemcpy(out, h->dkhist + 8, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->dkhist + 8, 0, sizeof(uint64_t) * 2));
     return SLAM_OK;
 }
 

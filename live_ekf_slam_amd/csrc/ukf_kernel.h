@@ -51,6 +51,9 @@ struct UkfStepParams {
     // offsets of every operand a thread touches in round t at state size n (built once by launch_ukf_rot_table); NULL = the
     // kernel derives them from the round-robin schedule itself, as the other variants do
     const uint4* rot_tab;
+    // workload statistics (optional): [0..7] instance-steps by detections in the message (7 = seven or more), [8] Jacobi sweeps
+    // that rotated something, [9] eigen-decompositions (slam_k_histogram / slam_ukf_sweep_stats)
+    unsigned long long* khist;
 };
 
 // Schedule table for ukf_sqrt_kernel<44, 256>: kUkfRotTabEntries uint4 entries (4 MB); see UkfStepParams::rot_tab.

@@ -298,7 +298,11 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
             }
         const int any_live = __syncthreads_or(live);
         SQ_STAMP(1);   // convergence check
-        if (!any_live) { converged = true; break; }
+        if (!any_live) {
+            converged = true;
+            if (tid == 0 && p.khist) { atomicAdd(&p.khist[8], (unsigned long long)sweep); atomicAdd(&p.khist[9], 1ull); }
+            break;
+        }
 #pragma unroll 1
         for (int t = 0; t < n - 1; ++t) {
             // the table entry of this round was requested a round ago (the parameter lanes need it at once: waiting for it
@@ -331,7 +335,11 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const double h = sqrt(fma(d, d, b2 * b2));
                     if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
                         const double w = fabs(d) + h;
-                        tt = b2 / (d >= 0.0 ? w : -w);
+                        // sign of t = sign of tau = d / (2 a_pq), +1 at d = 0 exactly (equal diagonal entries are common: every
+                        // landmark enters P with the same W block; letting the sign follow a_pq there made clusters of equal
+                        // eigenvalues cycle at the rounding level instead of settling)
+                        const bool pos = (d == 0.0) || ((d > 0.0) == (b2 > 0.0));
+                        tt = (pos ? fabs(b2) : -fabs(b2)) / w;
                         c = sqrt(w / (2.0 * h));
                         s = tt * c;
                     }
@@ -590,6 +598,7 @@ __global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
     UKF_STAMP(1);
     if (s_misc[0] > KCAP) flags |= SLAM_INST_CAPACITY;
     const int k = s_misc[0] < KCAP ? s_misc[0] : KCAP;
+    if (tid == 0 && p.khist) atomicAdd(&p.khist[k < 7 ? k : 7], 1ull);
     if (p.sim && p.meas_out != nullptr) {
         for (int i = tid; i < 3 * k && i < 3 * p.k_stride_out; i += TPB) p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = s_meas[i];
         if (tid == 0) p.meas_count_out[b] = k;

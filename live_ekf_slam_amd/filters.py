@@ -215,9 +215,15 @@ class BatchedFilter:
         return (buf[:, :steps] >> np.uint64(4)).astype(np.int64), (buf[:, :steps] & np.uint64(15)).astype(np.int64)
 
     def k_histogram(self, reset=False):
-        """Instance-steps by detections per message (k = 0..6, >= 7) since creation / the last reset (EKF kernel)."""
+        """Instance-steps by detections per message (k = 0..6, >= 7) since creation / the last reset (EKF and UKF step kernels)."""
         self._need(); out = np.zeros(8, dtype=np.uint64)
         _lib.check(_lib.lib().slam_k_histogram(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(bool(reset))))
+        return out
+
+    def sweep_stats(self, reset=False):
+        """UKF: (Jacobi sweeps that rotated something, eigen-decompositions) since creation / the last reset."""
+        self._need(); out = np.zeros(2, dtype=np.uint64)
+        _lib.check(_lib.lib().slam_ukf_sweep_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(bool(reset))))
         return out
 
     def sync(self):

@@ -74,7 +74,11 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
                     const double h = sqrt(std::fma(d, d, b2 * b2));
                     if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
                         const double w = fabs(d) + h;
-                        tt = b2 / (d >= 0.0 ? w : -w);
+                        // sign of t = sign of tau = d / (2 a_pq), +1 at d = 0 exactly (equal diagonal entries are common: every
+                        // landmark enters P with the same W block; letting the sign follow a_pq there made clusters of equal
+                        // eigenvalues cycle at the rounding level instead of settling)
+                        const bool pos = (d == 0.0) || ((d > 0.0) == (b2 > 0.0));
+                        tt = (pos ? fabs(b2) : -fabs(b2)) / w;
                         c = sqrt(w / (2.0 * h));
                         s = tt * c;
                     }

@@ -187,3 +187,17 @@ def test_ukf_double_trig_switch_is_close(oracle):
             u.update(fwd, ang, meas)
     d = np.abs(a.state()["x"] - b.state()["x"]).max()
     assert 0 < d < 1e-6
+
+
+def test_jacobi_settles_on_clusters_of_equal_eigenvalues(oracle):
+    """L=50 with every landmark mapped at step 0: P holds dozens of identical W blocks, so the scaled matrix has clusters of
+    EQUAL diagonal entries with off-diagonals at the rounding level between them.  A rotation-sign convention that follows
+    a_pq at a_pp == a_qq cycles there (30 % of the instances ran out of sweeps within 131 steps: SLAM_INST_SQRT_FAILED, a stale
+    sqtP); the reference's `tau >= 0 -> +1` does not.  Guards the convention: no instance may flag."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 50, 131, 8
+    lm, cmds = make_scenario(1234, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]
+    r = oracle.run_ukf_batch(lm, cmds[:T], B, L, nthreads=8, want_P=False, vision=vis)
+    assert not r["flags"].any(), r["flags"]
+    assert (r["M"] == L).all()

@@ -38,6 +38,13 @@ def test_ukf_update_on_reference_measurement_stream(S, oracle, fixture, L_max, T
             so = u.state()
             for b in (0, B - 1):
                 _eq(f.get_state(b), so)
+    # workload counters of the two kernels (what bench.py prices the UKF step with): one histogram entry and one
+    # eigen-decomposition per instance-step, the detection counts of the stream, the oracle's sweep counts (it also counts the
+    # final sweep that only writes zeros, which the kernel skips: DESIGN.md 4.2)
+    kh, sw = f.k_histogram(), f.sweep_stats()
+    assert int(kh.sum()) == B * T and int(sw[1]) == B * T
+    assert int((kh * np.arange(8)).sum()) == B * int(np.minimum(g["meas_count"][:T], 7).sum())
+    assert 1.0 <= sw[0] / sw[1] <= 12.0
     assert np.all(f.status() == 0) and u.state()["M"] >= 2
     pub = f.publishState(1)
     assert pub["M"] == u.state()["M"] and pub["P"].dtype == np.float32
