@@ -226,3 +226,20 @@ def test_run_sim_two_stream_split_is_bit_identical(S, oracle, monkeypatch):
         r = oracle.run_ukf_batch(lm, cmds, 1, L, seed=5, inst0=40 + inst, nthreads=1)
         n = 4 + 2 * r["M"][0]
         _eq(b[4][k], dict(M=r["M"][0], ids=r["ids"][0, :r["M"][0]], x=r["x"][0, :n], P=r["P"][0, :n * n].reshape(n, n)))
+
+
+@pytest.mark.parametrize("L", [20, 50])
+def test_bench_scenario_raises_no_flags(S, L):
+    """The secondary bench lines (bench.py --filter ukf, L=20 and L=50) on a small batch: no instance may flag (a Jacobi sign
+    convention that cycled on equal eigenvalues went unnoticed by the parity tests, because the oracle cycled with it)."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    T, B = 131, 64
+    lm, cmds = make_scenario(1234, L, T)
+    f = S.BatchedUKF(B, L).readParams(); f.set_map(lm); f.set_seed(2025); f.init(0.0, 0.0, 0.0)
+    f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
+    f.run_sim(cmds[1:T])
+    assert not f.status().any(), f.status()
+    assert (f.landmark_counts() == L).all()
+    sw = f.sweep_stats()
+    assert int(sw[1]) == B * T and 2.0 <= sw[0] / sw[1] <= 8.0
+    f.close()
