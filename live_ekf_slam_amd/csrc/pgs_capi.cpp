@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <thread>
 #include <vector>
@@ -36,6 +37,11 @@ struct pgs_handle {
     float* dmeas = nullptr; int32_t* dcount = nullptr; double* dsec = nullptr; int k_stride = 0;
     double* dout = nullptr;
     int max_trials = 400;
+    int lanes = 4;                             // slots per instance for speculative lambda lanes (SLAM_PGS_LANES, 1 = off)
+    int lanes_switch_all = 16;                 // ... from which down ALL lanes are used (SLAM_PGS_LANES_SWITCH_ALL)
+    int lanes_switch = 64;                     // active instances (of the whole batch) from which down the lanes are used (SLAM_PGS_LANES_SWITCH)
+    struct Slab { void* ptr; size_t bytes; };  // per-slot arrays the clones need a copy of when a solve begins (bytes per slot)
+    std::vector<Slab> clone_slabs;
     // solve groups: the batch is split into `groups` contiguous ranges whose LM loops run on their own streams, so
     // the latency-bound phases of one group overlap the bandwidth-bound phases of another (0 = choose from the batch)
     int groups = 0;
@@ -104,6 +110,9 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     h->cfg = *cfg; h->B = batch; h->N_max = N_max; h->L_max = L_max; h->KP = k_per_pose; h->device = device;
     h->LD = round_up(2 * L_max + 1, 64);
     if (const char* e = getenv("SLAM_PGS_MAX_TRIALS")) h->max_trials = atoi(e) > 0 ? atoi(e) : h->max_trials;
+    if (const char* e = getenv("SLAM_PGS_LANES")) h->lanes = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : h->lanes;
+    if (const char* e = getenv("SLAM_PGS_LANES_SWITCH")) h->lanes_switch = atoi(e);
+    if (const char* e = getenv("SLAM_PGS_LANES_SWITCH_ALL")) h->lanes_switch_all = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SYRK_TILE")) h->syrk_tile = atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : (atoi(e) == 1 ? 1 : 0));
     if (const char* e = getenv("SLAM_PGS_SYRK_INST_SWITCH")) h->syrk_inst_switch = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
@@ -120,25 +129,35 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     p.b_off = 0; p.b_cnt = batch;
     p.B = batch; p.N_max = N_max; p.L_max = L_max; p.KP = k_per_pose; p.LD = h->LD; p.N = 1;
     const size_t B = batch, N = N_max, L = L_max, K = (size_t)N_max * k_per_pose;
+    // Every per-instance array has `lanes` slots per instance: slot b is instance b, slot j * B + b its j-th lambda lane (a
+    // clone that pgs_solve fills from the instance; PgsParams::lanes_max).  Arrays only the instance itself uses keep B slots.
+    const size_t S = B * (size_t)h->lanes;
+    p.lanes_max = h->lanes; p.lanes = 1;
     int rc = SLAM_OK;
     auto A = [&](auto** ptr, size_t count) { if (rc == SLAM_OK) rc = dalloc(h, ptr, count); };
+    // AC: S slots, and the clones get the instance's content when a solve begins (per-slot element count given)
+    auto AC = [&](auto** ptr, size_t per_slot) {
+        if (rc == SLAM_OK) rc = dalloc(h, ptr, S * per_slot);
+        if (rc == SLAM_OK) h->clone_slabs.push_back({(void*)*ptr, per_slot * sizeof(**ptr)});
+    };
     A(&p.pose0, B * N * 3); A(&p.lm0, B * L * 2); A(&p.pose1, B * N * 3); A(&p.lm1, B * L * 2);
-    A(&p.ids, B * L); A(&p.M, B); A(&p.flags, B);
-    A(&p.cnt, B * N); A(&p.mlm, B * K); A(&p.mnext, B * K); A(&p.lm_head, B * L); A(&p.lm_last, B * L); A(&p.lm_first, B * L);
-    A(&p.mb, B * K); A(&p.mr, B * K);
+    A(&p.ids, B * L); AC(&p.M, 1); A(&p.flags, S);
+    AC(&p.cnt, N); AC(&p.mlm, K); AC(&p.mnext, K); AC(&p.lm_head, L); AC(&p.lm_last, L); AC(&p.lm_first, L);
+    AC(&p.mb, K); AC(&p.mr, K);
     A(&h->dcmds, N * 2); p.cmds = h->dcmds;
     A(&p.cur, B * 3); A(&p.truth, B * 3); A(&p.truth_hist, B * N * 2);
-    A(&p.pw, B * N * 3); A(&p.lw, B * L * 2); A(&p.pn, B * N * 3); A(&p.ln, B * L * 2);
-    A(&p.A, B * N * 9); A(&p.C, B * N * 9); A(&p.gp, B * N * 3); A(&p.E, B * K * 6); A(&p.Wl, B * K * 5);
-    A(&p.evt_start, B * (L + 1)); A(&p.evt_pose, B * K); A(&p.slot_pos, B * K); A(&p.Elm, B * K * 6);
-    A(&p.D, B * L * 3); A(&p.gl, B * L * 2); A(&p.Linv, B * N * 6); A(&p.G, B * N * 9);
+    AC(&p.pw, N * 3); AC(&p.lw, L * 2); A(&p.pn, S * N * 3); A(&p.ln, S * L * 2);
+    A(&p.A, S * N * 9); A(&p.C, S * N * 9); A(&p.gp, S * N * 3); A(&p.E, S * K * 6); A(&p.Wl, S * K * 5);
+    AC(&p.evt_start, L + 1); AC(&p.evt_pose, K); AC(&p.slot_pos, K); A(&p.Elm, S * K * 6);
+    A(&p.D, S * L * 3); A(&p.gl, S * L * 2); A(&p.Linv, S * N * 6); A(&p.G, S * N * 9);
     p.y_stride = (int64_t)round_up(3 * N_max, 4) * h->LD;
-    A(&p.Y, B * (size_t)p.y_stride); A(&p.S, B * (size_t)h->LD * h->LD);
-    A(&p.dl, B * L * 2); A(&p.dp, B * N * 3);
-    A(&p.lambda, B); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
-    A(&p.iters, B); A(&p.trials, B); A(&p.state, B); A(&p.solve_ok, B); A(&p.n_active, 16);
+    A(&p.Y, S * (size_t)p.y_stride); A(&p.S, S * (size_t)h->LD * h->LD);
+    A(&p.dl, S * L * 2); A(&p.dp, S * N * 3);
+    A(&p.lambda, S); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
+    A(&p.iters, B); A(&p.trials, B); A(&p.state, S); AC(&p.solve_ok, 1); A(&p.n_active, 64);
+    A(&p.nl, B); A(&p.nlin, S); A(&p.nerr, S); A(&p.nok, S);
     A(&h->dcount, B); A(&h->dsec, B * 3); A(&h->dout, B);
-    if (getenv("SLAM_PGS_PROF")) { A(&p.prof, B * 8); }
+    if (getenv("SLAM_PGS_PROF")) { A(&p.prof, S * 8); }
     if (rc != SLAM_OK) { pgs_destroy(h); return rc; }
     hipMemsetAsync(p.truth_hist, 0, sizeof(double) * B * N * 2, h->stream);
     hipMemsetAsync(p.cnt, 0, sizeof(int32_t) * B * N, h->stream);
@@ -252,8 +271,27 @@ int pgs_run_sim(pgs_handle* h, const float* cmds, int T) {
 
 namespace {
 
-// one tryLambda of the instances [p.b_off, p.b_off + p.b_cnt) on `stream`
-int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, hipStream_t stream, int trial_index, bool profile) {
+// after pgs_launch_lm_begin on the same stream: the clones (lambda lanes) of the group's instances get the instance's graph,
+// event lists, values and scalars - one contiguous copy per array and lane - and start inactive
+int clone_instances(pgs_handle* h, const slam::PgsParams& p, hipStream_t stream) {
+    const size_t B = (size_t)h->B, off = (size_t)p.b_off, cnt = (size_t)p.b_cnt;
+    for (int j = 1; j < h->lanes; ++j) {
+        for (const pgs_handle::Slab& sl : h->clone_slabs)
+            HIP_TRY(hipMemcpyAsync((char*)sl.ptr + ((size_t)j * B + off) * sl.bytes, (const char*)sl.ptr + off * sl.bytes, cnt * sl.bytes,
+                                   hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(p.state + (size_t)j * B + off), 1, cnt, stream));
+    }
+    return SLAM_OK;
+}
+
+// one tryLambda of the instances [p.b_off, p.b_off + p.b_cnt) on `stream`; `lanes` = the most slots any of them runs in this
+// trial (what the previous trial's pgs_decide_kernel reported; 1 for the first)
+int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lanes, hipStream_t stream, int trial_index, bool profile) {
+    p.lanes = lanes < 1 ? 1 : (lanes > h->lanes ? h->lanes : lanes);
+    // Few instances left: the per-trial latency counts and spare slots cost little.  Two lanes from `lanes_switch` active
+    // instances down (the common streak is one failure, then a success at 10 lambda), all of them from `lanes_switch_all` down.
+    p.lanes_next = active_hint <= h->lanes_switch_all ? h->lanes : (active_hint <= h->lanes_switch ? (h->lanes < 2 ? h->lanes : 2) : 1);
+    active_hint *= p.lanes;   // the kernel variants below are chosen by the number of slots that run, not of instances
     p.syrk_notrim = h->p_notrim;
     p.chol_threads = h->chol_threads ? h->chol_threads : (active_hint > h->chol_switch ? 256 : 1024);
     // 32x32 wavefront tiles by default; the 64x64 variant (more operand reuse, 4x fewer wavefronts) is kept for tuning
@@ -261,7 +299,7 @@ int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, hipStre
     // instance-resident accumulators (tile code 1) from syrk_inst_switch active instances; its staging registers are sized for LD <= 448
     if ((h->syrk_tile == 1 || (!h->syrk_tile && active_hint >= h->syrk_inst_switch)) && p.LD <= 448) p.syrk_wave_tile = 1;
     else if (p.syrk_wave_tile == 1) p.syrk_wave_tile = 32;
-    HIP_TRY(hipMemsetAsync(p.n_active, 0, sizeof(int32_t), stream));
+    HIP_TRY(hipMemsetAsync(p.n_active, 0, 2 * sizeof(int32_t), stream));
     for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
         if (profile) {
             const size_t need = (size_t)(trial_index + 1) * (slam::kPgsTrialKernels + 1);
@@ -287,15 +325,22 @@ int pgs_solve(pgs_handle* h) {
     if (h->profiling) G = 1;   // per-kernel timing wants the kernels of one stream back to back
     if (G <= 1) {
         HIP_TRY(slam::pgs_launch_lm_begin(h->p, h->stream));
+        TRY(clone_instances(h, h->p, h->stream));
         int trials = 0;
-        int32_t active = h->B;
+        int32_t act[2] = {h->B, 1};   // active instances, lanes of the next trial
         for (; trials < h->max_trials; ++trials) {
-            TRY(launch_trial(h, h->p, active, h->stream, trials, h->profiling));
-            active = 0;
-            HIP_TRY(hipMemcpyAsync(&active, h->p.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            TRY(launch_trial(h, h->p, act[0], act[1], h->stream, trials, h->profiling));
+            act[0] = 0; act[1] = 1;
+            HIP_TRY(hipMemcpyAsync(act, h->p.n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            if (h->trace) fprintf(stderr, "pgs trial %d: active %d\n", trials, (int)active);
-            if (active == 0) { trials += 1; break; }
+            if (h->trace) {
+                static thread_local double t_prev = 0.0;
+                timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+                const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+                fprintf(stderr, "pgs trial %d: %.2f ms, lanes %d -> active %d, lanes next %d\n", trials, trials ? now - t_prev : 0.0, (int)h->p.lanes, (int)act[0], (int)act[1]);
+                t_prev = now;
+            }
+            if (act[0] == 0) { trials += 1; break; }
         }
         h->last_trials = trials;
         HIP_TRY(slam::pgs_launch_lm_end(h->p, h->stream));
@@ -315,7 +360,7 @@ int pgs_solve(pgs_handle* h) {
     // ---- G groups, each with its own stream and LM loop; the host serves them round-robin ----
     while ((int)h->gstreams.size() < G) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); h->gstreams.push_back(st); }
     while ((int)h->gevents.size() < G + 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->gevents.push_back(e); }
-    if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 16, hipHostMallocDefault));
+    if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 64, hipHostMallocDefault));
     HIP_TRY(hipEventRecord(h->gevents[G], h->stream));   // everything queued on the handle's stream so far comes first
     std::vector<slam::PgsParams> gp(G, h->p);
     std::vector<int> gtrials(G, 0);
@@ -324,12 +369,13 @@ int pgs_solve(pgs_handle* h) {
     for (int g = 0; g < G; ++g) {
         gp[g].b_off = g * per;
         gp[g].b_cnt = (h->B - g * per) < per ? (h->B - g * per) : per;
-        gp[g].n_active = h->p.n_active + g;
+        gp[g].n_active = h->p.n_active + 2 * g;
         if (gp[g].b_cnt <= 0) { gdone[g] = 1; continue; }
         HIP_TRY(hipStreamWaitEvent(h->gstreams[g], h->gevents[G], 0));
         HIP_TRY(slam::pgs_launch_lm_begin(gp[g], h->gstreams[g]));
-        TRY(launch_trial(h, gp[g], h->B, h->gstreams[g], 0, false));
-        HIP_TRY(hipMemcpyAsync(h->h_active + g, gp[g].n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
+        TRY(clone_instances(h, gp[g], h->gstreams[g]));
+        TRY(launch_trial(h, gp[g], h->B, 1, h->gstreams[g], 0, false));
+        HIP_TRY(hipMemcpyAsync(h->h_active + 2 * g, gp[g].n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
         HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
     }
     // one host thread per group drives its LM loop (launch a trial, wait for its active count, decide); the HIP runtime
@@ -339,7 +385,7 @@ int pgs_solve(pgs_handle* h) {
         HIP_TRY(hipSetDevice(h->device));
         for (;;) {
             HIP_TRY(hipEventSynchronize(h->gevents[g]));
-            const int32_t active = h->h_active[g];
+            const int32_t active = h->h_active[2 * g], lanes_next = h->h_active[2 * g + 1];
             gtrials[g] += 1;
             if (h->trace) fprintf(stderr, "pgs group %d trial %d: active %d\n", g, gtrials[g] - 1, (int)active);
             if (active == 0 || gtrials[g] >= h->max_trials) {
@@ -347,8 +393,8 @@ int pgs_solve(pgs_handle* h) {
                 HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
                 return SLAM_OK;
             }
-            TRY(launch_trial(h, gp[g], active * G, h->gstreams[g], gtrials[g], false));
-            HIP_TRY(hipMemcpyAsync(h->h_active + g, gp[g].n_active, sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
+            TRY(launch_trial(h, gp[g], active * G, lanes_next, h->gstreams[g], gtrials[g], false));
+            HIP_TRY(hipMemcpyAsync(h->h_active + 2 * g, gp[g].n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
             HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
         }
     };

@@ -56,7 +56,21 @@ struct PgsParams {
     double* dl; double* dp;            // [B][L_max*2], [B][N_max*3]
     double* lambda; double* error; double* cur_error; double* err_init;
     int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done
-    int32_t* n_active;                 // [1]
+    int32_t* n_active;                 // [2] per solve group: active instances after the trial, lanes the next trial needs
+    // ---- speculative lambda lanes ----
+    // Every instance b owns `lanes_max` slots of every per-instance array: slot b (the instance itself) and the clones
+    // j * B + b, j = 1 .. lanes_max - 1.  After a failed tryLambda GTSAM multiplies lambda by 10 and tries again on the same
+    // linearisation.  An instance runs the next `nl[b]` lambdas of that sequence at once, one per slot (the clones hold a copy
+    // of its graph and values and are ordinary instances to kernels 0..4) - speculatively: slot j only matters if slots 0..j-1
+    // fail - and pgs_decide_kernel replays GTSAM's sequential logic over the slots in lambda order: the outcome, the
+    // iteration and the trial counts are those of the sequential loop.
+    int32_t lanes_max;                 // slots per instance (1 = no speculation)
+    int32_t lanes;                     // lanes covered by this launch of a trial kernel (grid = b_cnt * lanes)
+    int32_t lanes_next;                // slots an instance may use in the NEXT trial (the host's choice: 1 while the GPU is busy with
+                                       // many instances, lanes_max once few are left and the per-trial latency is what counts)
+    int32_t* nl;                       // [B]   lanes instance b runs in the current trial
+    double* nlin; double* nerr;        // [slots] linearised / true cost of the slot's candidate (pgs_evaluate_kernel)
+    int32_t* nok;                      // [slots] the slot's linear solve succeeded
     unsigned long long* prof;          // optional [B][8] phase timers of the chol kernel (100 MHz wall clock), debug only
     // ---- factor constants ----
     double prior[3];

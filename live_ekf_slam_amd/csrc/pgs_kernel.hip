@@ -259,6 +259,12 @@ __global__ __launch_bounds__(64) void pgs_run_sim_kernel(const PgsParams p, int 
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TPB = 512;   // threads of the per-pose kernels (two poses per thread at 1000 poses)
 
+// logical block `bl` of a trial-kernel launch -> slot: lane = bl / b_cnt, instance = b_off + bl % b_cnt (PgsParams::lanes)
+__device__ __forceinline__ int pgs_slot(const PgsParams& p, int bl) {
+    const int lane = bl / p.b_cnt;
+    return lane * p.B + p.b_off + (bl - lane * p.b_cnt);
+}
+
 __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     if (tid == 0) {
         p.error[b] = err; p.err_init[b] = err; p.cur_error[b] = err;
         p.lambda[b] = 1e-5;                    // LevenbergMarquardtParams::lambdaInitial
-        p.iters[b] = 0; p.trials[b] = 0; p.state[b] = 0; p.solve_ok[b] = 1;
+        p.iters[b] = 0; p.trials[b] = 0; p.state[b] = 0; p.solve_ok[b] = 1; p.nl[b] = 1;
         p.flags[b] &= ~(PGS_FLAG_NOT_CONVERGED | PGS_FLAG_NONFINITE);
     }
 }
@@ -319,7 +325,7 @@ __device__ __forceinline__ void add_JtJ(double A[9], const double* J) {
 }
 
 __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
-    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, KP = p.KP, M = p.M[b];
     const Inst g = inst_view(p, b);
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
     __shared__ double s_in[CHAIN_CH][18];          // A (6 unique), C (9), gp (3)
     __shared__ double s_ring[2][CHAIN_CH][18];     // Linv (6), G (9), gp (3)
     __shared__ int s_fail;
-    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, LD = p.LD, m2 = 2 * p.M[b];
     const double lambda = p.lambda[b];
@@ -602,8 +608,8 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
     const int ntl = ntr * (ntr + 1) / 2;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int bl = (q / ntl) * 8 + xcd;     // instance within the launched group
-    if (bl >= p.b_cnt) return;
-    const int b = bl + p.b_off;
+    if (bl >= p.b_cnt * p.lanes) return;
+    const int b = pgs_slot(p, bl);
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
     // decode the lower-triangular tile index
@@ -704,8 +710,8 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
     extern __shared__ double s_y[];   // [2][SI_ROWS][ldl]
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int bl = (q / SI_NB) * 8 + xcd, hb = q % SI_NB;
-    if (bl >= p.b_cnt) return;
-    const int b = bl + p.b_off;
+    if (bl >= p.b_cnt * p.lanes) return;
+    const int b = pgs_slot(p, bl);
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
     int ncol = (m2 + 1 + 31) & ~31;               // columns that hold data (incl. the z column), in 32-wide tiles
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(CTPB) void pgs_chol_kernel(const PgsParams p) {
     __shared__ double s_d[NB][NB + 1];
     __shared__ double s_diag[NB], s_rdiag[NB];
     __shared__ int s_fail;
-    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
     if (m2 == 0) return;
@@ -1060,7 +1066,7 @@ __device__ __forceinline__ void affine_scan_wave(const double* W, double* out, i
 
 constexpr int BTPB = 256;
 __global__ __launch_bounds__(BTPB) void pgs_backsolve_kernel(const PgsParams p) {
-    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
     const int N = p.N, KP = p.KP;
     const Inst g = inst_view(p, b);
@@ -1125,8 +1131,7 @@ __global__ __launch_bounds__(BTPB) void pgs_backsolve_kernel(const PgsParams p) 
 // defaultOptimize decisions for this instance (LevenbergMarquardtOptimizer.cpp, NonlinearOptimizer.cpp).
 __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
-    __shared__ int s_accept;
-    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, KP = p.KP, M = p.M[b];
     const Inst g = inst_view(p, b);
@@ -1179,30 +1184,54 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
         __syncthreads();   // candidate values are visible to the block
         newError = block_cost<TPB>(p, b, pose_n, lm_n, s_buf);
     }
+    if (tid == 0) {   // the decision is pgs_decide_kernel's: it needs the slots of an instance in lambda order
+        p.nok[b] = ok ? 1 : 0; p.nlin[b] = newLin; p.nerr[b] = newError;
+        p.solve_ok[b] = 1;
+    }
+}
+
+// GTSAM's tryLambda bookkeeping (LevenbergMarquardtOptimizer::tryLambda / iterate, default parameters) for one instance, replayed
+// over the `nl[b]` slots it ran in this trial in the order the sequential loop would have visited their lambdas: slot j holds the
+// trial at lambda * 10^j (repeated multiplication, as the loop computes it).  A success, a `stop`, or lambda reaching its upper
+// bound ends the inner loop and discards the later slots (they are trials the sequential loop never runs); if every slot failed
+// the streak goes on.  Iteration and trial counts are the sequential loop's.
+__global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
+    __shared__ int s_win, s_next;
+    const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
+    if (p.state[b]) return;
+    const int N = p.N, M = p.M[b], B = p.B;
     if (tid == 0) {
         const double lambdaFactor = 10.0, lambdaUpper = 1e5, minFidelity = 1e-3, relTol = 1e-5, absTol = 1e-5;
         const int maxIter = 100;
         double lambda = p.lambda[b], error = p.error[b];
-        int iters = p.iters[b];
-        bool success = false, stop = false, end_inner = false;
-        if (ok) {
-            const double oldLin = error;
-            const double linChange = oldLin - newLin;
-            if (linChange >= 0.0) {
-                const double costChange = error - newError;
-                if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > minFidelity;
-                if (fabs(costChange) < relTol * error) stop = true;
+        int iters = p.iters[b], trials = p.trials[b];
+        const int nl = p.nl[b] > 0 ? p.nl[b] : 1;
+        int win = -1, done = 0, fl = 0;
+        bool end_inner = false;
+        for (int j = 0; j < nl && !end_inner; ++j) {
+            const int sl = j * B + b;
+            const bool ok = p.nok[sl] != 0;
+            const double newLin = p.nlin[sl], newError = p.nerr[sl];
+            bool success = false, stop = false;
+            if (ok) {
+                const double oldLin = error;
+                const double linChange = oldLin - newLin;
+                if (linChange >= 0.0) {
+                    const double costChange = error - newError;
+                    if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > minFidelity;
+                    if (fabs(costChange) < relTol * error) stop = true;
+                }
+            }
+            trials += 1;
+            if (success) {
+                lambda = lambda / lambdaFactor; error = newError; iters += 1; end_inner = true; win = j;
+            } else if (!stop) {
+                lambda = lambda * lambdaFactor;
+                if (lambda >= lambdaUpper) end_inner = true;
+            } else {
+                end_inner = true;
             }
         }
-        if (success) {
-            lambda = lambda / lambdaFactor; error = newError; iters += 1; end_inner = true;
-        } else if (!stop) {
-            lambda = lambda * lambdaFactor;
-            if (lambda >= lambdaUpper) end_inner = true;
-        } else {
-            end_inner = true;
-        }
-        int done = 0, fl = 0;
         if (end_inner) {   // defaultOptimize's loop condition
             const double currentError = p.cur_error[b];
             const double absDec = currentError - error, relDec = absDec / currentError;
@@ -1211,16 +1240,43 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
             else if (error <= 0.0 || relDec <= relTol || absDec <= absTol) done = 1;
             else p.cur_error[b] = error;
         }
-        p.lambda[b] = lambda; p.error[b] = error; p.iters[b] = iters;
-        p.trials[b] += 1;
-        p.solve_ok[b] = 1;
-        if (done) { p.state[b] = 1; p.flags[b] |= fl; } else atomicAdd(p.n_active, 1);
-        s_accept = success ? 1 : 0;
+        p.lambda[b] = lambda; p.error[b] = error; p.iters[b] = iters; p.trials[b] = trials;
+        // the next trial runs the next `lanes_next` lambdas of the sequence GTSAM would walk if every one of them failed:
+        // lambda, 10 lambda, ... (lambda_j < lambdaUpper for j >= 1: reaching the bound ends the inner loop before that trial)
+        int nnext = 1;
+        if (!done) {
+            double lj = lambda;
+            const int want = p.lanes_next < p.lanes_max ? p.lanes_next : p.lanes_max;
+            while (nnext < want) {
+                lj = lj * lambdaFactor;
+                if (lj >= lambdaUpper) break;
+                p.lambda[nnext * B + b] = lj;
+                nnext += 1;
+            }
+        }
+        for (int j = 1; j < p.lanes_max; ++j) p.state[j * B + b] = (!done && j < nnext) ? 0 : 1;
+        p.nl[b] = nnext;
+        if (done) { p.state[b] = 1; p.flags[b] |= fl; }
+        else { atomicAdd(p.n_active, 1); atomicMax(p.n_active + 1, nnext); }
+        s_win = win; s_next = done ? 0 : nnext;
     }
     __syncthreads();
-    if (s_accept) {
+    double* pose = p.pw + (size_t)b * p.N_max * 3;
+    double* lm = p.lw + (size_t)b * p.L_max * 2;
+    if (s_win >= 0) {   // accept the winning slot's candidate
+        const int sl = s_win * B + b;
+        const double* pose_n = p.pn + (size_t)sl * p.N_max * 3;
+        const double* lm_n = p.ln + (size_t)sl * p.L_max * 2;
         for (int i = tid; i < 3 * N; i += TPB) pose[i] = pose_n[i];
         for (int a = tid; a < 2 * M; a += TPB) lm[a] = lm_n[a];
+    }
+    // clones that run in the next trial linearise at the instance's current values (after the accept above, if any: every
+    // thread re-reads the elements it wrote itself)
+    for (int j = 1; j < s_next; ++j) {
+        double* cp = p.pw + (size_t)(j * B + b) * p.N_max * 3;
+        double* cl = p.lw + (size_t)(j * B + b) * p.L_max * 2;
+        for (int i = tid; i < 3 * N; i += TPB) cp[i] = pose[i];
+        for (int a = tid; a < 2 * M; a += TPB) cl[a] = lm[a];
     }
 }
 
@@ -1288,9 +1344,10 @@ hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s) {
 }
 
 hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s) {
+    const int nslot = p.b_cnt * (p.lanes > 0 ? p.lanes : 1);   // slots covered: the instances of the group and their active lambda lanes
     switch (which) {
-    case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p); break;
-    case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(p.b_cnt), dim3(64 + p.LD), 0, s, p); break;
+    case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(nslot), dim3(TPB), 0, s, p); break;
+    case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(nslot), dim3(64 + p.LD), 0, s, p); break;
     case 2: {
         if (p.syrk_wave_tile == 1) {   // instance-resident accumulators
             static std::once_flag attr_once2;
@@ -1298,15 +1355,15 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
                 (void)hipFuncSetAttribute((const void*)pgs_syrk_inst_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             });
             const size_t lds = sizeof(double) * 2 * SI_ROWS * (size_t)(p.LD + 16);
-            hipLaunchKernelGGL(pgs_syrk_inst_kernel, dim3(8 * SI_NB * ((p.b_cnt + 7) / 8)), dim3(SI_TPB), lds, s, p);
+            hipLaunchKernelGGL(pgs_syrk_inst_kernel, dim3(8 * SI_NB * ((nslot + 7) / 8)), dim3(SI_TPB), lds, s, p);
             break;
         }
         if (p.syrk_wave_tile == 64) {
             const int nt = (p.LD + 127) / 128;
-            hipLaunchKernelGGL(pgs_syrk_kernel<64>, dim3(8 * (nt * (nt + 1) / 2) * ((p.b_cnt + 7) / 8)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(pgs_syrk_kernel<64>, dim3(8 * (nt * (nt + 1) / 2) * ((nslot + 7) / 8)), dim3(256), 0, s, p);
         } else {
             const int nt = (p.LD + 63) / 64;
-            hipLaunchKernelGGL(pgs_syrk_kernel<32>, dim3(8 * (nt * (nt + 1) / 2) * ((p.b_cnt + 7) / 8)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(pgs_syrk_kernel<32>, dim3(8 * (nt * (nt + 1) / 2) * ((nslot + 7) / 8)), dim3(256), 0, s, p);
         }
         break;
     }
@@ -1317,12 +1374,15 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
             (void)hipFuncSetAttribute((const void*)pgs_chol_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             (void)hipFuncSetAttribute((const void*)pgs_chol_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         });
-        if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(p.b_cnt), dim3(256), lds, s, p); break; }
-        hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(p.b_cnt), dim3(1024), lds, s, p);
+        if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(nslot), dim3(256), lds, s, p); break; }
+        hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(nslot), dim3(1024), lds, s, p);
         break;
     }
-    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(p.b_cnt), dim3(BTPB), 0, s, p); break;
-    default: hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(nslot), dim3(BTPB), 0, s, p); break;
+    default:   // the candidates of every slot, then GTSAM's accept / lambda / convergence logic per instance
+        hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(nslot), dim3(TPB), 0, s, p);
+        hipLaunchKernelGGL(pgs_decide_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
+        break;
     }
     return hipGetLastError();
 }
