@@ -64,7 +64,12 @@ int pgs_update_dev(pgs_handle* h, const float cmd[2], const float* d_meas, const
  * two calls above.  cmds [T][2] float32 host array. */
 int pgs_run_sim(pgs_handle* h, const float* cmds, int T);
 
-/* PoseGraph::solvePoseGraph (pose_graph.cpp:269-300) for every instance: LM from initial_estimate to `result`. */
+/* PoseGraph::solvePoseGraph (pose_graph.cpp:269-300) for every instance: LM from initial_estimate to `result`.
+ * The trials of a batch run in lockstep; once few instances are still active each runs the next lambdas of GTSAM's retry
+ * sequence (lambda, 10 lambda, ...) at once in spare slots and the sequential accept / lambda logic is replayed over them, so
+ * the result, pgs_get_stats' iteration and trial counts are those of the sequential loop.  The slots multiply the LM work
+ * space: SLAM_PGS_LANES slots per instance (default 4, 1 = off; reduced at pgs_create if they would take more than half of
+ * the free device memory). */
 int pgs_solve(pgs_handle* h);
 /* The solve splits the batch into `groups` contiguous ranges that run their LM loops on separate HIP streams (the
  * latency-bound phases of one group overlap the bandwidth-bound phases of another); results do not depend on it.

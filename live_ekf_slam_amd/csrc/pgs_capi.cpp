@@ -131,6 +131,13 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     const size_t B = batch, N = N_max, L = L_max, K = (size_t)N_max * k_per_pose;
     // Every per-instance array has `lanes` slots per instance: slot b is instance b, slot j * B + b its j-th lambda lane (a
     // clone that pgs_solve fills from the instance; PgsParams::lanes_max).  Arrays only the instance itself uses keep B slots.
+    {   // the lanes multiply the LM work space (Y alone is 3 N_max x LD doubles per slot): keep them within half of the free memory
+        const double per_slot = 8.0 * ((double)round_up(3 * N_max, 4) * h->LD + (double)h->LD * h->LD + (double)K * 17 + (double)N * 42 + (double)L * 12) +
+                                4.0 * ((double)K * 4 + (double)N + (double)L * 5);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (h->lanes > 1 && per_slot * (double)B * h->lanes > 0.5 * (double)free_b) h->lanes -= 1;
+    }
     const size_t S = B * (size_t)h->lanes;
     p.lanes_max = h->lanes; p.lanes = 1;
     int rc = SLAM_OK;
