@@ -17,6 +17,9 @@
 #ifndef SLAM_DEF_103
 #define SLAM_DEF_103 1444
 #endif
+#ifndef SLAM_DEF_103_F32
+#define SLAM_DEF_103_F32 1442   // fp32 storage: strips of two rows (0.88 vs 0.99 ms/step with four; fp64 prefers four: 0.92 vs 0.97)
+#endif
 
 namespace slam {
 
@@ -43,6 +46,7 @@ static int default_code(int nmax_class, int f32, int B) {
         if (!f32 && B >= 16384) return SLAM_DEF_43_LARGE;
         return SLAM_DEF_43;
     }
+    if (nmax_class == 103 && f32) return SLAM_DEF_103_F32;
     return SLAM_DEF_103;
 }
 
