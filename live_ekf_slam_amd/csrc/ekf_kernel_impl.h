@@ -1095,6 +1095,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 // ------------------------------------------------ STREAMERS ------------------------------------------------
                 __builtin_amdgcn_s_setprio(0);
                 const bool leader = (tid >> 6) == 1;
+                // never more than the ring holds: with KG < SLAM_PASS_MIN the control wavefront would wait for a slot and the
+                // leader for updates that cannot be published (a KG = 3 sweep variant hung the GPU that way)
+                constexpr int kPassMinCfg = kWide ? SLAM_PASS_MIN : SLAM_PASS_MIN_F32;
+                constexpr int kPassMin = kPassMinCfg < KG ? kPassMinCfg : KG;
                 int seen = 0;   // passes this wavefront has taken part in
 #pragma unroll 1
                 for (;;) {
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             app = ld_i(&s_ring[1]);
                             pend = ld_i(&s_ring[0]) - app;
                             const int ex = ld_i(&s_ring[3]);
-                            if (pend > 0 && (pend >= (kWide ? SLAM_PASS_MIN : SLAM_PASS_MIN_F32) || ex) && !ld_i(&s_ring[6])) break;
+                            if (pend > 0 && (pend >= kPassMin || ex) && !ld_i(&s_ring[6])) break;
                             if (ex && pend == 0) {   // re-read: an update published just before the exit flag
                                 if (ld_i(&s_ring[0]) - app == 0) { stop = true; break; }
                                 continue;
