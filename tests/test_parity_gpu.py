@@ -388,3 +388,30 @@ def test_large_state_100_landmarks(S, oracle):
         n = 3 + 2 * r["M"][b]
         _assert_state_equal(f.get_state(b), dict(M=r["M"][b], ids=r["ids"][b, :r["M"][b]], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
     f.close()
+
+
+@pytest.mark.parametrize("map_type,L,dtype,seed", [("grid", 50, "f64", 5), ("igvc1", 50, "f64", 6), ("demo", 20, "f32", 7), ("grid", 50, "f32", 8),
+                                                   ("random", 50, "f64", 9)])
+def test_long_runs_on_every_map_type(S, oracle, map_type, L, dtype, seed):
+    """600 timesteps in multi-step launches on the reference's other map generators (regular grids put many landmarks at equal
+    range: detection-heavy steps, landmarks entering and leaving the view all the time - the gather-without-drain, pre-flush and
+    overflow paths of the decoupled loop), whole batch against the oracle, bit for bit."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    T, B = 600, 192
+    lm, cmds = make_scenario(seed, L, T, map_type=map_type)
+    Lm = lm.shape[0]
+    f = S.BatchedEKF(B, Lm, dtype=S.F32 if dtype == "f32" else S.F64).readParams()
+    f.set_map(lm); f.set_seed(seed); f.set_instance_offset(1000 * seed); f.init(0, 0, 0)
+    f.run_sim(cmds[:37]); f.run_sim(cmds[37:400]); f.run_sim(cmds[400:])
+    mode = oracle.MODE_FAST | (oracle.STORAGE_F32 if dtype == "f32" else 0)
+    r = oracle.run_ekf_batch(lm, cmds, B, Lm, seed=seed, inst0=1000 * seed, nthreads=8, mode=mode)
+    assert np.array_equal(f.landmark_counts(), r["M"]) and np.array_equal(f.truth(), r["truth"])
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.status(), r["flags"])
+    for b in range(B):
+        n = 3 + 2 * r["M"][b]
+        _assert_state_equal(f.get_state(b), dict(M=r["M"][b], ids=r["ids"][b, :r["M"][b]], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    kh = f.k_histogram()
+    assert int(kh.sum()) == B * T
+    print(f"{map_type} L={Lm} {dtype}: mean M {r['M'].mean():.1f}, k histogram {kh.tolist()}, oracle {r['seconds']:.2f} s")
+    assert r["M"].mean() > 3 and kh[1:].sum() > B * T // 4
+    f.close()
