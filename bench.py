@@ -138,11 +138,11 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev):
 
 def pgs_traffic(B, L, N):
     """HBM-side bytes per solve of the two SYRK kernels (tile kernel + instance-resident kernel) from the committed PMC passes
-    (profiles/r01o_pgs/summary.json: FETCH_SIZE + WRITE_SIZE in KiB, raw: the guide's x2 applies to 16 B/lane streams and the
+    (profiles/r02d_pgs/summary.json: FETCH_SIZE + WRITE_SIZE in KiB, raw: the guide's x2 applies to 16 B/lane streams and the
     tile kernel loads 8 B/lane; the instance-resident kernel's 16-byte loads are NOT doubled here, so this is a lower bound
     for its 8.5 GB share), if the profiled workload is the one being run; else null."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01o_pgs", "summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02d_pgs", "summary.json")))
         c = d["bench_line"]["config"]
         if (c["batch_per_gpu"], c["landmarks"], c["poses"]) != (B, L, N):
             return None
