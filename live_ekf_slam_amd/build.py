@@ -23,7 +23,7 @@ EKF_DEFAULT_VARIANTS = [(43, 2, 4, 4, 0, 1), (43, 1, 2, 4, 0, 1), (103, 4, 4, 4,
 EKF_SWEEP_VARIANTS = [(103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
                       (103, 2, 4, 4, 0, 1), (103, 8, 4, 2, 0, 1), (103, 8, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1), (103, 4, 2, 4, 0, 1),
                       (103, 4, 4, 4, 1, 0), (103, 4, 4, 8, 1, 1), (103, 4, 4, 4, 1, 1), (103, 2, 4, 4, 1, 1), (103, 8, 4, 2, 1, 1),
-                      (103, 2, 4, 2, 1, 1), (103, 3, 4, 2, 1, 1), (103, 3, 4, 4, 0, 1), (103, 3, 4, 2, 0, 1),
+                      (103, 2, 4, 2, 1, 1), (103, 3, 4, 2, 1, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 6, 2, 1, 1), (103, 3, 4, 4, 0, 1), (103, 3, 4, 2, 0, 1),
                       (43, 2, 4, 4, 0, 0), (43, 1, 2, 4, 0, 0), (43, 4, 4, 4, 0, 1), (43, 1, 4, 8, 0, 1), (43, 2, 4, 8, 0, 1), (43, 2, 2, 4, 0, 1)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-function", "-x", "hip"]
