@@ -116,7 +116,10 @@ int slam_set_map(slam_handle* h, const double* map_xy, int L);
  * slam_step_sim, consecutive calls are queued (up to slam_set_lazy_steps timesteps, messages of at most 4 detections per
  * instance) and run as one multi-step launch; every other entry point runs what is queued first. */
 int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* meas_count, int k_stride);
-/* Same, with DEVICE pointers (no copy). */
+/* Same, with DEVICE pointers (no host copy).  The buffers are read in the order of the handle's stream: they may be
+ * overwritten by work enqueued on that stream after the call returns.  EKF handles queue the call like slam_step does (the
+ * message is copied device-to-device into a queue of slam_set_lazy_steps entries, which run as one multi-step launch; any other
+ * entry point runs the queue first). */
 int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_meas_count,
                   int k_stride);
 /* One timestep where the device-side generator (a port of get_cmd, sim_node.py:209-250) advances each

@@ -108,6 +108,14 @@ struct slam_handle {
         bool in_use = false;
     } extq[2];
     int extq_cur = 0;
+    // slam_step_dev (EKF, DEVICE measurements): the same queueing.  The message is copied device-to-device into the queue on
+    // the compute stream at the call (so the caller may overwrite its buffers in stream order, as with an immediate launch)
+    // and up to lazy_max of them run as one multi-step launch.  One buffer suffices: copies and launches share the stream.
+    struct DevQueue {
+        float* dmeas = nullptr; int32_t* dcount = nullptr;   // [cap][B][ks][3], [cap][B]
+        std::vector<float> cmds;
+        int cap = 0, ks = 0, n = 0;
+    } devq;
     double* dscalar = nullptr;
     unsigned long long* dprof = nullptr;
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
@@ -229,6 +237,7 @@ bool parse_scalar(const char* line, const char* key, double* out) {
 static int run_sim_now(slam_handle* h, const float* cmds, int T);
 static int flush_lazy(slam_handle* h);
 static int flush_ext(slam_handle* h);
+static int flush_dev(slam_handle* h);
 // The queues exist to give the GPU long multi-step launches while the caller keeps calling once per tick; when the GPU has
 // nothing to do, waiting for the queue to fill only delays the work (a run of K calls paid one whole queue of packing with
 // the GPU idle before the first launch).  So a queued step is launched at once if the compute stream is idle.
@@ -415,6 +424,7 @@ int slam_destroy(slam_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); hipEventDestroy(h->aux_ev[0]); hipEventDestroy(h->aux_ev[1]); }
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    if (h->devq.dmeas) { hipFree(h->devq.dmeas); hipFree(h->devq.dcount); }
     for (auto& q : h->extq) {
         if (q.hmeas) { hipHostFree(q.hmeas); hipHostFree(q.hcount); hipHostFree(q.hcmds); hipFree(q.dmeas); hipFree(q.dcount); }
         if (q.copied) { hipEventDestroy(q.copied); hipEventDestroy(q.used); }
@@ -503,10 +513,26 @@ int slam_set_map(slam_handle* h, const double* map_xy, int L) {
 
 int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_count, int k_stride) {
     if (!h || !cmd || !d_meas || !d_count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
-    FLUSH(h);
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
-    if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->kind == SLAM_EKF_SLAM && h->lazy_max > 1 && h->run_chunk != 1 && !h->dump_meas) {
+        slam_handle::DevQueue& q = h->devq;
+        if (!h->lazy_cmds.empty() || h->extq[h->extq_cur].n > 0 || (q.n > 0 && q.ks != k_stride)) FLUSH(h);   // earlier steps first
+        const size_t B = (size_t)h->B;
+        if (q.cap < h->lazy_max || q.ks != k_stride) {
+            if (q.dmeas) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(q.dmeas); hipFree(q.dcount); q.dmeas = nullptr; q.dcount = nullptr; }
+            q.cap = h->lazy_max; q.ks = k_stride;
+            HIP_TRY(hipMalloc(&q.dmeas, sizeof(float) * 3 * (size_t)k_stride * B * q.cap));
+            HIP_TRY(hipMalloc(&q.dcount, sizeof(int32_t) * B * q.cap));
+        }
+        HIP_TRY(hipMemcpyAsync(q.dmeas + (size_t)q.n * B * k_stride * 3, d_meas, sizeof(float) * 3 * (size_t)k_stride * B, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(q.dcount + (size_t)q.n * B, d_count, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, h->stream));
+        q.cmds.push_back(cmd[0]); q.cmds.push_back(cmd[1]);
+        q.n += 1;
+        return q.n >= h->lazy_max ? flush_dev(h) : SLAM_OK;
+    }
+    FLUSH(h);
+    if (h->kind == SLAM_UKF_LOC && !h->dmapf) return fail(SLAM_ERR_STATE, "UKF_LOC needs the known map: call slam_set_map first (localization_node.cpp:113-116)");
     return launch_step(h, cmd, 0, d_meas, d_count, k_stride);
 }
 
@@ -725,7 +751,36 @@ static int flush_ext(slam_handle* h) {
     return SLAM_OK;
 }
 
+static int flush_dev(slam_handle* h) {
+    slam_handle::DevQueue& q = h->devq;
+    if (q.n == 0) return SLAM_OK;
+    const int T = q.n;
+    q.n = 0;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->cmds_cap < T) {
+        if (h->dcmds) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(h->dcmds); h->dcmds = nullptr; }
+        HIP_TRY(hipMalloc(&h->dcmds, sizeof(float) * 2 * (size_t)T));
+        h->cmds_cap = T;
+    }
+    // pageable source: the copy is staged by the runtime before the call returns, so q.cmds may be reused at once
+    HIP_TRY(hipMemcpyAsync(h->dcmds, q.cmds.data(), sizeof(float) * 2 * (size_t)T, hipMemcpyHostToDevice, h->stream));
+    slam::EkfStepParams p;
+    fill_params(h, p, q.cmds.data());
+    p.sim = 0;
+    p.meas_in = q.dmeas; p.meas_count_in = q.dcount; p.k_stride_in = q.ks;
+    p.cmds = h->dcmds;
+    p.T = T;
+    q.cmds.clear();
+    HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
+    h->step += (uint32_t)T;
+    return SLAM_OK;
+}
+
 static int flush_lazy(slam_handle* h) {
+    {
+        const int rc = flush_dev(h);
+        if (rc) return rc;
+    }
     if (!h->lazy_cmds.empty()) {
         std::vector<float> c;
         c.swap(h->lazy_cmds);

@@ -415,3 +415,55 @@ def test_long_runs_on_every_map_type(S, oracle, map_type, L, dtype, seed):
     print(f"{map_type} L={Lm} {dtype}: mean M {r['M'].mean():.1f}, k histogram {kh.tolist()}, oracle {r['seconds']:.2f} s")
     assert r["M"].mean() > 3 and kh[1:].sum() > B * T // 4
     f.close()
+
+
+def test_step_dev_queued_equals_immediate(S):
+    """slam_step_dev (device-resident messages) queues its calls like slam_step / slam_step_sim: each message is copied into a
+    device-side queue at the call and 16 of them run as one multi-step launch.  Same bits as one launch per call,
+    from Filter::init through insertions and messages with eight detections (several update groups inside a multi-step launch)."""
+    import ctypes as C
+    from live_ekf_slam_amd import _lib
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, T, KS = 20, 64, 75, 8
+    lm, cmds = make_scenario(11, L, T)
+    def make():
+        f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(5); f.set_instance_offset(900); f.init(0, 0, 0)
+        return f
+    hip = C.CDLL("libamdhip64.so")
+    def to_device(a):
+        a = np.ascontiguousarray(a); d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), a.nbytes) == 0 and hip.hipMemcpy(d, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+        return d
+    rec = make()
+    rec.last_meas(KS)   # measurement dump on
+    msgs, kmax = [], 0
+    for t in range(T):
+        if t in (2, 30): rec.set_vision(1e9, -4.0, 4.0)      # two messages with every landmark in view (clipped to KS detections)
+        if t in (3, 31): rec.set_vision(3.0, -1.57, 1.57)
+        rec.update_sim(cmds[t])
+        m, c = rec.last_meas(KS)
+        kmax = max(kmax, int(c.max()))
+        msgs.append((to_device(m), to_device(c)))
+    assert kmax > 4
+    Lc = _lib.lib()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    outs = []
+    for lazy in (16, 0, 5):
+        f = make()
+        _lib.check(Lc.slam_set_lazy_steps(f.h, lazy))
+        for t in range(T):
+            cm = np.ascontiguousarray(cmds[t], dtype=np.float32)
+            _lib.check(Lc.slam_step_dev(f.h, fp(cm), msgs[t][0], msgs[t][1], KS))
+            if t == 40:
+                f.get_state(3)   # a getter in the middle of a queue flushes it
+        outs.append(f)
+    ref = outs[1]   # one launch per call (the wide messages were clipped to KS detections, so the generator's own filter saw more)
+    assert ref.landmark_counts().min() >= 8 and not ref.status().any()
+    for f in (outs[0], outs[2]):
+        assert np.array_equal(f.landmark_counts(), ref.landmark_counts()) and np.array_equal(f.status(), ref.status())
+        for b in range(B):
+            _assert_state_equal(f.get_state(b), ref.get_state(b))
+    for f in outs + [rec]:
+        f.close()
+    for m, c in msgs:
+        hip.hipFree(m); hip.hipFree(c)
