@@ -90,6 +90,15 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
 #define SLAM_DBG(x) 0
 #endif
 
+#ifndef SLAM_SLEEP_RING
+#define SLAM_SLEEP_RING 1     // polling intervals of the decoupled loop (units of 64 cycles): control wavefront waiting for a ring slot,
+#endif
+#ifndef SLAM_SLEEP_LEADER
+#define SLAM_SLEEP_LEADER 2   // pass leader waiting for pending updates,
+#endif
+#ifndef SLAM_SLEEP_PASS
+#define SLAM_SLEEP_PASS 1     // streamers waiting for the next pass
+#endif
 #ifndef SLAM_PASS_MIN_F32
 #define SLAM_PASS_MIN_F32 3   // fp32 storage: a pass moves half the bytes, so starting one slot earlier (the control wavefront keeps a free slot) wins: 1.07 -> 0.99 ms/step
 #endif
@@ -998,7 +1007,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         double H[8], Si[4], nu0, nu1;
                         if (!leader_chain(ii, si, r_m, b_m, H, nu0, nu1, Si)) fl_or |= SLAM_INST_S_SINGULAR;
                         SLAM_STAMP(20);  // scalar chain of the update
-                        while (pub - ld_i(&s_ring[1]) >= KG) __builtin_amdgcn_s_sleep(1);   // a free slot in the ring
+                        while (pub - ld_i(&s_ring[1]) >= KG) __builtin_amdgcn_s_sleep(SLAM_SLEEP_RING);   // a free slot in the ring
                         SLAM_STAMP(21);  // waiting for a ring slot
                         const int slot = pub % KG;
                         double2* __restrict__ HPu = s_HP + slot * HPW;
@@ -1115,7 +1124,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                 if (ld_i(&s_ring[0]) - app == 0) { stop = true; break; }
                                 continue;
                             }
-                            __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_s_sleep(SLAM_SLEEP_LEADER);
                         }
                         int cnt = pend < KG ? pend : KG;
                         if constexpr (!kWide) {
@@ -1157,7 +1166,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                 }
                             }
                         }
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(SLAM_SLEEP_PASS);
                     }
                     seen += 1;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
