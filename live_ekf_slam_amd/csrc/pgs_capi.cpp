@@ -293,7 +293,18 @@ int clone_instances(pgs_handle* h, const slam::PgsParams& p, hipStream_t stream)
 
 // one tryLambda of the instances [p.b_off, p.b_off + p.b_cnt) on `stream`; `lanes` = the most slots any of them runs in this
 // trial (what the previous trial's pgs_decide_kernel reported; 1 for the first)
-int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lanes, hipStream_t stream, int trial_index, bool profile) {
+// The first two operations of a trial - clearing its counters and the linearisation - depend on nothing the host decides
+// (kernel variants, lanes), so they are put on the stream BEFORE the host waits for the previous trial's active count: the
+// linearize kernel covers the round trip of that wait and of the next launches.  Every slot is covered (inactive ones return).
+int prelaunch_trial(pgs_handle* h, slam::PgsParams& p, hipStream_t stream) {
+    p.lanes = h->lanes;
+    HIP_TRY(hipMemsetAsync(p.n_active, 0, 2 * sizeof(int32_t), stream));
+    HIP_TRY(slam::pgs_launch_trial_kernel(p, 0, stream));
+    return SLAM_OK;
+}
+
+int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lanes, hipStream_t stream, int trial_index, bool profile,
+                 bool prelaunched = false) {
     p.lanes = lanes < 1 ? 1 : (lanes > h->lanes ? h->lanes : lanes);
     // Few instances left: the per-trial latency counts and spare slots cost little.  Two lanes from `lanes_switch` active
     // instances down (the common streak is one failure, then a success at 10 lambda), all of them from `lanes_switch_all` down.
@@ -306,8 +317,8 @@ int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lan
     // instance-resident accumulators (tile code 1) from syrk_inst_switch active instances; its staging registers are sized for LD <= 448
     if ((h->syrk_tile == 1 || (!h->syrk_tile && active_hint >= h->syrk_inst_switch)) && p.LD <= 448) p.syrk_wave_tile = 1;
     else if (p.syrk_wave_tile == 1) p.syrk_wave_tile = 32;
-    HIP_TRY(hipMemsetAsync(p.n_active, 0, 2 * sizeof(int32_t), stream));
-    for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
+    if (!prelaunched) HIP_TRY(hipMemsetAsync(p.n_active, 0, 2 * sizeof(int32_t), stream));
+    for (int k = prelaunched ? 1 : 0; k < slam::kPgsTrialKernels; ++k) {
         if (profile) {
             const size_t need = (size_t)(trial_index + 1) * (slam::kPgsTrialKernels + 1);
             while (h->events.size() < need) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->events.push_back(e); }
@@ -335,11 +346,17 @@ int pgs_solve(pgs_handle* h) {
         TRY(clone_instances(h, h->p, h->stream));
         int trials = 0;
         int32_t act[2] = {h->B, 1};   // active instances, lanes of the next trial
+        if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 64, hipHostMallocDefault));
+        while ((int)h->gevents.size() < 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->gevents.push_back(e); }
+        const bool pipe = !h->profiling;   // per-kernel timing wants every kernel of a trial between its own events
+        if (pipe) TRY(prelaunch_trial(h, h->p, h->stream));
         for (; trials < h->max_trials; ++trials) {
-            TRY(launch_trial(h, h->p, act[0], act[1], h->stream, trials, h->profiling));
-            act[0] = 0; act[1] = 1;
-            HIP_TRY(hipMemcpyAsync(act, h->p.n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            TRY(launch_trial(h, h->p, act[0], act[1], h->stream, trials, h->profiling, pipe));
+            HIP_TRY(hipMemcpyAsync(h->h_active, h->p.n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipEventRecord(h->gevents[0], h->stream));
+            if (pipe) TRY(prelaunch_trial(h, h->p, h->stream));   // the next trial's linearisation runs while the host waits below
+            HIP_TRY(hipEventSynchronize(h->gevents[0]));
+            act[0] = h->h_active[0]; act[1] = h->h_active[1];
             if (h->trace) {
                 static thread_local double t_prev = 0.0;
                 timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -384,6 +401,7 @@ int pgs_solve(pgs_handle* h) {
         TRY(launch_trial(h, gp[g], h->B, 1, h->gstreams[g], 0, false));
         HIP_TRY(hipMemcpyAsync(h->h_active + 2 * g, gp[g].n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
         HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
+        TRY(prelaunch_trial(h, gp[g], h->gstreams[g]));
     }
     // one host thread per group drives its LM loop (launch a trial, wait for its active count, decide); the HIP runtime
     // is thread-safe and the groups touch disjoint instance ranges
@@ -400,9 +418,10 @@ int pgs_solve(pgs_handle* h) {
                 HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
                 return SLAM_OK;
             }
-            TRY(launch_trial(h, gp[g], active * G, lanes_next, h->gstreams[g], gtrials[g], false));
+            TRY(launch_trial(h, gp[g], active * G, lanes_next, h->gstreams[g], gtrials[g], false, true));
             HIP_TRY(hipMemcpyAsync(h->h_active + 2 * g, gp[g].n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
             HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
+            TRY(prelaunch_trial(h, gp[g], h->gstreams[g]));
         }
     };
     std::vector<std::thread> workers;
