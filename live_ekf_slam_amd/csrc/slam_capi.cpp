@@ -546,7 +546,7 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
         for (size_t b = 0; b < B; ++b) kmax = count[b] > kmax ? count[b] : kmax;   // 65 536 ints: ~20 us
         kmax = kmax < k_stride ? kmax : k_stride;
         if (kmax <= kExtQ) {
-            if (!h->lazy_cmds.empty()) FLUSH(h);   // generator steps queued before this one run first
+            if (!h->lazy_cmds.empty() || h->devq.n > 0) FLUSH(h);   // steps queued through the other entry points run first
             slam_handle::ExtQueue& q = h->extq[h->extq_cur];
             if (q.cap < h->lazy_max) {
                 if (q.n > 0) FLUSH(h);
@@ -628,7 +628,7 @@ int slam_step_sim(slam_handle* h, const float cmd[2]) {
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     if (!h->dmap) return fail(SLAM_ERR_STATE, "slam_set_map has not been called");
     if (h->kind == SLAM_EKF_SLAM && h->lazy_max > 1 && !h->dump_meas && h->run_chunk != 1) {
-        if (h->extq[h->extq_cur].n > 0) FLUSH(h);   // host-measurement steps queued before this one run first
+        if (h->extq[h->extq_cur].n > 0 || h->devq.n > 0) FLUSH(h);   // measurement-driven steps queued before this one run first
         h->lazy_cmds.push_back(cmd[0]); h->lazy_cmds.push_back(cmd[1]);
         return (int)(h->lazy_cmds.size() / 2) >= h->lazy_max ? flush_lazy(h) : SLAM_OK;
     }

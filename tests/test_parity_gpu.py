@@ -463,7 +463,34 @@ def test_step_dev_queued_equals_immediate(S):
         assert np.array_equal(f.landmark_counts(), ref.landmark_counts()) and np.array_equal(f.status(), ref.status())
         for b in range(B):
             _assert_state_equal(f.get_state(b), ref.get_state(b))
-    for f in outs + [rec]:
+    # the three per-step entry points interleaved (generator / device message / host message): each flushes what the others
+    # queued, so the order of the steps is the order of the calls
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    host = []
+    mixed = []
+    for lazy in (16, 0):
+        f = make()
+        _lib.check(Lc.slam_set_lazy_steps(f.h, lazy))
+        for t in range(T):
+            cm = np.ascontiguousarray(cmds[t], dtype=np.float32)
+            if t % 3 == 0:
+                _lib.check(Lc.slam_step_sim(f.h, fp(cm)))
+            elif t % 3 == 1:
+                _lib.check(Lc.slam_step_dev(f.h, fp(cm), msgs[t][0], msgs[t][1], KS))
+            else:
+                if len(host) <= t:
+                    host.extend([None] * (t + 1 - len(host)))
+                if host[t] is None:
+                    m = np.zeros((B, KS, 3), dtype=np.float32); c = np.zeros(B, dtype=np.int32)
+                    assert hip.hipMemcpy(m.ctypes.data_as(C.c_void_p), msgs[t][0], m.nbytes, 2) == 0
+                    assert hip.hipMemcpy(c.ctypes.data_as(C.c_void_p), msgs[t][1], c.nbytes, 2) == 0
+                    host[t] = (m, c)
+                _lib.check(Lc.slam_step(f.h, fp(cm), fp(host[t][0]), ip(host[t][1]), KS))
+        mixed.append(f)
+    assert np.array_equal(mixed[0].landmark_counts(), mixed[1].landmark_counts()) and np.array_equal(mixed[0].status(), mixed[1].status())
+    for b in range(B):
+        _assert_state_equal(mixed[0].get_state(b), mixed[1].get_state(b))
+    for f in outs + mixed + [rec]:
         f.close()
     for m, c in msgs:
         hip.hipFree(m); hip.hipFree(c)
