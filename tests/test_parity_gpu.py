@@ -419,7 +419,7 @@ def test_long_runs_on_every_map_type(S, oracle, map_type, L, dtype, seed):
 
 def test_step_dev_queued_equals_immediate(S):
     """slam_step_dev (device-resident messages) queues its calls like slam_step / slam_step_sim: each message is copied into a
-    device-side queue at the call and 16 of them run as one multi-step launch.  Same bits as one launch per call,
+    device-side queue at the call and a queue of them runs as one multi-step launch.  Same bits as one launch per call,
     from Filter::init through insertions and messages with eight detections (several update groups inside a multi-step launch)."""
     import ctypes as C
     from live_ekf_slam_amd import _lib
@@ -448,7 +448,7 @@ def test_step_dev_queued_equals_immediate(S):
     Lc = _lib.lib()
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
     outs = []
-    for lazy in (16, 0, 5):
+    for lazy in (32, 0, 5):
         f = make()
         _lib.check(Lc.slam_set_lazy_steps(f.h, lazy))
         for t in range(T):
