@@ -123,7 +123,8 @@ struct slam_handle {
     double* dxprev = nullptr;                         // UKF: x_t the last sigma points were drawn around
     double* dvt = nullptr; int32_t* dvage = nullptr;  // UKF: V^T of the last eigen-decomposition + warm-start age
     uint4* drot = nullptr;                            // UKF (n <= 44): Jacobi schedule table of the fast sqrt kernel
-    hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[2] = {nullptr, nullptr};   // UKF run_sim: second half of the batch
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr}; hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // UKF run_sim: the other parts of the batch
+    int ukf_parts = 2;                                                               // streams the UKF batch is split over (SLAM_UKF_PARTS, 1..4)
     int ukf_split_min = 1024;                                                        // batch size from which it is used
     bool predicted = false; float pred_cmd[2] = {0.f, 0.f};   // UKF: slam_predict done, slam_update_dev pending
     float* dmapf = nullptr;                           // UKF_LOC: the known map as float32 [id, x, y] triplets
@@ -357,6 +358,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
 #endif
     env = getenv("SLAM_UKF_SPLIT_MIN");   // batch size from which UKF run_sim splits the batch over two streams
     if (env) h->ukf_split_min = atoi(env);
+    env = getenv("SLAM_UKF_PARTS");   // streams the UKF batch is split over in run_sim (2..4)
+    if (env) h->ukf_parts = atoi(env);
     env = getenv("SLAM_LAZY_STEPS");   // slam_step_sim calls queued per multi-step launch (0 = one launch per call)
     if (env) h->lazy_max = atoi(env);
     env = getenv("SLAM_EAGER_FLUSH");   // queued steps from which an idle GPU is given work before the queue is full (0 = never)
@@ -423,7 +426,8 @@ int slam_destroy(slam_handle* h) {
     flush_lazy(h);
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); hipEventDestroy(h->aux_ev[0]); hipEventDestroy(h->aux_ev[1]); }
+    for (auto& st : h->aux_stream) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+    for (auto& ev : h->aux_ev) if (ev) hipEventDestroy(ev);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
     if (h->devq.dmeas) { hipFree(h->devq.dmeas); hipFree(h->devq.dcount); }
     for (auto& q : h->extq) {
@@ -662,30 +666,35 @@ static int run_sim_now(slam_handle* h, const float* cmds, int T) {
         // UKF: two launches per timestep (LDS-bound eigen-sqrt, then the latency-heavier sigma-point kernel).  The two
         // halves of the batch run on two streams and drift apart, so one half's sqrt overlaps the other's step kernel.
         HIP_TRY(hipSetDevice(h->device));
-        if (!h->aux_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&h->aux_ev[0], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&h->aux_ev[1], hipEventDisableTiming));
-        }
+        const int NP = h->ukf_parts < 2 ? 2 : (h->ukf_parts > 4 ? 4 : h->ukf_parts);
+        for (int a = 0; a < NP - 1; ++a)
+            if (!h->aux_stream[a]) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream[a], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&h->aux_ev[a + 1], hipEventDisableTiming));
+            }
+        if (!h->aux_ev[0]) HIP_TRY(hipEventCreateWithFlags(&h->aux_ev[0], hipEventDisableTiming));
         HIP_TRY(hipEventRecord(h->aux_ev[0], h->stream));
-        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_ev[0], 0));
-        const int half = h->B / 2;
+        for (int a = 0; a < NP - 1; ++a) HIP_TRY(hipStreamWaitEvent(h->aux_stream[a], h->aux_ev[0], 0));
+        const int per = (h->B + NP - 1) / NP;
         for (int t = 0; t < T; ++t) {
             slam::UkfStepParams p;
             fill_ukf_params(h, p, cmds + 2 * (size_t)t);
             p.sim = 1;
-            for (int part = 0; part < 2; ++part) {
-                p.b_off = part ? half : 0;
-                p.b_cnt = part ? h->B - half : half;
-                hipStream_t st = part ? h->aux_stream : h->stream;
+            for (int part = 0; part < NP; ++part) {
+                p.b_off = part * per;
+                p.b_cnt = h->B - p.b_off < per ? h->B - p.b_off : per;
+                if (p.b_cnt <= 0) continue;
+                hipStream_t st = part ? h->aux_stream[part - 1] : h->stream;
                 HIP_TRY(slam::launch_ukf_sqrt(p, st));
                 HIP_TRY(slam::launch_ukf_step(p, st));
             }
             std::swap(h->dP, h->dP2);
             h->step += 1;
         }
-        HIP_TRY(hipEventRecord(h->aux_ev[1], h->aux_stream));
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->aux_ev[1], 0));
+        for (int a = 0; a < NP - 1; ++a) {
+            HIP_TRY(hipEventRecord(h->aux_ev[a + 1], h->aux_stream[a]));
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->aux_ev[a + 1], 0));
+        }
         return SLAM_OK;
     }
     if (h->kind != SLAM_EKF_SLAM || h->dump_meas || h->run_chunk == 1) {
