@@ -858,7 +858,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int n = na, ldn = ekf_ld(n, ESZ);
             ST* const Pbuf = Pcur;
             constexpr int NS = W - 1;                 // streamers
-            constexpr bool kGen = W >= 3;             // the last streamer also runs the measurement generator ahead of the filter
+            constexpr bool kGen = W >= 2;             // the last streamer also runs the measurement generator ahead of the filter (with two
+                                                      // wavefronts that is the pass leader: it generates while no pass is due)
             if (tid == 0) {
                 s_ring[0] = nu; s_ring[1] = 0; s_ring[2] = 0; s_ring[3] = 0; s_ring[4] = t; s_ring[5] = 0; s_ring[6] = 0; s_ring[7] = 0;
                 s_pass[0] = 0; s_pass[1] = 0; s_pass[2] = 0; s_pass[3] = 0;
@@ -1124,6 +1125,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                 if (ld_i(&s_ring[0]) - app == 0) { stop = true; break; }
                                 continue;
                             }
+                            if constexpr (W == 2) {   // the only streamer: no pass is due, so generate a timestep ahead if the ring has room
+                                const int ts = ld_i(&s_sim[0]);
+                                if (ts < T && ts < ld_i(&s_sim[1]) + SD && !ex) {
+                                    simgen(ts);
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                    if (lane == 0) st_i(&s_sim[0], ts + 1);
+                                    continue;
+                                }
+                            }
                             __builtin_amdgcn_s_sleep(SLAM_SLEEP_LEADER);
                         }
                         int cnt = pend < KG ? pend : KG;
@@ -1155,7 +1165,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         }
                     }
                     while (ld_i(&s_pass[0]) <= seen) {
-                        if constexpr (kGen) {
+                        if constexpr (kGen && W >= 3) {
                             if ((tid >> 6) == W - 1) {   // between passes: run the measurement generator ahead of the filter
                                 const int ts = ld_i(&s_sim[0]);
                                 if (ts < T && ts < ld_i(&s_sim[1]) + SD && !ld_i(&s_ring[3])) {

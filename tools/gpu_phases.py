@@ -15,7 +15,7 @@ names = {0: "init loads", 1: "pre-step(0)", 2: "wait for pre-step", 3: "group fo
 dt = sys.argv[1] if len(sys.argv) > 1 else "f64"
 if len(sys.argv) > 2:
     os.environ["SLAM_WAVES_PER_FILTER"] = sys.argv[2]
-L, B, t0, steps = 50, 65536, 644, int(os.environ.get("PHASE_STEPS", "100"))
+L, B, t0, steps = int(os.environ.get("PHASE_L", "50")), int(os.environ.get("PHASE_B", "65536")), int(os.environ.get("PHASE_T0", "644")), int(os.environ.get("PHASE_STEPS", "100"))
 lm, cmds = make_scenario(1234, L, t0 + steps + 1)
 f = S.BatchedEKF(B, L, dtype=S.F32 if dt == "f32" else S.F64).readParams(); f.set_map(lm); f.set_seed(2025); f.init(0, 0, 0)
 f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
