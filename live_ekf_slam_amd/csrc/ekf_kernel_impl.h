@@ -899,38 +899,68 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         while (ld_i(&s_ring[7])) __builtin_amdgcn_s_sleep(1);        // pass in flight
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         const int app = ld_i(&s_ring[1]);
+                        // two slots (the row and column pair of one landmark) per trip: their row and column loads are issued together, one HBM round
+                        // trip per 64 state indices instead of one per slot and 64 indices
+                        int sl = 0;
 #pragma unroll 1
-                        for (int sl = 0; sl < nTq; ++sl) {
-                            if (s_need[sl] != 1) continue;
-                            const int t_s = s_T[sl];
+                        while (sl < nTq) {
+                            constexpr int GB = 2;
+                            int ss[GB], ts[GB], nb = 0;
+#pragma unroll
+                            for (int g = 0; g < GB; ++g) { ss[g] = 0; ts[g] = 0; }
+#pragma unroll 1
+                            while (sl < nTq && nb < GB) {
+                                if (s_need[sl] == 1) {
+#pragma unroll
+                                    for (int g = 0; g < GB; ++g)
+                                        if (g == nb) { ss[g] = sl; ts[g] = s_T[sl]; }
+                                    nb += 1;
+                                }
+                                sl += 1;
+                            }
+                            if (nb == 0) break;
 #pragma unroll 1
                             for (int j = lane; j < LDP; j += 64) {
-                                double rv = 0.0, cv = 0.0;
-                                if (j < n) {
-                                    rv = (double)Pbuf[(size_t)t_s * ldn + j];   // P[t_s][j]
-                                    cv = (double)Pbuf[(size_t)j * ldn + t_s];   // P[j][t_s]
+                                double rv[GB], cv[GB];
+                                const int jc = j < n ? j : 0;
+#pragma unroll
+                                for (int g = 0; g < GB; ++g) {
+                                    rv[g] = (double)Pbuf[(size_t)ts[g] * ldn + jc];   // P[t_s][j]
+                                    cv[g] = (double)Pbuf[(size_t)jc * ldn + ts[g]];   // P[j][t_s]
+                                }
 #pragma unroll 1
-                                    for (int u = app; u < pub; ++u) {
-                                        const int us = u % KG;
-                                        const double2* Ku = s_K + us * LDP;
-                                        const double2* HPu = s_HP + us * HPW;
-                                        const double2 kt = Ku[t_s], ht = HPu[hpi(t_s)], kj = Ku[j], hj = HPu[hpi(j)];
-                                        rv = rv - (kt.x * hj.x + kt.y * hj.y);
-                                        cv = cv - (kj.x * ht.x + kj.y * ht.y);
+                                for (int u = app; u < pub; ++u) {
+                                    const int us = u % KG;
+                                    const double2* Ku = s_K + us * LDP;
+                                    const double2* HPu = s_HP + us * HPW;
+                                    const double2 kj = Ku[jc], hj = HPu[hpi(jc)];
+                                    bool we = false;
+                                    if constexpr (!kWide) we = s_wend[us] != 0;
+#pragma unroll
+                                    for (int g = 0; g < GB; ++g) {
+                                        const double2 kt = Ku[ts[g]], ht = HPu[hpi(ts[g])];
+                                        rv[g] = rv[g] - (kt.x * hj.x + kt.y * hj.y);
+                                        cv[g] = cv[g] - (kj.x * ht.x + kj.y * ht.y);
                                         if constexpr (!kWide) {
-                                            if (s_wend[us]) { rv = (double)(ST)rv; cv = (double)(ST)cv; }   // end of a timestep: storage rounding
+                                            if (we) { rv[g] = (double)(ST)rv[g]; cv[g] = (double)(ST)cv[g]; }   // end of a timestep: storage rounding
                                         }
                                     }
                                 }
-                                s_R[sl * LDP + j] = rv;
-                                s_C[sl * LDP + j] = cv;
+#pragma unroll
+                                for (int g = 0; g < GB; ++g)
+                                    if (g < nb) {
+                                        s_R[ss[g] * LDP + j] = j < n ? rv[g] : 0.0;
+                                        s_C[ss[g] * LDP + j] = j < n ? cv[g] : 0.0;
+                                    }
                             }
                             // entries against the vehicle states come from the resident vehicle columns / rows (HBM does not
                             // have the predictions of the steps since the loop began)
-                            if (sl >= 3 && lane < 3) {
-                                s_R[sl * LDP + lane] = s_C[lane * LDP + t_s];   // P[t_s][c], c < 3
-                                s_C[sl * LDP + lane] = s_R[lane * LDP + t_s];   // P[r][t_s], r < 3
-                            }
+#pragma unroll
+                            for (int g = 0; g < GB; ++g)
+                                if (g < nb && ss[g] >= 3 && lane < 3) {
+                                    s_R[ss[g] * LDP + lane] = s_C[lane * LDP + ts[g]];   // P[t_s][c], c < 3
+                                    s_C[ss[g] * LDP + lane] = s_R[lane * LDP + ts[g]];   // P[r][t_s], r < 3
+                                }
                         }
                         if (lane == 0) st_i(&s_ring[6], 0);
                     }
