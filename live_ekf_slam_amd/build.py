@@ -23,7 +23,7 @@ EKF_DEFAULT_VARIANTS = [(43, 2, 4, 4, 0, 1), (43, 1, 2, 4, 0, 1), (103, 4, 4, 4,
 EKF_SWEEP_VARIANTS = [(103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
                       (103, 2, 4, 4, 0, 1), (103, 8, 4, 2, 0, 1), (103, 8, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1), (103, 4, 2, 4, 0, 1),
                       (103, 4, 4, 4, 1, 0), (103, 4, 4, 8, 1, 1), (103, 4, 4, 4, 1, 1), (103, 2, 4, 4, 1, 1), (103, 8, 4, 2, 1, 1),
-                      (103, 2, 4, 2, 1, 1), (103, 3, 4, 2, 1, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 6, 2, 1, 1), (103, 3, 4, 4, 0, 1), (103, 3, 4, 2, 0, 1),
+                      (103, 2, 4, 2, 1, 1), (103, 3, 4, 2, 1, 1), (43, 2, 4, 2, 1, 1), (43, 2, 4, 2, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 6, 2, 1, 1), (103, 3, 4, 4, 0, 1), (103, 3, 4, 2, 0, 1),
                       (43, 2, 4, 4, 0, 0), (43, 1, 2, 4, 0, 0), (43, 4, 4, 4, 0, 1), (43, 1, 4, 8, 0, 1), (43, 2, 4, 8, 0, 1), (43, 2, 2, 4, 0, 1)]
 # EKF_FLAGS, -disable-machine-licm: with the register budget these kernels run at (128 VGPRs at four waves per SIMD), hoisting the
 # materialisation of fp64 constants out of loops pins registers the loops need; the compiler then SPILLED the hoisted constants
