@@ -9,7 +9,7 @@ import live_ekf_slam_amd as S
 from live_ekf_slam_amd.scenario import make_scenario
 
 L, B, K, KS = 50, 65536, int(os.environ.get('PCIE_K', '40')), 8
-lm, cmds = make_scenario(1234, L, 400)
+lm, cmds = make_scenario(1234, L, max(400, 200 + K))
 def fresh():
     g = S.BatchedEKF(B, L).readParams(); g.set_map(lm); g.init(0, 0, 0)
     g.set_vision(1e9, -4.0, 4.0); g.update_sim(cmds[0]); g.set_vision(3.0, -1.57, 1.57)
