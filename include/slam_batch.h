@@ -114,21 +114,29 @@ int slam_set_map(slam_handle* h, const double* map_xy, int L);
  * padded to k_stride detections per instance); meas_count: [batch].  HOST pointers: the message is copied before the call
  * returns (mirroring `lm_meas = lmMeasMsg->data`, ekf.cpp:64), so the caller may reuse its buffers at once.  EKF: like
  * slam_step_sim, consecutive calls are queued (up to slam_set_lazy_steps timesteps, messages of at most 4 detections per
- * instance) and run as one multi-step launch; every other entry point runs what is queued first. */
+ * instance) and run as one multi-step launch; every other entry point runs what is queued first.
+ * QUEUED MEANS NOT ENQUEUED: until the queue runs (it is full, another slam_* entry point is called, or slam_sync), nothing of
+ * a queued step is on the handle's stream, so an event recorded or a stream synchronised right after the call sees no work
+ * of that step, and a HIP error of a queued step is reported by the call that runs the queue (the queued timesteps are
+ * kept, not dropped, when that launch fails).  slam_set_lazy_steps(h, 0) restores one launch per call. */
 int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32_t* meas_count, int k_stride);
 /* Same, with DEVICE pointers (no host copy).  The buffers are read in the order of the handle's stream: they may be
- * overwritten by work enqueued on that stream after the call returns.  EKF handles queue the call like slam_step does (the
- * message is copied device-to-device into a queue of slam_set_lazy_steps entries, which run as one multi-step launch; any other
- * entry point runs the queue first). */
+ * overwritten by work enqueued on that stream after the call returns.  By default every call enqueues its step on the stream
+ * at once (caller-owned buffers on a caller-owned stream: events and stream synchronisation around the call see the step).
+ * Queueing is OPT-IN for this entry point: after slam_set_lazy_steps(h, n > 1) (or with SLAM_LAZY_STEPS set) the message is
+ * copied device-to-device into a queue of n entries, which run as one multi-step launch; any other entry point runs the queue
+ * first, with the caveat stated at slam_step. */
 int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const int32_t* d_meas_count,
                   int k_stride);
 /* One timestep where the device-side generator (a port of get_cmd, sim_node.py:209-250) advances each
  * instance's true pose with its own noise stream and produces its measurements, then the filter consumes
  * them in the same kernel.  Also accumulates the position error of plotting_node.py:209-212. */
 int slam_step_sim(slam_handle* h, const float cmd[2]);
-/* EKF: consecutive slam_step_sim calls are queued on the host and run as one multi-step launch of up to n timesteps (default
- * 16, environment variable SLAM_LAZY_STEPS; 0 = one launch per call); every other entry point runs what is queued first, so
- * the results seen through the API do not change (a multi-step launch gives the same bits as single steps), only the speed. */
+/* EKF: consecutive slam_step_sim / slam_step calls are queued on the host and run as one multi-step launch of up to n
+ * timesteps (default 32, environment variable SLAM_LAZY_STEPS; 0 = one launch per call); every other entry point runs what is
+ * queued first, so the results seen through the API do not change (a multi-step launch gives the same bits as single steps),
+ * only the speed — and the moment the work reaches the stream (see slam_step).  Calling it also switches the queue of
+ * slam_step_dev on (n > 1) or off. */
 int slam_set_lazy_steps(slam_handle* h, int n);
 /* T consecutive slam_step_sim calls; cmds = [T][2] float32 host array (precomputed trajectory,
  * sim_node.py:142-152). */
@@ -188,6 +196,18 @@ int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset);
  * by the square-root kernel since slam_create or the last reset: out[0] / out[1] is the mean number of sweeps the
  * `nearestSPD` + `.sqrt()` of ukf.cpp:106-123,208 took, which sets the arithmetic of a UKF step.  Synchronises. */
 int slam_ukf_sweep_stats(slam_handle* h, uint64_t out[2], int reset);
+/* EKF handles: what the step kernels moved through global memory, counted ON THE DEVICE (one accumulation per pass and
+ * workgroup, summed per launch like the k histogram) since slam_create or the last reset: out[0] = bytes the passes of the
+ * P stream read + wrote (`P -= K (H P)`, ekf.cpp:140, applied for a group of deferred updates at once), out[1] = every other
+ * global byte (thin row / column gathers, the vehicle rows / columns the prediction changes, x / ids / scalars at launch
+ * start and end), out[2] = passes, out[3] = rank-2 updates those passes applied.  bench.py's roofline.traffic is
+ * out[0] + out[1] of the timed launches; profiles/r03* hold the rocprofv3 PMC cross-check.  Synchronises. */
+int slam_traffic_counters(slam_handle* h, uint64_t out[4], int reset);
+/* The step-kernel instantiation this handle launches (multi_step != 0: the multi-step launch of slam_run_sim / the queues,
+ * else the one-step launch): name as rocprofv3 prints it (e.g. "ekf_step_kernel<103,4,4,4,double,1,true>"), and
+ * out = {static LDS bytes per workgroup, VGPRs, threads per workgroup, workgroups one CU holds at once, CUs of the device}.
+ * Needs a HIP device (the runtime is asked, nothing is hard-coded). */
+int slam_kernel_info(slam_handle* h, int multi_step, char* name, int name_cap, int32_t out[5]);
 /* Diagnostics: flag 32 = every workgroup of the EKF multi-step kernel stamps the wall clock and its detection count per
  * timestep (read back by the profiling tools / bench.py's per-k table), flag 4 = per-phase cycle counters; 0 = off (default;
  * the environment variable SLAM_DEBUG_FLAGS sets the initial value). */

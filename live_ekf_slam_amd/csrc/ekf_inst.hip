@@ -16,7 +16,8 @@ typedef float StorageT;
 typedef double StorageT;
 #endif
 EkfVariant g_variant = {V_NMAX, V_PIPE * 1000 + V_W * 100 + V_KG * 10 + V_UNR, V_F32,
-                        &launch_variant<V_NMAX, V_W, V_KG, V_UNR, StorageT, V_PIPE>, nullptr};
+                        &launch_variant<V_NMAX, V_W, V_KG, V_UNR, StorageT, V_PIPE>,
+                        &variant_info<V_NMAX, V_W, V_KG, V_UNR, StorageT, V_PIPE>, nullptr};
 struct Registrar {
     Registrar() { register_ekf_variant(&g_variant); }
 } g_registrar;

@@ -49,7 +49,7 @@ struct EkfStepParams {
     // ---- geometry ----
     int32_t B, L_max, pstride, xstride;
     int32_t sim;  // 1 = SIM mode, 0 = EXT mode
-    unsigned long long* khist; // [8] instance-steps by detections in their message (k = 0..6, >= 7), accumulated over
+    unsigned long long* khist; // [16]; [0..7] instance-steps by detections in their message (k = 0..6, >= 7), accumulated over
                                // launches (one atomicAdd per bin and workgroup at the end of a launch); may be NULL
     unsigned long long* prof;  // optional [B][PROF_SLOTS] per-block stamps of the last launch (dbg & 4 | 32), NULL otherwise
     int32_t dbg;  // SLAM_DEBUG_FLAGS: 4 = phase cycle counters, 32 = wall-clock stamp + detection count per timestep of a
@@ -65,6 +65,8 @@ __host__ __device__ constexpr int ekf_ld(int n, int elem_bytes) {
 }
 
 static constexpr int kEkfProfSlots = 128;   // per-block slots of EkfStepParams::prof
+static constexpr int kEkfTrafficSlot = 10;  // khist[10..13]: bytes moved by the P-stream passes (read + write), other global bytes
+                                            // (thin gathers, vehicle rows / columns, state vectors), passes, updates applied by passes
 
 // Largest landmark capacity of the instantiated variants (n = 3+2L <= 203; the limit is LDS, not registers).
 // fp32 storage is instantiated up to 50 landmarks.
@@ -79,9 +81,16 @@ static constexpr int kEkfMaxLandmarksF32 = 50;
 //   UNR  rows per strip of the bulk stream = 16-byte vectors in flight per lane
 //   PIPE 1 = the stream loads the next chunk while it updates and stores the current one
 // The release library holds the defaults only; `SLAM_SWEEP=1 python -m live_ekf_slam_amd.build` adds the sweep set.
+// what the runtime says about one instantiation (slam_kernel_info): name as the profiler prints it, static LDS per workgroup,
+// registers, threads per workgroup, workgroups one CU holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)
+struct EkfKernelInfo {
+    char name[96];
+    int lds_bytes, vgprs, sgprs, threads, wg_per_cu;
+};
 struct EkfVariant {
     int nmax, code, f32;
     hipError_t (*launch)(const EkfStepParams&, hipStream_t);
+    hipError_t (*info)(int multi, EkfKernelInfo*);
     EkfVariant* next;
 };
 void register_ekf_variant(EkfVariant* v);
@@ -91,6 +100,8 @@ int ekf_variant_available(int L_max, int f32_storage, int variant);
 
 // variant: 0 = the library's default for the size class and batch; otherwise a variant code (or just W).
 hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage, hipStream_t stream);
+// the instantiation launch_ekf_step would pick for (L_max, batch, variant, storage); multi = multi-step launch
+hipError_t ekf_kernel_info(int L_max, int B, int variant, int f32_storage, int multi, EkfKernelInfo* out);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)
 hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, int elem_bytes, double* out, hipStream_t stream);

@@ -73,6 +73,12 @@ hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage,
     return v->launch(p, stream);
 }
 
+hipError_t ekf_kernel_info(int L_max, int B, int variant, int f32_storage, int multi, EkfKernelInfo* out) {
+    const EkfVariant* v = pick_variant(L_max, B, variant, f32_storage);
+    if (!v) return hipErrorInvalidConfiguration;
+    return v->info(multi, out);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void alg_bytes_kernel(const int32_t* M, int B, int base, int elem_bytes, double* out) {
     double acc = 0.0;

@@ -25,6 +25,8 @@
 #pragma once
 #include "ekf_kernel.h"
 
+#include <stdio.h>
+
 #include <type_traits>
 
 #include "../../include/slam_batch.h"
@@ -195,6 +197,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                           // flag bits raised by the control wavefront, hold (no new pass), pass in flight
     __shared__ int s_pass[4];             // decoupled loop: pass id, first update, number of updates, streamers done
     __shared__ int s_wend[KG];            // fp32 storage: a timestep ends after this update of the open group (P is rounded there)
+    __shared__ unsigned s_cnt[4];         // traffic of this launch: P-stream bytes / 16 (passes read + write), other global bytes / 8 (thin
+                                          // gathers, vehicle rows / columns, state vectors), passes, updates applied by passes
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -265,6 +269,15 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if (tid < 8) s_kh[tid] = 0;
     if (tid < KG) s_wend[tid] = 0;
     if (tid < 2) s_sim[tid] = 0;
+    if (tid < 4) s_cnt[tid] = tid == 1 ? (unsigned)((n_init + M_init / 2 + 8) * ESZ / 8) : 0u;   // x_t, ids, scalars read by the prologue
+    // one lane accounts for what a phase moves (wave-uniform arguments; LDS atomics, a handful per timestep)
+    // (32-bit arithmetic and no captured state on purpose: the kernel sits at its register limit)
+    auto count_pass = [](unsigned* cnt, int vec16, int nupd) {   // vec16: 16-byte vectors read + written
+        atomicAdd(&cnt[0], (unsigned)vec16);
+        atomicAdd(&cnt[2], 1u);
+        atomicAdd(&cnt[3], (unsigned)nupd);
+    };
+    auto count_other = [](unsigned* cnt, int elems) { atomicAdd(&cnt[1], (unsigned)(elems * ESZ) / 8u); };
 
     // state -> HBM at the end of the launch (or when the instance freezes): x_t lives in s_xt
     // `pre`: the instance freezes in its PRE-step state (x, P, timestep, error sum and the true pose alike)
@@ -286,6 +299,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             p.truth[3 * (size_t)b + tid] = steps_done == 0 && !pre ? s_keep[tid] : s_tru[(tq % SD) * 6 + (pre ? 0 : 3) + tid];
         }
         if (p.khist != nullptr && tid < 8 && s_kh[tid] != 0) atomicAdd(&p.khist[tid], (unsigned long long)s_kh[tid]);
+        if (p.khist != nullptr && tid >= 8 && tid < 12) {   // slam_traffic_counters: bytes of the P stream, other bytes, passes, updates
+            const unsigned long long v = s_cnt[tid - 8] + (tid == 9 ? (unsigned long long)((nfin + 8) * ESZ / 8) : 0ull);
+            const unsigned long long unit = tid == 8 ? 16ull : (tid == 9 ? 8ull : 1ull);
+            if (v != 0ull) atomicAdd(&p.khist[kEkfTrafficSlot + tid - 8], v * unit);
+        }
     };
 
     int M = M_init;
@@ -765,6 +783,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     auto write_vehicle = [&](ST* Pbuf, int n) {
         const int ldn = ekf_ld(n, ESZ);
         const int tsk = opaque(tid);
+        if (tsk == 0) count_other(s_cnt, 6 * n - 9);
 #pragma unroll 1
         for (int i = tsk; i < 3 * n; i += TPB) {
             const int r = i / n, c = i - r * n;
@@ -803,6 +822,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     };
     if (W == 1) pregather(tid, TPB);
     else if (tid >= 64) pregather(tid - 64, TPB - 64);
+    if (tid == TPB - 1) count_other(s_cnt, 6 * n_init);
     if (tid < 64) prestep(0);
     if (tid >= TPB - 3) s_need[tid - (TPB - 3)] = 0;   // slots 0..2 are resident (visible after the barrier at the top of the step)
     SLAM_STAMP(1);   // measurements, association, motion scalars of the first step
@@ -919,6 +939,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                 sl += 1;
                             }
                             if (nb == 0) break;
+                            if (lane == 0) count_other(s_cnt, 2 * nb * n);
 #pragma unroll 1
                             for (int j = lane; j < LDP; j += 64) {
                                 double rv[GB], cv[GB];
@@ -1190,6 +1211,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             s_pass[2] = stop ? -1 : cnt;
                             s_pass[3] = 0;
                             s_chunk = 0;
+                            if (!stop) count_pass(s_cnt, 2 * n * (ldn / VEC), cnt);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             st_i(&s_pass[0], seen + 1);
                         }
@@ -1396,6 +1418,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             pa.src = Pin; pa.dst = const_cast<ST*>(Pin); pa.mid = nullptr;
             pa.nf = n_old; pa.ldd = lds; pa.lds = lds; pa.nsrc = n_old; pa.nu = nu;
             __builtin_amdgcn_s_setprio(0);
+            if (tid == 0) count_pass(s_cnt, 2 * n_old * (lds / VEC), nu);
             stream_pass(std::integral_constant<int, 1>{}, pa);
             __builtin_amdgcn_s_setprio(SLAM_PRIO_THIN);
             nu = 0;
@@ -1451,6 +1474,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             };
             if (!kWide && src_mid) gather(0.0, Pmid);
             else gather((ST)0, srcS);
+            if (tid < nT && s_need[tid] == 1 && s_T[tid] < nsrc) count_other(s_cnt, 2 * nsrc);
         }
         __syncthreads();
         if (tid < TS) s_need[tid] = 0;
@@ -1669,12 +1693,19 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             pa.src = first ? Pin : Pout; pa.dst = Pout; pa.mid = Pmid;
             pa.nf = nf; pa.ldd = ldd; pa.lds = lds; pa.nsrc = nsrc; pa.nu = nu;
             if (first && !more && nf == n_old) {
-                if (nu == 0 && !SLAM_DBG(p.dbg & 16)) write_vehicle(Pout, nf);   // nothing pending: only the prediction's rows / columns
-                else stream_pass(std::integral_constant<int, 1>{}, pa);
+                if (nu == 0 && !SLAM_DBG(p.dbg & 16)) {   // nothing pending: only the prediction's rows / columns
+                    write_vehicle(Pout, nf);
+                } else {
+                    if (tid == 0) count_pass(s_cnt, 2 * nf * (ldd / VEC), nu);
+                    stream_pass(std::integral_constant<int, 1>{}, pa);
+                }
             } else if (kWide || (first && !more)) {
+                if (tid == 0) count_pass(s_cnt, nsrc * (lds / VEC) + nf * (ldd / VEC), nu);
                 stream_pass(std::integral_constant<int, 0>{}, pa);
             } else {
                 pa.src = Pin;
+                // the fp64 slab between the groups of one fp32-storage step moves 8-byte elements
+                if (tid == 0) count_pass(s_cnt, (nsrc * lds * (first ? ESZ : 8) + nf * ldd * (more ? 8 : ESZ)) / 16, nu);
                 mid_pass(!first, more, pa);
             }
             nu = 0;
@@ -1719,6 +1750,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         // fewer insertions than provisioned (unknown-id mode over-estimates): re-pack from the leading dimension of nf
         // to the one of na in place.  Rows move towards lower addresses, so go row by row with a barrier in between.
         const int ldf = ekf_ld(nf, ESZ), lda = ekf_ld(na, ESZ);
+        if (tid == 0) count_other(s_cnt, 2 * na * na);
 #pragma unroll 1
         for (int r = 0; r < na; ++r) {
             ST tmp[(LDP + TPB - 1) / TPB];
@@ -1747,7 +1779,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         __syncthreads();
         if (Pfinal != frz_P) {
             const int nn = frz_n * ekf_ld(frz_n, ESZ);
+            if (tid == 0) count_other(s_cnt, 2 * nn);
             for (int i = tid; i < nn; i += TPB) Pfinal[i] = frz_P[i];
+            __syncthreads();
         }
         finish(frz_at, frz_M, flags | SLAM_INST_INDEX_OOR, true);
         return;
@@ -1755,7 +1789,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if (Pcur != Pfinal) {   // an odd number of layout changes in this launch: bring P_t back to the host's buffer
         __syncthreads();
         const int nn = na * ekf_ld(na, ESZ);
+        if (tid == 0) count_other(s_cnt, 2 * nn);
         for (int i = tid; i < nn; i += TPB) Pfinal[i] = Pcur[i];
+        __syncthreads();
     }
 
     finish(T, M, flags, false);
@@ -1771,5 +1807,24 @@ hipError_t launch_variant(const EkfStepParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int NMAX, int W, int KG_, int UNR_, class ST, int PIPE>
+hipError_t variant_info(int multi, EkfKernelInfo* out) {
+    const void* fn = multi ? reinterpret_cast<const void*>(&ekf_step_kernel<NMAX, W, KG_, UNR_, ST, PIPE, true>)
+                           : reinterpret_cast<const void*>(&ekf_step_kernel<NMAX, W, KG_, UNR_, ST, PIPE, false>);
+    hipFuncAttributes a;
+    hipError_t e = hipFuncGetAttributes(&a, fn);
+    if (e != hipSuccess) return e;
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * W, 0);
+    if (e != hipSuccess) return e;
+    snprintf(out->name, sizeof(out->name), "ekf_step_kernel<%d,%d,%d,%d,%s,%d,%s>", NMAX, W, KG_, UNR_,
+             sizeof(ST) == 8 ? "double" : "float", PIPE, multi ? "true" : "false");
+    out->lds_bytes = (int)a.sharedSizeBytes;
+    out->vgprs = a.numRegs;
+    out->sgprs = 0;
+    out->threads = 64 * W;
+    out->wg_per_cu = nb;
+    return hipSuccess;
+}
 
 }  // namespace slam

@@ -95,6 +95,7 @@ struct slam_handle {
     std::vector<float> lazy_cmds;
     int eager_init = 2;                                        // first idle-GPU launch size (SLAM_EAGER_FLUSH, 0 = off)
     int eager_target = 2;                                      // queued steps an idle GPU is given at once (doubles per such launch)
+    bool lazy_explicit = false;                                // slam_set_lazy_steps / SLAM_LAZY_STEPS asked for queueing: slam_step_dev queues only then
     int lazy_max = 32;                                         // 0 / 1 = off (SLAM_LAZY_STEPS, slam_set_lazy_steps); per launch a workgroup pays
                                                                // ~25 us of start / drain: 16 -> 61 M, 32 -> 66 M, 64 -> 70 M steps/s (one launch: 73 M)
     // slam_step (EKF, HOST measurements): the same queueing.  Each call packs its message (stride kExtQ detections per
@@ -105,6 +106,8 @@ struct slam_handle {
         float* hmeas = nullptr; int32_t* hcount = nullptr; float* hcmds = nullptr;   // pinned: [cap][B][kExtQ][3], [cap][B], [cap][2]
         float* dmeas = nullptr; int32_t* dcount = nullptr;                           // device
         int cap = 0, n = 0;
+        int ks = 0;                                                                  // detections per instance of this fill (<= kExtQ)
+        size_t meas_cap = 0;                                                         // floats in hmeas / dmeas
         hipEvent_t copied = nullptr, used = nullptr;
         bool in_use = false;
     } extq[2];
@@ -361,7 +364,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     env = getenv("SLAM_UKF_PARTS");   // streams the UKF batch is split over in run_sim (2..4)
     if (env) h->ukf_parts = atoi(env);
     env = getenv("SLAM_LAZY_STEPS");   // slam_step_sim calls queued per multi-step launch (0 = one launch per call)
-    if (env) h->lazy_max = atoi(env);
+    if (env) { h->lazy_max = atoi(env); h->lazy_explicit = true; }
     env = getenv("SLAM_EAGER_FLUSH");   // queued steps from which an idle GPU is given work before the queue is full (0 = never)
     if (env) h->eager_init = h->eager_target = atoi(env);
     env = getenv("SLAM_RUN_CHUNK");   // timesteps per launch of slam_run_sim (1 = one launch per step)
@@ -520,7 +523,9 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
     if (!h || !cmd || !d_meas || !d_count || k_stride <= 0) return fail(SLAM_ERR_ARG, "bad argument");
     if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->kind == SLAM_EKF_SLAM && h->lazy_max > 1 && h->run_chunk != 1 && !h->dump_meas) {
+    // Device buffers on the caller's stream: queueing is OPT-IN here (slam_set_lazy_steps / SLAM_LAZY_STEPS), because a queued
+    // call enqueues only its device-to-device copy on the stream, not the step itself
+    if (h->kind == SLAM_EKF_SLAM && h->lazy_explicit && h->lazy_max > 1 && h->run_chunk != 1 && !h->dump_meas) {
         slam_handle::DevQueue& q = h->devq;
         if (!h->lazy_cmds.empty() || h->extq[h->extq_cur].n > 0 || (q.n > 0 && q.ks != k_stride)) FLUSH(h);   // earlier steps first
         const size_t B = (size_t)h->B;
@@ -552,29 +557,43 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
         kmax = kmax < k_stride ? kmax : k_stride;
         if (kmax <= kExtQ) {
             if (!h->lazy_cmds.empty() || h->devq.n > 0) FLUSH(h);   // steps queued through the other entry points run first
+            // a fill of the queue has ONE stride (detections per instance): that of its first message, at least 2; a later message
+            // with more detections ends the fill (the queued steps run) and starts one with the larger stride
+            if (h->extq[h->extq_cur].n > 0 && kmax > h->extq[h->extq_cur].ks) FLUSH(h);
             slam_handle::ExtQueue& q = h->extq[h->extq_cur];
-            if (q.cap < h->lazy_max) {
+            if (q.n == 0) q.ks = kmax < 2 ? 2 : kmax;
+            const size_t need = (size_t)3 * q.ks * B * h->lazy_max;
+            if (q.cap < h->lazy_max || q.meas_cap < need) {   // sized from the strides actually seen, not for kExtQ up front
                 if (q.n > 0) FLUSH(h);
                 if (q.in_use) { HIP_TRY(hipEventSynchronize(q.used)); q.in_use = false; }
                 if (q.hmeas) { hipHostFree(q.hmeas); hipHostFree(q.hcount); hipHostFree(q.hcmds); hipFree(q.dmeas); hipFree(q.dcount); }
-                q.cap = h->lazy_max;
-                HIP_TRY(hipHostMalloc((void**)&q.hmeas, sizeof(float) * 3 * kExtQ * B * q.cap, hipHostMallocNonCoherent));
-                HIP_TRY(hipHostMalloc((void**)&q.hcount, sizeof(int32_t) * B * q.cap, hipHostMallocNonCoherent));
-                HIP_TRY(hipHostMalloc((void**)&q.hcmds, sizeof(float) * 2 * q.cap, hipHostMallocNonCoherent));
-                HIP_TRY(hipMalloc(&q.dmeas, sizeof(float) * 3 * kExtQ * B * q.cap));
-                HIP_TRY(hipMalloc(&q.dcount, sizeof(int32_t) * B * q.cap));
+                q.hmeas = nullptr; q.hcount = nullptr; q.hcmds = nullptr; q.dmeas = nullptr; q.dcount = nullptr;
+                q.cap = 0; q.meas_cap = 0;
+                HIP_TRY(hipHostMalloc((void**)&q.hmeas, sizeof(float) * need, hipHostMallocNonCoherent));
+                HIP_TRY(hipHostMalloc((void**)&q.hcount, sizeof(int32_t) * B * h->lazy_max, hipHostMallocNonCoherent));
+                HIP_TRY(hipHostMalloc((void**)&q.hcmds, sizeof(float) * 2 * h->lazy_max, hipHostMallocNonCoherent));
+                HIP_TRY(hipMalloc(&q.dmeas, sizeof(float) * need));
+                HIP_TRY(hipMalloc(&q.dcount, sizeof(int32_t) * B * h->lazy_max));
+                q.cap = h->lazy_max; q.meas_cap = need;
                 if (!q.copied) {
                     HIP_TRY(hipEventCreateWithFlags(&q.copied, hipEventDisableTiming));
                     HIP_TRY(hipEventCreateWithFlags(&q.used, hipEventDisableTiming));
                 }
             }
             if (q.n == 0 && q.in_use) { HIP_TRY(hipEventSynchronize(q.used)); q.in_use = false; }   // the launch that read this queue is done
-            float* dst = q.hmeas + (size_t)q.n * B * kExtQ * 3;
-            const int kc = k_stride < kExtQ ? k_stride : kExtQ;
+            const int ks = q.ks;
+            float* dst = q.hmeas + (size_t)q.n * B * ks * 3;
+            int32_t* dcnt = q.hcount + (size_t)q.n * B;
+            const int kc = k_stride < ks ? k_stride : ks;   // detections per instance that are packed
             host_parallel(B, [&](size_t b0, size_t b1) {
-                for (size_t b = b0; b < b1; ++b) memcpy(dst + b * kExtQ * 3, meas + b * (size_t)k_stride * 3, sizeof(float) * 3 * kc);
+                for (size_t b = b0; b < b1; ++b) {
+                    // the count is clamped to what was packed, like the immediate path clamps to k_stride: the kernel
+                    // never reads a slot this call did not fill
+                    const int cb = count[b] < 0 ? 0 : (count[b] < kc ? count[b] : kc);
+                    dcnt[b] = cb;
+                    memcpy(dst + b * ks * 3, meas + b * (size_t)k_stride * 3, sizeof(float) * 3 * cb);
+                }
             });
-            memcpy(q.hcount + (size_t)q.n * B, count, sizeof(int32_t) * B);
             q.hcmds[2 * q.n] = cmd[0]; q.hcmds[2 * q.n + 1] = cmd[1];
             q.n += 1;
             return (q.n >= h->lazy_max || eager_flush(h, q.n)) ? flush_ext(h) : SLAM_OK;
@@ -646,6 +665,7 @@ int slam_set_lazy_steps(slam_handle* h, int n) {
     if (!h || n < 0) return fail(SLAM_ERR_ARG, "bad argument");
     FLUSH(h);
     h->lazy_max = n;
+    h->lazy_explicit = true;
     return SLAM_OK;
 }
 
@@ -734,11 +754,12 @@ static int flush_ext(slam_handle* h) {
     if (q.n == 0) return SLAM_OK;
     const int T = q.n;
     const size_t B = (size_t)h->B;
-    q.n = 0;
+    // q.n is reset only after the launch has been enqueued: a failing flush keeps the queued timesteps (and fails again on the
+    // next call) instead of dropping them silently
     HIP_TRY(hipSetDevice(h->device));
     if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipMemcpyAsync(q.dcount, q.hcount, sizeof(int32_t) * B * T, hipMemcpyHostToDevice, h->copy_stream));
-    HIP_TRY(hipMemcpyAsync(q.dmeas, q.hmeas, sizeof(float) * 3 * kExtQ * B * T, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipMemcpyAsync(q.dmeas, q.hmeas, sizeof(float) * 3 * q.ks * B * T, hipMemcpyHostToDevice, h->copy_stream));
     HIP_TRY(hipEventRecord(q.copied, h->copy_stream));
     if (h->cmds_cap < T) {
         if (h->dcmds) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(h->dcmds); h->dcmds = nullptr; }
@@ -750,10 +771,11 @@ static int flush_ext(slam_handle* h) {
     slam::EkfStepParams p;
     fill_params(h, p, q.hcmds);
     p.sim = 0;
-    p.meas_in = q.dmeas; p.meas_count_in = q.dcount; p.k_stride_in = kExtQ;
+    p.meas_in = q.dmeas; p.meas_count_in = q.dcount; p.k_stride_in = q.ks;
     p.cmds = h->dcmds;
     p.T = T;
     HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
+    q.n = 0;
     h->step += (uint32_t)T;
     HIP_TRY(hipEventRecord(q.used, h->stream));
     q.in_use = true;
@@ -765,7 +787,6 @@ static int flush_dev(slam_handle* h) {
     slam_handle::DevQueue& q = h->devq;
     if (q.n == 0) return SLAM_OK;
     const int T = q.n;
-    q.n = 0;
     HIP_TRY(hipSetDevice(h->device));
     if (h->cmds_cap < T) {
         if (h->dcmds) { HIP_TRY(hipStreamSynchronize(h->stream)); hipFree(h->dcmds); h->dcmds = nullptr; }
@@ -780,8 +801,9 @@ static int flush_dev(slam_handle* h) {
     p.meas_in = q.dmeas; p.meas_count_in = q.dcount; p.k_stride_in = q.ks;
     p.cmds = h->dcmds;
     p.T = T;
-    q.cmds.clear();
     HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
+    q.n = 0;               // only now: a failed flush keeps its timesteps
+    q.cmds.clear();
     h->step += (uint32_t)T;
     return SLAM_OK;
 }
@@ -795,7 +817,7 @@ static int flush_lazy(slam_handle* h) {
         std::vector<float> c;
         c.swap(h->lazy_cmds);
         const int rc = run_sim_now(h, c.data(), (int)(c.size() / 2));
-        if (rc) return rc;
+        if (rc) { if (h->lazy_cmds.empty()) h->lazy_cmds.swap(c); return rc; }   // a failed launch keeps the queued commands
     }
     return flush_ext(h);
 }
@@ -1014,6 +1036,32 @@ int slam_k_histogram(slam_handle* h, uint64_t out[8], int reset) {
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram element size");
     HIP_TRY(hipMemcpy(out, h->dkhist, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(h->dkhist, 0, sizeof(uint64_t) * 8));
+    return SLAM_OK;
+}
+
+int slam_traffic_counters(slam_handle* h, uint64_t out[4], int reset) {
+    if (!h || !out) return fail(SLAM_ERR_ARG, "bad argument");
+    if (h->kind != SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "the traffic counters are kept by the EKF step kernels");
+    FLUSH(h);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->dkhist + slam::kEkfTrafficSlot, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->dkhist + slam::kEkfTrafficSlot, 0, sizeof(uint64_t) * 4));
+    return SLAM_OK;
+}
+
+int slam_kernel_info(slam_handle* h, int multi_step, char* name, int name_cap, int32_t out[5]) {
+    if (!h || (!name && !out)) return fail(SLAM_ERR_ARG, "bad argument");
+    if (h->kind != SLAM_EKF_SLAM) return fail(SLAM_ERR_UNSUPPORTED, "EKF handles only");
+    HIP_TRY(hipSetDevice(h->device));
+    slam::EkfKernelInfo ki;
+    HIP_TRY(slam::ekf_kernel_info(h->L_max, h->B, h->waves_per_filter, h->esz == 4, multi_step ? 1 : 0, &ki));
+    if (name && name_cap > 0) { strncpy(name, ki.name, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    if (out) {
+        hipDeviceProp_t pr;
+        HIP_TRY(hipGetDeviceProperties(&pr, h->device));
+        out[0] = ki.lds_bytes; out[1] = ki.vgprs; out[2] = ki.threads; out[3] = ki.wg_per_cu; out[4] = pr.multiProcessorCount;
+    }
     return SLAM_OK;
 }
 

@@ -226,6 +226,23 @@ class BatchedFilter:
         _lib.check(_lib.lib().slam_ukf_sweep_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(bool(reset))))
         return out
 
+    def traffic_counters(self, reset=False):
+        """EKF: device-counted (P-stream bytes read + written by passes, other global bytes, passes, updates applied by passes)
+        since creation / the last reset (slam_traffic_counters)."""
+        self._need(); out = np.zeros(4, dtype=np.uint64)
+        _lib.check(_lib.lib().slam_traffic_counters(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(bool(reset))))
+        return out
+
+    def kernel_info(self, multi_step=True):
+        """EKF: the step-kernel instantiation this handle launches and what the runtime reports about it."""
+        self._need(); name = C.create_string_buffer(128); out = np.zeros(5, dtype=np.int32)
+        _lib.check(_lib.lib().slam_kernel_info(self.h, int(bool(multi_step)), name, 128, _i(out)))
+        return dict(name=name.value.decode(), lds_bytes=int(out[0]), vgprs=int(out[1]), threads=int(out[2]),
+                    workgroups_per_cu=int(out[3]), cus=int(out[4]))
+
+    def set_lazy_steps(self, n):
+        self._need(); _lib.check(_lib.lib().slam_set_lazy_steps(self.h, int(n)))
+
     def sync(self):
         self._need(); _lib.check(_lib.lib().slam_sync(self.h))
 

@@ -34,7 +34,16 @@ def test_single_gpu_line_has_the_contract_fields():
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64" and d["value"] > 1e6
     assert d["config"]["state_rmse_vs_oracle"] == 0.0 and d["config"]["instances_flagged"] == 0
-    assert d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 4.0
+    r = d["roofline"]
+    # physical by construction: bytes the kernel counted on the device / launch duration / peak
+    assert r["bound"] == "hbm" and 0.0 < r["frac"] <= 1.0 and r["traffic"] > 0 and r["peak"] == 8000.0
+    assert abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 0.01 * r["achieved"] + 0.1
+    assert r["kernel"].startswith("ekf_step_kernel<103,") and r["kernel"].endswith(",true>")   # the variant actually launched
+    assert r["lds_bytes_per_workgroup"] > 0 and r["workgroups_per_cu"] >= 1 and r["cycles_per_workgroup_step_at_2p4GHz"] > 0
+    assert 0.0 < r["passes_per_instance_step"] <= 1.0 and 1.0 <= r["updates_per_pass"] <= 4.0
+    o = r["once_per_step"]
+    assert o["launches"] == 5 and 0.0 < o["frac"] <= 1.0 and o["kernel"].endswith(",false>") and o["traffic"] > 0
+    assert "secondary" not in d   # only the default headline configuration carries the secondary lines
 
 
 def test_two_ranks_strong_scaling_on_one_gpu():

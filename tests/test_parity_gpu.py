@@ -494,3 +494,76 @@ def test_step_dev_queued_equals_immediate(S):
         f.close()
     for m, c in msgs:
         hip.hipFree(m); hip.hipFree(c)
+
+
+def test_traffic_counters_count_what_the_kernel_streams(S):
+    """slam_traffic_counters (bench.py's roofline.traffic) against what the algorithm must have moved.  Steady state (every
+    landmark mapped, n = 3 + 2 L, ld = n + 1): with one launch per timestep every instance-step with a detection is exactly one
+    in-place pass over P (2 n ld 8 bytes), a step without one writes only the vehicle rows / columns; in a multi-step launch the
+    deferred groups take FEWER passes for the same number of rank-2 updates.  Updates applied = detections (k histogram)."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, T = 20, 96, 81
+    lm, cmds = make_scenario(31, L, T)
+    n, ld = 3 + 2 * L, 4 + 2 * L
+    res = {}
+    for chunk in (1, 0):
+        f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(3); f.set_instance_offset(40); f.init(0, 0, 0)
+        f.set_vision(1e9, -4.0, 4.0); f.run_sim(cmds[:1]); f.set_vision(3.0, -1.57, 1.57)
+        assert np.all(f.landmark_counts() == L)
+        f.set_run_chunk(chunk)
+        f.k_histogram(reset=True); f.traffic_counters(reset=True)
+        f.run_sim(cmds[1:T])
+        kh = f.k_histogram().astype(np.int64); tc = f.traffic_counters().astype(np.int64)
+        assert kh.sum() == B * (T - 1) and kh[5:].sum() == 0          # this scenario never shows more than KG = 4 landmarks at once
+        dets = int((kh * np.arange(8)).sum())
+        assert tc[3] == dets                                           # every detection is one rank-2 update applied by some pass
+        assert tc[0] == tc[2] * 2 * n * ld * 8                         # a pass reads and writes the n x ld matrix once
+        assert tc[1] > 0
+        if chunk == 1:
+            assert tc[2] == kh[1:].sum()                               # one pass per instance-step that has a detection
+        else:
+            assert 0 < tc[2] < res[1][2] and tc[2] * 4 >= dets         # deferred groups: fewer passes, at most KG updates each
+        res[chunk] = tc
+        f.close()
+    assert res[0][0] < res[1][0]
+
+
+def test_step_dev_is_enqueued_at_the_call_unless_queueing_was_asked_for(S):
+    """slam_step_dev takes caller-owned device buffers on a caller-owned stream, so by default the step is on the
+    stream when the call returns (an event recorded after it covers the kernel); the queue is opt-in (slam_set_lazy_steps)."""
+    import ctypes as C
+    from live_ekf_slam_amd import _lib
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B = 20, 8192
+    lm, cmds = make_scenario(11, L, 12)
+    hip = C.CDLL("libamdhip64.so")
+    st, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0 and hip.hipEventCreate(C.byref(e0)) == 0 and hip.hipEventCreate(C.byref(e1)) == 0
+    dm, dc = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(dm), B * 4 * 3 * 4) == 0 and hip.hipMalloc(C.byref(dc), B * 4) == 0
+    assert hip.hipMemset(dm, 0, B * 4 * 3 * 4) == 0 and hip.hipMemset(dc, 0, B * 4) == 0
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    Lc = _lib.lib()
+    ms = {}
+    for mode in ("default", "queued"):
+        f = S.BatchedEKF(B, L).readParams(); f.set_stream(st.value); f.set_map(lm); f.set_seed(5); f.init(0, 0, 0)
+        if mode == "queued":
+            f.set_lazy_steps(32)
+        f.sync()
+        assert hip.hipEventRecord(e0, st) == 0
+        for t in range(8):
+            cm = np.ascontiguousarray(cmds[t], dtype=np.float32)
+            _lib.check(Lc.slam_step_dev(f.h, fp(cm), dm, dc, 4))
+        assert hip.hipEventRecord(e1, st) == 0 and hip.hipEventSynchronize(e1) == 0
+        # which timestep the DEVICE has reached when the event has fired, without going through a flushing getter:
+        # a raw copy of the handle's timestep array is not part of the ABI, so use the stream itself: after the event,
+        # queued mode has run nothing, default mode all eight steps -> the elapsed time shows it
+        el = C.c_float(0)
+        assert hip.hipEventElapsedTime(C.byref(el), e0, e1) == 0
+        ms[mode] = el.value
+        assert f.get_state(0)["timestep"] == 8   # either way the getter sees all eight steps
+        f.close()
+    assert ms["default"] > 4 * ms["queued"], ms   # eight kernels between the events vs eight small copies
+    for q in (dm, dc):
+        hip.hipFree(q)
+    hip.hipEventDestroy(e0); hip.hipEventDestroy(e1); hip.hipStreamDestroy(st)

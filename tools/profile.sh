@@ -3,15 +3,15 @@
 # itself follows `--`).  Usage (on the box, from the repo root): bash tools/profile.sh <tag> [K W] [extra bench args]
 #   -> gpurun_out/prof_<tag>/ ; copy summary.json / summary.txt / kernel_stats.csv into profiles/<tag>/ afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 K=${2:-20}
 W=${3:-5}
-shift 3 2>/dev/null
+shift $(( $# < 3 ? $# : 3 ))   # (a plain `shift 3` with fewer arguments fails and keeps them all: ADVICE r02)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="bench.py --steps $K --warmup $W --no-cpu-baseline --no-long-runs --no-parity-check $*"
-python3 $ARGS > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+ARGS="bench.py --steps $K --warmup $W --no-cpu-baseline --no-long-runs --no-parity-check --no-once-per-step --no-secondary $*"
+python3 $ARGS > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || { echo "unprofiled bench run failed:"; tail -5 $OUT/bench_unprofiled.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ARGS > $OUT/bench_stats.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ARGS > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $ARGS > $OUT/bench_pmc_write.log 2>&1
