@@ -305,7 +305,7 @@ def main():
     if args.filter == "pgs":
         return finish(bench_pgs(args, torch, dist, rank, local_rank, world, dev), dist, rank, world)
     line = bench_ekf(args, torch, dist, rank, local_rank, world, dev)
-    if world == 1 and line is not None and not args.no_secondary and args.dtype == "f64" and args.landmarks == 50:
+    if world == 1 and line is not None and not args.no_secondary and args.dtype == "f64" and args.landmarks == 50 and args.batch == 65536:
         line["secondary"] = secondary_lines(args, torch, dist, rank, local_rank, world, dev)
     return finish(line, dist, rank, world)
 

@@ -89,6 +89,7 @@ inline std::vector<double> load_fixed_map(const std::string& json_path, const st
     size_t p = txt.find("\"" + name + "\"");
     if (p == std::string::npos) throw std::runtime_error("no map '" + name + "' in " + json_path);
     p = txt.find('[', p);
+    if (p == std::string::npos) throw std::runtime_error("malformed map '" + name + "' in " + json_path);
     std::vector<double> out;
     int depth = 0;
     for (size_t i = p; i < txt.size(); ++i) {
@@ -111,7 +112,11 @@ inline std::vector<double> generate_landmarks(const std::string& map_type, int n
     std::vector<double> lm;
     if (map_type == "demo" || map_type == "igvc1") return load_fixed_map(fixed_maps_json, map_type);
     if (map_type == "random" || map_type == "rand") {
+        // rejection sampling cannot place more landmarks than the region holds at the minimum separation: bound the attempts
+        long attempts = 0;
         while ((int)(lm.size() / 2) < num_landmarks) {
+            if (++attempts > 1000L * (num_landmarks > 0 ? num_landmarks : 1) + 100000L)
+                throw std::runtime_error("generate_landmarks: cannot place that many landmarks at this separation");
             const double x = 2 * o.bound * rng.random() - o.bound;     // sim_node.py:179 (x drawn first)
             const double y = 2 * o.bound * rng.random() - o.bound;
             bool close = false;
@@ -136,6 +141,9 @@ inline std::vector<double> generate_full_trajectory(const std::vector<double>& l
                                                     const ScenarioOptions& o = ScenarioOptions(), double x0 = 0.0, double y0 = 0.0,
                                                     double yaw0 = 0.0) {
     const int L = (int)(landmarks.size() / 2);
+    // the reference's planner indexes its first landmark unconditionally (sim_node.py:90-94: IndexError on an empty map)
+    if (L <= 0) throw std::runtime_error("generate_full_trajectory needs at least one landmark");
+    if (num_iterations < 0) throw std::runtime_error("num_iterations must not be negative");
     const double lo = -o.bound * o.display_region_mult + 1, hi = o.bound * o.display_region_mult - 1;
     std::vector<double> rough(2 * L);
     for (int i = 0; i < L; ++i) {   // planner's noisy copy of the map: 2 draws per landmark, x then y (:82-87)

@@ -19,6 +19,7 @@
 
 #include "../../../include/slam_filter.hpp"
 #include "../../../include/slam_scenario.hpp"
+#include "stream_parse.h"
 
 using namespace slam_amd;
 
@@ -53,26 +54,26 @@ static int run_stream(const std::string& kind, int B, int L, const char* stream_
     int ticks_without_input = 0;
     node.iterate();                                                                     // timer fires before anything arrived: early return
     node.initCallback(0.f, 0.f, 0.f);                                                   // :90-106
+    int lineno = 0;
     while (std::getline(in, line)) {
-        std::istringstream ls(line);
-        std::string first;
-        ls >> first;
-        if (first == "map") {                                                           // the simulator publishes the true map once
-            int Lm; ls >> Lm;
+        lineno += 1;
+        if (line.find_first_not_of(" \t\r") == std::string::npos || line[line.find_first_not_of(" \t")] == '#') continue;
+        slam_host::StreamLine sl;   // the file is untrusted text: bounded counts, finite values (host/stream_parse.h)
+        std::string perr;
+        if (!slam_host::parse_stream_line(line, &sl, &perr))
+            throw std::runtime_error(std::string(stream_path) + ":" + std::to_string(lineno) + ": " + perr);
+        if (sl.is_map) {                                                                // the simulator publishes the true map once
             auto m = std::make_shared<Float32MultiArray>();
-            m->data.resize((size_t)3 * Lm);
-            for (auto& v : m->data) ls >> v;
+            m->data = sl.data;
             if (kind == "ukf_loc" && node.iterate()) throw std::runtime_error("UKF_LOC iterated before the map arrived");
             node.trueMapCallback(m);
             continue;
         }
         auto cmd = std::make_shared<Command>();
-        cmd->fwd = std::strtof(first.c_str(), nullptr);
-        ls >> cmd->ang;
-        int k = 0; ls >> k;
+        cmd->fwd = sl.fwd;
+        cmd->ang = sl.ang;
         auto meas = std::make_shared<Float32MultiArray>();
-        meas->data.resize((size_t)3 * k);
-        for (auto& v : meas->data) ls >> v;
+        meas->data = sl.data;
         // the two topics arrive independently: the command first, a timer tick in between (iterate must wait for the
         // measurement, :109-112), then the measurement
         node.cmdCallback(cmd);

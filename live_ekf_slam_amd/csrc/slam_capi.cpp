@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "capi_internal.h"
+#include "host/config_parse.h"
 #include "ekf_kernel.h"
 #include "slam_math.h"
 #include "ukf_kernel.h"
@@ -220,23 +221,6 @@ int ensure_meas_buffers(slam_handle* h, int k_stride) {
     return SLAM_OK;
 }
 
-bool parse_scalar(const char* line, const char* key, double* out) {
-    // matches "<spaces>key: value [# comment]"
-    const char* p = line;
-    while (*p == ' ' || *p == '\t') ++p;
-    const size_t kl = strlen(key);
-    if (strncmp(p, key, kl) != 0 || p[kl] != ':') return false;
-    p += kl + 1;
-    while (*p == ' ' || *p == '\t') ++p;
-    if (strncmp(p, "true", 4) == 0) { *out = 1.0; return true; }
-    if (strncmp(p, "false", 5) == 0) { *out = 0.0; return true; }
-    char* end = nullptr;
-    const double v = strtod(p, &end);
-    if (end == p) return false;
-    *out = v;
-    return true;
-}
-
 }  // namespace
 
 static int run_sim_now(slam_handle* h, const float* cmds, int T);
@@ -294,39 +278,13 @@ int slam_config_default(slam_config* c) {
 }
 
 // The reference reads one YAML file with nested maps; the keys the hot path needs are unique leaf names
-// except min_landmark_separation (constraints.measurements vs map), disambiguated by section tracking.
+// except min_landmark_separation (constraints.measurements vs map), disambiguated by section tracking.  The reader
+// itself is host/config_parse.h (host-only, also compiled under ASan + UBSan by `make -C oracle asan`).
 int slam_config_load(slam_config* c, const char* path) {
     if (!c || !path) return fail(SLAM_ERR_ARG, "NULL argument");
-    FILE* f = fopen(path, "r");
-    if (!f) return fail(SLAM_ERR_IO, "cannot open %s", path);
-    char line[1024];
-    std::string section;
-    double v;
-    while (fgets(line, sizeof(line), f)) {
-        if (line[0] != ' ' && line[0] != '#' && line[0] != '\n') {  // top-level key
-            char key[128];
-            if (sscanf(line, "%127[^:]:", key) == 1) section = key;
-        }
-        if (parse_scalar(line, "v_d", &v)) c->v_d = (float)v;
-        else if (parse_scalar(line, "v_th", &v)) c->v_th = (float)v;
-        else if (parse_scalar(line, "V_00", &v)) c->V_00 = v;
-        else if (parse_scalar(line, "V_11", &v)) c->V_11 = v;
-        else if (parse_scalar(line, "w_r", &v)) c->w_r = (float)v;
-        else if (parse_scalar(line, "w_b", &v)) c->w_b = (float)v;
-        else if (parse_scalar(line, "W_00", &v)) c->W_00 = v;
-        else if (parse_scalar(line, "W_11", &v)) c->W_11 = v;
-        else if (parse_scalar(line, "landmark_id_is_known", &v)) c->landmark_id_is_known = (int)v;
-        else if (parse_scalar(line, "min_landmark_separation", &v)) { if (section == "constraints") c->min_landmark_separation = (float)v; }
-        else if (parse_scalar(line, "d_max", &v)) c->d_max = v;
-        else if (parse_scalar(line, "th_max", &v)) c->th_max = v;
-        else if (parse_scalar(line, "range_max", &v)) c->range_max = v;
-        else if (parse_scalar(line, "fov_min", &v)) c->fov_min = v;
-        else if (parse_scalar(line, "fov_max", &v)) c->fov_max = v;
-        else if (section == "init_pose" && parse_scalar(line, "x", &v)) c->init_x = v;
-        else if (section == "init_pose" && parse_scalar(line, "y", &v)) c->init_y = v;
-        else if (section == "init_pose" && parse_scalar(line, "yaw", &v)) c->init_yaw = v;
-    }
-    fclose(f);
+    std::string err;
+    const int rc = slam_host::config_parse_file(c, path, &err);
+    if (rc) return fail(SLAM_ERR_IO, "%s", err.c_str());
     return SLAM_OK;
 }
 
