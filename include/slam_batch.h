@@ -44,8 +44,9 @@ enum slam_instance_flags {
     SLAM_INST_NONFINITE = 1,     /* x or P became non-finite                                                    */
     SLAM_INST_S_SINGULAR = 2,    /* zero pivot while inverting the 2x2 innovation covariance (ekf.cpp:135)      */
     SLAM_INST_INDEX_OOR = 4,     /* landmark index outside x_t (ekf.cpp:115 under the duplicate/unknown-id quirk) */
-    SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max, or a message held more than 64 detections; the
-                                    surplus detections were dropped                                              */
+    SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146), or a
+                                    message held more detections than the landmark capacity of the handle's size class (20 / 50 /
+                                    100), which takes repeated ids; the surplus was dropped                      */
     SLAM_INST_SQRT_FAILED = 16   /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
 };
 

@@ -41,7 +41,8 @@ struct EkfGeom {
     static constexpr int TPB = 64 * W;
     static constexpr int LDP = (NMAX + 2) & ~1;          // LDS row length (> NMAX, even)
     static constexpr int LMAX = (NMAX - 3) / 2;
-    static constexpr int KCAP = LMAX > 64 ? 64 : (LMAX > 0 ? LMAX : 1);   // detections held per step (one wavefront associates them)
+    static constexpr int KCAP = LMAX > 0 ? LMAX : 1;     // detections held per step = the landmark capacity: every message without
+                                                         // repeated ids fits (one wavefront associates them, 64 at a time)
     static constexpr int KG = KG_;                       // detections per group
     static constexpr int TS = 3 + 2 * KG;                // thin rows / cols held in LDS
     static constexpr int UNR = UNR_;                     // register pairs in flight per lane in the bulk stream
@@ -375,34 +376,46 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
         if (p.id_known) {
             const int kn = kraw < KCAP ? kraw : KCAP;
-            // lanes scan lm_IDs in parallel for each detection (first match wins, ekf.cpp:102-107); lane l then
-            // keeps the result of detection l
-            int idx = -1;
-            bool isnew = false, dup = false;
-            const int myid = lane < kn ? (int)meas[3 * lane] : -1;
+            // lanes scan lm_IDs in parallel for each detection (first match wins, ekf.cpp:102-107); lane l % 64 then keeps the
+            // result of detection l.  The message is walked 64 detections at a time (ekf.cpp:73 loops over any number of them).
+            int cnt = 0;                    // new ids so far in this message
+            bool anydup = false;
 #pragma unroll 1
-            for (int l = 0; l < kn; ++l) {
-                const int id = (int)meas[3 * l];
-                int found = -1;
+            for (int c0 = 0; c0 < kn; c0 += 64) {
+                int idx = -1;
+                bool isnew = false, dup = false;
+                const int lend = kn - c0 < 64 ? kn - c0 : 64;
 #pragma unroll 1
-                for (int j0 = 0; j0 < M && found < 0; j0 += 64) {
-                    const int j = j0 + lane;
-                    const unsigned long long m = __ballot(j < M && s_ids[j] == id);
-                    if (m != 0ull) found = j0 + (__ffsll((long long)m) - 1);
+                for (int ll = 0; ll < lend; ++ll) {
+                    const int l = c0 + ll;
+                    const int id = (int)meas[3 * l];
+                    int found = -1;
+#pragma unroll 1
+                    for (int j0 = 0; j0 < M && found < 0; j0 += 64) {
+                        const int j = j0 + lane;
+                        const unsigned long long m = __ballot(j < M && s_ids[j] == id);
+                        if (m != 0ull) found = j0 + (__ffsll((long long)m) - 1);
+                    }
+                    // among the NEW ids: has an earlier detection of this message the same id?
+                    bool e = false;
+#pragma unroll 1
+                    for (int q0 = 0; q0 < l && !e; q0 += 64) {
+                        const int q = q0 + lane;
+                        e = __ballot(q < l && (int)meas[3 * (q < l ? q : 0)] == id) != 0ull;
+                    }
+                    if (lane == ll) { idx = found; isnew = found < 0; dup = isnew && e; }
                 }
-                // among the NEW ids: has an earlier detection of this message the same id?
-                const unsigned long long e = __ballot(lane < l && myid == id);
-                if (lane == l) { idx = found; isnew = found < 0; dup = isnew && e != 0ull; }
+                // a repeated NEW id would be found among the ids pushed this step and index x_t out of range
+                // (ekf.cpp:115 -> eigen_assert -> exception, filter.h:5): the reference dies, we freeze.
+                anydup = anydup || __ballot(dup) != 0ull;
+                const unsigned long long nmask = __ballot(isnew);
+                const int rank = cnt + __popcll(nmask & ((1ull << lane) - 1ull));
+                if (isnew) idx = (M + rank < p.L_max && M + rank < LMAX) ? M + rank : -1;
+                if (lane < lend) didx[c0 + lane] = idx;
+                cnt += __popcll(nmask);
             }
-            // a repeated NEW id would be found among the ids pushed this step and index x_t out of range
-            // (ekf.cpp:115 -> eigen_assert -> exception, filter.h:5): the reference dies, we freeze.
-            const unsigned long long dmask = __ballot(dup);
-            const unsigned long long nmask = __ballot(isnew);
-            const int rank = __popcll(nmask & ((1ull << lane) - 1ull));
-            if (isnew) idx = (M + rank < p.L_max && M + rank < LMAX) ? M + rank : -1;
-            if (lane < kn) didx[lane] = idx;
             if (lane == 0) {
-                const int cnt = __popcll(nmask);
+                const unsigned long long dmask = anydup ? 1ull : 0ull;
                 const int room = (p.L_max < LMAX ? p.L_max : LMAX) - M;
                 nx[3] = cnt > room ? 1 : 0;           // capacity overflow
                 nx[1] = cnt > room ? room : cnt;      // insertions
@@ -842,7 +855,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __builtin_amdgcn_s_setprio(SLAM_PRIO_THIN);   // the thin phases are dependent chains: let them issue ahead of other workgroups' streams
     __syncthreads();   // the pre-step results of this timestep are visible
     const int kraw = s_next[4 * pb];
-    if (kraw > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than one wavefront associates
+    if (kraw > KCAP) flags |= SLAM_INST_CAPACITY;   // more detections in one message than the landmark capacity (only possible with repeated ids)
     const int k = kraw < KCAP ? kraw : KCAP;
     if (tid == 0) s_kh[k < 7 ? k : 7] += 1;
     if (p.sim && p.meas_out != nullptr && t == T - 1) {
@@ -1295,8 +1308,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             if (tid < 64) {
                 int fb = 0, lim = KG;
                 if (first && nu > 0) {   // pre-flush decision (see the serial path below for the rules)
-                    const bool isupd = lane < k && didx_t[lane] >= 0 && didx_t[lane] < M;
-                    const int kupd = __popcll(__ballot(isupd));
+                    int kupd = 0;
+#pragma unroll 1
+                    for (int q0 = 0; q0 < k; q0 += 64) {
+                        const int q = q0 + lane;
+                        const bool isupd = q < k && didx_t[q < k ? q : 0] >= 0 && didx_t[q < k ? q : 0] < M;
+                        kupd += __popcll(__ballot(isupd));
+                    }
                     fb = (frz_top || n_ins > 0 || nu + kupd > KG) ? 1 : 0;
                     lim = fb ? KG : KG - nu;
                 }

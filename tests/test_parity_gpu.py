@@ -370,17 +370,25 @@ def test_fp32_storage_variant(S, oracle, L, T, B):
     f.close()
 
 
-def test_large_state_100_landmarks(S, oracle):
-    """n = 203 (L = 100): the streaming kernel has no register-imposed limit on n; only the LDS arrays grow."""
+@pytest.mark.parametrize("first_wide", [0, 1])
+def test_large_state_100_landmarks(S, oracle, first_wide):
+    """n = 203 (L = 100): the streaming kernel has no register-imposed limit on n; only the LDS arrays grow.  first_wide: the
+    first message shows ALL 100 landmarks (the reference loops over any number of detections, ekf.cpp:65,73; until round 3 one
+    wavefront associated at most 64 and flagged the rest SLAM_INST_CAPACITY), later wide looks carry 100 updates in one message."""
     from live_ekf_slam_amd.scenario import make_scenario
     L, T, B = 100, 120, 12
     lm, cmds = make_scenario(77, L, T)
     vis = np.tile([3.0, -1.57, 1.57], (T, 1))
     for t in (2, 30, 60, 90, 110):
-        vis[t] = [7.5, -3.2, 3.2]       # wide looks: many insertions / updates per step, but <= 64 detections
+        vis[t] = [7.5, -3.2, 3.2]       # wide looks: many insertions / updates per step
+    if first_wide:
+        vis[0] = [1e9, -4.0, 4.0]
+        vis[45] = [1e9, -4.0, 4.0]      # 100 updates in one message
     f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(4); f.init(0, 0, 0)
     for t in range(T):
         f.set_vision(*vis[t]); f.update_sim(cmds[t])
+        if first_wide and t == 0:
+            assert np.all(f.landmark_counts() == L) and not f.status().any()
     r = oracle.run_ekf_batch(lm, cmds, B, L, seed=4, nthreads=4, vision=vis)
     assert np.array_equal(f.landmark_counts(), r["M"]) and r["M"].max() > 50
     assert np.array_equal(f.status(), r["flags"])
