@@ -160,6 +160,16 @@ int slam_get_state(slam_handle* h, int instance, double* x, double* P, int32_t* 
 /* UKF only — UKFState.X (ukf.cpp:92-101, UKFState.msg): the sigma points of the last prediction stage, COLUMN-major
  * rows x cols = n x (2n+1) with n = 4 + 2*M at the start of that step; X needs n_max*(2*n_max+1) doubles (may be NULL). */
 int slam_get_sigma_points(slam_handle* h, int instance, double* X, int32_t* rows, int32_t* cols);
+/* publishState EVERY tick at batch speed (the reference's loop is update -> publishState, localization_node.cpp:131-139).
+ * Every getter runs the queued timesteps of the whole batch first, so reading one instance's state after every step call
+ * would force one launch per tick.  After slam_track_instance(h, b) the library runs instance b ALSO in a one-instance shadow
+ * filter - same config, seed, map and global instance id, therefore the same bits (results do not depend on how a batch is
+ * partitioned) - stepped at once at every slam_step / slam_step_sim / slam_step_dev / slam_run_sim call on its own stream, and
+ * slam_get_state(h, b, ...) answers from the shadow while the batch's steps stay queued.  The instance's current state is
+ * copied into the shadow, so tracking may start at any time; instance = -1 switches it off.  EKF handles only (the UKF kinds
+ * launch every step at the call; nothing is queued there).  (slam_step_dev: the shadow's
+ * step waits for what is already enqueued on the handle's stream, since it reads the caller's device buffers.) */
+int slam_track_instance(slam_handle* h, int instance);
 /* Vehicle pose estimate (x, y, yaw) of every instance: [batch][3] (EKFState x_v,y_v,yaw_v). */
 int slam_get_poses(slam_handle* h, double* poses);
 int slam_get_landmark_counts(slam_handle* h, int32_t* M);            /* [batch] */

@@ -57,8 +57,11 @@ public:
     virtual ~Filter() = default;
     // trueMapCallback stores `filter->map = msg->data` (localization_node.cpp:152-156); a batched filter also uploads it
     virtual void setTrueMap(const std::vector<float>& id_x_y) { map = id_x_y; }
-    // Filter::setupStatePublisher(ros::NodeHandle) (filter.h:65) advertises the state topic; without ROS there is nothing to
-    // advertise: publishState() leaves the message payload in `last_state` of the concrete class instead.
+    // Filter::setupStatePublisher(ros::NodeHandle) (filter.h:65) advertises the state topic that publishState() feeds every
+    // tick (localization_node.cpp:139).  Without ROS there is nothing to advertise (publishState() leaves the payload in
+    // `last_state` of the concrete class), but the batched EKF / UKF use the call for what it announces: instance 0's state
+    // will be read after every update, so they start tracking it (slam_track_instance) and the per-tick publishState does not
+    // force one launch per tick for the whole batch.
     virtual void setupStatePublisher() {}
     virtual void readParams(const slam_config& config) = 0;                     // filter.h:59 (YAML::Node there)
     virtual void init(float x_0, float y_0, float yaw_0) = 0;                   // filter.h:60
@@ -93,6 +96,8 @@ public:
         check(slam_config_load(&c, params_yaml.c_str()));
         readParams(c);
     }
+    void setupStatePublisher() override { trackInstance(0); }
+    void trackInstance(int instance) { need(); check(slam_track_instance(h_, instance)); }   // -1 = off
     void init(float x_0, float y_0, float yaw_0) override {
         need();
         check(slam_init(h_, x_0, y_0, yaw_0));

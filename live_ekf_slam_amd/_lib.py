@@ -44,6 +44,7 @@ SIGNATURES = {
     "slam_update_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),
     "slam_get_state": (C.c_int, [_H, C.c_int, _dp, _dp, _ip, _ip, _ip]),
     "slam_get_sigma_points": (C.c_int, [_H, C.c_int, _dp, _ip, _ip]),
+    "slam_track_instance": (C.c_int, [_H, C.c_int]),
     "slam_get_poses": (C.c_int, [_H, _dp]),
     "slam_get_landmark_counts": (C.c_int, [_H, _ip]),
     "slam_get_truth": (C.c_int, [_H, _dp]),
@@ -86,6 +87,24 @@ SIGNATURES = {
     "pgs_last_solve_kernel_ms": (C.c_int, [_H, _dp]),
     "pgs_sync": (C.c_int, [_H]),
     "pgs_timestep": (C.c_int, [_H]),
+    # include/slam_multi.h
+    "slam_shard_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "slam_multi_create": (C.c_int, [C.POINTER(SlamConfig), C.c_int, C.c_int64, C.c_int, C.c_int, _ip, C.c_int, C.POINTER(_H)]),
+    "slam_multi_destroy": (C.c_int, [_H]),
+    "slam_multi_devices": (C.c_int, [_H]),
+    "slam_multi_batch": (C.c_int64, [_H]),
+    "slam_multi_handle": (_H, [_H, C.c_int]),
+    "slam_multi_shard": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "slam_multi_set_seed": (C.c_int, [_H, C.c_uint64]),
+    "slam_multi_set_vision": (C.c_int, [_H, C.c_double, C.c_double, C.c_double]),
+    "slam_multi_set_map": (C.c_int, [_H, _dp, C.c_int]),
+    "slam_multi_init": (C.c_int, [_H, C.c_float, C.c_float, C.c_float]),
+    "slam_multi_step_sim": (C.c_int, [_H, _fp]),
+    "slam_multi_run_sim": (C.c_int, [_H, _fp, C.c_int]),
+    "slam_multi_sync": (C.c_int, [_H]),
+    "slam_multi_error_stats": (C.c_int, [_H, _dp, C.c_int]),
+    "slam_multi_status": (C.c_int, [_H, _ip]),
+    "slam_multi_get_state": (C.c_int, [_H, C.c_int64, _dp, _dp, _ip, _ip, _ip]),
     "slam_last_error": (C.c_char_p, []),
     "slam_version": (C.c_char_p, []),
 }

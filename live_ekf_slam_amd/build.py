@@ -11,10 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslam_hip.so")
-SOURCES = ["ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp", "scenario_capi.cpp"]
+SOURCES = ["ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp", "scenario_capi.cpp", "multi_capi.cpp"]
 HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h",
            "capi_internal.h", "../../include/slam_batch.h", "../../include/slam_pgs.h", "../../include/slam_scenario.hpp",
-           "../../include/slam_filter.hpp", "host/filter_driver.cpp", "host/config_parse.h", "host/stream_parse.h"]
+           "../../include/slam_filter.hpp", "../../include/slam_multi.h", "host/filter_driver.cpp", "host/config_parse.h", "host/stream_parse.h"]
 # Instantiations of the EKF step kernel: (NMAX, W, KG, UNR, f32 storage, PIPE); variant code = PIPE*1000 + W*100 + KG*10 + UNR
 # (ekf_kernel.h).  The release library holds the defaults only (they must match SLAM_DEF_* in ekf_kernel.hip); the sweep
 # set is for tuning sessions: SLAM_SWEEP=1 python -m live_ekf_slam_amd.build --force
@@ -81,7 +81,7 @@ def build_extension(force=False, verbose=False):
             failed.append(name)
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     build_driver()
     return LIB

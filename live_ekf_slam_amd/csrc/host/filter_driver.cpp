@@ -9,6 +9,9 @@
 //   filter_driver run <ekf|ukf> <batch> <L> <steps> [seed]
 //       A BASELINE-style run: map + TSP commands from make_scenario(seed, L, steps) (reference generators, bit-exact), the
 //       measurements generated per instance on the device (slam_run_sim / slam_step_sim); prints the error statistic.
+//   filter_driver run_multi <ekf|ukf> <global batch> <L> <steps> <gpus> [seed] [gather: 0 host concat | 1 RCCL]
+//       The same run with the global batch sharded over <gpus> devices of this node from ONE process (include/slam_multi.h):
+//       contiguous shards, noise keyed by global instance id, no collective until the gather of the error statistics.
 //   filter_driver pose_graph <batch> <L> <steps>
 //       `filter: pose_graph` with the NaiveFilter secondary (localization_node.cpp:62-69,124-131) over the same harness.
 #include <cstdio>
@@ -18,6 +21,7 @@
 #include <sstream>
 
 #include "../../../include/slam_filter.hpp"
+#include "../../../include/slam_multi.h"
 #include "../../../include/slam_scenario.hpp"
 #include "stream_parse.h"
 
@@ -129,6 +133,34 @@ static int run_scenario(const std::string& kind, int B, int L, int T, uint64_t s
     return 0;
 }
 
+// the global batch over several GPUs of the node from this one process (SURVEY.md section 8(e) "Host")
+static int run_multi(const std::string& kind, int64_t B, int L, int T, int gpus, uint64_t seed, int gather_mode) {
+    const Scenario sc = make_scenario(seed, L, T);
+    slam_config cfg;
+    check(slam_config_default(&cfg));
+    std::vector<int> devices(gpus);
+    for (int i = 0; i < gpus; ++i) devices[i] = i;
+    slam_multi* m = nullptr;
+    check(slam_multi_create(&cfg, kind == "ekf" ? SLAM_EKF_SLAM : SLAM_UKF_SLAM, B, L, SLAM_F64, devices.data(), gpus, &m));
+    check(slam_multi_set_map(m, sc.map_xy.data(), L));
+    check(slam_multi_init(m, 0.f, 0.f, 0.f));
+    check(slam_multi_run_sim(m, sc.cmds.data(), T));          // every device: get_cmd + Filter::update for its shard, T ticks
+    check(slam_multi_sync(m));
+    std::vector<double> err((size_t)B);
+    check(slam_multi_error_stats(m, err.data(), gather_mode));   // the one gather of the run
+    std::vector<int32_t> fl((size_t)B);
+    check(slam_multi_status(m, fl.data()));
+    double mean = 0;
+    int flagged = 0;
+    for (int64_t i = 0; i < B; ++i) { mean += err[(size_t)i]; flagged += fl[(size_t)i] != 0; }
+    int64_t f0 = 0, c0 = 0;
+    check(slam_multi_shard(m, gpus - 1, &f0, &c0));
+    std::printf("driver ok: run_multi %s global_batch=%lld gpus=%d gather=%s last_shard=[%lld,+%lld) flagged=%d mean_avg_err=%.9f\n", kind.c_str(),
+                (long long)B, gpus, gather_mode ? "rccl" : "host", (long long)f0, (long long)c0, flagged, mean / (double)B);
+    slam_multi_destroy(m);
+    return 0;
+}
+
 // `filter: "pose_graph"` (params.yaml:11): the node runs a secondary filter first and hands its estimate to the pose
 // graph every tick (localization_node.cpp:124-131); the pose graph solves when timestep+1 >= num_iterations.
 static int run_pose_graph(int B, int L, int T) {
@@ -157,11 +189,18 @@ static int run_pose_graph(int B, int L, int T) {
 int main(int argc, char** argv) {
     try {
         const std::string mode = argc > 1 ? argv[1] : "";
+        if (mode == "run_multi" && argc >= 7)
+            return run_multi(argv[2], atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argc > 7 ? strtoull(argv[7], nullptr, 10) : 1234ull,
+                             argc > 8 ? atoi(argv[8]) : 0);
+        if (mode == "run_multi" && argc >= 7)
+            return run_multi(argv[2], atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argc > 7 ? strtoull(argv[7], nullptr, 10) : 1234ull,
+                             argc > 8 ? atoi(argv[8]) : 0);
         if (mode == "stream" && argc >= 7) return run_stream(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5], argv[6]);
         if (mode == "run" && argc >= 6) return run_scenario(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? strtoull(argv[6], nullptr, 10) : 1234ull);
         if (mode == "pose_graph" && argc >= 5) return run_pose_graph(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
         std::fprintf(stderr, "usage: filter_driver stream <ekf|ukf|ukf_loc> <batch> <L_max> <stream.txt> <dump.bin>\n"
                              "       filter_driver run <ekf|ukf> <batch> <L> <steps> [seed]\n"
+                             "       filter_driver run_multi <ekf|ukf> <global batch> <L> <steps> <gpus> [seed] [gather 0|1]\n"
                              "       filter_driver pose_graph <batch> <L> <steps>\n");
         return 2;
     } catch (const std::exception& e) {

@@ -171,6 +171,10 @@ class BatchedFilter:
         n = self._n(M.value)
         return dict(x=x[:n].copy(), P=P[:n * n].reshape(n, n).copy(), M=M.value, ids=ids[:M.value].copy(), timestep=ts.value)
 
+    def track_instance(self, instance):
+        """publishState(instance) every tick without running the batch's queued steps (slam_track_instance); -1 = off."""
+        self._need(); _lib.check(_lib.lib().slam_track_instance(self.h, int(instance)))
+
     def poses(self):
         self._need(); out = np.zeros((self.batch, 3)); _lib.check(_lib.lib().slam_get_poses(self.h, _d(out))); return out
 

@@ -13,7 +13,7 @@ from live_ekf_slam_amd.config import SlamConfig, default_config
 
 def _declared_symbols():
     out = set()
-    for hdr in ("slam_batch.h", "slam_pgs.h"):
+    for hdr in ("slam_batch.h", "slam_pgs.h", "slam_multi.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         out |= set(re.findall(r"\b((?:slam|pgs)_[a-z_0-9]+)\s*\(", txt))

@@ -108,3 +108,102 @@ def test_cpp_ukf_driver_runs():
     M0, ts, plen, xlen = map(int, m.groups())
     n = 4 + 2 * M0
     assert ts == 80 and plen == n * n and xlen > 0
+
+
+def test_single_process_multi_gpu_entry_points(oracle):
+    """include/slam_multi.h on the one GPU of the box (N = 1, the degenerate plan) and shard invariance: the global batch
+    through slam_multi == the same instances through one plain handle == the oracle keyed by global instance id; the gather of
+    the error statistics by host concatenation (mode 0) and by RCCL all-gather (mode 1) give the same array."""
+    import ctypes as C
+    from live_ekf_slam_amd import _lib
+    from live_ekf_slam_amd.config import default_config
+    from live_ekf_slam_amd.scenario import make_scenario
+    import live_ekf_slam_amd as S
+    Lc = _lib.lib()
+    L, B, T = 20, 96, 90
+    lm, cmds = make_scenario(21, L, T)
+    lm = np.ascontiguousarray(lm, dtype=np.float64); cm = np.ascontiguousarray(cmds, dtype=np.float32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)); fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    cfg = default_config(); m = C.c_void_p(); dev = (C.c_int32 * 1)(0)
+    _lib.check(Lc.slam_multi_create(C.byref(cfg), S.EKF_SLAM, B, L, S.F64, dev, 1, C.byref(m)))
+    assert Lc.slam_multi_devices(m) == 1 and Lc.slam_multi_batch(m) == B
+    _lib.check(Lc.slam_multi_set_seed(m, 77)); _lib.check(Lc.slam_multi_set_map(m, dp(lm), L)); _lib.check(Lc.slam_multi_init(m, 0.0, 0.0, 0.0))
+    _lib.check(Lc.slam_multi_run_sim(m, fp(cm), T - 1)); _lib.check(Lc.slam_multi_step_sim(m, fp(cm[T - 1]))); _lib.check(Lc.slam_multi_sync(m))
+    e0, e1 = np.zeros(B), np.zeros(B); fl = np.zeros(B, dtype=np.int32)
+    _lib.check(Lc.slam_multi_error_stats(m, dp(e0), 0))
+    _lib.check(Lc.slam_multi_error_stats(m, dp(e1), 1))      # RCCL: ncclCommInitAll over the one device + ncclAllGather
+    _lib.check(Lc.slam_multi_status(m, ip(fl)))
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=77, inst0=0, nthreads=8)
+    assert np.array_equal(e0, r["avg_err"]) and np.array_equal(e1, e0) and np.array_equal(fl, r["flags"])
+    nmax = 3 + 2 * L
+    for g in (0, 41, B - 1):
+        x = np.zeros(nmax); P = np.zeros(nmax * nmax); M = C.c_int32(); ts = C.c_int32(); ids = np.zeros(L, dtype=np.int32)
+        _lib.check(Lc.slam_multi_get_state(m, g, dp(x), dp(P), C.byref(M), ip(ids), C.byref(ts)))
+        n = 3 + 2 * int(r["M"][g])
+        assert M.value == r["M"][g] and ts.value == T and np.array_equal(x[:n], r["x"][g, :n]) and np.array_equal(P[:n * n], r["P"][g, :n * n])
+    # a shard of a larger plan: shard 1 of 3 over the same global batch, run through a plain handle, equals the slice
+    f1, c1 = C.c_int64(), C.c_int64()
+    _lib.check(Lc.slam_shard_range(B, 1, 3, C.byref(f1), C.byref(c1)))
+    f = S.BatchedEKF(int(c1.value), L).readParams(); f.set_map(lm); f.set_seed(77); f.set_instance_offset(int(f1.value)); f.init(0, 0, 0)
+    f.run_sim(cmds)
+    assert np.array_equal(f.error_stats(), e0[f1.value:f1.value + c1.value])
+    f.close()
+    _lib.check(Lc.slam_multi_destroy(m))
+
+
+def test_cpp_driver_run_multi():
+    out = subprocess.run([EXE, "run_multi", "ekf", "4096", "20", "60", "1", "1234", "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    a = re.search(r"mean_avg_err=([0-9.eE+-]+)", out.stdout)
+    out2 = subprocess.run([EXE, "run", "ekf", "4096", "20", "60", "1234"], capture_output=True, text=True, timeout=600)
+    b = re.search(r"mean_avg_err=([0-9.eE+-]+)", out2.stdout)
+    assert a and b and a.group(1) == b.group(1), (out.stdout, out2.stdout)
+    assert "flagged=0" in out.stdout and "gpus=1" in out.stdout
+
+
+def test_publish_state_every_tick_from_the_tracked_instance(oracle):
+    """The reference's loop is update -> publishState every tick (localization_node.cpp:131-139).  With slam_track_instance the
+    published instance runs in a one-instance shadow and slam_get_state answers from it while the batch's steps stay queued:
+    every tick's state must be bit-identical to the oracle's (and so to a run that flushes the whole batch every tick), for
+    the host-message entry point and for the device generator, with tracking switched on in the middle of a run."""
+    import ctypes as C
+    import live_ekf_slam_amd as S
+    from live_ekf_slam_amd import _lib
+    g = load_golden("sim_seed1234_L50_T400.npz")
+    L, B, T = 50, 256, 150
+    f = S.BatchedEKF(B, L).readParams(); f.init(0, 0, 0)
+    f.set_lazy_steps(32)
+    o = oracle.OracleEKF(L_max=L); o.init(0, 0, 0)
+    inst = 5
+    flushes = 0
+    for t in range(T):
+        if t == 20:
+            f.track_instance(inst)          # mid-run: the instance's current state is copied into the shadow
+        k = int(g["meas_count"][t])
+        f.update(g["cmds"][t], g["meas"][t, :k])
+        o.update(g["cmds"][t, 0], g["cmds"][t, 1], g["meas"][t, :k])
+        if t >= 20:
+            sg, so = f.get_state(inst), o.state()          # publishState(inst) every tick
+            assert sg["M"] == so["M"] and sg["timestep"] == t + 1
+            assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"]), t
+    # the batch itself: every instance got the same messages, so all of them equal the oracle at the end
+    for b in (0, inst, B - 1):
+        sg, so = f.get_state(b), o.state()
+        assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"])
+    f.track_instance(-1)
+    f.close()
+    # device generator + per-instance noise: the shadow is keyed by the GLOBAL instance id
+    from live_ekf_slam_amd.scenario import make_scenario
+    lm, cmds = make_scenario(3, 20, 80)
+    f = S.BatchedEKF(128, 20).readParams(); f.set_map(lm); f.set_seed(9); f.set_instance_offset(1000); f.init(0, 0, 0)
+    f.track_instance(77)
+    for t in range(80):
+        f.update_sim(cmds[t])
+        if t % 7 == 0 or t == 79:
+            r = oracle.run_ekf_batch(lm, cmds[:t + 1], 1, 20, seed=9, inst0=1077)
+            sg = f.get_state(77); n = 3 + 2 * int(r["M"][0])
+            assert sg["M"] == r["M"][0] and np.array_equal(sg["x"], r["x"][0, :n]) and np.array_equal(sg["P"].ravel(), r["P"][0, :n * n])
+    r = oracle.run_ekf_batch(lm, cmds, 128, 20, seed=9, inst0=1000, nthreads=8)
+    assert np.array_equal(f.error_stats(), r["avg_err"])
+    f.close()

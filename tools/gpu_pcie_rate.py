@@ -43,6 +43,7 @@ for i in range(K):   # every step's message resident on the device: the GPU time
     hip.hipMemcpy(a_, rec[i][0].ctypes.data_as(C.c_void_p), B * KS * 12, 1); hip.hipMemcpy(b_, rec[i][1].ctypes.data_as(C.c_void_p), B * 4, 1)
     dms.append(a_); dcs.append(b_)
 g2 = fresh()
+g2.set_lazy_steps(32)   # the queue of slam_step_dev is opt-in (round 3): by default every call enqueues its step at once
 import time as _t
 def run2(label, fn, flt):
     flt.sync(); t0 = _t.perf_counter(); hostt = 0.0
@@ -68,7 +69,21 @@ g4.close()
 g5 = fresh()
 run2("slam_step_sim over the same steps", lambda i: _lib.check(Lc.slam_step_sim(g5.h, fp(cm[20 + i]))), g5)
 g5.close()
+f.set_lazy_steps(32)
 run("slam_step_dev (one msg repeated)", lambda i: _lib.check(Lc.slam_step_dev(f.h, fp(cm[140 + i]), dm, dc, KS)))
+# ---- the reference's loop: update -> publishState every tick (localization_node.cpp:131-139) ----
+def tick_loop(label, flt, track):
+    if track: flt.track_instance(0)
+    for i in range(2): _lib.check(Lc.slam_step(flt.h, fp(cm[20 + i]), fp(rec[i][0]), ip(rec[i][1]), KS)); flt.sync()
+    n = K - 2
+    flt.sync(); t0 = _t.perf_counter()
+    for i in range(n):
+        _lib.check(Lc.slam_step(flt.h, fp(cm[22 + i]), fp(rec[2 + i][0]), ip(rec[2 + i][1]), KS))
+        st = flt.publishState(0)
+    flt.sync(); dt = _t.perf_counter() - t0
+    print(f"{label:34s} {dt / n * 1e3:7.3f} ms/step  {B * n / dt / 1e6:6.2f} M steps/s   (last published timestep {st['timestep']})")
+g6 = fresh(); tick_loop("slam_step + publishState(0), tracked", g6, True); g6.close()
+g7 = fresh(); tick_loop("slam_step + publishState(0), flushing", g7, False); g7.close()
 kmax = max(int(r[1].max()) for r in rec)
 print(f"caller buffers per step: {B * KS * 12 / 1e6:.1f} MB measurements (stride {KS}) + {B * 4 / 1e6:.2f} MB counts in pageable host memory; "
       f"slam_step packs them to stride max(count) = {kmax} into pinned staging and copies on its own stream")
