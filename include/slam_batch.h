@@ -47,7 +47,10 @@ enum slam_instance_flags {
     SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146), or a
                                     message held more detections than the landmark capacity of the handle's size class (20 / 50 /
                                     100), which takes repeated ids; the surplus was dropped                      */
-    SLAM_INST_SQRT_FAILED = 16   /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
+    SLAM_INST_SQRT_FAILED = 16,  /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
+    SLAM_INST_WATCHDOG = 32      /* EKF: a polling loop of the step kernel's intra-workgroup protocol exceeded its budget (~0.1 s);
+                                    the instance is frozen with an undefined state instead of hanging the GPU.  Never seen on a
+                                    correct build (tests/test_ring_protocol_model.py checks the protocol exhaustively)            */
 };
 
 /* Flat mirror of the YAML keys the hot path reads (ekf_ws/src/base_pkg/config/params.yaml; key names kept).
@@ -139,6 +142,9 @@ int slam_step_sim(slam_handle* h, const float cmd[2]);
  * only the speed — and the moment the work reaches the stream (see slam_step).  Calling it also switches the queue of
  * slam_step_dev on (n > 1) or off. */
 int slam_set_lazy_steps(slam_handle* h, int n);
+/* Timesteps the per-tick entry points have accepted but not yet enqueued on the handle's stream (0 = everything the caller
+ * asked for is on the stream: an event recorded now covers it). */
+int slam_queued_steps(const slam_handle* h);
 /* T consecutive slam_step_sim calls; cmds = [T][2] float32 host array (precomputed trajectory,
  * sim_node.py:142-152). */
 int slam_run_sim(slam_handle* h, const float* cmds, int T);

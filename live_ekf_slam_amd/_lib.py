@@ -39,6 +39,7 @@ SIGNATURES = {
     "slam_step_dev": (C.c_int, [_H, _fp, C.c_void_p, C.c_void_p, C.c_int]),
     "slam_step_sim": (C.c_int, [_H, _fp]),
     "slam_set_lazy_steps": (C.c_int, [_H, C.c_int]),
+    "slam_queued_steps": (C.c_int, [_H]),
     "slam_run_sim": (C.c_int, [_H, _fp, C.c_int]),
     "slam_predict": (C.c_int, [_H, _fp]),
     "slam_update_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),

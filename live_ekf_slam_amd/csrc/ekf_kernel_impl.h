@@ -841,6 +841,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     SLAM_STAMP(1);   // measurements, association, motion scalars of the first step
 
     // a freezing instance leaves both loops and writes its PRE-step state below (the reference node died at that step)
+    bool wd_fired = false;
     int frz_at = -1, frz_M = 0, frz_n = 0;
     const ST* frz_P = nullptr;
 #pragma unroll 1
@@ -900,6 +901,17 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             __syncthreads();
             auto ld_i = [](int* q) -> int { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
             auto st_i = [](int* q, int v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+            // WATCHDOG.  Every polling loop below counts its polls; one that exceeds the budget (~0.1 s: thousands of passes)
+            // raises s_ring[2], every other loop sees that and leaves, and the instance is flagged SLAM_INST_WATCHDOG and frozen
+            // instead of hanging the GPU.  tests/test_ring_protocol_model.py checks the protocol itself exhaustively; this is the
+            // net under it (one tuning variant did deadlock in round 2).  p.dbg & 128 (tests only) makes the pass leader lose its
+            // `applied` update so that the control wavefront starves.
+            constexpr int kSpinBudget = 1 << 21;
+            auto spin_over = [&](int& spins) -> bool {
+                spins += 1;
+                if (spins > kSpinBudget) st_i(&s_ring[2], 1);
+                return ld_i(&s_ring[2]) != 0;
+            };
             if (tid < 64) {
                 // ------------------------------------------------ CONTROL ------------------------------------------------
                 __builtin_amdgcn_s_setprio(3);
@@ -929,7 +941,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         // must end first (P is half-updated meanwhile), and no new one may start during the gather.
                         if (lane == 0) st_i(&s_ring[6], 1);                          // hold
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                        while (ld_i(&s_ring[7])) __builtin_amdgcn_s_sleep(1);        // pass in flight
+                        for (int sp = 0; ld_i(&s_ring[7]) && !spin_over(sp);) __builtin_amdgcn_s_sleep(1);   // pass in flight
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         const int app = ld_i(&s_ring[1]);
                         // two slots (the row and column pair of one landmark) per trip: their row and column loads are issued together, one HBM round
@@ -1072,7 +1084,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         double H[8], Si[4], nu0, nu1;
                         if (!leader_chain(ii, si, r_m, b_m, H, nu0, nu1, Si)) fl_or |= SLAM_INST_S_SINGULAR;
                         SLAM_STAMP(20);  // scalar chain of the update
-                        while (pub - ld_i(&s_ring[1]) >= KG) __builtin_amdgcn_s_sleep(SLAM_SLEEP_RING);   // a free slot in the ring
+                        for (int sp = 0; pub - ld_i(&s_ring[1]) >= KG && !spin_over(sp);) __builtin_amdgcn_s_sleep(SLAM_SLEEP_RING);   // a free slot in the ring
+                        if (ld_i(&s_ring[2])) break;   // watchdog
                         SLAM_STAMP(21);  // waiting for a ring slot
                         const int slot = pub % KG;
                         double2* __restrict__ HPu = s_HP + slot * HPW;
@@ -1111,6 +1124,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         // thin copies follow the same downdate  P -= K (H P)
                         thin_downdate(lane, 64, 0, 1, nTq, n, Ku, HPu);
                     }
+                    if (ld_i(&s_ring[2])) break;   // watchdog fired: the instance is frozen below
                     SLAM_STAMP(23);  // thin downdates (+ loop)
                     // ---- end of the step: error statistic, x_t = x_pred (ekf.cpp:176), storage rounding ----
                     if (p.sim && lane == 0) {   // plotting_node.py:209-212 with the float32 wire format of EKFState.x_v / y_v
@@ -1151,7 +1165,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     SLAM_STAMP(24);  // end of step
                     if (tt >= T) break;
                     if constexpr (kGen) {   // the measurements of timestep tt come from the generator wavefront
-                        while (ld_i(&s_sim[0]) <= tt) __builtin_amdgcn_s_sleep(1);
+                        for (int sp = 0; ld_i(&s_sim[0]) <= tt && !spin_over(sp);) __builtin_amdgcn_s_sleep(1);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     prestep(tt);
@@ -1163,6 +1177,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     s_ring[5] = fl_or;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     st_i(&s_ring[3], 1);   // exit: the streamers drain the ring and leave
+                    if (ld_i(&s_ring[2])) st_i(&s_ring[6], 0);   // watchdog: never leave a hold behind
                 }
                 __builtin_amdgcn_s_setprio(0);
             } else {
@@ -1174,6 +1189,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 constexpr int kPassMinCfg = kWide ? SLAM_PASS_MIN : SLAM_PASS_MIN_F32;
                 constexpr int kPassMin = kPassMinCfg < KG ? kPassMinCfg : KG;
                 int seen = 0;   // passes this wavefront has taken part in
+                int sp = 0;     // polls since this wavefront last made progress (watchdog)
 #pragma unroll 1
                 for (;;) {
                     if (leader) {
@@ -1181,6 +1197,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         bool stop = false;
 #pragma unroll 1
                         for (;;) {
+                            if (spin_over(sp)) { stop = true; break; }   // watchdog: tell the other streamers to leave
                             app = ld_i(&s_ring[1]);
                             pend = ld_i(&s_ring[0]) - app;
                             const int ex = ld_i(&s_ring[3]);
@@ -1229,7 +1246,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                             st_i(&s_pass[0], seen + 1);
                         }
                     }
-                    while (ld_i(&s_pass[0]) <= seen) {
+                    while (ld_i(&s_pass[0]) <= seen && !spin_over(sp)) {
                         if constexpr (kGen && W >= 3) {
                             if ((tid >> 6) == W - 1) {   // between passes: run the measurement generator ahead of the filter
                                 const int ts = ld_i(&s_sim[0]);
@@ -1244,9 +1261,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         __builtin_amdgcn_s_sleep(SLAM_SLEEP_PASS);
                     }
                     seen += 1;
+                    sp = 0;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const int lo = ld_i(&s_pass[1]), cnt = ld_i(&s_pass[2]);
-                    if (cnt < 0) break;
+                    if (cnt < 0 || ld_i(&s_ring[2])) break;
                     PassArgs pa;
                     pa.src = Pbuf; pa.dst = Pbuf; pa.mid = nullptr;
                     pa.nf = n; pa.ldd = ldn; pa.lds = ldn; pa.nsrc = n; pa.nu = cnt; pa.lo = lo;
@@ -1254,15 +1272,20 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wavefront's stores of the pass have landed
                     if (lane == 0) atomicAdd(&s_pass[3], 1);
                     if (leader) {
-                        while (ld_i(&s_pass[3]) < NS) __builtin_amdgcn_s_sleep(1);
+                        while (ld_i(&s_pass[3]) < NS && !spin_over(sp)) __builtin_amdgcn_s_sleep(1);
+                        sp = 0;
                         if (lane == 0) {
-                            st_i(&s_ring[1], lo + cnt);   // the ring slots are free, P holds these updates
-                            st_i(&s_ring[7], 0);
+                            if (!(p.dbg & 128)) st_i(&s_ring[1], lo + cnt);   // the ring slots are free, P holds these updates
+                            st_i(&s_ring[7], 0);                               // (dbg & 128, tests only: lose the update -> the watchdog must fire)
                         }
                     }
                 }
             }
             __syncthreads();
+            if (s_ring[2]) {   // the watchdog fired: P is half-updated; flag and freeze the instance (later launches skip it)
+                wd_fired = true;
+                break;
+            }
             // back to the synchronised path: everything published is in P; write what the loop left aside
             nu = 0;
             flags |= s_ring[5];
@@ -1793,6 +1816,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     SLAM_STAMP(10);   // end of step: x_t = x_pred, flags, stamps
     }   // timestep loop
 
+    if (wd_fired) {
+        finish(0, M, flags | SLAM_INST_WATCHDOG | SLAM_INST_INDEX_OOR, true);
+        return;
+    }
     if (frz_at >= 0) {   // pre-step state of the frozen instance into the buffer the host reads next
         __syncthreads();
         if (Pfinal != frz_P) {

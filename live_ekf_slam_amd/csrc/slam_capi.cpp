@@ -115,6 +115,7 @@ struct slam_handle {
         bool in_use = false;
     } extq[2];
     int extq_cur = 0;
+    int extq_ks = 2;                                                                 // stride of the next fill: largest message seen so far
     // slam_step_dev (EKF, DEVICE measurements): the same queueing.  The message is copied device-to-device into the queue on
     // the compute stream at the call (so the caller may overwrite its buffers in stream order, as with an immediate launch)
     // and up to lazy_max of them run as one multi-step launch.  One buffer suffices: copies and launches share the stream.
@@ -323,7 +324,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     env = getenv("SLAM_DEBUG_FLAGS");   // 4 / 32: phase and per-step timers.  The ablation bits (1, 2, 16: WRONG results) are
     if (env) h->dbg = atoi(env);        // compiled out of the release kernels (-DSLAM_ABLATE builds only)
 #ifndef SLAM_ABLATE
-    h->dbg &= (4 | 32);
+    h->dbg &= (4 | 32 | 128);
 #endif
     env = getenv("SLAM_UKF_SPLIT_MIN");   // batch size from which UKF run_sim splits the batch over two streams
     if (env) h->ukf_split_min = atoi(env);
@@ -549,13 +550,20 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
         kmax = kmax < k_stride ? kmax : k_stride;
         if (kmax <= kExtQ) {
             if (!h->lazy_cmds.empty() || h->devq.n > 0) FLUSH(h);   // steps queued through the other entry points run first
-            // a fill of the queue has ONE stride (detections per instance): that of its first message, at least 2; a later message
-            // with more detections ends the fill (the queued steps run) and starts one with the larger stride
-            if (h->extq[h->extq_cur].n > 0 && kmax > h->extq[h->extq_cur].ks) FLUSH(h);
+            // a fill of the queue has ONE stride (detections per instance): the largest message this handle has seen so far, at
+            // least 2 (a high-water mark: a stride per fill taken from its first message ended fills early whenever a larger
+            // message followed, 46 instead of 65 M steps/s); a message above the mark ends the fill and raises it
+            if (kmax > h->extq_ks) {
+                if (h->extq[h->extq_cur].n > 0) FLUSH(h);
+                h->extq_ks = kmax;
+            }
             slam_handle::ExtQueue& q = h->extq[h->extq_cur];
-            if (q.n == 0) q.ks = kmax < 2 ? 2 : kmax;
-            const size_t need = (size_t)3 * q.ks * B * h->lazy_max;
-            if (q.cap < h->lazy_max || q.meas_cap < need) {   // sized from the strides actually seen, not for kExtQ up front
+            if (q.n == 0) q.ks = h->extq_ks;
+            // capacity: the full stride kExtQ at once while that stays below 128 MB per queue (re-pinning 100 MB of host memory
+            // costs ~40 ms each time the stride grows: 0.5 ms per step over a 300-step run); above that, the stride actually seen
+            const size_t full = (size_t)3 * kExtQ * B * h->lazy_max;
+            const size_t need = sizeof(float) * full <= ((size_t)128 << 20) ? full : (size_t)3 * q.ks * B * h->lazy_max;
+            if (q.cap < h->lazy_max || q.meas_cap < need) {
                 if (q.n > 0) FLUSH(h);
                 if (q.in_use) { HIP_TRY(hipEventSynchronize(q.used)); q.in_use = false; }
                 if (q.hmeas) { hipHostFree(q.hmeas); hipHostFree(q.hcount); hipHostFree(q.hcmds); hipFree(q.dmeas); hipFree(q.dcount); }
@@ -662,6 +670,11 @@ int slam_step_sim(slam_handle* h, const float cmd[2]) {
     FLUSH(h);
     HIP_TRY(hipSetDevice(h->device));
     return launch_step(h, cmd, 1, nullptr, nullptr, 0);
+}
+
+int slam_queued_steps(const slam_handle* h) {
+    if (!h) return 0;
+    return (int)(h->lazy_cmds.size() / 2) + h->extq[h->extq_cur].n + h->devq.n;
 }
 
 int slam_set_lazy_steps(slam_handle* h, int n) {
@@ -1064,7 +1077,7 @@ int slam_set_debug_flags(slam_handle* h, int flags) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
 #ifndef SLAM_ABLATE
-    flags &= (4 | 32);
+    flags &= (4 | 32 | 128);   // 128: tests only, provokes the watchdog of the EKF step kernel
 #endif
     if ((flags & (4 | 32)) && !h->dprof) {
         const size_t bytes = sizeof(unsigned long long) * slam::kEkfProfSlots * (size_t)h->B;

@@ -228,9 +228,13 @@ def ukf_sqrt_probe(P, scale):
     return out, sweeps
 
 
-def run_ukf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, nthreads=1, want_P=True, vision=None, loc=False):
+def run_ukf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MATH_DET, nthreads=1, want_P=True, vision=None, loc=False,
+                  ref_order=False):
+    """ref_order: reference-order arithmetic (no fused multiply-adds, textbook Jacobi parameters, cold start every step) instead
+    of the device-order evaluation the GPU parity tests compare with bit for bit."""
     cfg = (cfg or default_config()).copy()
     cfg.reserved[0] = 1 if loc else 0
+    cfg.reserved[1] = 1 if ref_order else 0
     map_xy = np.ascontiguousarray(map_xy, dtype=np.float64); cmds = np.ascontiguousarray(cmds, dtype=np.float32)
     L, T, nmax = map_xy.shape[0], cmds.shape[0], 4 + 2 * L_max
     x = np.zeros((B, nmax)); P = np.zeros((B, nmax * nmax)) if want_P else None

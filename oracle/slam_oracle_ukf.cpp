@@ -37,7 +37,13 @@ using namespace orc;
 //               timestep; the small-element rule applies from the first sweep (the off-diagonal part is a small
 //               perturbation from the start), and a few sweeps instead of 8-10 reach convergence.
 constexpr int kUkfWarmMaxAge = 100;   // consecutive warm starts before a cold one (bounds the loss of orthogonality in V)
-int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = false) {
+// refmode = true: REFERENCE-ORDER arithmetic, independent of the device's instruction selection - no fused
+// multiply-adds (the reference's catkin build has no FMA contraction: -std=c++17 only => SSE2), the textbook rotation parameters
+// tau = (a_qq - a_pp) / (2 a_pq), t = sign(tau) / (|tau| + sqrt(tau^2 + 1)), c = 1 / sqrt(t^2 + 1), s = t c.  The default mode
+// (false) evaluates the same mathematics the way the kernel does (fused products, tau-free parameters) so that GPU == oracle
+// is a bit-exact statement; tests/test_oracle_ukf.py bounds the difference between the two over long trajectories.
+static inline double mul_add(bool refmode, double a, double b, double c) { return refmode ? a * b + c : std::fma(a, b, c); }
+int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = false, bool refmode = false) {
     const int m = n / 2;
     std::vector<int> pp(m), qq(m);
     std::vector<double> cs(m), sn(m), tn(m);
@@ -71,8 +77,13 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
                     // (three dependent sqrt / div instead of five; the device's critical path per round).  Products that feed
                     // an addition are fused (std::fma) here and in the rotations below, as the kernel evaluates them.
                     const double d = aqq - app, b2 = 2.0 * apq;
-                    const double h = sqrt(std::fma(d, d, b2 * b2));
-                    if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
+                    const double h = refmode ? sqrt(d * d + b2 * b2) : sqrt(std::fma(d, d, b2 * b2));
+                    if (refmode && h > 0.0) {
+                        const double tau = d / b2;
+                        tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(tau * tau + 1.0));
+                        c = 1.0 / sqrt(tt * tt + 1.0);
+                        s = tt * c;
+                    } else if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
                         const double w = fabs(d) + h;
                         // sign of t = sign of tau = d / (2 a_pq), +1 at d = 0 exactly (equal diagonal entries are common: every
                         // landmark enters P with the same W block; letting the sign follow a_pq there made clusters of equal
@@ -94,10 +105,10 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
                     const double cj = cs[j], sj = sn[j];
                     const double b00 = A[(size_t)pi * n + pj], b01 = A[(size_t)pi * n + qj];
                     const double b10 = A[(size_t)qi * n + pj], b11 = A[(size_t)qi * n + qj];
-                    const double t00 = std::fma(ci, b00, -(si * b10)), t01 = std::fma(ci, b01, -(si * b11));
-                    const double t10 = std::fma(si, b00, ci * b10), t11 = std::fma(si, b01, ci * b11);
-                    const double r00 = std::fma(t00, cj, -(t01 * sj)), r01 = std::fma(t00, sj, t01 * cj);
-                    const double r10 = std::fma(t10, cj, -(t11 * sj)), r11 = std::fma(t10, sj, t11 * cj);
+                    const double t00 = mul_add(refmode, ci, b00, -(si * b10)), t01 = mul_add(refmode, ci, b01, -(si * b11));
+                    const double t10 = mul_add(refmode, si, b00, ci * b10), t11 = mul_add(refmode, si, b01, ci * b11);
+                    const double r00 = mul_add(refmode, t00, cj, -(t01 * sj)), r01 = mul_add(refmode, t00, sj, t01 * cj);
+                    const double r10 = mul_add(refmode, t10, cj, -(t11 * sj)), r11 = mul_add(refmode, t10, sj, t11 * cj);
                     A[(size_t)pi * n + pj] = r00; A[(size_t)pj * n + pi] = r00;
                     A[(size_t)pi * n + qj] = r01; A[(size_t)qj * n + pi] = r01;
                     A[(size_t)qi * n + pj] = r10; A[(size_t)pj * n + qi] = r10;
@@ -107,8 +118,8 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
             for (int i = 0; i < m; ++i) {  // diagonal blocks
                 const int p = pp[i], q = qq[i];
                 const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q], apq = A[(size_t)q * n + p];
-                A[(size_t)p * n + p] = std::fma(-tn[i], apq, app);
-                A[(size_t)q * n + q] = std::fma(tn[i], apq, aqq);
+                A[(size_t)p * n + p] = mul_add(refmode, -tn[i], apq, app);
+                A[(size_t)q * n + q] = mul_add(refmode, tn[i], apq, aqq);
                 if (apq != 0.0) { A[(size_t)q * n + p] = 0.0; A[(size_t)p * n + q] = 0.0; }   // rotated away, or tiny (zr[i])
             }
             for (int i = 0; i < m; ++i) {  // V <- V J
@@ -116,8 +127,8 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
                 const double c = cs[i], s = sn[i];
                 for (int k = 0; k < n; ++k) {
                     const double vp = V[(size_t)k * n + p], vq = V[(size_t)k * n + q];
-                    V[(size_t)k * n + p] = std::fma(c, vp, -(s * vq));
-                    V[(size_t)k * n + q] = std::fma(s, vp, c * vq);
+                    V[(size_t)k * n + p] = mul_add(refmode, c, vp, -(s * vq));
+                    V[(size_t)k * n + q] = mul_add(refmode, s, vp, c * vq);
                 }
             }
         }
@@ -184,7 +195,9 @@ struct Ukf {
         // Warm start (an implementation choice of this build, not of the reference: Eigen's solver has no such notion;
         // the mathematical result Qv sqrt(D+) Qv^T is the same): rotate into the previous step's eigenbasis, extended by
         // the identity for landmarks inserted since.  T = Y V0, B = V0^T T, sums in ascending k.
-        const bool warm = v_age >= 0 && v_age < kUkfWarmMaxAge && n_sq > 0 && n_sq <= nn;
+        // reference-order mode (cfg.reserved[1] = 1): cold start every step, like Eigen's solver, and unfused arithmetic throughout
+        const bool refmode = cfg.reserved[1] == 1;
+        const bool warm = !refmode && v_age >= 0 && v_age < kUkfWarmMaxAge && n_sq > 0 && n_sq <= nn;
         if (warm) {
             for (int r = 0; r < nn; ++r)
                 for (int c = 0; c < nn; ++c) V[(size_t)r * nn + c] = (r < n_sq && c < n_sq) ? Vprev[(size_t)r * n_sq + c] : (r == c ? 1.0 : 0.0);
@@ -202,7 +215,7 @@ struct Ukf {
                     Y[(size_t)r * nn + c] = acc; Y[(size_t)c * nn + r] = acc;
                 }
         }
-        const int sweeps = jacobi_round_robin(Y.data(), V.data(), nn, 60, warm);
+        const int sweeps = jacobi_round_robin(Y.data(), V.data(), nn, 60, warm, refmode);
         last_sweeps = sweeps;
         if (sweeps >= 0) { Vprev = V; v_age = warm ? v_age + 1 : 0; } else { v_age = -1; }
         if (sweeps < 0) {
@@ -264,7 +277,7 @@ struct Ukf {
                 // each term fused: acc = fma(w_i d_r, d_c, acc).  The reference leaves the contraction of `P += (w d) d^T` to Eigen and
                 // the compiler (ukf.cpp:235-238); the device evaluates it with v_mfma_f64_16x16x4_f64, whose result is this
                 // chain in ascending i, bit for bit (tools/ubench_mfma_f64.hip).
-                for (int i = 0; i < ns; ++i) acc = std::fma(wt(i, nn) * D[(size_t)r * ns + i], D[(size_t)c * ns + i], acc);
+                for (int i = 0; i < ns; ++i) acc = mul_add(refmode, wt(i, nn) * D[(size_t)r * ns + i], D[(size_t)c * ns + i], acc);
                 P_pred[(size_t)r * nn + c] = acc;
             }
         // + Q (ukf.cpp:182-186, 240): signed diagonal from the yaw of x_t

@@ -201,3 +201,20 @@ def test_jacobi_settles_on_clusters_of_equal_eigenvalues(oracle):
     r = oracle.run_ukf_batch(lm, cmds[:T], B, L, nthreads=8, want_P=False, vision=vis)
     assert not r["flags"].any(), r["flags"]
     assert (r["M"] == L).all()
+
+
+def test_device_order_and_reference_order_arithmetic_stay_together(oracle):
+    """the UKF oracle evaluates the eigen-iteration and the weighted covariance the way the kernel does (fused
+    products in MFMA order, tau-free rotation parameters, warm start) so that GPU == oracle can be bit-exact.  Its
+    REFERENCE-ORDER mode keeps the independent statement of ukf.cpp / Eigen semantics: no FMA (the reference's build has no
+    contraction), textbook tau / t / c / s, a cold start every step.  The two must stay within rounding-level distance over a
+    long trajectory, so that a device-driven change of the default mode cannot drift from the reference semantics unnoticed."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, T = 20, 6, 300
+    lm, cmds = make_scenario(77, L, T)
+    a = oracle.run_ukf_batch(lm, cmds, B, L, seed=5, nthreads=6)
+    b = oracle.run_ukf_batch(lm, cmds, B, L, seed=5, nthreads=6, ref_order=True)
+    assert not a["flags"].any() and not b["flags"].any() and np.array_equal(a["M"], b["M"]) and a["M"].max() >= 5
+    dx = np.abs(a["x"] - b["x"]).max(); dP = np.abs(a["P"] - b["P"]).max()
+    assert 0.0 < dx < 2e-5 and dP < 2e-5, (dx, dP)      # not the same bits (different rounding), the same filter
+    assert np.abs(a["avg_err"] - b["avg_err"]).max() < 1e-6

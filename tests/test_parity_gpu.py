@@ -538,40 +538,56 @@ def test_traffic_counters_count_what_the_kernel_streams(S):
 
 def test_step_dev_is_enqueued_at_the_call_unless_queueing_was_asked_for(S):
     """slam_step_dev takes caller-owned device buffers on a caller-owned stream, so by default the step is on the
-    stream when the call returns (an event recorded after it covers the kernel); the queue is opt-in (slam_set_lazy_steps)."""
+    stream when the call returns (slam_queued_steps == 0: an event recorded after the call covers the kernel); its queue is
+    opt-in (slam_set_lazy_steps).  slam_step_sim / slam_step queue by default; a getter runs what is queued."""
     import ctypes as C
     from live_ekf_slam_amd import _lib
     from live_ekf_slam_amd.scenario import make_scenario
-    L, B = 20, 8192
+    L, B = 20, 512
     lm, cmds = make_scenario(11, L, 12)
     hip = C.CDLL("libamdhip64.so")
-    st, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    assert hip.hipStreamCreate(C.byref(st)) == 0 and hip.hipEventCreate(C.byref(e0)) == 0 and hip.hipEventCreate(C.byref(e1)) == 0
     dm, dc = C.c_void_p(), C.c_void_p()
     assert hip.hipMalloc(C.byref(dm), B * 4 * 3 * 4) == 0 and hip.hipMalloc(C.byref(dc), B * 4) == 0
     assert hip.hipMemset(dm, 0, B * 4 * 3 * 4) == 0 and hip.hipMemset(dc, 0, B * 4) == 0
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
     Lc = _lib.lib()
-    ms = {}
     for mode in ("default", "queued"):
-        f = S.BatchedEKF(B, L).readParams(); f.set_stream(st.value); f.set_map(lm); f.set_seed(5); f.init(0, 0, 0)
+        f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(5); f.init(0, 0, 0)
         if mode == "queued":
             f.set_lazy_steps(32)
-        f.sync()
-        assert hip.hipEventRecord(e0, st) == 0
         for t in range(8):
             cm = np.ascontiguousarray(cmds[t], dtype=np.float32)
             _lib.check(Lc.slam_step_dev(f.h, fp(cm), dm, dc, 4))
-        assert hip.hipEventRecord(e1, st) == 0 and hip.hipEventSynchronize(e1) == 0
-        # which timestep the DEVICE has reached when the event has fired, without going through a flushing getter:
-        # a raw copy of the handle's timestep array is not part of the ABI, so use the stream itself: after the event,
-        # queued mode has run nothing, default mode all eight steps -> the elapsed time shows it
-        el = C.c_float(0)
-        assert hip.hipEventElapsedTime(C.byref(el), e0, e1) == 0
-        ms[mode] = el.value
-        assert f.get_state(0)["timestep"] == 8   # either way the getter sees all eight steps
+            assert Lc.slam_queued_steps(f.h) == (t + 1 if mode == "queued" else 0)
+        f.update_sim(cmds[8])                                  # the generator-driven entry point queues by default
+        assert Lc.slam_queued_steps(f.h) == 1
+        assert f.get_state(0)["timestep"] == 9 and Lc.slam_queued_steps(f.h) == 0   # the getter ran the queue
         f.close()
-    assert ms["default"] > 4 * ms["queued"], ms   # eight kernels between the events vs eight small copies
     for q in (dm, dc):
         hip.hipFree(q)
-    hip.hipEventDestroy(e0); hip.hipEventDestroy(e1); hip.hipStreamDestroy(st)
+
+
+def test_watchdog_turns_a_stuck_protocol_into_a_flag(S):
+    """The polling loops of the step kernel's control / streamer protocol carry a budget: debug flag 128 makes the pass leader
+    lose its `applied` update, so the control wavefront starves for a ring slot - the launch must END (about 0.1 s per resident
+    round), with the instances flagged SLAM_INST_WATCHDOG and frozen, not hang the GPU.  Without the flag: no flags."""
+    import time
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, T = 50, 512, 60
+    lm, cmds = make_scenario(1234, L, T)
+    f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(1); f.init(0, 0, 0)
+    f.set_vision(1e9, -4.0, 4.0); f.run_sim(cmds[:1]); f.set_vision(3.0, -1.57, 1.57)
+    f.run_sim(cmds[1:20]); f.sync()
+    assert not f.status().any()
+    f.set_debug_flags(128)
+    t0 = time.perf_counter()
+    f.run_sim(cmds[20:T]); f.sync()
+    dt = time.perf_counter() - t0
+    st = f.status()
+    assert dt < 20.0
+    assert np.all(st & 32) and np.all(st & 4)          # SLAM_INST_WATCHDOG, frozen
+    ts = np.array([f.get_state(b)["timestep"] for b in (0, B - 1)])
+    f.set_debug_flags(0)
+    f.run_sim(cmds[20:30]); f.sync()                   # frozen instances are skipped by later launches
+    assert np.array_equal(np.array([f.get_state(b)["timestep"] for b in (0, B - 1)]), ts)
+    f.close()
