@@ -46,7 +46,7 @@ enum slam_instance_flags {
     SLAM_INST_INDEX_OOR = 4,     /* landmark index outside x_t (ekf.cpp:115 under the duplicate/unknown-id quirk) */
     SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146), or a
                                     message held more detections than the landmark capacity of the handle's size class (20 / 50 /
-                                    100), which takes repeated ids; the surplus was dropped                      */
+                                    100 / 200), which takes repeated ids; the surplus was dropped                      */
     SLAM_INST_SQRT_FAILED = 16,  /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
     SLAM_INST_WATCHDOG = 32      /* EKF: a polling loop of the step kernel's intra-workgroup protocol exceeded its budget (~0.1 s);
                                     the instance is frozen with an undefined state instead of hanging the GPU.  Never seen on a
@@ -91,7 +91,9 @@ int slam_config_load(slam_config* cfg, const char* yaml_path);
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
 /* Replaces the filter factory `std::make_unique<EKF|UKF>()` + `filter->readParams(config)`
  * (localization_node.cpp:33-47).  batch = number of instances on THIS device, L_max = landmark capacity
- * (EKF_SLAM: <= 100 in fp64, <= 50 in fp32 storage; UKF_SLAM: <= 50; UKF_LOC: ignored, the state holds no landmarks).
+ * (EKF_SLAM: <= 200 in fp64 [size classes 20 / 50 / 100 / 200], <= 50 in fp32 storage; UKF_SLAM: <= 50; UKF_LOC: ignored, the
+ * state holds no landmarks).  The reference grows the state without limit (ekf.cpp:144-146); here the limit is what one
+ * workgroup keeps in the 160 KB of LDS of a CU.
  * dtype SLAM_F32 (fp32 storage of x and P, fp64 arithmetic) is available for EKF_SLAM. */
 int slam_create(const slam_config* cfg, int filter_kind, int batch, int L_max, int dtype, int device,
                 slam_handle** out);

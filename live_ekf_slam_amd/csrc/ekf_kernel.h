@@ -68,9 +68,10 @@ static constexpr int kEkfProfSlots = 128;   // per-block slots of EkfStepParams:
 static constexpr int kEkfTrafficSlot = 10;  // khist[10..13]: bytes moved by the P-stream passes (read + write), other global bytes
                                             // (thin gathers, vehicle rows / columns, state vectors), passes, updates applied by passes
 
-// Largest landmark capacity of the instantiated variants (n = 3+2L <= 203; the limit is LDS, not registers).
+// Largest landmark capacity of the instantiated variants (n = 3+2L <= 403: 145 KB of the CU's 160 KB of LDS, one workgroup per CU;
+// n <= 203: 72 KB, two per CU; the limit is LDS, not registers).
 // fp32 storage is instantiated up to 50 landmarks.
-static constexpr int kEkfMaxLandmarks = 100;
+static constexpr int kEkfMaxLandmarks = 200;
 static constexpr int kEkfMaxLandmarksF32 = 50;
 
 // Tuning variants of the step kernel.  Every instantiation unit (ekf_inst.hip compiled with -DV_NMAX=.. -DV_W=.. -DV_KG=..

@@ -38,7 +38,7 @@ void register_ekf_variant(EkfVariant* v) {
 }
 
 // Default variant code per size class (chosen by sweeps on the GPU, tools/gpu_sweep.py).  NMAX only sizes the LDS arrays
-// (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103, L_max <= 100 -> n <= 203).
+// (L_max <= 20 -> n <= 43, L_max <= 50 -> n <= 103, L_max <= 100 -> n <= 203, L_max <= 200 -> n <= 403).
 static int default_code(int nmax_class, int f32, int B) {
     if (nmax_class == 43) {
         // two wavefronts per filter at every batch size: control + one streamer that also generates the measurements ahead
@@ -54,7 +54,7 @@ static int default_code(int nmax_class, int f32, int B) {
 
 static const EkfVariant* pick_variant(int L_max, int B, int variant, int f32_storage) {
     const int nmax = 3 + 2 * L_max;
-    const int cls = nmax <= 43 ? 43 : (nmax <= 103 ? 103 : (nmax <= 203 ? 203 : -1));
+    const int cls = nmax <= 43 ? 43 : (nmax <= 103 ? 103 : (nmax <= 203 ? 203 : (nmax <= 403 ? 403 : -1)));
     if (cls < 0) return nullptr;
     if (variant <= 0) return find_variant(cls, f32_storage, default_code(cls, f32_storage, B));
     const EkfVariant* v = find_variant(cls, f32_storage, variant);

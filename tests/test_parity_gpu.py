@@ -591,3 +591,25 @@ def test_watchdog_turns_a_stuck_protocol_into_a_flag(S):
     f.run_sim(cmds[20:30]); f.sync()                   # frozen instances are skipped by later launches
     assert np.array_equal(np.array([f.get_state(b)["timestep"] for b in (0, B - 1)]), ts)
     f.close()
+
+
+def test_state_of_200_landmarks(S, oracle):
+    """n = 403 (L = 200, the pose-graph config's map size): the largest size class - thin rows / columns and update slots of one
+    instance take 145 KB of the CU's 160 KB of LDS.  A first look at all 200 landmarks (200 insertions in one message), 200
+    updates in one message, ordinary steps in between; bit-identical to the oracle."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 200, 40, 6
+    lm, cmds = make_scenario(99, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1))
+    vis[0] = [1e9, -4.0, 4.0]; vis[17] = [1e9, -4.0, 4.0]; vis[30] = [6.0, -3.2, 3.2]
+    f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(8); f.init(0, 0, 0)
+    t = 0
+    for t1 in (1, 17, 18, 30, 31, T):
+        f.set_vision(*vis[t]); f.run_sim(cmds[t:t1]); t = t1
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=8, nthreads=6, vision=vis)
+    assert np.all(r["M"] == L) and np.array_equal(f.landmark_counts(), r["M"]) and np.array_equal(f.status(), r["flags"])
+    for b in range(B):
+        n = 3 + 2 * L
+        _assert_state_equal(f.get_state(b), dict(M=L, ids=r["ids"][b, :L], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    assert f.kernel_info()["name"].startswith("ekf_step_kernel<403,")
+    f.close()
