@@ -199,6 +199,16 @@ int slam_status(slam_handle* h, int32_t* per_instance_flags);       /* [batch] s
 int slam_scenario_make(const char* map_type, const char* fixed_maps_json, uint64_t seed, int num_landmarks, int num_iterations,
                        double* map_xy, int map_capacity, int32_t* num_landmarks_out, float* cmds);
 
+/* ---- checkpoint / resume --------------------------------------------------------------------------------- */
+/* The reference keeps the filter only in memory (a killed node loses the run).  slam_save_state writes everything a handle
+ * needs to continue - x, P, landmark counts and ids, status, timestep, the simulator's true pose, the error accumulators,
+ * the RNG step / seed / instance offset (UKF: also the square root of the last prediction stage and the warm-start
+ * eigenvectors) - to one binary file (raw slabs, 64 MB at a time through the host); slam_load_state restores it into a handle
+ * created with the same kind, batch, L_max and dtype (the map, the config and the sensor limits are the caller's to set
+ * again).  A run continued from a loaded state is bit-identical to the uninterrupted one. */
+int slam_save_state(slam_handle* h, const char* path);
+int slam_load_state(slam_handle* h, const char* path);
+
 /* ---- misc ------------------------------------------------------------------------------------------------ */
 int slam_sync(slam_handle* h);
 int slam_batch(const slam_handle* h);

@@ -46,6 +46,8 @@ SIGNATURES = {
     "slam_get_state": (C.c_int, [_H, C.c_int, _dp, _dp, _ip, _ip, _ip]),
     "slam_get_sigma_points": (C.c_int, [_H, C.c_int, _dp, _ip, _ip]),
     "slam_track_instance": (C.c_int, [_H, C.c_int]),
+    "slam_save_state": (C.c_int, [_H, C.c_char_p]),
+    "slam_load_state": (C.c_int, [_H, C.c_char_p]),
     "slam_get_poses": (C.c_int, [_H, _dp]),
     "slam_get_landmark_counts": (C.c_int, [_H, _ip]),
     "slam_get_truth": (C.c_int, [_H, _dp]),

@@ -1007,6 +1007,90 @@ int slam_error_stats(slam_handle* h, double* avg) {
     return SLAM_OK;
 }
 
+// ---- checkpoint / resume (the reference keeps the filter only in memory) ------------------------------
+namespace {
+struct CkptHeader {
+    char magic[8];            // "SLAMCKP1"
+    int32_t kind, B, L_max, dtype, n_max, pstride, xstride, esz;
+    uint32_t step;
+    int32_t inited, reserved0;
+    uint64_t seed;
+    int64_t inst0;
+};
+struct CkptItem { void* dev; size_t bytes; };
+
+std::vector<CkptItem> ckpt_items(slam_handle* h) {
+    const size_t B = (size_t)h->B, e = (size_t)h->esz;
+    std::vector<CkptItem> it = {
+        {h->dP, e * B * h->pstride}, {h->dx, e * B * h->xstride}, {h->dM, sizeof(int32_t) * B}, {h->dids, sizeof(int32_t) * B * h->L_max},
+        {h->dflags, sizeof(int32_t) * B}, {h->dts, sizeof(int32_t) * B}, {h->dtruth, sizeof(double) * B * 3}, {h->derr, sizeof(double) * B},
+    };
+    if (h->kind != SLAM_EKF_SLAM) {   // UKF: the square root of the last prediction stage and the warm-start eigenvectors
+        it.push_back({h->dsq, sizeof(double) * B * h->pstride}); it.push_back({h->dnsq, sizeof(int32_t) * B});
+        it.push_back({h->dxprev, sizeof(double) * B * h->xstride}); it.push_back({h->dvt, sizeof(double) * B * h->pstride});
+        it.push_back({h->dvage, sizeof(int32_t) * B});
+    }
+    return it;
+}
+}  // namespace
+
+int slam_save_state(slam_handle* h, const char* path) {
+    if (!h || !path) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
+    if (h->predicted) return fail(SLAM_ERR_STATE, "a prediction stage is pending: call slam_update_dev first");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(h->kind == SLAM_EKF_SLAM ? hipStreamSynchronize(h->stream) : hipDeviceSynchronize());
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(SLAM_ERR_IO, "cannot write %s", path);
+    CkptHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    memcpy(hd.magic, "SLAMCKP1", 8);
+    hd.kind = h->kind; hd.B = h->B; hd.L_max = h->L_max; hd.dtype = h->dtype; hd.n_max = h->n_max; hd.pstride = h->pstride; hd.xstride = h->xstride;
+    hd.esz = h->esz; hd.step = h->step; hd.inited = h->inited ? 1 : 0; hd.seed = h->seed; hd.inst0 = h->inst0;
+    bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1;
+    std::vector<char> buf((size_t)64 << 20);
+    for (const CkptItem& it : ckpt_items(h))
+        for (size_t off = 0; ok && off < it.bytes; off += buf.size()) {
+            const size_t nb = it.bytes - off < buf.size() ? it.bytes - off : buf.size();
+            if (hipMemcpy(buf.data(), (const char*)it.dev + off, nb, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return fail(SLAM_ERR_HIP, "copying the state to the host failed"); }
+            ok = fwrite(buf.data(), 1, nb, f) == nb;
+        }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? SLAM_OK : fail(SLAM_ERR_IO, "short write to %s", path);
+}
+
+int slam_load_state(slam_handle* h, const char* path) {
+    if (!h || !path) return fail(SLAM_ERR_ARG, "bad argument");
+    FLUSH(h);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(h->kind == SLAM_EKF_SLAM ? hipStreamSynchronize(h->stream) : hipDeviceSynchronize());
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(SLAM_ERR_IO, "cannot open %s", path);
+    CkptHeader hd;
+    if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, "SLAMCKP1", 8) != 0) { fclose(f); return fail(SLAM_ERR_IO, "%s is not a state file of this library", path); }
+    if (hd.kind != h->kind || hd.B != h->B || hd.L_max != h->L_max || hd.dtype != h->dtype || hd.pstride != h->pstride || hd.xstride != h->xstride || hd.esz != h->esz) {
+        fclose(f);
+        return fail(SLAM_ERR_ARG, "%s holds kind %d, batch %d, L_max %d, dtype %d; the handle is kind %d, batch %d, L_max %d, dtype %d", path, hd.kind, hd.B, hd.L_max,
+                    hd.dtype, h->kind, h->B, h->L_max, h->dtype);
+    }
+    std::vector<char> buf((size_t)64 << 20);
+    for (const CkptItem& it : ckpt_items(h))
+        for (size_t off = 0; off < it.bytes; off += buf.size()) {
+            const size_t nb = it.bytes - off < buf.size() ? it.bytes - off : buf.size();
+            if (fread(buf.data(), 1, nb, f) != nb) { fclose(f); return fail(SLAM_ERR_IO, "%s is truncated", path); }
+            if (hipMemcpy((char*)it.dev + off, buf.data(), nb, hipMemcpyHostToDevice) != hipSuccess) { fclose(f); return fail(SLAM_ERR_HIP, "copying the state to the device failed"); }
+        }
+    fclose(f);
+    h->step = hd.step; h->inited = hd.inited != 0; h->seed = hd.seed; h->inst0 = hd.inst0;
+    h->predicted = false;
+    if (h->shadow) {   // the tracked instance restarts from the loaded state
+        const int tr = h->tracked;
+        const int rc = slam_track_instance(h, tr);
+        if (rc) return rc;
+    }
+    return SLAM_OK;
+}
+
 int slam_track_instance(slam_handle* h, int inst) {
     if (!h || inst >= h->B) return fail(SLAM_ERR_ARG, "bad instance");
     FLUSH(h);

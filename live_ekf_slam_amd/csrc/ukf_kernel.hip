@@ -215,23 +215,62 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     __syncthreads();
     if (warm) {
         // T = A V0 (n x n, through the V slab in HBM/L2 as scratch: its content is in sVt now, and the stale sqtP must
-        // survive a failed decomposition, ukf.cpp:209-211), then B = V0^T T (lower triangle) into sA
-        for (int e = tid; e < n * n; e += TPB) {
-            const int r = e / n, c = e - r * n;
-            double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc = acc + AT(r, k) * sVt[c * n + k];
-            Vs[e] = acc;
+        // survive a failed decomposition, ukf.cpp:209-211), then B = V0^T T (lower triangle) into sA.  Round 3: both products
+        // on v_mfma_f64_16x16x4_f64 (they were 14.5 % of this kernel as 2 n^3 scalar multiply-adds out of LDS): one 16 x 16
+        // tile per wavefront at a time, k in steps of four; per output element the instruction chain is
+        // acc = fma(a_k, b_k, acc) in ascending k (tools/ubench_mfma_f64.hip), which is what the oracle evaluates; rows,
+        // columns and k beyond n give zero operands (fma(0, 0, acc) = acc).
+        const int nt = (n + 15) >> 4, nk = (n + 3) >> 2;
+        const int wv = tid >> 6, ln = tid & 63, kq = ln >> 4, cl = ln & 15;
+#pragma unroll 1
+        for (int t = wv; t < nt * nt; t += TPB / 64) {
+            const int tr = t / nt, tc = t - tr * nt;
+            const int ar = 16 * tr + cl, bc = 16 * tc + cl;     // A-operand row (of A), B-operand column (of V0)
+            const bool va = ar < n, vb = bc < n;
+            const int arc = va ? ar : 0, bcc = vb ? bc : 0;
+            dbl4_t acc = dbl4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+            for (int ks = 0; ks < nk; ++ks) {
+                const int k = 4 * ks + kq;
+                const bool vk = k < n;
+                const int kc = vk ? k : 0;
+                double a = arc >= kc ? sA[arc * (arc + 1) / 2 + kc] : sA[kc * (kc + 1) / 2 + arc];   // A(ar, k), symmetric
+                double bv = sVt[bcc * n + kc];                                                       // V0(k, bc)
+                a = (va && vk) ? a : 0.0;
+                bv = (vb && vk) ? bv : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {   // C/D layout: row = (lane >> 4) + 4 * reg, column = lane & 15
+                const int r = 16 * tr + kq + 4 * r4, c = 16 * tc + cl;
+                if (r < n && c < n) Vs[(size_t)r * n + c] = acc[r4];
+            }
         }
         __syncthreads();
-        for (int e = tid; e < n * (n + 1) / 2; e += TPB) {
-            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while (r * (r + 1) / 2 > e) --r;
-            while ((r + 1) * (r + 2) / 2 <= e) ++r;
-            const int c = e - r * (r + 1) / 2;
-            double acc = 0.0;
-#pragma unroll 11
-            for (int k = 0; k < n; ++k) acc = acc + sVt[r * n + k] * Vs[(size_t)k * n + c];   // T comes back from L2: many loads in flight, sums in order
-            sA[e] = acc;
+#pragma unroll 1
+        for (int t = wv; t < nt * nt; t += TPB / 64) {
+            const int tr = t / nt, tc = t - tr * nt;
+            if (tc > tr) continue;                              // lower triangle of B only (wave-uniform)
+            const int ar = 16 * tr + cl, bc = 16 * tc + cl;     // A-operand: column ar of V0 (row of V0^T); B-operand: column bc of T
+            const bool va = ar < n, vb = bc < n;
+            const int arc = va ? ar : 0, bcc = vb ? bc : 0;
+            dbl4_t acc = dbl4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int ks = 0; ks < nk; ++ks) {
+                const int k = 4 * ks + kq;
+                const bool vk = k < n;
+                const int kc = vk ? k : 0;
+                double a = sVt[arc * n + kc];                   // V0(k, ar)
+                double bv = Vs[(size_t)kc * n + bcc];           // T(k, bc): back from L2, several k-steps in flight
+                a = (va && vk) ? a : 0.0;
+                bv = (vb && vk) ? bv : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = 16 * tr + kq + 4 * r4, c = 16 * tc + cl;
+                if (r < n && c <= r) sA[r * (r + 1) / 2 + c] = acc[r4];
+            }
         }
         __syncthreads();
     }

@@ -175,6 +175,15 @@ class BatchedFilter:
         """publishState(instance) every tick without running the batch's queued steps (slam_track_instance); -1 = off."""
         self._need(); _lib.check(_lib.lib().slam_track_instance(self.h, int(instance)))
 
+    def save_state(self, path):
+        """Checkpoint of the whole batch (slam_save_state)."""
+        self._need(); _lib.check(_lib.lib().slam_save_state(self.h, str(path).encode()))
+
+    def load_state(self, path):
+        """Resume from a checkpoint written by a handle of the same kind / batch / L_max / dtype (slam_load_state)."""
+        self._need(); _lib.check(_lib.lib().slam_load_state(self.h, str(path).encode()))
+        self.isInit = True
+
     def poses(self):
         self._need(); out = np.zeros((self.batch, 3)); _lib.check(_lib.lib().slam_get_poses(self.h, _d(out))); return out
 

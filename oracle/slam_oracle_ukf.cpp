@@ -205,13 +205,14 @@ struct Ukf {
             for (int r = 0; r < nn; ++r)
                 for (int c = 0; c < nn; ++c) {
                     double acc = 0.0;
-                    for (int k = 0; k < nn; ++k) acc = acc + Y[(size_t)r * nn + k] * V[(size_t)k * nn + c];
+                    // each term fused, ascending k: the device forms both products of the warm start with v_mfma_f64_16x16x4_f64
+                    for (int k = 0; k < nn; ++k) acc = std::fma(Y[(size_t)r * nn + k], V[(size_t)k * nn + c], acc);
                     T[(size_t)r * nn + c] = acc;
                 }
             for (int r = 0; r < nn; ++r)
                 for (int c = 0; c <= r; ++c) {
                     double acc = 0.0;
-                    for (int k = 0; k < nn; ++k) acc = acc + V[(size_t)k * nn + r] * T[(size_t)k * nn + c];
+                    for (int k = 0; k < nn; ++k) acc = std::fma(V[(size_t)k * nn + r], T[(size_t)k * nn + c], acc);
                     Y[(size_t)r * nn + c] = acc; Y[(size_t)c * nn + r] = acc;
                 }
         }

@@ -613,3 +613,40 @@ def test_state_of_200_landmarks(S, oracle):
         _assert_state_equal(f.get_state(b), dict(M=L, ids=r["ids"][b, :L], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
     assert f.kernel_info()["name"].startswith("ekf_step_kernel<403,")
     f.close()
+
+
+@pytest.mark.parametrize("kind", ["ekf", "ekf_f32", "ukf"])
+def test_checkpoint_and_resume_are_bit_identical(S, tmp_path, kind):
+    """slam_save_state / slam_load_state (the reference keeps the filter only in memory): a run continued from a checkpoint
+    in a NEW handle equals the uninterrupted run bit for bit - state, counters, error statistics, true poses."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, T1, T2 = 20, 48, 70, 60
+    lm, cmds = make_scenario(5, L, T1 + T2)
+    def make():
+        if kind == "ukf":
+            f = S.BatchedUKF(B, L).readParams()
+        else:
+            f = S.BatchedEKF(B, L, dtype=S.F32 if kind == "ekf_f32" else S.F64).readParams()
+        f.set_map(lm); f.set_seed(21); f.set_instance_offset(300)
+        return f
+    a = make(); a.init(0, 0, 0); a.run_sim(cmds[:T1])
+    path = tmp_path / "batch.ckpt"
+    a.save_state(path)
+    a.run_sim(cmds[T1:])
+    b = make(); b.load_state(path); b.run_sim(cmds[T1:])
+    assert np.array_equal(a.landmark_counts(), b.landmark_counts()) and np.array_equal(a.status(), b.status())
+    assert np.array_equal(a.error_stats(), b.error_stats()) and np.array_equal(a.truth(), b.truth())
+    for i in (0, 17, B - 1):
+        sa, sb = a.get_state(i), b.get_state(i)
+        assert sa["timestep"] == sb["timestep"] == T1 + T2 and sa["M"] == sb["M"] and np.array_equal(sa["ids"], sb["ids"])
+        assert np.array_equal(sa["x"], sb["x"]) and np.array_equal(sa["P"], sb["P"])
+    # a file of another shape is refused, a truncated one too
+    c = S.BatchedEKF(B + 1, L).readParams()
+    with pytest.raises(Exception):
+        c.load_state(path)
+    raw = open(path, "rb").read()
+    open(tmp_path / "short.ckpt", "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(Exception):
+        make().load_state(tmp_path / "short.ckpt")
+    for f in (a, b, c):
+        f.close()
