@@ -43,8 +43,11 @@ struct EkfGeom {
     static constexpr int LMAX = (NMAX - 3) / 2;
     static constexpr int KCAP = LMAX > 0 ? LMAX : 1;     // detections held per step = the landmark capacity: every message without
                                                          // repeated ids fits (one wavefront associates them, 64 at a time)
-    static constexpr int KG = KG_;                       // detections per group
-    static constexpr int TS = 3 + 2 * KG;                // thin rows / cols held in LDS
+    static constexpr int KG = KG_;                       // slots of the K / H P ring = updates one pass over P can apply
+    static constexpr int KP = KG_ > 4 ? 4 : KG_;         // landmark slot pairs of the thin rows / cols = DISTINCT landmarks one group /
+                                                         // one decoupled timestep can update (a fifth ring slot costs 3.4 KB of LDS, a
+                                                         // fifth pair another 3.3 KB: the ring may be deeper than the pairs)
+    static constexpr int TS = 3 + 2 * KP;                // thin rows / cols held in LDS
     static constexpr int UNR = UNR_;                     // register pairs in flight per lane in the bulk stream
 };
 
@@ -106,7 +109,9 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
 #define SLAM_PASS_MIN_F32 3   // fp32 storage: a pass moves half the bytes, so starting one slot earlier (the control wavefront keeps a free slot) wins: 1.07 -> 0.99 ms/step
 #endif
 #ifndef SLAM_PASS_MIN
-#define SLAM_PASS_MIN 4   // decoupled loop: the streamers start a pass when this many updates are pending (or on request)
+#define SLAM_PASS_MIN 4   // decoupled loop: the streamers start a pass when this many updates are pending (or on request).  With the default
+                          // ring of KG = 5 slots that leaves one free for the control wavefront during a pass (KG = 5 with passes at five pending:
+                          // 20 % fewer passes and bytes but the stall is back, 72 vs 78 M steps/s; fp32 storage gains nothing from a fifth slot)
 #endif
 #ifndef SLAM_PRIO_THIN
 #define SLAM_PRIO_THIN 2
@@ -163,7 +168,7 @@ __device__ __forceinline__ unsigned hi_abs(double v) {
 template <int NMAX, int W, int KG_, int UNR_, class ST, int PIPE, bool MULTI>
 __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(const EkfStepParams p) {
     using G = EkfGeom<NMAX, W, KG_, UNR_>;
-    constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, TS = G::TS, UNR = G::UNR;
+    constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, KP = G::KP, TS = G::TS, UNR = G::UNR;
 
     __shared__ double s_xt[LDP];          // x_t  (posterior of the previous step; landmark positions for H)
     __shared__ double s_xp[LDP];          // x_pred
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ double2 s_HP[KG * HPW];    // per update of the group: (H P)[0..1][c] at hpi(c) (de-interleaved by c % VEC)
     __shared__ double s_sc[16];           // scalars computed by the leader lane (H entries, nu, S^-1, G_x ...)
     // The measurement generator does not depend on the filter, so it may run AHEAD of it: a ring of SD timesteps, slot = t % SD.
-    constexpr int SD = sizeof(ST) == 8 ? 4 : 3;   // (fp32 storage: 3, to stay within 40 KB of LDS = 4 workgroups per CU)
+    constexpr int SD = 3;   // (three, to stay within 40 KB of LDS = 4 workgroups per CU; fp64 had four until the ring got its fifth slot)
     __shared__ float s_meas[SD * 3 * KCAP];  // [t % SD][detection][id, range, bearing]
     __shared__ double s_tru[SD * 6];         // [t % SD] true pose before (0..2) and after (3..5) timestep t
     __shared__ int s_kraw[SD];               // [t % SD] detections in the message of timestep t (uncapped)
@@ -191,8 +196,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     __shared__ signed char s_slot[LDP];   // state index -> thin slot or -1
     __shared__ signed char s_need[TS];    // slot was (re)assigned: 1 = gather from HBM, 2 = new landmark (zero)
     __shared__ int s_misc[8];             // -, -, freeze, capacity (unknown ids), l1, nT, singular-S
-    __shared__ double s_keep[4 + 2 * 64]; // values that live across the timesteps of one launch: true pose, error
-                                          // sum, map entries of ids 0..63 (kept out of registers on purpose)
+    __shared__ double s_keep[4];          // values that live across the timesteps of one launch: true pose, error sum (kept out of
+                                          // registers on purpose).  The map entries of ids 0..63 lived here too (1 KB) until round 3;
+                                          // the generator reads them from global memory now (L1 / L2 hits, off the filter's critical path)
     __shared__ int s_kh[8];               // instance-steps of this launch by detection count
     __shared__ int s_ring[8];             // decoupled loop: published updates, applied updates, (unused), exit, next timestep,
                                           // flag bits raised by the control wavefront, hold (no new pass), pass in flight
@@ -233,11 +239,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         xpre[u] = (i < p.xstride && i < LDP) ? (double)xb[i] : 0.0;   // beyond n_old the slab holds stale values: masked below
     }
     const int idpre = (tid < p.L_max) ? p.ids[(size_t)b * p.L_max + tid] : 0;
-    double keep0 = 0.0, keep1 = 0.0, keep2 = 0.0;
+    double keep0 = 0.0;
     if (p.sim && tid < 64) {
         if (tid < 3) keep0 = p.truth[3 * (size_t)b + tid];
         if (tid == 3) keep0 = p.err_sum[b];
-        if (tid < p.L) { keep1 = p.map[2 * tid]; keep2 = p.map[2 * tid + 1]; }
     }
     const int n_init = 3 + 2 * M_init;
     const int ts0 = p.timestep[b];
@@ -256,11 +261,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         }
     }
     if (tid < M_init) s_ids[tid] = idpre;
-    if (tid < 64) {
-        if (tid < 4) s_keep[tid] = keep0;
-        s_keep[4 + tid] = keep1;
-        s_keep[4 + 64 + tid] = keep2;
-    }
+    if (tid < 4) s_keep[tid] = keep0;
 #pragma unroll 1
     for (int i = tid; i < LDP; i += TPB) s_slot[i] = (signed char)(i < 3 ? i : -1);
     if (tid < TS) {
@@ -336,8 +337,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         const float ang_n = MULTI ? p.cmds[2 * tn + 1] : p.ang;
         double tx = s_keep[0], ty = s_keep[1], tth = s_keep[2];
         if (lane == 0) { s_tru[sq * 6 + 0] = tx; s_tru[sq * 6 + 1] = ty; s_tru[sq * 6 + 2] = tth; }
-        const int kr = sim_wave<KCAP, false>(p, b, lane, fwd_n, ang_n, p.step + (uint32_t)tn, tx, ty, tth, s_keep[4 + lane],
-                                             s_keep[4 + 64 + lane], s_meas + sq * 3 * KCAP);   // the true pose goes to HBM in finish()
+        const double lmx0 = lane < p.L ? p.map[2 * lane] : 0.0, lmy0 = lane < p.L ? p.map[2 * lane + 1] : 0.0;
+        const int kr = sim_wave<KCAP, false>(p, b, lane, fwd_n, ang_n, p.step + (uint32_t)tn, tx, ty, tth, lmx0, lmy0,
+                                             s_meas + sq * 3 * KCAP);   // the true pose goes to HBM in finish()
         if (lane == 0) {
             s_keep[0] = tx; s_keep[1] = ty; s_keep[2] = tth;
             s_tru[sq * 6 + 3] = tx; s_tru[sq * 6 + 4] = ty; s_tru[sq * 6 + 5] = tth;
@@ -471,25 +473,25 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     //      high-water mark of the slots in use.  Same assignment as the serial path for unknown ids below. ----
     auto form_known = [&](const int* didx_g, int k, int l0, int lim, int nsrc, int& l1_out, int& nT_out) -> int {
         const int l1 = (k - l0 < lim) ? k : l0 + lim;
-        const int ng = l1 - l0;                                   // detections of this group (<= KG)
+        const int ng = l1 - l0;                                   // detections of this group (<= KP)
         const int idx = (lane < ng) ? didx_g[l0 + lane] : -1;
         const int myii = idx >= 0 ? 3 + 2 * idx : -1;             // wanted state index of detection lane
-        const int cur = (lane < KG) ? s_T[3 + 2 * lane] : -1;     // landmark in slot pair lane
+        const int cur = (lane < KP) ? s_T[3 + 2 * lane] : -1;     // landmark in slot pair lane
         bool dupl = false, has = false, keep = false;
 #pragma unroll
-        for (int w = 0; w < KG; ++w) {
+        for (int w = 0; w < KP; ++w) {
             const int ii_w = __shfl(myii, w), cur_w = __shfl(cur, w);
             dupl = dupl || (w < lane && ii_w == myii);            // an earlier detection wants the same landmark
             has = has || (cur_w >= 0 && cur_w == myii);           // my landmark already has a slot
             keep = keep || (ii_w >= 0 && ii_w == cur);            // somebody wants the landmark in my slot
         }
         const bool wantv = myii >= 0 && !dupl;
-        const bool release = lane < KG && cur >= 0 && !keep;
+        const bool release = lane < KP && cur >= 0 && !keep;
         if (release) {   // the pending updates (or the last pass) produce this row / column in HBM bit for bit
             s_slot[cur] = (signed char)-1; s_slot[cur + 1] = (signed char)-1;
             s_T[3 + 2 * lane] = -1; s_T[4 + 2 * lane] = -1;
         }
-        const bool freeslot = lane < KG && (cur < 0 || !keep);
+        const bool freeslot = lane < KP && (cur < 0 || !keep);
         const unsigned long long fmask = __ballot(freeslot);
         const bool needs = wantv && !has;
         const unsigned long long nmask = __ballot(needs);
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         {
             unsigned long long fm = fmask;
 #pragma unroll
-            for (int w = 0; w < KG; ++w) {
+            for (int w = 0; w < KP; ++w) {
                 const int lowest = __ffsll((long long)fm) - 1;
                 if (w == rank) j = lowest;
                 fm &= fm - 1ull;
@@ -513,12 +515,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             gath = nd == 1;
         }
         // occupied pairs after release + assignment: the kept ones and the lowest free ones the needing lanes took
-        unsigned long long occ = __ballot(lane < KG && cur >= 0 && keep);
+        unsigned long long occ = __ballot(lane < KP && cur >= 0 && keep);
         {
             unsigned long long fm = fmask;
             const int ntake = __popcll(nmask);
 #pragma unroll
-            for (int w = 0; w < KG; ++w) {
+            for (int w = 0; w < KP; ++w) {
                 const int lowest = __ffsll((long long)fm) - 1;
                 if (w < ntake && lowest >= 0) occ |= 1ull << lowest;
                 fm &= fm - 1ull;
@@ -884,7 +886,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if constexpr (MULTI && W >= 2) {
         auto fastable = [&](int tq) -> bool {   // step tq (its pre-step results are in the parity buffers) can run decoupled
             const int* nx = s_next + 4 * (tq & 1);
-            return nx[0] <= KG && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
+            return nx[0] <= KP && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
         };
         const bool fast_ok = p.id_known && p.meas_out == nullptr && fastable(t) &&
                              !SLAM_DBG(p.dbg & (2 | 16 | 64));
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     if (lane < 3) s_xp[lane] = s_ps[10 * pq + lane];
                     SLAM_STAMP(16);  // loop overhead
                     int l1q, nTq;
-                    const int needg = form_known(didx_q, kq, 0, KG, n, l1q, nTq);
+                    const int needg = form_known(didx_q, kq, 0, KP, n, l1q, nTq);
                     SLAM_STAMP(17);  // group formation
                     const bool veh = s_need[0] == 1;   // first step of the launch: the vehicle rows / columns are still in HBM only
                     if (needg || veh) {
@@ -1329,7 +1331,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             // lane-parallel in wavefront 0: lane l <-> detection l0 + l of the group AND thin slot pair l; votes via
             // ballot, a handful of LDS round trips instead of a serial chain of them on the critical path of every step.
             if (tid < 64) {
-                int fb = 0, lim = KG;
+                int fb = 0, lim = KP;
                 if (first && nu > 0) {   // pre-flush decision (see the serial path below for the rules)
                     int kupd = 0;
 #pragma unroll 1
@@ -1339,7 +1341,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         kupd += __popcll(__ballot(isupd));
                     }
                     fb = (frz_top || n_ins > 0 || nu + kupd > KG) ? 1 : 0;
-                    lim = fb ? KG : KG - nu;
+                    lim = fb ? KP : (KG - nu < KP ? KG - nu : KP);
                 }
                 int l1g, nTg;
                 const int needg = form_known(didx_t, k, l0, lim, nsrc, l1g, nTg);
@@ -1354,18 +1356,18 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         } else if (tid == 0) {
             int l1 = l0, na_g = na, M_g = M;
             int frz = 0;
-            int want[KG], nw = 0;
+            int want[KP], nw = 0;
 #pragma unroll
-            for (int w = 0; w < KG; ++w) want[w] = -1;
+            for (int w = 0; w < KP; ++w) want[w] = -1;
             // Pre-flush: the open group (nu pending updates of earlier timesteps) is streamed into P BEFORE this step if the
             // step cannot join it: it inserts landmarks (layout change), its updates do not fit into the free slots, it
             // needs a thin row / column from HBM (which must then be current), or the instance freezes.
-            int fb = 0, lim = KG;
+            int fb = 0, lim = KP;
             if (first && nu > 0) {
                 int kupd = 0;
                 for (int l = 0; l < k; ++l) kupd += (didx_t[l] >= 0 && didx_t[l] < M_g) ? 1 : 0;
                 fb = (frz_top || n_ins > 0 || nu + kupd > KG) ? 1 : 0;
-                lim = fb ? KG : KG - nu;
+                lim = fb ? KP : (KG - nu < KP ? KG - nu : KP);
             }
             int needg = 0;
 #pragma unroll 1
@@ -1398,10 +1400,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     const int ii = 3 + 2 * idx;
                     bool have = false;
 #pragma unroll
-                    for (int w = 0; w < KG; ++w) have = have || (want[w] == ii);
+                    for (int w = 0; w < KP; ++w) have = have || (want[w] == ii);
                     if (!have) {   // at most KG detections per group, so a pair is always free
 #pragma unroll
-                        for (int w = 0; w < KG; ++w)
+                        for (int w = 0; w < KP; ++w)
                             if (w == nw) want[w] = ii;
                         nw += 1;
                     }
@@ -1411,12 +1413,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             }
             // release the pairs this group does not touch: the last bulk pass already wrote them to HBM
 #pragma unroll
-            for (int j = 0; j < KG; ++j) {
+            for (int j = 0; j < KP; ++j) {
                 const int ii = s_T[3 + 2 * j];
                 if (ii >= 0) {
                     bool keep = false;
 #pragma unroll
-                    for (int w = 0; w < KG; ++w) keep = keep || (want[w] == ii);
+                    for (int w = 0; w < KP; ++w) keep = keep || (want[w] == ii);
                     if (!keep) {
                         s_slot[ii] = (signed char)-1; s_slot[ii + 1] = (signed char)-1;
                         s_T[3 + 2 * j] = -1; s_T[4 + 2 * j] = -1;
@@ -1425,11 +1427,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             }
             // every wanted landmark without a slot takes a free pair
 #pragma unroll
-            for (int w = 0; w < KG; ++w) {
+            for (int w = 0; w < KP; ++w) {
                 const int ii = want[w];
                 if (ii >= 0 && s_slot[ii] < 0) {
                     int j = 0;
-                    while (j < KG - 1 && s_T[3 + 2 * j] >= 0) ++j;
+                    while (j < KP - 1 && s_T[3 + 2 * j] >= 0) ++j;
                     s_T[3 + 2 * j] = ii; s_T[4 + 2 * j] = ii + 1;
                     s_slot[ii] = (signed char)(3 + 2 * j); s_slot[ii + 1] = (signed char)(4 + 2 * j);
                     const signed char nd = (signed char)(ii < nsrc ? 1 : 2);   // known landmark: gather, new one: zeros
@@ -1439,7 +1441,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             }
             int nT = 3;
 #pragma unroll
-            for (int j = 0; j < KG; ++j)
+            for (int j = 0; j < KP; ++j)
                 if (s_T[3 + 2 * j] >= 0) nT = 5 + 2 * j;
             s_chunk = 0;
             s_misc[4] = l1;

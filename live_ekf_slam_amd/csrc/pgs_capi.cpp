@@ -377,6 +377,7 @@ int pgs_solve(pgs_handle* h) {
                     const size_t e0 = (size_t)t * (slam::kPgsTrialKernels + 1) + k;
                     HIP_TRY(hipEventElapsedTime(&ms, h->events[e0], h->events[e0 + 1]));
                     h->kernel_ms[k] += ms;
+                    if (h->trace) fprintf(stderr, "%s%.3f%s", k == 0 ? "pgs trial kernels (ms): " : " ", ms, k + 1 == slam::kPgsTrialKernels ? "\n" : "");
                 }
         }
         return SLAM_OK;
