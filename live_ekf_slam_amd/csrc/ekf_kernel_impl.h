@@ -382,6 +382,27 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             // result of detection l.  The message is walked 64 detections at a time (ekf.cpp:73 loops over any number of them).
             int cnt = 0;                    // new ids so far in this message
             bool anydup = false;
+            if (kn <= 64 && M <= 64) {
+                // the common case in registers: lane l holds the id of detection l and lm_IDs[l]; the id of detection l reaches the
+                // others by v_readlane, a match is one ballot (one LDS round trip for the whole message instead of two per detection)
+                const int myid = lane < kn ? (int)meas[3 * lane] : -1;
+                const int sid = lane < M ? s_ids[lane] : -2;
+                int idx = -1;
+                bool isnew = false, dup = false;
+#pragma unroll 1
+                for (int l = 0; l < kn; ++l) {
+                    const int id = __builtin_amdgcn_readlane(myid, l);
+                    const unsigned long long m = __ballot(sid == id);                    // first match wins (ekf.cpp:102-107)
+                    const unsigned long long e = __ballot(lane < l && myid == id);       // an earlier detection of this message has the id
+                    if (lane == l) { idx = m ? __ffsll((long long)m) - 1 : -1; isnew = m == 0ull; dup = isnew && e != 0ull; }
+                }
+                anydup = __ballot(dup) != 0ull;
+                const unsigned long long nmask = __ballot(isnew);
+                const int rank = __popcll(nmask & ((1ull << lane) - 1ull));
+                if (isnew) idx = (M + rank < p.L_max && M + rank < LMAX) ? M + rank : -1;
+                if (lane < kn) didx[lane] = idx;
+                cnt = __popcll(nmask);
+            } else
 #pragma unroll 1
             for (int c0 = 0; c0 < kn; c0 += 64) {
                 int idx = -1;
@@ -480,7 +501,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
         bool dupl = false, has = false, keep = false;
 #pragma unroll
         for (int w = 0; w < KP; ++w) {
-            const int ii_w = __shfl(myii, w), cur_w = __shfl(cur, w);
+            const int ii_w = __builtin_amdgcn_readlane(myii, w), cur_w = __builtin_amdgcn_readlane(cur, w);   // (v_readlane: no LDS crossbar trip)
             dupl = dupl || (w < lane && ii_w == myii);            // an earlier detection wants the same landmark
             has = has || (cur_w >= 0 && cur_w == myii);           // my landmark already has a slot
             keep = keep || (ii_w >= 0 && ii_w == cur);            // somebody wants the landmark in my slot
@@ -552,6 +573,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             }
         }
     };
+
+    // (Round 3, measured and dropped: a one-wavefront variant that keeps a lane's K / (H P) entries in registers and fetches the slot
+    // operands once per slot - thin downdates 5.3 k -> 4.8 k cycles per step, but five more spilled registers moved the same cycles
+    // into the prediction and the end of the step: 77.4 vs 77.1 M steps/s.  At 128 VGPRs every added live range is paid elsewhere.)
 
     struct PassArgs {
         const ST* src; ST* dst; double* mid;
@@ -1170,6 +1195,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         for (int sp = 0; ld_i(&s_sim[0]) <= tt && !spin_over(sp);) __builtin_amdgcn_s_sleep(1);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
+                    SLAM_STAMP(26);  // waiting for the generator wavefront
                     prestep(tt);
                     SLAM_STAMP(25);  // pre-step of the next timestep
                     if (!fastable(tt)) break;   // that step goes through the synchronised path
