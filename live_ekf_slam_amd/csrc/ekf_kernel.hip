@@ -18,10 +18,15 @@
 #define SLAM_DEF_43_LARGE 1124
 #endif
 #ifndef SLAM_DEF_103
-#define SLAM_DEF_103 1454   // round 3: a FIFTH ring slot while passes still start at four pending updates, so the control wavefront keeps a free
-                            // slot during a pass instead of stalling behind it (same passes, same bytes: 71 -> 78 M steps/s in steady state);
-                            // the thin rows / cols keep four landmark pairs (EkfGeom::KP), the 3.4 KB come from the map copy and a shorter
-                            // measurement ring
+#define SLAM_DEF_103 1464   // round 3: SIX ring slots, passes at five pending updates - one slot stays free, so the control wavefront does not
+                            // stall behind a pass, and a pass carries 4.75 updates instead of 3.83 (20 % fewer bytes per timestep).  The LDS
+                            // for it (4 workgroups per CU = 40 960 B each): three landmark pairs of thin rows / cols instead of four (a
+                            // timestep with more distinct detections runs as two groups inside the decoupled loop), the map copy out of
+                            // LDS, a measurement ring of three.  Same-box A/B (profiles/r03h): 1444 57.0 / 71.1 M (20-step window / steady
+                            // state), 1454 61.5 / 80.0, 1464 64.9 / 82.9, 1464 with passes at four 62.4 / 79.4
+#endif
+#ifndef SLAM_DEF_203
+#define SLAM_DEF_203 1454
 #endif
 #ifndef SLAM_DEF_103_F32
 #define SLAM_DEF_103_F32 1442   // fp32 storage: strips of two rows (0.88 vs 0.99 ms/step with four; fp64 prefers four: 0.92 vs 0.97)
@@ -56,6 +61,7 @@ static int default_code(int nmax_class, int f32, int B) {
     }
     if (nmax_class == 103 && f32) return SLAM_DEF_103_F32;
     if (nmax_class == 403) return 1444;   // 145 KB of LDS with four ring slots; one workgroup per CU either way
+    if (nmax_class == 203) return SLAM_DEF_203;
     return SLAM_DEF_103;
 }
 

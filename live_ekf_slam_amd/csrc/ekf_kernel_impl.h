@@ -44,9 +44,11 @@ struct EkfGeom {
     static constexpr int KCAP = LMAX > 0 ? LMAX : 1;     // detections held per step = the landmark capacity: every message without
                                                          // repeated ids fits (one wavefront associates them, 64 at a time)
     static constexpr int KG = KG_;                       // slots of the K / H P ring = updates one pass over P can apply
-    static constexpr int KP = KG_ > 4 ? 4 : KG_;         // landmark slot pairs of the thin rows / cols = DISTINCT landmarks one group /
-                                                         // one decoupled timestep can update (a fifth ring slot costs 3.4 KB of LDS, a
-                                                         // fifth pair another 3.3 KB: the ring may be deeper than the pairs)
+    static constexpr int KP = (KG_ > 5 && NMAX > 43) ? 3 : (KG_ > 4 ? 4 : KG_);   // landmark slot pairs of the thin rows / cols = DISTINCT landmarks ONE GROUP of
+                                                         // updates can touch (a ring slot costs 3.4 KB of LDS, a pair 3.3 KB: the ring may be
+                                                         // deeper than the pairs; a timestep with more detections than pairs runs as several
+                                                         // groups, in the decoupled loop too).  The smallest size class has LDS to spare.
+    static constexpr int KLOOP = 2 * KP;                 // detections of a timestep the decoupled loop takes (<= two groups)
     static constexpr int TS = 3 + 2 * KP;                // thin rows / cols held in LDS
     static constexpr int UNR = UNR_;                     // register pairs in flight per lane in the bulk stream
 };
@@ -168,7 +170,7 @@ __device__ __forceinline__ unsigned hi_abs(double v) {
 template <int NMAX, int W, int KG_, int UNR_, class ST, int PIPE, bool MULTI>
 __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(const EkfStepParams p) {
     using G = EkfGeom<NMAX, W, KG_, UNR_>;
-    constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, KP = G::KP, TS = G::TS, UNR = G::UNR;
+    constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, KP = G::KP, KLOOP = G::KLOOP, TS = G::TS, UNR = G::UNR;
 
     __shared__ double s_xt[LDP];          // x_t  (posterior of the previous step; landmark positions for H)
     __shared__ double s_xp[LDP];          // x_pred
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if constexpr (MULTI && W >= 2) {
         auto fastable = [&](int tq) -> bool {   // step tq (its pre-step results are in the parity buffers) can run decoupled
             const int* nx = s_next + 4 * (tq & 1);
-            return nx[0] <= KP && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
+            return nx[0] <= KLOOP && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
         };
         const bool fast_ok = p.id_known && p.meas_out == nullptr && fastable(t) &&
                              !SLAM_DBG(p.dbg & (2 | 16 | 64));
@@ -957,8 +959,17 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     first_it = false;
                     if (lane < 3) s_xp[lane] = s_ps[10 * pq + lane];
                     SLAM_STAMP(16);  // loop overhead
-                    int l1q, nTq;
-                    const int needg = form_known(didx_q, kq, 0, KP, n, l1q, nTq);
+                    int lastu = -1;
+                    if constexpr (!kWide) {
+                        const bool isupd = lane < kq && didx_q[lane] >= 0;
+                        const unsigned long long um = __ballot(isupd);
+                        lastu = um ? 63 - __clzll((long long)um) : -1;
+                    }
+                    // the detections of the timestep in groups of at most KP (one landmark slot pair each); nearly always one group
+                    int l0q = 0, l1q, nTq;
+#pragma unroll 1
+                    do {
+                    const int needg = form_known(didx_q, kq, l0q, KP, n, l1q, nTq);
                     SLAM_STAMP(17);  // group formation
                     const bool veh = s_need[0] == 1;   // first step of the launch: the vehicle rows / columns are still in HBM only
                     if (needg || veh) {
@@ -1040,7 +1051,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     if (lane < TS) s_need[lane] = 0;
                     SLAM_STAMP(18);  // flush wait + gather
                     // ---- prediction on the thin copies (ekf.cpp:41-61), one wavefront: see the synchronised path ----
-                    {
+                    if (l0q == 0) {
                         const double* const ps = s_ps + 10 * pq;
                         const double* const r2o = s_R + 2 * LDP;
                         const double* const c2o = s_C + 2 * LDP;
@@ -1094,15 +1105,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         }
                     }
                     SLAM_STAMP(19);  // prediction
-                    // ---- detections in message order (all of them updates: the step inserts nothing) ----
-                    int lastu = -1;
-                    if constexpr (!kWide) {
-                        const bool isupd = lane < kq && didx_q[lane] >= 0;
-                        const unsigned long long um = __ballot(isupd);
-                        lastu = um ? 63 - __clzll((long long)um) : -1;
-                    }
+                    // ---- detections of the group in message order (all of them updates: the step inserts nothing) ----
 #pragma unroll 1
-                    for (int l = 0; l < kq; ++l) {
+                    for (int l = l0q; l < l1q; ++l) {
                         const int idx = didx_q[l];
                         if (idx < 0) continue;
                         const float r_m = meas_q[3 * l + 1], b_m = meas_q[3 * l + 2];
@@ -1151,6 +1156,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         // thin copies follow the same downdate  P -= K (H P)
                         thin_downdate(lane, 64, 0, 1, nTq, n, Ku, HPu);
                     }
+                    l0q = l1q;
+                    } while (l0q < kq && !ld_i(&s_ring[2]));
                     if (ld_i(&s_ring[2])) break;   // watchdog fired: the instance is frozen below
                     SLAM_STAMP(23);  // thin downdates (+ loop)
                     // ---- end of the step: error statistic, x_t = x_pred (ekf.cpp:176), storage rounding ----
@@ -1214,7 +1221,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                 const bool leader = (tid >> 6) == 1;
                 // never more than the ring holds: with KG < SLAM_PASS_MIN the control wavefront would wait for a slot and the
                 // leader for updates that cannot be published (a KG = 3 sweep variant hung the GPU that way)
-                constexpr int kPassMinCfg = kWide ? SLAM_PASS_MIN : SLAM_PASS_MIN_F32;
+#ifdef SLAM_PASS_MIN_FORCE
+                constexpr int kPassMinCfg = SLAM_PASS_MIN_FORCE;
+#else
+                // fp64: a pass starts at SLAM_PASS_MIN = 4 pending updates, and from five ring slots on at KG - 1 (one slot stays free)
+                constexpr int kPassMinCfg = kWide ? (KG > SLAM_PASS_MIN + 1 ? KG - 1 : SLAM_PASS_MIN) : SLAM_PASS_MIN_F32;
+#endif
                 constexpr int kPassMin = kPassMinCfg < KG ? kPassMinCfg : KG;
                 int seen = 0;   // passes this wavefront has taken part in
                 int sp = 0;     // polls since this wavefront last made progress (watchdog)

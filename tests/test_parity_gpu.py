@@ -69,7 +69,7 @@ def test_device_math_bit_exact(S, oracle):
 
 @pytest.mark.parametrize("fixture,L_max,wpf", [("sim_seed0_L20_T1000.npz", 20, 0), ("sim_seed1_L20_T400.npz", 20, 1124),
                                                ("sim_seed1_L20_T400.npz", 20, 1148),
-                                               ("sim_seed2_L50_T1000.npz", 50, 1248), ("sim_seed2_L50_T1000.npz", 50, 1444), ("sim_seed2_L50_T1000.npz", 50, 1454),
+                                               ("sim_seed2_L50_T1000.npz", 50, 1248), ("sim_seed2_L50_T1000.npz", 50, 1444), ("sim_seed2_L50_T1000.npz", 50, 1454), ("sim_seed2_L50_T1000.npz", 50, 1464),
                                                ("sim_seed1_L20_T400.npz", 20, 1244),
                                                ("sim_seed1234_L50_T400.npz", 50, 1424), ("sim_seed0_L20_T1000.npz", 50, 444),
                                                ("sim_seed0_L20_T1000.npz", 90, 0),
@@ -100,7 +100,7 @@ def test_update_on_reference_measurement_stream(S, oracle, monkeypatch, fixture,
     f.close()
 
 
-@pytest.mark.parametrize("L,T,B,wpf", [(20, 400, 192, 0), (50, 400, 96, 1842), (50, 400, 96, 0), (50, 400, 96, 1444), (20, 400, 96, 1124), (20, 300, 64, 1224), (20, 300, 64, 1244),
+@pytest.mark.parametrize("L,T,B,wpf", [(20, 400, 192, 0), (50, 400, 96, 1842), (50, 400, 96, 0), (50, 400, 96, 1444), (50, 400, 96, 1454), (20, 400, 96, 1124), (20, 300, 64, 1224), (20, 300, 64, 1244),
                                        (50, 300, 64, 1448)])
 def test_sim_step_parity(S, oracle, monkeypatch, L, T, B, wpf):
     """Device-side generator + filter in one kernel vs oracle generator + oracle filter, per-instance noise
