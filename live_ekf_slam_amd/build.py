@@ -21,7 +21,7 @@ HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", 
 EKF_DEFAULT_VARIANTS = [(43, 2, 5, 4, 0, 1), (43, 2, 4, 4, 0, 1), (43, 1, 2, 4, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 4, 4, 0, 1),
                         (203, 4, 5, 4, 0, 1), (203, 4, 4, 4, 0, 1), (403, 4, 4, 4, 0, 1),
                         (43, 2, 4, 4, 1, 1), (103, 4, 4, 2, 1, 1)]
-EKF_SWEEP_VARIANTS = [(103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1), (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 4, 5, 2, 1, 1), (103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
+EKF_SWEEP_VARIANTS = [(103, 4, 5, 4, 0, 2), (103, 4, 5, 2, 0, 2), (103, 4, 4, 4, 0, 2), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1), (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 4, 5, 2, 1, 1), (103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
                       (103, 2, 4, 4, 0, 1), (103, 8, 4, 2, 0, 1), (103, 8, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1), (103, 4, 2, 4, 0, 1),
                       (103, 4, 4, 4, 1, 0), (103, 4, 4, 8, 1, 1), (103, 4, 4, 4, 1, 1), (103, 2, 4, 4, 1, 1), (103, 8, 4, 2, 1, 1),
                       (103, 2, 4, 2, 1, 1), (103, 3, 4, 2, 1, 1), (43, 2, 4, 2, 1, 1), (43, 2, 4, 2, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 6, 2, 1, 1), (103, 3, 4, 4, 0, 1), (103, 3, 4, 2, 0, 1),

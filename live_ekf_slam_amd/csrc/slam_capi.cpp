@@ -1245,7 +1245,7 @@ int slam_debug_read_prof(slam_handle* h, unsigned long long* out) {
     const size_t S = h->kind == SLAM_EKF_SLAM ? slam::kEkfProfSlots : 16;   // the UKF kernels use 16 slots per block
     std::vector<unsigned long long> buf(S * h->B);
     HIP_TRY(hipMemcpy(buf.data(), h->dprof, sizeof(unsigned long long) * buf.size(), hipMemcpyDeviceToHost));
-    const int nslot = h->kind == SLAM_EKF_SLAM ? 32 : 16;   // out[32] for the EKF (slots 16.. = decoupled loop), out[16] for the UKF
+    const int nslot = h->kind == SLAM_EKF_SLAM ? 64 : 16;   // out[64] for the EKF (slots 16.. = decoupled loop, 40.. = split control), out[16] for the UKF
     for (int i = 0; i < nslot; ++i) out[i] = 0;
     for (int b = 0; b < h->B; ++b)
         for (int i = 0; i < nslot; ++i) out[i] += buf[S * b + i];
