@@ -99,6 +99,11 @@ int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launch
  * of the LAST solve spent in {linearize, chain, syrk, chol, backsolve, evaluate}, summed over its trials. */
 int pgs_set_profiling(pgs_handle* h, int on);
 int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]);
+/* The last solve run with profiling on, split by how the Schur complement was formed: out = {algorithmic SYRK FLOP of the trials
+ * that ran the separate SYRK kernels, FLOP of the trials that ran the fused chain + SYRK kernel, ms spent in those SYRK
+ * launches, ms spent in those fused launches}.  (Few running slots: the chain is replicated on 2-4 CUs per instance with the
+ * SYRK tiles shared among them; between one and two rounds of that, chain and SYRK are two launches.) */
+int pgs_last_solve_paths(pgs_handle* h, double out[4]);
 int pgs_sync(pgs_handle* h);
 int pgs_timestep(const pgs_handle* h);
 

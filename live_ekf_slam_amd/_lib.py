@@ -88,6 +88,7 @@ SIGNATURES = {
     "pgs_last_solve_work": (C.c_int, [_H, _dp, _ip]),
     "pgs_set_profiling": (C.c_int, [_H, C.c_int]),
     "pgs_last_solve_kernel_ms": (C.c_int, [_H, _dp]),
+    "pgs_last_solve_paths": (C.c_int, [_H, _dp]),
     "pgs_sync": (C.c_int, [_H]),
     "pgs_timestep": (C.c_int, [_H]),
     # include/slam_multi.h

@@ -51,12 +51,18 @@ struct pgs_handle {
     int p_notrim = 0;
     int chol_threads = 0, chol_switch = 256;   // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces; else 256 while > chol_switch instances are active
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
-    int syrk_inst_switch = 160;                  // SLAM_PGS_SYRK_INST_SWITCH: active count from which the instance-resident SYRK runs (SLAM_PGS_SYRK_TILE=1 forces it)
+    double path_ms[2] = {0.0, 0.0};           // profiled solve: ms in the separate SYRK launches / in the fused chain + SYRK launches
+    bool fused_ok = false;                    // this solve's graphs fit the fused kernel (decided in pgs_solve from max M)
+    int cus = 256;                            // compute units of the device
+    bool use_list = true;                     // SLAM_PGS_LIST=0: full-size grids, inactive workgroups return (the round-2 launch shape)
+    int fused_mode = -1;                      // SLAM_PGS_FUSED: 0 = chain and SYRK as two launches, -1 (default) = fused when the tiles fit
+    int syrk_inst_switch = 100;                  // SLAM_PGS_SYRK_INST_SWITCH: active count from which the instance-resident SYRK runs (SLAM_PGS_SYRK_TILE=1 forces it)
     int syrk_tile = 0, syrk_switch = 1 << 30;    // SLAM_PGS_SYRK_TILE = 32 | 64 forces a variant; SLAM_PGS_SYRK_SWITCH = active count from which
                                              // the 64x64-per-wavefront variant is used (default: never — measured slower at every batch size)
     int last_trials = 0;
     bool profiling = false;                  // per-kernel hipEvent timing of pgs_solve (pgs_set_profiling)
     std::vector<hipEvent_t> events;
+    std::vector<int> trial_fused;             // profiled solve: the fused choice (0 | 2 | 3 | 4) of every trial
     double kernel_ms[slam::kPgsTrialKernels] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -108,6 +114,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     HIP_TRY(hipSetDevice(device));
     pgs_handle* h = new pgs_handle();
     h->cfg = *cfg; h->B = batch; h->N_max = N_max; h->L_max = L_max; h->KP = k_per_pose; h->device = device;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->cus = cu; }
     h->LD = round_up(2 * L_max + 1, 64);
     if (const char* e = getenv("SLAM_PGS_MAX_TRIALS")) h->max_trials = atoi(e) > 0 ? atoi(e) : h->max_trials;
     if (const char* e = getenv("SLAM_PGS_LANES")) h->lanes = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : h->lanes;
@@ -117,6 +124,8 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_SYRK_INST_SWITCH")) h->syrk_inst_switch = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
     h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
+    if (const char* e = getenv("SLAM_PGS_FUSED")) h->fused_mode = atoi(e);
+    if (const char* e = getenv("SLAM_PGS_LIST")) h->use_list = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PGS_NOTRIM")) h->p_notrim = atoi(e) ? atoi(e) : 1;
     if (const char* e = getenv("SLAM_PGS_GROUPS")) h->groups = atoi(e);
     if (const char* e = getenv("SLAM_PGS_CHOL_THREADS")) h->chol_threads = atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0);
@@ -161,10 +170,10 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     A(&p.Y, S * (size_t)p.y_stride); A(&p.S, S * (size_t)h->LD * h->LD);
     A(&p.dl, S * L * 2); A(&p.dp, S * N * 3);
     A(&p.lambda, S); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
-    A(&p.iters, B); A(&p.trials, B); A(&p.state, S); AC(&p.solve_ok, 1); A(&p.n_active, 64);
+    A(&p.iters, B); A(&p.trials, B); A(&p.state, S); AC(&p.solve_ok, 1); A(&p.n_active, 64); A(&p.alist, S); A(&p.inst_flop, B); A(&p.work, 2);
     A(&p.nl, B); A(&p.nlin, S); A(&p.nerr, S); A(&p.nok, S);
     A(&h->dcount, B); A(&h->dsec, B * 3); A(&h->dout, B);
-    if (getenv("SLAM_PGS_PROF")) { A(&p.prof, S * 8); }
+    if (getenv("SLAM_PGS_PROF")) { A(&p.prof, S * 24); }   // [S][8] chol phase timers, then [S][2][8] per-workgroup stamps of the fused chain
     if (rc != SLAM_OK) { pgs_destroy(h); return rc; }
     hipMemsetAsync(p.truth_hist, 0, sizeof(double) * B * N * 2, h->stream);
     hipMemsetAsync(p.cnt, 0, sizeof(int32_t) * B * N, h->stream);
@@ -298,18 +307,33 @@ int clone_instances(pgs_handle* h, const slam::PgsParams& p, hipStream_t stream)
 // linearize kernel covers the round trip of that wait and of the next launches.  Every slot is covered (inactive ones return).
 int prelaunch_trial(pgs_handle* h, slam::PgsParams& p, hipStream_t stream) {
     p.lanes = h->lanes;
-    HIP_TRY(hipMemsetAsync(p.n_active, 0, 2 * sizeof(int32_t), stream));
+    p.use_list = 0;   // the host does not know the list's length yet
+    HIP_TRY(hipMemsetAsync(p.n_active, 0, 4 * sizeof(int32_t), stream));
     HIP_TRY(slam::pgs_launch_trial_kernel(p, 0, stream));
     return SLAM_OK;
 }
 
-int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lanes, hipStream_t stream, int trial_index, bool profile,
-                 bool prelaunched = false) {
+int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lanes, int32_t nslots, hipStream_t stream, int trial_index,
+                 bool profile, bool prelaunched = false) {
     p.lanes = lanes < 1 ? 1 : (lanes > h->lanes ? h->lanes : lanes);
+    p.use_list = h->use_list ? 1 : 0; p.n_list = nslots;   // the slots pgs_decide_kernel (or lm_begin) listed for this trial
+    {   // Chain + SYRK fused: NB workgroups per slot, each alone on a CU.  With idle CUs to spare the chain is replicated on up to
+        // four of them so that a workgroup's share of the tiles stays in the shadow of the recursion; between one and two rounds of
+        // NB = 2 the two-launch path (instance-resident SYRK) is faster; a full batch of 2 x 256 workgroups is two clean rounds.
+        const int run = p.use_list ? nslots : p.b_cnt * p.lanes;
+        p.fused = 0;
+        if (h->fused_ok) {
+            if (h->fused_mode >= 2 && h->fused_mode <= 4) p.fused = h->fused_mode;
+            else if (4 * run <= h->cus) p.fused = 4;
+            else if (3 * run <= h->cus) p.fused = 3;
+            else if (2 * run <= h->cus) p.fused = 2;
+            else if (run > (h->cus * 2) / 3 && run <= h->cus) p.fused = 2;
+        }
+    }
     // Few instances left: the per-trial latency counts and spare slots cost little.  Two lanes from `lanes_switch` active
     // instances down (the common streak is one failure, then a success at 10 lambda), all of them from `lanes_switch_all` down.
     p.lanes_next = active_hint <= h->lanes_switch_all ? h->lanes : (active_hint <= h->lanes_switch ? (h->lanes < 2 ? h->lanes : 2) : 1);
-    active_hint *= p.lanes;   // the kernel variants below are chosen by the number of slots that run, not of instances
+    active_hint *= p.lanes;   // the kernel variants below are chosen by the number of slots that run (an upper bound), not of instances
     p.syrk_notrim = h->p_notrim;
     p.chol_threads = h->chol_threads ? h->chol_threads : (active_hint > h->chol_switch ? 256 : 1024);
     // 32x32 wavefront tiles by default; the 64x64 variant (more operand reuse, 4x fewer wavefronts) is kept for tuning
@@ -317,7 +341,8 @@ int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lan
     // instance-resident accumulators (tile code 1) from syrk_inst_switch active instances; its staging registers are sized for LD <= 448
     if ((h->syrk_tile == 1 || (!h->syrk_tile && active_hint >= h->syrk_inst_switch)) && p.LD <= 448) p.syrk_wave_tile = 1;
     else if (p.syrk_wave_tile == 1) p.syrk_wave_tile = 32;
-    if (!prelaunched) HIP_TRY(hipMemsetAsync(p.n_active, 0, 2 * sizeof(int32_t), stream));
+    if (profile) { if ((int)h->trial_fused.size() <= trial_index) h->trial_fused.resize(trial_index + 1); h->trial_fused[trial_index] = p.fused; }
+    if (!prelaunched) HIP_TRY(hipMemsetAsync(p.n_active, 0, 4 * sizeof(int32_t), stream));
     for (int k = prelaunched ? 1 : 0; k < slam::kPgsTrialKernels; ++k) {
         if (profile) {
             const size_t need = (size_t)(trial_index + 1) * (slam::kPgsTrialKernels + 1);
@@ -337,6 +362,21 @@ int pgs_solve(pgs_handle* h) {
     if (!h->inited) return fail(SLAM_ERR_STATE, "pgs_init must be called before pgs_solve");
     h->p.N = h->timestep + 1;
     h->p.b_off = 0; h->p.b_cnt = h->B;
+    {   // chain + SYRK in one launch (Y stays in LDS) is possible while the lower triangle of every instance fits the 72 wavefront
+        // tiles of pgs_chain_syrk_kernel, a column of Y per lane (2M + 1 <= 448) and its event staging (32 factor slots per pose)
+        h->fused_ok = false; h->p.fused = 0;
+        if (h->fused_mode != 0 && h->p.LD <= 448 && h->p.KP <= 32) {
+            std::vector<int32_t> M((size_t)h->B);
+            HIP_TRY(hipMemcpyAsync(M.data(), h->p.M, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            int mx = 0;
+            for (int32_t m : M) mx = m > mx ? m : mx;
+            const int nt = (2 * mx + 31) / 32;
+            h->fused_ok = nt * (nt + 1) / 2 <= 72;
+        }
+    }
+    HIP_TRY(hipMemsetAsync(h->p.work, 0, 2 * sizeof(double), h->stream));
+    h->path_ms[0] = h->path_ms[1] = 0.0;
     int G = h->groups > 0 ? h->groups : (h->B >= 512 ? 2 : 1);
     if (G > 16) G = 16;
     if (G > h->B) G = h->B;
@@ -345,18 +385,18 @@ int pgs_solve(pgs_handle* h) {
         HIP_TRY(slam::pgs_launch_lm_begin(h->p, h->stream));
         TRY(clone_instances(h, h->p, h->stream));
         int trials = 0;
-        int32_t act[2] = {h->B, 1};   // active instances, lanes of the next trial
+        int32_t act[3] = {h->B, 1, h->B};   // active instances, lanes and active slots of the next trial
         if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 64, hipHostMallocDefault));
         while ((int)h->gevents.size() < 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->gevents.push_back(e); }
         const bool pipe = !h->profiling;   // per-kernel timing wants every kernel of a trial between its own events
         if (pipe) TRY(prelaunch_trial(h, h->p, h->stream));
         for (; trials < h->max_trials; ++trials) {
-            TRY(launch_trial(h, h->p, act[0], act[1], h->stream, trials, h->profiling, pipe));
-            HIP_TRY(hipMemcpyAsync(h->h_active, h->p.n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            TRY(launch_trial(h, h->p, act[0], act[1], act[2], h->stream, trials, h->profiling, pipe));
+            HIP_TRY(hipMemcpyAsync(h->h_active, h->p.n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipEventRecord(h->gevents[0], h->stream));
             if (pipe) TRY(prelaunch_trial(h, h->p, h->stream));   // the next trial's linearisation runs while the host waits below
             HIP_TRY(hipEventSynchronize(h->gevents[0]));
-            act[0] = h->h_active[0]; act[1] = h->h_active[1];
+            act[0] = h->h_active[0]; act[1] = h->h_active[1]; act[2] = h->h_active[2];
             if (h->trace) {
                 static thread_local double t_prev = 0.0;
                 timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -377,6 +417,9 @@ int pgs_solve(pgs_handle* h) {
                     const size_t e0 = (size_t)t * (slam::kPgsTrialKernels + 1) + k;
                     HIP_TRY(hipEventElapsedTime(&ms, h->events[e0], h->events[e0 + 1]));
                     h->kernel_ms[k] += ms;
+                    const int tf = t < (int)h->trial_fused.size() ? h->trial_fused[t] : 0;
+                    if (k == 1 && tf) h->path_ms[1] += ms;      // chain + SYRK in one launch
+                    if (k == 2 && !tf) h->path_ms[0] += ms;     // the SYRK launch of the two-launch path
                     if (h->trace) fprintf(stderr, "%s%.3f%s", k == 0 ? "pgs trial kernels (ms): " : " ", ms, k + 1 == slam::kPgsTrialKernels ? "\n" : "");
                 }
         }
@@ -394,13 +437,14 @@ int pgs_solve(pgs_handle* h) {
     for (int g = 0; g < G; ++g) {
         gp[g].b_off = g * per;
         gp[g].b_cnt = (h->B - g * per) < per ? (h->B - g * per) : per;
-        gp[g].n_active = h->p.n_active + 2 * g;
+        gp[g].n_active = h->p.n_active + 4 * g;
+        gp[g].alist = h->p.alist + (size_t)g * per * h->lanes;
         if (gp[g].b_cnt <= 0) { gdone[g] = 1; continue; }
         HIP_TRY(hipStreamWaitEvent(h->gstreams[g], h->gevents[G], 0));
         HIP_TRY(slam::pgs_launch_lm_begin(gp[g], h->gstreams[g]));
         TRY(clone_instances(h, gp[g], h->gstreams[g]));
-        TRY(launch_trial(h, gp[g], h->B, 1, h->gstreams[g], 0, false));
-        HIP_TRY(hipMemcpyAsync(h->h_active + 2 * g, gp[g].n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
+        TRY(launch_trial(h, gp[g], h->B, 1, gp[g].b_cnt, h->gstreams[g], 0, false));
+        HIP_TRY(hipMemcpyAsync(h->h_active + 4 * g, gp[g].n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
         HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
         TRY(prelaunch_trial(h, gp[g], h->gstreams[g]));
     }
@@ -411,7 +455,7 @@ int pgs_solve(pgs_handle* h) {
         HIP_TRY(hipSetDevice(h->device));
         for (;;) {
             HIP_TRY(hipEventSynchronize(h->gevents[g]));
-            const int32_t active = h->h_active[2 * g], lanes_next = h->h_active[2 * g + 1];
+            const int32_t active = h->h_active[4 * g], lanes_next = h->h_active[4 * g + 1], nslots = h->h_active[4 * g + 2];
             gtrials[g] += 1;
             if (h->trace) fprintf(stderr, "pgs group %d trial %d: active %d\n", g, gtrials[g] - 1, (int)active);
             if (active == 0 || gtrials[g] >= h->max_trials) {
@@ -419,8 +463,8 @@ int pgs_solve(pgs_handle* h) {
                 HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
                 return SLAM_OK;
             }
-            TRY(launch_trial(h, gp[g], active * G, lanes_next, h->gstreams[g], gtrials[g], false, true));
-            HIP_TRY(hipMemcpyAsync(h->h_active + 2 * g, gp[g].n_active, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
+            TRY(launch_trial(h, gp[g], active * G, lanes_next, nslots, h->gstreams[g], gtrials[g], false, true));
+            HIP_TRY(hipMemcpyAsync(h->h_active + 4 * g, gp[g].n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
             HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
             TRY(prelaunch_trial(h, gp[g], h->gstreams[g]));
         }
@@ -530,6 +574,16 @@ int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launch
     return SLAM_OK;
 }
 
+// The last PROFILED solve by path: out = {algorithmic SYRK FLOP of the trials that ran pgs_syrk_*_kernel, of the trials that ran
+// pgs_chain_syrk_kernel, ms in those SYRK launches, ms in those fused launches}
+int pgs_last_solve_paths(pgs_handle* h, double out[4]) {
+    TRY(check(h));
+    if (!out) return fail(SLAM_ERR_ARG, "NULL output");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->p.work, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    out[2] = h->path_ms[0]; out[3] = h->path_ms[1];
+    return SLAM_OK;
+}
 int pgs_set_profiling(pgs_handle* h, int on) { TRY(check(h)); h->profiling = on != 0; return SLAM_OK; }
 int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]) {
     TRY(check(h));
@@ -543,6 +597,14 @@ int pgs_debug_prof(pgs_handle* h, unsigned long long* out) {
     if (!h->p.prof) return fail(SLAM_ERR_STATE, "set SLAM_PGS_PROF before pgs_create");
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out, h->p.prof, sizeof(unsigned long long) * 8 * (size_t)h->B, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+// debug only: begin / end / HW_ID / XCC_ID of the two workgroups of every instance in the last fused chain launch + phase times, [batch][2][8]
+int pgs_debug_prof2(pgs_handle* h, unsigned long long* out) {
+    TRY(check(h));
+    if (!h->p.prof) return fail(SLAM_ERR_STATE, "set SLAM_PGS_PROF before pgs_create");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->p.prof + (size_t)h->B * h->lanes * 8, sizeof(unsigned long long) * 16 * (size_t)h->B, hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 int pgs_sync(pgs_handle* h) { TRY(check(h)); HIP_TRY(hipStreamSynchronize(h->stream)); return SLAM_OK; }

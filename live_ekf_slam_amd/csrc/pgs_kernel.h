@@ -18,6 +18,7 @@ struct PgsParams {
     int32_t chol_threads;              // 1024 or 256: workgroup size of the dense Cholesky of the next trial
     int32_t syrk_notrim;               // experiment: do not trim the k range (tiles of an instance then march in step)
     int32_t syrk_wave_tile;            // 64 or 32: SYRK variant of the next trial (chosen by the host from the active count)
+    int32_t fused;                     // 0: chain and SYRK are two launches; 2 | 3 | 4: one (pgs_chain_syrk_kernel), that many workgroups per instance
     // ---- the graph (pose_graph.cpp: graph + initial_estimate + result) ----
     double* pose0; double* lm0;        // initial_estimate: [B][N_max][3], [B][L_max][2]
     double* pose1; double* lm1;        // result
@@ -56,7 +57,13 @@ struct PgsParams {
     double* dl; double* dp;            // [B][L_max*2], [B][N_max*3]
     double* lambda; double* error; double* cur_error; double* err_init;
     int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done
-    int32_t* n_active;                 // [2] per solve group: active instances after the trial, lanes the next trial needs
+    int32_t* n_active;                 // [4] per solve group: active instances after the trial, lanes the next trial needs, active SLOTS
+    // The slots that run in the next trial, compacted by pgs_decide_kernel (order = arrival order of its atomics; the mapping of
+    // workgroups to instances does not touch any result).  A launch over the list has exactly one workgroup (or FC_NB / SI_NB) per
+    // running slot with consecutive ids - the dispatcher deals ids round-robin over XCDs and shader engines, so a sparse set of
+    // live ids in a full-size grid left engines idle while others queued (158 live workgroups of 512 took two rounds).
+    int32_t* alist;                    // [b_cnt * lanes_max] of this solve group
+    int32_t use_list, n_list;          // the launch's block index -> slot through alist[0 .. n_list) (else: lane * B + instance)
     // ---- speculative lambda lanes ----
     // Every instance b owns `lanes_max` slots of every per-instance array: slot b (the instance itself) and the clones
     // j * B + b, j = 1 .. lanes_max - 1.  After a failed tryLambda GTSAM multiplies lambda by 10 and tries again on the same
@@ -71,6 +78,9 @@ struct PgsParams {
     int32_t* nl;                       // [B]   lanes instance b runs in the current trial
     double* nlin; double* nerr;        // [slots] linearised / true cost of the slot's candidate (pgs_evaluate_kernel)
     int32_t* nok;                      // [slots] the slot's linear solve succeeded
+    double* inst_flop;                 // [B] algorithmic FLOP of ONE Schur-complement SYRK of instance b (pgs_lm_begin_kernel)
+    double* work;                      // [2] algorithmic SYRK FLOP of the trials GTSAM's loop consumed so far in this solve, by path:
+                                       //     [0] pgs_syrk_*_kernel launches, [1] pgs_chain_syrk_kernel (pgs_decide_kernel adds)
     unsigned long long* prof;          // optional [B][8] phase timers of the chol kernel (100 MHz wall clock), debug only
     // ---- factor constants ----
     double prior[3];

@@ -261,9 +261,12 @@ constexpr int TPB = 512;   // threads of the per-pose kernels (two poses per thr
 
 // logical block `bl` of a trial-kernel launch -> slot: lane = bl / b_cnt, instance = b_off + bl % b_cnt (PgsParams::lanes)
 __device__ __forceinline__ int pgs_slot(const PgsParams& p, int bl) {
+    if (p.use_list) return p.alist[bl];
     const int lane = bl / p.b_cnt;
     return lane * p.B + p.b_off + (bl - lane * p.b_cnt);
 }
+// slots a trial-kernel launch covers
+__host__ __device__ __forceinline__ int pgs_nslot(const PgsParams& p) { return p.use_list ? p.n_list : p.b_cnt * (p.lanes > 0 ? p.lanes : 1); }
 
 __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
@@ -301,11 +304,21 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
         }
     }
     __syncthreads();
+    {   // algorithmic FLOP of one SYRK of this instance: 2 per stored lower-triangle element of S_ext and per k where its row of
+        // Y^T can be non-zero (from the first detection of the row's landmark; the right-hand-side row is dense in k)
+        const int32_t* first = p.lm_first + (size_t)b * p.L_max;
+        const int m2 = 2 * M, K3 = 3 * N;
+        double f = 0.0;
+        for (int r = tid; r < m2; r += TPB) f += 2.0 * (r + 1) * (double)(K3 - 3 * first[r >> 1]);
+        f = block_sum<TPB>(f, s_buf);
+        if (tid == 0) p.inst_flop[b] = f + 2.0 * m2 * (double)K3;
+    }
     const double err = block_cost<TPB>(p, b, pw, lw, s_buf);
     if (tid == 0) {
         p.error[b] = err; p.err_init[b] = err; p.cur_error[b] = err;
         p.lambda[b] = 1e-5;                    // LevenbergMarquardtParams::lambdaInitial
         p.iters[b] = 0; p.trials[b] = 0; p.state[b] = 0; p.solve_ok[b] = 1; p.nl[b] = 1;
+        p.alist[blockIdx.x] = b;               // first trial: every instance of the group, one lane
         p.flags[b] &= ~(PGS_FLAG_NOT_CONVERGED | PGS_FLAG_NONFINITE);
     }
 }
@@ -608,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
     const int ntl = ntr * (ntr + 1) / 2;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int bl = (q / ntl) * 8 + xcd;     // instance within the launched group
-    if (bl >= p.b_cnt * p.lanes) return;
+    if (bl >= pgs_nslot(p)) return;
     const int b = pgs_slot(p, bl);
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
@@ -710,7 +723,7 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
     extern __shared__ double s_y[];   // [2][SI_ROWS][ldl]
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int bl = (q / SI_NB) * 8 + xcd, hb = q % SI_NB;
-    if (bl >= p.b_cnt * p.lanes) return;
+    if (bl >= pgs_nslot(p)) return;
     const int b = pgs_slot(p, bl);
     if (p.state[b] || !p.solve_ok[b]) return;
     const int LD = p.LD, m2 = 2 * p.M[b];
@@ -726,9 +739,18 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
     const int nchunk = (K3 + SI_ROWS - 1) / SI_ROWS;
     const double* Yb = p.Y + (size_t)b * p.y_stride;
 
-    int rowbase[SI_NS], colbase[SI_NS], c0[SI_NS];
-    bool have[SI_NS];
+    // Per 16-row half of a tile the first chunk that can hold a non-zero: rows of Y^T are zero before the first detection of
+    // their landmark and landmarks are numbered by first detection, so half h of a tile starts at the chunk of
+    // lm_first[(rowbase + 16 h) / 2]; a half without landmark rows (>= 2M) never runs.  The z row (2M: the right-hand side
+    // gl - Y^T z, dense in k) is NOT given to the matrix pipe - it would keep the whole last tile row at the full k range,
+    // 22 % of the MFMA work of an instance at 1000 x 171 - but accumulated on the VALU by the wavefront that holds the tile:
+    // lane -> (column, half of the chunk's rows), eight FMAs per chunk.
+    int rowbase[SI_NS], colbase[SI_NS], c0[SI_NS][2];
+    bool have[SI_NS], dg[SI_NS];
+    int zcol = -1;                                // column base of this wavefront's tile of the last tile row
     dbl4_t acc[SI_NS][2][2];
+    const int32_t* lmf = p.lm_first + (size_t)b * p.L_max;
+    const bool trim = !(p.syrk_notrim & 1);
 #pragma unroll
     for (int s = 0; s < SI_NS; ++s) {
         const int t = gw + 16 * SI_NB * s;
@@ -738,15 +760,21 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         const int tj = t - ti * (ti + 1) / 2;
         rowbase[s] = have[s] ? 32 * ti : 0; colbase[s] = have[s] ? 32 * tj : 0;
-        // rows of Y^T are zero before the first detection of their landmark; landmarks are numbered by first detection
-        c0[s] = 0;
-        if (have[s] && rowbase[s] + 31 < m2 && !(p.syrk_notrim & 1)) c0[s] = (3 * p.lm_first[(size_t)b * p.L_max + (rowbase[s] >> 1)]) / SI_ROWS;
-        if (!have[s]) c0[s] = 0x7fffffff;
+        dg[s] = ti == tj;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rb = rowbase[s] + 16 * h;
+            c0[s][h] = 0x7fffffff;
+            if (have[s] && rb < m2) c0[s][h] = trim ? (3 * lmf[rb >> 1]) / SI_ROWS : 0;
+        }
+        if (have[s] && rowbase[s] + 31 >= m2) zcol = colbase[s];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[s][i][j] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
     }
+    double zacc = 0.0;
+    const int zoff = (lane >> 5) * (SI_ROWS / 2) * ldl;   // this lane's half of a chunk's rows
 
     // staging: a chunk is SI_ROWS x ncol doubles = SI_ROWS * ncol / 2 16-byte vectors
     const int vpr = ncol >> 1;                    // vectors per row
@@ -779,21 +807,32 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk && !(p.syrk_notrim & 4)) fetch(c + 1);
-        const double* src = s_y + (size_t)(c & 1) * SI_ROWS * ldl + kq * ldl + cl;
+        const double* cbuf = s_y + (size_t)(c & 1) * SI_ROWS * ldl;
+        const double* src = cbuf + kq * ldl + cl;
 #pragma unroll
         for (int s = 0; s < SI_NS; ++s) {
-            if (c < c0[s] || (p.syrk_notrim & 2)) continue;               // wave-uniform
+            if (c < c0[s][0] || (p.syrk_notrim & 2)) continue;            // wave-uniform
+            const bool both = c >= c0[s][1];                              // rows 16..31 of the tile have begun
             const double* sa = src + rowbase[s];
             const double* sb = src + colbase[s];
 #pragma unroll
             for (int ks = 0; ks < SI_ROWS / 4; ++ks) {
-                const double a0 = sa[ks * 4 * ldl], a1 = sa[ks * 4 * ldl + 16];
+                const double a0 = sa[ks * 4 * ldl];
                 const double b0 = sb[ks * 4 * ldl], b1 = sb[ks * 4 * ldl + 16];
                 acc[s][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[s][0][0], 0, 0, 0);
-                acc[s][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[s][0][1], 0, 0, 0);
-                acc[s][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[s][1][0], 0, 0, 0);
-                acc[s][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[s][1][1], 0, 0, 0);
+                if (!dg[s]) acc[s][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[s][0][1], 0, 0, 0);   // strictly upper on a diagonal tile
+                if (both) {
+                    const double a1 = sa[ks * 4 * ldl + 16];
+                    acc[s][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[s][1][0], 0, 0, 0);
+                    acc[s][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[s][1][1], 0, 0, 0);
+                }
             }
+        }
+        if (zcol >= 0) {                                                  // wave-uniform: the z row of this wavefront's tile
+            const double* zy = cbuf + zoff;
+            const int cc = zcol + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < SI_ROWS / 2; ++r) zacc = fma(zy[r * ldl + m2], zy[r * ldl + cc], zacc);
         }
         if (c + 1 < nchunk) put((c + 1) & 1);
         __syncthreads();
@@ -802,13 +841,15 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
     const double* Db = p.D + (size_t)b * p.L_max * 3;
     const double* glb = p.gl + (size_t)b * p.L_max * 2;
     double* Sb = p.S + (size_t)b * LD * LD;
+    zacc = zacc + __shfl_xor(zacc, 32);           // both halves of the chunks' rows: lane l (and l + 32) holds column zcol + (l & 31)
 #pragma unroll
     for (int s = 0; s < SI_NS; ++s) {
         if (!have[s]) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                const double zj = __shfl(zacc, 16 * j + cl);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int r = rowbase[s] + 16 * i + kq + 4 * r4;   // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg
@@ -818,11 +859,413 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
                     if (r < m2) {
                         if (cc == r) v += Db[3 * (r >> 1) + ((r & 1) ? 2 : 0)] + lambda;
                         else if ((cc >> 1) == (r >> 1)) v += Db[3 * (r >> 1) + 1];
-                    } else if (cc < m2) {
-                        v += glb[cc];
+                    } else {
+                        v = -zj;                                       // row 2M comes from the VALU sum, not from the MFMA
+                        if (cc < m2) v += glb[cc];
                     }
                     Sb[(size_t)r * LD + cc] = v;
                 }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// chain + SYRK FUSED (while every instance's lower triangle fits FC_TILES wavefront tiles): Y never
+// goes to HBM.  NB = 2, 3 or 4 workgroups of 8 wavefronts per instance (the host's choice per trial: as many as leave every
+// workgroup of the launch a CU of its own); all run the whole chain (the sequential 3x3
+// recursion is the critical path of a trial and costs one lane), each keeps its share of the instance's 32x32 tiles of
+// S = D + lambda I - Y^T Y as MFMA accumulators (NS tiles = 32 NS VGPRs per wavefront at two wavefronts per SIMD).
+//   wavefront 0         PRODUCER, as in pgs_chain_kernel but in chunks of FC_P poses and with the next chunk's inputs
+//                       fetched under the current chunk's recursion; works one chunk ahead
+//   wavefronts 1..7     one column of Y per lane (448 >= 2M + 1): the column recurrence of chunk n into an LDS buffer
+//                       of 3 FC_P rows (double-buffered) and the lane's term of the right-hand-side row gl - Y^T z
+//   wavefronts 1-3, 5-7 one barrier later: v_mfma_f64_16x16x4_f64 over those rows for the wavefront's tiles (16-row halves
+//                       trimmed by first detection)
+//   wavefront 4         shares its SIMD with the producer and therefore holds NO tiles: on gfx950 the fp64 MFMA runs at the
+//                       vector fp64 rate - on the same units - and a dependent v_mul_f64 of the recursion queued behind
+//                       64-cycle MFMAs (recursion 0.56 -> 0.79 ms).  It stages the bearing-range blocks of the next chunk instead.
+// Time per workgroup ~ max(recursion + its staging, columns + MFMA of the busiest SIMD) per chunk.  Same arithmetic per
+// element of Y and per tile as the unfused pair (the k order of the MFMA accumulation is the same; only row 2M is
+// summed on the VALU instead of the matrix pipe).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int FC_P = 4, FC_ROWS = 3 * FC_P, FC_TPB = 512, FC_TILES = 72;   // tiles an instance may have: NB workgroups x 6 wavefronts x NS
+constexpr int FC_KP = 32, FC_LMAX = 224;           // factor slots per pose / landmarks the event staging is sized for
+constexpr int FC_NF = FC_P * FC_KP / 64, FC_NE = FC_P * FC_KP * 3 / 64;   // per lane of the staging wavefront: factor slots, 16-byte pieces of E
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+template <int NS, int NB>
+__global__ __launch_bounds__(FC_TPB) void pgs_chain_syrk_kernel(const PgsParams p) {
+    constexpr int FC_NB = NB, FC_NW = 6 * NB;
+    extern __shared__ double s_yb[];                // [2][FC_ROWS][ldl]
+    __shared__ double s_in[2][FC_P][18];            // A (6 unique), C (9), gp (3)
+    __shared__ double s_ring[2][FC_P][18];          // Linv (6), G (9), gp (3)
+    // The E blocks of a chunk's bearing-range factors, staged by wavefront 4 (pose-major, as linearize
+    // wrote them: one contiguous piece per chunk) and an index (pose of the chunk, landmark) -> factor slot, tagged with the
+    // pose number so that it never needs clearing.  The column lanes pick their E entries from LDS: a lane that fetched its
+    // next event from HBM when the previous one fired made its whole wavefront wait for that load at the next pose.
+    __shared__ dbl2_t s_E[2][FC_P * FC_KP * 3 + 3];   // + one all-zero block: what a column without an event adds
+    __shared__ int s_idx[2][FC_P][FC_LMAX];
+    __shared__ int s_fail;
+    const int bl = blockIdx.x / FC_NB, hb = blockIdx.x - bl * FC_NB;
+    const int b = pgs_slot(p, bl), tid = threadIdx.x;
+    if (p.state[b]) {
+        if (p.prof && tid == 0) p.prof[(size_t)p.B * p.lanes_max * 8 + (size_t)b * 16 + 8 * hb + 1] = 0;   // debug: no stamp from this launch
+        return;
+    }
+    const int N = p.N, LD = p.LD, m2 = 2 * p.M[b];
+    const int nch = (N + FC_P - 1) / FC_P;
+    const int ncol = (m2 + 1 + 31) & ~31, ldl = ncol + 16;
+    if (tid == 0) s_fail = 0;
+    if (p.prof && (p.syrk_notrim & 16)) {            // debug: which SIMD each wavefront of the workgroup runs on (HW_ID bits 5:4)
+        if ((tid & 63) == 0) p.prof[(size_t)p.B * p.lanes_max * 8 + (size_t)b * 16 + 8 * hb + (tid >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        return;
+    }
+    for (int k = tid; k < 2 * FC_P * FC_LMAX; k += FC_TPB) (&s_idx[0][0][0])[k] = -1;
+    if (tid < 6) s_E[tid / 3][FC_P * FC_KP * 3 + tid % 3] = (dbl2_t){0.0, 0.0};
+    __syncthreads();
+    if (tid < 64) {
+        // ------------------------------------------------ producer ------------------------------------------------
+        const unsigned long long t_begin = p.prof ? wall_clock64() : 0ull;
+        unsigned long long t_rec = 0, t_pre = 0, t_post = 0;   // debug: time inside the recursion proper, before (loads issued) and after it (staging)
+        const double lambda = p.lambda[b];
+        const double* Ab = p.A + (size_t)b * p.N_max * 9;
+        const double* Cb = p.C + (size_t)b * p.N_max * 9;
+        const double* gpb = p.gp + (size_t)b * p.N_max * 3;
+        double* Lb = p.Linv + (size_t)b * p.N_max * 6;
+        double* Gb = p.G + (size_t)b * p.N_max * 9;
+        double stg[18];
+        auto load_in = [&](int ch) {                // inputs of pose ch * FC_P + tid into registers (lanes < FC_P)
+            const int i = ch * FC_P + tid;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) stg[k] = 0.0;
+            if (tid < FC_P && i < N) {
+                const double* A = Ab + 9 * i;
+                stg[0] = A[0]; stg[1] = A[3]; stg[2] = A[4]; stg[3] = A[6]; stg[4] = A[7]; stg[5] = A[8];
+                if (i > 0) {
+                    const double* C = Cb + 9 * (i - 1);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) stg[6 + k] = C[k];
+                }
+                stg[15] = gpb[3 * i]; stg[16] = gpb[3 * i + 1]; stg[17] = gpb[3 * i + 2];
+            }
+        };
+        auto store_in = [&](int buf) {
+            if (tid < FC_P) {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) s_in[buf][tid][k] = stg[k];
+            }
+        };
+        load_in(0);
+        store_in(0);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        double I0 = 0, I1 = 0, I2 = 0, I3 = 0, I4 = 0, I5 = 0;   // lane 0: Linv of the previous pose
+#pragma unroll 1
+        for (int it = 0; it <= nch + 1; ++it) {
+            if (it < nch) {
+                const int base = it * FC_P;
+                const int n = (N - base) < FC_P ? (N - base) : FC_P;
+                const unsigned long long tpa = p.prof ? wall_clock64() : 0ull;
+                if (it + 1 < nch) load_in(it + 1);
+                const unsigned long long tp0 = p.prof ? wall_clock64() : 0ull;
+                t_pre += tp0 - tpa;
+                if (tid == 0) {
+                    double (*out)[18] = s_ring[it & 1];
+                    const double (*sin)[18] = s_in[it & 1];
+                    bool ok = s_fail == 0;
+                    double in[18], nx[18];
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) in[k] = sin[0][k];
+#pragma unroll 1
+                    for (int l = 0; l < n && ok; ++l) {
+                        const int ln = l + 1 < n ? l + 1 : l;
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) nx[k] = sin[ln][k];
+                        double G[9];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {   // G = C Linv_prev^T (zero for the first pose: C = 0)
+                            G[3 * r + 0] = in[6 + 3 * r] * I0;
+                            G[3 * r + 1] = in[6 + 3 * r] * I1 + in[6 + 3 * r + 1] * I2;
+                            G[3 * r + 2] = (in[6 + 3 * r] * I3 + in[6 + 3 * r + 1] * I4) + in[6 + 3 * r + 2] * I5;
+                        }
+                        const double T0 = (in[0] + lambda) - ((G[0] * G[0] + G[1] * G[1]) + G[2] * G[2]);
+                        const double T3 = in[1] - ((G[3] * G[0] + G[4] * G[1]) + G[5] * G[2]);
+                        const double T4 = (in[2] + lambda) - ((G[3] * G[3] + G[4] * G[4]) + G[5] * G[5]);
+                        const double T6 = in[3] - ((G[6] * G[0] + G[7] * G[1]) + G[8] * G[2]);
+                        const double T7 = in[4] - ((G[6] * G[3] + G[7] * G[4]) + G[8] * G[5]);
+                        const double T8 = (in[5] + lambda) - ((G[6] * G[6] + G[7] * G[7]) + G[8] * G[8]);
+                        if (!(T0 > 0.0)) { ok = false; break; }
+                        I0 = rsqrt_nr(T0);
+                        const double l10 = T3 * I0, l20 = T6 * I0;
+                        const double t11 = T4 - l10 * l10;
+                        if (!(t11 > 0.0)) { ok = false; break; }
+                        I2 = rsqrt_nr(t11);
+                        const double l21 = (T7 - l20 * l10) * I2;
+                        const double t22 = (T8 - l20 * l20) - l21 * l21;
+                        if (!(t22 > 0.0)) { ok = false; break; }
+                        I5 = rsqrt_nr(t22);
+                        I1 = -(l10 * I0) * I2;
+                        I4 = -(l21 * I2) * I5;
+                        I3 = -(l20 * I0 + l21 * I1) * I5;
+                        double* o = out[l];
+                        o[0] = I0; o[1] = I1; o[2] = I2; o[3] = I3; o[4] = I4; o[5] = I5;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) o[6 + k] = G[k];
+                        o[15] = in[15]; o[16] = in[16]; o[17] = in[17];
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) in[k] = nx[k];
+                    }
+                    if (!ok) s_fail = 1;
+                    for (int l = n; l < FC_P; ++l)   // past the last pose: Linv = G = 0, the columns then write zero rows
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) out[l][k] = 0.0;
+                }
+                const unsigned long long tp1 = p.prof ? wall_clock64() : 0ull;
+                t_rec += tp1 - tp0;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (it + 1 < nch) store_in((it + 1) & 1);
+                if (hb == 0 && tid < n && s_fail == 0) {   // factor to HBM for the pose back-substitution
+                    const double* o = s_ring[it & 1][tid];
+                    double* L = Lb + 6 * (base + tid);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) L[k] = o[k];
+                    double* Go = Gb + 9 * (base + tid);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Go[k] = o[6 + k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (p.prof) t_post += wall_clock64() - tp1;
+            }
+            __syncthreads();
+            if (s_fail) break;
+        }
+        if (tid == 0 && hb == 0) p.solve_ok[b] = s_fail ? 0 : 1;
+        if (p.prof && tid == 0) {   // debug: [slots][2][8] after the chol timers: per workgroup begin, end (100 MHz), producer: before / after the recursion, recursion, wavefront 1: columns, tiles, barrier
+            unsigned long long* o = p.prof + (size_t)p.B * p.lanes_max * 8 + (size_t)b * 16 + 8 * hb;
+            o[0] = t_begin; o[1] = wall_clock64();
+            o[2] = t_pre; o[3] = t_post;
+            o[4] = t_rec;
+        }
+        return;
+    }
+    // -------------------------------------------------- consumers --------------------------------------------------
+    const int w = tid >> 6, lane = tid & 63;
+    const int c = tid - 64;                          // column of Y
+    const int kq = lane >> 4, cl = lane & 15;
+    // column recurrence state
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, zacc = 0.0;
+    const int KP = p.KP, myj = (c >> 1) < FC_LMAX ? (c >> 1) : 0, myd = c & 1;
+    const bool is_z = c == m2;                       // the gradient column: its right-hand side is gp, it has no factors (s_idx[.][M] stays -1)
+    unsigned long long tc[3] = {0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
+#define FC_STAMP(i) do { if (p.prof && tid == 64) { const unsigned long long now_ = wall_clock64(); tc[i] += now_ - tprev; tprev = now_; } } while (0)
+    auto columns = [&](int it) {
+        if (it >= 1 && it <= nch && c <= m2) {       // column recurrence of chunk it - 1 -> s_yb[(it - 1) & 1]
+            const int base = (it - 1) * FC_P;
+            const int buf = (it - 1) & 1;
+            const double (*rg)[18] = s_ring[buf];
+            double* yo = s_yb + (size_t)buf * FC_ROWS * ldl + c;
+            const double* Eq = reinterpret_cast<const double*>(&s_E[buf][0]) + myd;
+            // branch-free: a column without a factor at pose i adds the all-zero block, poses past N have a zero ring entry
+            int slot[FC_P];
+#pragma unroll
+            for (int l = 0; l < FC_P; ++l) {
+                const int ent = s_idx[buf][l][myj];
+                slot[l] = (ent >> 8) == base + l ? 6 * (l * KP + (ent & 255)) : 6 * FC_P * FC_KP;
+            }
+#pragma unroll
+            for (int l = 0; l < FC_P; ++l) {
+                const double* o = rg[l];
+                const double* Ek = Eq + slot[l];
+                double u0 = is_z ? o[15] : 0.0, u1 = is_z ? o[16] : 0.0, u2 = is_z ? o[17] : 0.0;
+                u0 -= (o[6] * y0 + o[7] * y1) + o[8] * y2;      // G is zero for pose 0
+                u1 -= (o[9] * y0 + o[10] * y1) + o[11] * y2;
+                u2 -= (o[12] * y0 + o[13] * y1) + o[14] * y2;
+                u0 += Ek[0]; u1 += Ek[2]; u2 += Ek[4];
+                y0 = o[0] * u0;
+                y1 = o[1] * u0 + o[2] * u1;
+                y2 = (o[3] * u0 + o[4] * u1) + o[5] * u2;
+                yo[(3 * l) * ldl] = y0; yo[(3 * l + 1) * ldl] = y1; yo[(3 * l + 2) * ldl] = y2;
+            }
+        }
+        FC_STAMP(0);
+    };
+    auto zdot = [&](int it) {                        // the lane's term of row 2M over chunk it - 2 (complete in s_yb[it & 1])
+        if (it >= 2 && hb == 0 && c <= m2) {
+            const double* cbuf = s_yb + (size_t)(it & 1) * FC_ROWS * ldl;
+#pragma unroll
+            for (int r = 0; r < FC_ROWS; ++r) zacc = fma(cbuf[r * ldl + m2], cbuf[r * ldl + c], zacc);
+        }
+    };
+    if (w == 4) {
+        // ------------- wavefront 4: columns + the bearing-range blocks of the chunk the producer is working on -------------
+        const int KP = p.KP;
+        const int32_t* cntb = p.cnt + (size_t)b * p.N_max;
+        const int32_t* mlmb = p.mlm + (size_t)b * p.N_max * KP;
+        const dbl2_t* Eb2 = reinterpret_cast<const dbl2_t*>(p.E + (size_t)b * p.N_max * KP * 6);
+        dbl2_t ev[FC_NE];
+        int fl[FC_NF], fc[FC_NF];
+        auto load_ev = [&](int ch) {                // the chunk's factor slots: landmark, count of its pose, E blocks
+            const int base = ch * FC_P;
+            const int nq = ((N - base) < FC_P ? (N - base) : FC_P) * KP;
+#pragma unroll
+            for (int u = 0; u < FC_NF; ++u) {
+                const int q = lane + 64 * u;
+                fl[u] = 0; fc[u] = 0;
+                if (q < nq) { fl[u] = mlmb[(size_t)base * KP + q]; fc[u] = cntb[base + q / KP]; }
+            }
+#pragma unroll
+            for (int u = 0; u < FC_NE; ++u) {
+                const int v = lane + 64 * u;
+                ev[u] = (dbl2_t){0.0, 0.0};
+                if (v < 3 * nq) ev[u] = Eb2[(size_t)base * KP * 3 + v];
+            }
+        };
+        auto store_ev = [&](int ch) {
+            const int base = ch * FC_P, buf = ch & 1;
+#pragma unroll
+            for (int u = 0; u < FC_NE; ++u) s_E[buf][lane + 64 * u] = ev[u];
+#pragma unroll
+            for (int u = 0; u < FC_NF; ++u) {
+                const int q = lane + 64 * u, l = q / KP, sl = q - l * KP;
+                // the loaded words are first touched HERE: without the barrier the compiler masks / compares them where they
+                // are loaded, i.e. waits for HBM before the recursion instead of after it (1 us per chunk)
+                int f = fl[u], n = fc[u];
+                asm volatile("" : "+v"(f), "+v"(n) : : "memory");
+                if (sl < n) s_idx[buf][l][f & (kPgsFirstBit - 1)] = ((base + l) << 8) | sl;
+            }
+        };
+#pragma unroll 1
+        for (int it = 0; it <= nch + 1; ++it) {
+            if (it < nch) load_ev(it);
+            columns(it);
+            zdot(it);
+            if (it < nch) store_ev(it);
+            __syncthreads();
+            if (s_fail) break;
+        }
+    } else {
+        // ------------------------------------- wavefronts 1-3, 5-7: columns + tiles -------------------------------------
+        const int nt = (m2 + 31) >> 5, ntile = nt * (nt + 1) / 2;   // tiles over the landmark rows; row 2M is the VALU's
+        const int mw = (w < 4 ? w - 1 : w - 2) * FC_NB + hb;   // MFMA wavefront number within the instance (wavefronts 1-3, 5-7)
+        const int32_t* lmf = p.lm_first + (size_t)b * p.L_max;
+        const bool trim = !(p.syrk_notrim & 1);
+        // tile descriptors are wavefront-uniform: kept in SGPRs (readfirstlane) so that the phase below branches on scalars and the
+        // operand reads of a tile can all be issued ahead of its MFMAs
+        int rowbase[NS], colbase[NS], k0[NS][2];
+        bool have[NS];
+        dbl4_t acc[NS][2][2];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int t = __builtin_amdgcn_readfirstlane(mw + FC_NW * s);
+            have[s] = t < ntile;
+            int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (ti * (ti + 1) / 2 > t) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            const int tj = t - ti * (ti + 1) / 2;
+            rowbase[s] = have[s] ? 32 * ti : 0; colbase[s] = have[s] ? 32 * tj : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rb = rowbase[s] + 16 * h;
+                int kk = 0x7fffffff;                    // first row of Y where this half of the tile can be non-zero
+                if (have[s] && rb < m2) kk = trim ? 3 * lmf[rb >> 1] : 0;
+                k0[s][h] = __builtin_amdgcn_readfirstlane(kk);
+            }
+            rowbase[s] = __builtin_amdgcn_readfirstlane(rowbase[s]); colbase[s] = __builtin_amdgcn_readfirstlane(colbase[s]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[s][i][j] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+        }
+        auto tiles = [&](int it) {
+            if (it >= 2) {                               // chunk it - 2 is complete in s_yb[it & 1]: tiles + right-hand-side row
+                const double* cbuf = s_yb + (size_t)(it & 1) * FC_ROWS * ldl;
+                const int kend = (it - 1) * FC_ROWS;     // one past the chunk's last row of Y
+                const double* src = cbuf + kq * ldl + cl;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (kend <= k0[s][0]) continue;                          // scalar
+                    const double* sa = src + rowbase[s];
+                    const double* sb = src + colbase[s];
+                    double a0[FC_ROWS / 4], b0[FC_ROWS / 4], b1[FC_ROWS / 4];
+#pragma unroll
+                    for (int ks = 0; ks < FC_ROWS / 4; ++ks) { a0[ks] = sa[ks * 4 * ldl]; b0[ks] = sb[ks * 4 * ldl]; b1[ks] = sb[ks * 4 * ldl + 16]; }
+                    if (kend > k0[s][1]) {                                   // scalar: rows 16..31 of the tile have begun
+                        double a1[FC_ROWS / 4];
+#pragma unroll
+                        for (int ks = 0; ks < FC_ROWS / 4; ++ks) a1[ks] = sa[ks * 4 * ldl + 16];
+#pragma unroll
+                        for (int ks = 0; ks < FC_ROWS / 4; ++ks) {
+                            acc[s][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b0[ks], acc[s][0][0], 0, 0, 0);
+                            acc[s][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b1[ks], acc[s][0][1], 0, 0, 0);
+                            acc[s][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b0[ks], acc[s][1][0], 0, 0, 0);
+                            acc[s][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b1[ks], acc[s][1][1], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < FC_ROWS / 4; ++ks) {
+                            acc[s][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b0[ks], acc[s][0][0], 0, 0, 0);
+                            acc[s][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b1[ks], acc[s][0][1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            FC_STAMP(1);
+        };
+#pragma unroll 1
+        for (int it = 0; it <= nch + 1; ++it) {
+            columns(it);
+            tiles(it);
+            zdot(it);
+            __syncthreads();
+            FC_STAMP(2);
+            if (s_fail) break;
+        }
+        if (p.prof && tid == 64) {
+            unsigned long long* o = p.prof + (size_t)p.B * p.lanes_max * 8 + (size_t)b * 16 + 8 * hb;
+            o[5] = tc[0]; o[6] = tc[1]; o[7] = tc[2];
+        }
+        if (!s_fail) {
+            const double lambda = p.lambda[b];
+            const double* Db = p.D + (size_t)b * p.L_max * 3;
+            double* Sb = p.S + (size_t)b * LD * LD;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!have[s]) continue;
+                if (rowbase[s] == colbase[s]) {              // scalar: only a diagonal tile holds elements of D + lambda I
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int r = rowbase[s] + 16 * i + kq + 4 * r4;   // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg
+                            const int rr = r < m2 ? r : 0;
+                            const double dd = Db[3 * (rr >> 1) + ((rr & 1) ? 2 : 0)] + lambda, dx = Db[3 * (rr >> 1) + 1];
+#pragma unroll
+                            for (int j = 0; j <= i; ++j) {
+                                const int cc = colbase[s] + 16 * j + cl;
+                                if (r >= m2 || cc > r) continue;
+                                double v = -acc[s][i][j][r4];
+                                if (cc == r) v += dd;
+                                else if ((cc >> 1) == (r >> 1)) v += dx;
+                                Sb[(size_t)r * LD + cc] = v;
+                            }
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) {
+                                const int r = rowbase[s] + 16 * i + kq + 4 * r4;
+                                const int cc = colbase[s] + 16 * j + cl;
+                                if (r < m2) Sb[(size_t)r * LD + cc] = -acc[s][i][j][r4];   // below the diagonal: cc < r, cc < 2M
+                            }
+                }
+            }
+        }
+    }
+#undef FC_STAMP
+    if (!s_fail && hb == 0 && c <= m2) {
+        const double* glb = p.gl + (size_t)b * p.L_max * 2;
+        p.S[(size_t)b * LD * LD + (size_t)m2 * LD + c] = (c < m2 ? glb[c] : 0.0) - zacc;
     }
 }
 
@@ -1240,6 +1683,7 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
             else if (error <= 0.0 || relDec <= relTol || absDec <= absTol) done = 1;
             else p.cur_error[b] = error;
         }
+        atomicAdd(p.work + (p.fused ? 1 : 0), (double)(trials - p.trials[b]) * p.inst_flop[b]);   // reporting only
         p.lambda[b] = lambda; p.error[b] = error; p.iters[b] = iters; p.trials[b] = trials;
         // the next trial runs the next `lanes_next` lambdas of the sequence GTSAM would walk if every one of them failed:
         // lambda, 10 lambda, ... (lambda_j < lambdaUpper for j >= 1: reaching the bound ends the inner loop before that trial)
@@ -1257,7 +1701,11 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
         for (int j = 1; j < p.lanes_max; ++j) p.state[j * B + b] = (!done && j < nnext) ? 0 : 1;
         p.nl[b] = nnext;
         if (done) { p.state[b] = 1; p.flags[b] |= fl; }
-        else { atomicAdd(p.n_active, 1); atomicMax(p.n_active + 1, nnext); }
+        else {
+            atomicAdd(p.n_active, 1); atomicMax(p.n_active + 1, nnext);
+            const int at = atomicAdd(p.n_active + 2, nnext);
+            for (int j = 0; j < nnext; ++j) p.alist[at + j] = j * B + b;
+        }
         s_win = win; s_next = done ? 0 : nnext;
     }
     __syncthreads();
@@ -1344,11 +1792,30 @@ hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s) {
 }
 
 hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s) {
-    const int nslot = p.b_cnt * (p.lanes > 0 ? p.lanes : 1);   // slots covered: the instances of the group and their active lambda lanes
+    const int nslot = pgs_nslot(p);   // slots covered: the instances of the group and their active lambda lanes, or the compacted list
+    if (nslot <= 0) return hipSuccess;
     switch (which) {
     case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(nslot), dim3(TPB), 0, s, p); break;
-    case 1: hipLaunchKernelGGL(pgs_chain_kernel, dim3(nslot), dim3(64 + p.LD), 0, s, p); break;
+    case 1: {
+        if (p.fused) {   // chain + SYRK in one launch, Y stays in LDS
+            static std::once_flag attr_once3;
+            std::call_once(attr_once3, []() {   // 22 KB static + the Y buffers (89 KB at LD = 448) of the 160 KB
+                (void)hipFuncSetAttribute((const void*)pgs_chain_syrk_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute((const void*)pgs_chain_syrk_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute((const void*)pgs_chain_syrk_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            });
+            const size_t lds = sizeof(double) * 2 * FC_ROWS * (size_t)(p.LD + 16);
+            // p.fused = workgroups per instance: the more, the fewer tiles (and MFMA time) per workgroup next to the recursion
+            if (p.fused == 4) hipLaunchKernelGGL((pgs_chain_syrk_kernel<3, 4>), dim3(4 * nslot), dim3(FC_TPB), lds, s, p);
+            else if (p.fused == 3) hipLaunchKernelGGL((pgs_chain_syrk_kernel<4, 3>), dim3(3 * nslot), dim3(FC_TPB), lds, s, p);
+            else hipLaunchKernelGGL((pgs_chain_syrk_kernel<6, 2>), dim3(2 * nslot), dim3(FC_TPB), lds, s, p);
+            break;
+        }
+        hipLaunchKernelGGL(pgs_chain_kernel, dim3(nslot), dim3(64 + p.LD), 0, s, p);
+        break;
+    }
     case 2: {
+        if (p.fused) break;   // done by the chain launch
         if (p.syrk_wave_tile == 1) {   // instance-resident accumulators
             static std::once_flag attr_once2;
             std::call_once(attr_once2, []() {

@@ -234,6 +234,11 @@ class BatchedPoseGraph:
         self._need(); ms = np.zeros(6); _lib.check(_lib.lib().pgs_last_solve_kernel_ms(self.h, _d(ms)))
         return dict(zip(("linearize", "chain", "syrk", "chol", "backsolve", "evaluate"), ms.tolist()))
 
+    def last_solve_paths(self):
+        """The last profiled solve by path: algorithmic SYRK FLOP and ms of the separate SYRK launches / of the fused chain + SYRK launches."""
+        self._need(); o = np.zeros(4); _lib.check(_lib.lib().pgs_last_solve_paths(self.h, _d(o)))
+        return dict(flop_separate=o[0], flop_fused=o[1], ms_separate_syrk=o[2], ms_fused=o[3])
+
     def sync(self):
         self._need(); _lib.check(_lib.lib().pgs_sync(self.h))
 
