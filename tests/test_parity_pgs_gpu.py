@@ -254,6 +254,7 @@ def test_syrk_variants_agree_with_the_oracle(monkeypatch, oracle, L, T):
     r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=6, cfg=cfg, nthreads=8)
     # SYRK: 32x32 tiles / 64x64 tiles / instance-resident accumulators; Cholesky: 1024 or 256 threads per instance (the
     # 256-thread one is otherwise chosen only above 256 active instances, i.e. by no other test)
+    monkeypatch.setenv("SLAM_PGS_FUSED", "0")   # chain and SYRK as two launches (few slots would otherwise run the fused kernel)
     for tile, chol in (("32", "1024"), ("1", "1024"), ("64", "256"), ("1", "256")):
         monkeypatch.setenv("SLAM_PGS_SYRK_TILE", tile)
         monkeypatch.setenv("SLAM_PGS_CHOL_THREADS", chol)
@@ -262,3 +263,29 @@ def test_syrk_variants_agree_with_the_oracle(monkeypatch, oracle, L, T):
         pg.run_sim(cmds); pg.solvePoseGraph()
         _compare(pg, r, B)
         pg.close()
+
+
+@pytest.mark.parametrize("L,T,KP,B", [(20, 150, 8, 12), (100, 250, 24, 6), (200, 999, 32, 5)])
+def test_fused_chain_syrk_and_slot_list_agree_with_the_oracle(monkeypatch, oracle, L, T, KP, B):
+    """Round 3: the trial kernels are launched over the compacted list of running slots (SLAM_PGS_LIST, default on) and
+    chain + SYRK run as ONE launch with Y in LDS on 2, 3 or 4 workgroups per instance (SLAM_PGS_FUSED = 2 | 3 | 4 forces a
+    variant, 0 = two launches, default = chosen per trial from the number of running slots).  Every combination follows the
+    oracle's LM path (same iteration / trial counts) to the usual tolerance; the last size is BASELINE configs[4]."""
+    import live_ekf_slam_amd as S
+    lm, cmds = make_scenario(55 + L, L, T)
+    cfg = default_config()
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=8, cfg=cfg, nthreads=8)
+    res = {}
+    for fused, lst in (("0", "1"), ("0", "0"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("-1", "1")):
+        monkeypatch.setenv("SLAM_PGS_FUSED", fused)
+        monkeypatch.setenv("SLAM_PGS_LIST", lst)
+        pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+        pg.set_map(lm); pg.set_seed(8); pg.init(0.0, 0.0, 0.0)
+        pg.run_sim(cmds); pg.solvePoseGraph()
+        _compare(pg, r, B)
+        res[(fused, lst)] = [pg.get_graph(b, 1)["poses"] for b in range(B)]
+        pg.close()
+    for b in range(B):   # the slot list only changes which workgroup serves which instance; the fused variants share their arithmetic
+        assert np.array_equal(res[("0", "1")][b], res[("0", "0")][b])
+        assert np.array_equal(res[("4", "1")][b], res[("4", "0")][b])
+        assert np.array_equal(res[("2", "1")][b], res[("4", "1")][b]) and np.array_equal(res[("3", "1")][b], res[("4", "1")][b])
