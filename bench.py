@@ -132,26 +132,6 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=10.0
     return line
 
 
-def pgs_traffic(B, L, N):
-    """HBM-side bytes per solve of the two SYRK kernels (tile kernel + instance-resident kernel) from the committed PMC passes
-    (profiles/r02d_pgs/summary.json: FETCH_SIZE + WRITE_SIZE in KiB, raw: the guide's x2 applies to 16 B/lane streams and the
-    tile kernel loads 8 B/lane; the instance-resident kernel's 16-byte loads are NOT doubled here, so this is a lower bound
-    for its 8.5 GB share), if the profiled workload is the one being run; else null."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02d_pgs", "summary.json")))
-        c = d["bench_line"]["config"]
-        if (c["batch_per_gpu"], c["landmarks"], c["poses"]) != (B, L, N):
-            return None
-        tot = 0.0
-        for name in ("pgs_syrk_kernel", "pgs_syrk_inst_kernel"):
-            k = d["kernels"].get(name)
-            if k:
-                tot += k["fetch_GB_per_solve_raw"] + k["write_GB_per_solve"]
-        return round(tot * 1e9)
-    except Exception:
-        return None
-
-
 def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0):
     """Secondary line: pose-graph SLAM solves/s (BASELINE configs[4]: 1000 poses x 200 landmarks, batched LM).
     One "step" = solvePoseGraph() of every instance of the batch from its initial estimate (one-time mode,
@@ -232,7 +212,7 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
                              "algorithmic_flop_per_solve": flop / K, "algorithmic_flop_in_kernel": dom["algorithmic_flop"],
                              "other_path": oth,
                              "limiter": "latency of the chain's sequential 3x3 recursion (0.56 ms per trial whatever the batch) and, at a full batch, "
-                                        "the shared fp64 units: on gfx950 v_mfma_f64 runs at the vector fp64 rate (measured 71.6 TFLOP/s sustained, tools/calib_mfma64)"}}
+                                        "the fp64 units: on gfx950 v_mfma_f64 runs at the vector fp64 rate of its SIMD (71.8 TFLOP/s sustained on the chip, tools/calib_mfma64)"}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             Bc = max(2, int((48 if L >= 100 else 256) * cpu_budget_s / 15.0))    # about cpu_budget_s of single-thread work

@@ -882,8 +882,9 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
 //   wavefronts 1-3, 5-7 one barrier later: v_mfma_f64_16x16x4_f64 over those rows for the wavefront's tiles (16-row halves
 //                       trimmed by first detection)
 //   wavefront 4         shares its SIMD with the producer and therefore holds NO tiles: on gfx950 the fp64 MFMA runs at the
-//                       vector fp64 rate - on the same units - and a dependent v_mul_f64 of the recursion queued behind
-//                       64-cycle MFMAs (recursion 0.56 -> 0.79 ms).  It stages the bearing-range blocks of the next chunk instead.
+//                       vector fp64 rate of its SIMD and a dependent fp64 chain beside it takes 27.5 instead of 11.5 cycles
+//                       per link (tools/calib_mfma64; recursion 0.56 -> 0.79 ms).  It stages the bearing-range blocks of the
+//                       next chunk instead.
 // Time per workgroup ~ max(recursion + its staging, columns + MFMA of the busiest SIMD) per chunk.  Same arithmetic per
 // element of Y and per tile as the unfused pair (the k order of the MFMA accumulation is the same; only row 2M is
 // summed on the VALU instead of the matrix pipe).

@@ -3,8 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
-// mode 0: every wavefront runs NACC independent accumulators of MFMAs; mode 1: wavefront 0 of each SIMD pair runs a dependent
-// v_fma_f64 chain instead (what the pose-graph producer does) and reports ITS time
+// mode 0: every wavefront runs NACC independent accumulators of MFMAs; mode 1: wavefront 0 runs a dependent v_fma_f64 chain
+// instead (what the pose-graph producer does) and reports ITS time; mode 2: only the two wavefronts of one SIMD run MFMAs;
+// mode 3: the chain alone; mode 4: the chain, its SIMD-mate idle, MFMAs on the other three SIMDs
 template <int NACC>
 __global__ __launch_bounds__(512) void k(double* out, unsigned long long* cyc, int iters, int mode) {
     const int w = threadIdx.x >> 6;
@@ -13,11 +14,13 @@ __global__ __launch_bounds__(512) void k(double* out, unsigned long long* cyc, i
     double a = threadIdx.x * 1e-3, b = 1.0 + blockIdx.x * 1e-6, x = a;
     const unsigned long long t0 = __builtin_readcyclecounter();
     const unsigned long long w0 = wall_clock64();
-    if (mode == 1 && w == 0) {
+    if ((mode == 1 || mode == 3 || mode == 4) && w == 0) {
         for (int it = 0; it < iters * 4; ++it) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) x = __builtin_fma(x, b, a);
         }
+    } else if (mode == 3 || (mode == 4 && w == 4)) {
+        // mode 3: the chain alone; mode 4: the chain with an idle SIMD-mate, MFMAs on the other three SIMDs only
     } else if (!(mode == 2 && w != 0 && w != 4)) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -36,7 +39,7 @@ int main() {
     double* out; unsigned long long* cyc;
     hipMalloc(&out, sizeof(double) * nb * 512); hipMalloc(&cyc, sizeof(unsigned long long) * nb * 16);
     unsigned long long h[nb * 16];
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k<8>, dim3(nb), dim3(512), 0, 0, out, cyc, 100, mode);
         hipEventRecord(e0);
@@ -46,8 +49,8 @@ int main() {
         hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
         const double nm = (double)iters * 8;
         printf("mode %d: %.3f ms; wavefront 0: %.1f shader cycles, %.1f ns (100 MHz clock) per %s; wavefront 1: %.1f ns per MFMA; ",
-               mode, ms, (double)h[0] / (mode == 1 ? nm * 4 : nm), (double)h[1] * 10.0 / (mode == 1 ? nm * 4 : nm), mode == 1 ? "dependent FMA" : "MFMA", (double)h[3] * 10.0 / nm);
-        const double flops = (mode == 0 ? 8.0 : (mode == 1 ? 7.0 : 2.0)) * nb * nm * 2048.0;
+               mode, ms, (double)h[0] / ((mode == 1 || mode >= 3) ? nm * 4 : nm), (double)h[1] * 10.0 / ((mode == 1 || mode >= 3) ? nm * 4 : nm), (mode == 1 || mode >= 3) ? "dependent FMA" : "MFMA", (double)h[3] * 10.0 / nm);
+        const double flops = (mode == 0 ? 8.0 : (mode == 1 ? 7.0 : (mode == 2 ? 2.0 : (mode == 3 ? 0.0 : 6.0)))) * nb * nm * 2048.0;
         printf("MFMA rate %.1f TFLOP/s\n", flops / (ms * 1e-3) / 1e12);
     }
     return 0;

@@ -11,7 +11,7 @@ res = {"solves_profiled": SOLVES, "kernels": {}}
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(pgs_\w+)", row["Name"])
+        m = re.search(r"(pgs_\w+(?:<[^>]*>)?)", row["Name"])
         if not m:
             continue
         res["kernels"][m.group(1)] = {"calls": int(row["Calls"]), "total_ms": float(row["TotalDurationNs"]) / 1e6,
@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recurs
 for tag in ("pmc_mfma", "pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            m = re.search(r"(pgs_\w+)", row["Kernel_Name"])
+            m = re.search(r"(pgs_\w+(?:<[^>]*>)?)", row["Kernel_Name"])
             if not m or m.group(1) not in res["kernels"]:
                 continue
             k = res["kernels"][m.group(1)].setdefault("pmc", {})
