@@ -69,7 +69,12 @@ int pgs_run_sim(pgs_handle* h, const float* cmds, int T);
  * sequence (lambda, 10 lambda, ...) at once in spare slots and the sequential accept / lambda logic is replayed over them, so
  * the result, pgs_get_stats' iteration and trial counts are those of the sequential loop.  The slots multiply the LM work
  * space: SLAM_PGS_LANES slots per instance (default 4, 1 = off; reduced at pgs_create if they would take more than half of
- * the free device memory). */
+ * the free device memory).
+ * Launch shape (results do not depend on it beyond the tolerance of the SYRK's summation order): the kernels of a trial run over
+ * the compacted list of running slots (SLAM_PGS_LIST=0: full-size grids); with at most 128 running slots, or a batch that fills
+ * the device twice, the block-tridiagonal chain and the Schur-complement SYRK are ONE launch with Y kept in LDS, replicated on
+ * 2 - 4 CUs per instance (SLAM_PGS_FUSED=0: always two launches; 2 | 3 | 4: that many workgroups per instance).  The fused
+ * kernel needs 2 M + 1 <= 448, M <= 176 mapped landmarks and k_per_pose <= 32; other graphs take the two-launch path. */
 int pgs_solve(pgs_handle* h);
 /* The solve splits the batch into `groups` contiguous ranges that run their LM loops on separate HIP streams (the
  * latency-bound phases of one group overlap the bandwidth-bound phases of another); results do not depend on it.
