@@ -136,8 +136,9 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
     """Secondary line: pose-graph SLAM solves/s (BASELINE configs[4]: 1000 poses x 200 landmarks, batched LM).
     One "step" = solvePoseGraph() of every instance of the batch from its initial estimate (one-time mode,
     pose_graph.cpp:208-214,269-300).  Graphs are built on the device (simulator + NaiveFilter secondary) before the
-    timed region.  Roofline object: the Schur-complement SYRK (v_mfma_f64_16x16x4_f64), its algorithmic FLOP over its
-    HIP-event time, against the 78.6 TFLOP/s fp64 matrix peak."""
+    timed region.  Roofline object: the launches that form the Schur complement (v_mfma_f64_16x16x4_f64) - the fused chain +
+    SYRK kernel or the separate SYRK kernels, whichever did most of the solve's algorithmic FLOP (pgs_last_solve_paths); the
+    other kind is reported beside it - algorithmic FLOP over HIP-event time, against the 78.6 TFLOP/s fp64 matrix peak."""
     import live_ekf_slam_amd as S
     from live_ekf_slam_amd.scenario import make_scenario
     L, B, K, W = args.landmarks, args.batch, args.steps, args.warmup
