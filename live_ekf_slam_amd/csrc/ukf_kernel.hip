@@ -308,7 +308,8 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     // together and the round costs ONE LDS round trip instead of three dependent ones per item (rotation parameters ->
     // indices -> data).  The V row-pairs are mapped so that a thread's rows all belong to one pair: TPB / m threads per
     // pair, ITV rows each.  Items are independent, so the mapping does not change a single bit.
-    constexpr bool kFast = (MMAX * (MMAX + 1) / 2 <= TPB);
+    constexpr int ITB = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB;   // pair-block / diagonal items per thread (they are the first items)
+    constexpr bool kFast = ITB <= 2;                               // n <= 103 with 1024 threads: two per thread
     constexpr int ITV = kFast ? (NMAX + (TPB / MMAX) - 1) / (TPB / MMAX) : 1;
     const int tp = TPB / m;                 // threads per pair (V rows)
     const int iv = tid / tp, subk = tid - iv * tp;
@@ -452,33 +453,36 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     const int kk = k < n ? k : 0;
                     xp[u] = sVt[vpi * n + kk]; xq[u] = sVt[vqi * n + kk];
                 }
-                // ---- the thread's pair-block or diagonal block ----
-                const int d = desc[0];
-                const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
-                if (kind == 0) {
-                    int pi, qi, pj, qj;
-                    rr_pair(i, t, n, pi, qi);
-                    rr_pair(j, t, n, pj, qj);
-                    const double2 csi = s_csn[i], csj = s_csn[j];
-                    auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
-                    const int a00 = idx(pi, pj), a01 = idx(pi, qj), a10 = idx(qi, pj), a11 = idx(qi, qj);
-                    const double b00 = sA[a00], b01 = sA[a01], b10 = sA[a10], b11 = sA[a11];
-                    const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
-                    if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
-                        const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
-                        const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
-                        sA[a00] = fma(t00, cj, -(t01 * sj)); sA[a01] = fma(t00, sj, t01 * cj);
-                        sA[a10] = fma(t10, cj, -(t11 * sj)); sA[a11] = fma(t10, sj, t11 * cj);
+                // ---- the thread's pair-blocks / diagonal blocks (items are independent: any order, any owner, same bits) ----
+#pragma unroll
+                for (int ub = 0; ub < ITB; ++ub) {
+                    const int d = desc[ub];
+                    const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
+                    if (kind == 0) {
+                        int pi, qi, pj, qj;
+                        rr_pair(i, t, n, pi, qi);
+                        rr_pair(j, t, n, pj, qj);
+                        const double2 csi = s_csn[i], csj = s_csn[j];
+                        auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
+                        const int a00 = idx(pi, pj), a01 = idx(pi, qj), a10 = idx(qi, pj), a11 = idx(qi, qj);
+                        const double b00 = sA[a00], b01 = sA[a01], b10 = sA[a10], b11 = sA[a11];
+                        const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
+                        if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
+                            const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
+                            const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
+                            sA[a00] = fma(t00, cj, -(t01 * sj)); sA[a01] = fma(t00, sj, t01 * cj);
+                            sA[a10] = fma(t10, cj, -(t11 * sj)); sA[a11] = fma(t10, sj, t11 * cj);
+                        }
+                    } else if (kind == 1) {
+                        int pq, qq;
+                        rr_pair(i, t, n, pq, qq);
+                        const int app_i = pq * (pq + 1) / 2 + pq, aqq_i = qq * (qq + 1) / 2 + qq, apq_i = qq * (qq + 1) / 2 + pq;
+                        const double tn = s_tn[i];
+                        const double app = sA[app_i], aqq = sA[aqq_i], apq = sA[apq_i];
+                        sA[app_i] = fma(-tn, apq, app);
+                        sA[aqq_i] = fma(tn, apq, aqq);
+                        if (apq != 0.0) sA[apq_i] = 0.0;
                     }
-                } else if (kind == 1) {
-                    int pq, qq;
-                    rr_pair(i, t, n, pq, qq);
-                    const int app_i = pq * (pq + 1) / 2 + pq, aqq_i = qq * (qq + 1) / 2 + qq, apq_i = qq * (qq + 1) / 2 + pq;
-                    const double tn = s_tn[i];
-                    const double app = sA[app_i], aqq = sA[aqq_i], apq = sA[apq_i];
-                    sA[app_i] = fma(-tn, apq, app);
-                    sA[aqq_i] = fma(tn, apq, aqq);
-                    if (apq != 0.0) sA[apq_i] = 0.0;
                 }
                 // ---- V <- V J ----
                 if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
