@@ -1056,7 +1056,8 @@ __global__ __launch_bounds__(FC_TPB) void pgs_chain_syrk_kernel(const PgsParams 
     const int KP = p.KP, myj = (c >> 1) < FC_LMAX ? (c >> 1) : 0, myd = c & 1;
     const bool is_z = c == m2;                       // the gradient column: its right-hand side is gp, it has no factors (s_idx[.][M] stays -1)
     unsigned long long tc[3] = {0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
-#define FC_STAMP(i) do { if (p.prof && tid == 64) { const unsigned long long now_ = wall_clock64(); tc[i] += now_ - tprev; tprev = now_; } } while (0)
+    const int stamp_tid = 64 * (1 + ((p.syrk_notrim >> 8) & 7));   // debug: the consumer wavefront whose phases are timed (SLAM_PGS_NOTRIM bits 8-10; default wavefront 1)
+#define FC_STAMP(i) do { if (p.prof && tid == stamp_tid) { const unsigned long long now_ = wall_clock64(); tc[i] += now_ - tprev; tprev = now_; } } while (0)
     auto columns = [&](int it) {
         if (it >= 1 && it <= nch && c <= m2) {       // column recurrence of chunk it - 1 -> s_yb[(it - 1) & 1]
             const int base = (it - 1) * FC_P;
@@ -1219,7 +1220,7 @@ __global__ __launch_bounds__(FC_TPB) void pgs_chain_syrk_kernel(const PgsParams 
             FC_STAMP(2);
             if (s_fail) break;
         }
-        if (p.prof && tid == 64) {
+        if (p.prof && tid == stamp_tid) {
             unsigned long long* o = p.prof + (size_t)p.B * p.lanes_max * 8 + (size_t)b * 16 + 8 * hb;
             o[5] = tc[0]; o[6] = tc[1]; o[7] = tc[2];
         }

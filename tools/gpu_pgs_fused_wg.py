@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup begin / end / placement of the last fused chain + SYRK launch of a pose-graph solve (debug).
-usage: gpu_pgs_fused_wg.py [trials]   (the solve stops after `trials` trials; the stamps are those of the last one)"""
+usage: gpu_pgs_fused_wg.py [trials]   (the solve stops after `trials` trials; the stamps are those of the last one)
+SLAM_PGS_NOTRIM=256*(w-1) times the phases of consumer wavefront w (1..7) instead of wavefront 1; =16 prints the SIMD of every wavefront."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,5 +35,5 @@ print(f"{len(w)} workgroups stamped; duration us: min {dur.min():.0f} median {np
 late = (t0 - base) > 10000
 if late.any():
     print("late starters begin at us:", np.sort((t0[late] - base) / 100.0)[:10], "...")
-print("mean us per workgroup: producer before %.0f, after %.0f, recursion %.0f | wavefront 1: columns %.0f, tiles + z %.0f, barrier %.0f" % tuple(w[:, 2:8].astype(np.float64).mean(0) / 100.0))
+print("mean us per workgroup: producer before %.0f, after %.0f, recursion %.0f | timed consumer wavefront: columns %.0f, tiles + z %.0f, barrier %.0f" % tuple(w[:, 2:8].astype(np.float64).mean(0) / 100.0))
 print("kernel ms:", pg.last_solve_kernel_ms())
