@@ -18,10 +18,12 @@ HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", 
 # Instantiations of the EKF step kernel: (NMAX, W, KG, UNR, f32 storage, PIPE); variant code = PIPE*1000 + W*100 + KG*10 + UNR
 # (ekf_kernel.h).  The release library holds the defaults only (they must match SLAM_DEF_* in ekf_kernel.hip); the sweep
 # set is for tuning sessions: SLAM_SWEEP=1 python -m live_ekf_slam_amd.build --force
-EKF_DEFAULT_VARIANTS = [(43, 2, 5, 4, 0, 1), (43, 2, 4, 4, 0, 1), (43, 1, 2, 4, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 4, 4, 0, 1),
+EKF_DEFAULT_VARIANTS = [(43, 2, 5, 4, 0, 1), (43, 2, 4, 4, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 4, 4, 0, 1),
                         (203, 4, 5, 4, 0, 1), (203, 4, 4, 4, 0, 1), (403, 4, 4, 4, 0, 1),
                         (43, 2, 4, 4, 1, 1), (103, 4, 4, 2, 1, 1)]
-EKF_SWEEP_VARIANTS = [(103, 4, 5, 4, 0, 2), (103, 4, 5, 2, 0, 2), (103, 4, 4, 4, 0, 2), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1), (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 4, 5, 2, 1, 1), (103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
+# (43, 1, 2, 4, 0, 1), the one-wavefront variant, left the release build in round 3: it fails tools/gpu_soak_ekf.py when a second
+# multi-step launch continues a run (vehicle row of P; the decoupled loop of the W >= 2 kernels does not take that path)
+EKF_SWEEP_VARIANTS = [(43, 1, 2, 4, 0, 1), (103, 4, 5, 4, 0, 2), (103, 4, 5, 2, 0, 2), (103, 4, 4, 4, 0, 2), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1), (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 4, 5, 2, 1, 1), (103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
                       (103, 2, 4, 4, 0, 1), (103, 8, 4, 2, 0, 1), (103, 8, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1), (103, 4, 2, 4, 0, 1),
                       (103, 4, 4, 4, 1, 0), (103, 4, 4, 8, 1, 1), (103, 4, 4, 4, 1, 1), (103, 2, 4, 4, 1, 1), (103, 8, 4, 2, 1, 1),
                       (103, 2, 4, 2, 1, 1), (103, 3, 4, 2, 1, 1), (43, 2, 4, 2, 1, 1), (43, 2, 4, 2, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 6, 2, 1, 1), (103, 3, 4, 4, 0, 1), (103, 3, 4, 2, 0, 1),

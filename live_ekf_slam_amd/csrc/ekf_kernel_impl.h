@@ -915,7 +915,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             p.meas_out[(size_t)b * p.k_stride_out * 3 + i] = meas_t[i];
         if (tid == 0) p.meas_count_out[b] = k;
     }
-    const int n_ins = p.id_known ? s_next[4 * pb + 1] : k;  // insertions this step (upper bound k for unknown ids)
+    // insertions this step; unknown ids: an upper bound - every detection could be a new landmark - but never more than the
+    // capacity has room for (the matrix of this step is laid out for n_old + 2 n_ins: without the clamp a wide message at a full
+    // map provisioned rows past the instance's slab - found by tools/gpu_soak_ekf.py, a memory fault with fp32 storage)
+    const int room_ins = (p.L_max < LMAX ? p.L_max : LMAX) - M_old;
+    const int n_ins = p.id_known ? s_next[4 * pb + 1] : (k < room_ins ? k : (room_ins > 0 ? room_ins : 0));
     const bool frz_top = p.id_known && s_next[4 * pb + 2];  // freeze in the pre-step state (after the pending group is flushed)
     if (p.id_known && s_next[4 * pb + 3]) flags |= SLAM_INST_CAPACITY;
     SLAM_STAMP(2);   // association
@@ -935,7 +939,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
     if constexpr (MULTI && W >= 2) {
         auto fastable = [&](int tq) -> bool {   // step tq (its pre-step results are in the parity buffers) can run decoupled
             const int* nx = s_next + 4 * (tq & 1);
-            return nx[0] <= KLOOP && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
+            // fp32 storage rounds P once per timestep, so a pass may only end where a step ends (s_wend): the updates of a step
+            // must fit the ring, or the control wavefront waits for a slot that only a pass could free while no pass can be cut
+            // (the several-groups-per-step loop of round 3 let steps of up to 2 KP detections in: a deadlock the watchdog turned
+            // into SLAM_INST_WATCHDOG, found by tools/gpu_soak_ekf.py).  fp64 passes may end anywhere.
+            constexpr int kStepMax = sizeof(ST) == 8 ? KLOOP : (KLOOP < KG ? KLOOP : KG);
+            return nx[0] <= kStepMax && nx[1] == 0 && nx[2] == 0 && nx[3] == 0;
         };
         const bool fast_ok = p.id_known && p.meas_out == nullptr && fastable(t) &&
                              !SLAM_DBG(p.dbg & (2 | 16 | 64));

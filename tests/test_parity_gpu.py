@@ -652,3 +652,37 @@ def test_checkpoint_and_resume_are_bit_identical(S, tmp_path, kind):
         make().load_state(tmp_path / "short.ckpt")
     for f in (a, b, c):
         f.close()
+
+
+@pytest.mark.parametrize("L,T,B,seed,scenario,inst0,f32,idknown,wide,chunk,split", [
+    (50, 319, 7, 266407250, 165103127, 500196, True, 1, False, 3, 269),     # fp32: a timestep with more updates than ring slots (watchdog)
+    (5, 398, 14, 904105935, 949266288, 153131, True, 1, True, 32, 281),      # fp32: five new landmarks in the first message (watchdog)
+    (35, 180, 5, 836420149, 169661810, 226515, True, 0, True, 32, 90),       # unknown ids, wide sensor, full map: memory fault
+    (35, 180, 5, 836420149, 169661810, 226515, False, 0, True, 32, 90),      # the same in fp64: neighbours' M / flags overwritten
+    (150, 26, 6, 177541356, 1028310476, 83458, False, 0, True, 3, 14),
+    (35, 393, 23, 409736089, 89432125, 553749, False, 0, True, 32, 164),
+])
+def test_configurations_the_random_soak_found(S, oracle, monkeypatch, L, T, B, seed, scenario, inst0, f32, idknown, wide, chunk, split):
+    """tools/gpu_soak_ekf.py (random sizes / seeds / modes against the oracle) found two bugs in round 3: (1) unknown-id mode
+    provisioned the step's matrix for k insertions even when the capacity had no room left - rows past the instance's slab; (2)
+    the fp32 decoupled loop admitted timesteps with more updates than ring slots (its passes must end at a step end) - a
+    deadlock the in-kernel watchdog turned into SLAM_INST_WATCHDOG.  These are the configurations it reported, replayed:
+    flags equal the oracle's for every instance, state bit-exact for every unflagged one."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    monkeypatch.setenv("SLAM_RUN_CHUNK", str(chunk))
+    monkeypatch.delenv("SLAM_WAVES_PER_FILTER", raising=False)
+    lm, cmds = make_scenario(scenario, L, T)
+    cfg = S.default_config(); cfg.landmark_id_is_known = idknown
+    if wide:
+        cfg.range_max = 1e9; cfg.fov_min = -4.0; cfg.fov_max = 4.0
+    f = S.BatchedEKF(B, L, dtype=S.F32 if f32 else S.F64).readParams(cfg)
+    f.set_map(lm); f.set_seed(seed); f.set_instance_offset(inst0); f.init(0, 0, 0)
+    f.run_sim(cmds[:split]); f.run_sim(cmds[split:])
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=seed, inst0=inst0, nthreads=8, cfg=cfg, mode=oracle.MODE_FAST | (oracle.STORAGE_F32 if f32 else 0))
+    assert np.array_equal(f.status(), r["flags"]) and np.array_equal(f.truth(), r["truth"])
+    clean = r["flags"] == 0
+    assert np.array_equal(f.landmark_counts()[clean], r["M"][clean])
+    for b in np.flatnonzero(clean):
+        n = 3 + 2 * r["M"][b]
+        _assert_state_equal(f.get_state(int(b)), dict(M=r["M"][b], ids=r["ids"][b, :r["M"][b]], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    f.close()

@@ -256,3 +256,19 @@ def test_the_checker_rejects_broken_handshakes(mutant):
     wavefront does not wait for a pass in flight): the model must see a pass streaming P during a gather."""
     n, bad = explore(4, 4, 2, 3, 0, mutant=mutant)
     assert any("gathers" in b[0] or "differs" in b[0] for b in bad), [b[0] for b in bad][:3]
+
+
+def test_the_checker_finds_the_fp32_deadlock_of_steps_larger_than_the_ring():
+    """Round 3 let the decoupled loop take timesteps of up to 2 KP detections (several groups per step).  fp32 storage cuts
+    its passes where a timestep ends, so a step with more updates than the ring has slots leaves the control wavefront waiting
+    for a slot and the leader for a step end: a deadlock.  The model with its old step sizes (k <= KG) could not see it; a
+    random soak on the GPU did (tools/gpu_soak_ekf.py, SLAM_INST_WATCHDOG on the default fp32 kernels).  With k = KG + 1
+    in the menu the checker must report it for fp32 storage - and only for fp32 storage (fp64 passes may end anywhere)."""
+    n, bad = explore(4, 3, 2, 3, 1, k_choices=(0, 1, 4, 5))
+    assert any("deadlock" in b[0] for b in bad)
+    n, bad = explore(4, 4, 2, 3, 0, k_choices=(0, 1, 4, 5, 8))
+    assert not bad, bad[0]
+    # the fix (fastable: k <= min(2 KP, KG) for fp32 storage) = the step sizes the kernel now admits
+    for KG in (2, 3, 4):
+        n, bad = explore(KG, 3, 2, 3, 1, k_choices=tuple(range(KG + 1)))
+        assert not bad, (KG, bad[0])

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Soak test of the pose-graph solver against the CPU oracle: random map sizes, pose counts, factor slots, batch sizes, seeds
+and launch shapes (slot list on / off, chain + SYRK fused with 2 / 3 / 4 workgroups per instance, two launches, solve
+groups) for a given number of seconds.  Same criteria as tests/test_parity_pgs_gpu.py (identical LM iteration / trial
+counts and flags, 1e-7 m on poses and landmarks).  usage: gpu_soak_pgs.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as O
+import live_ekf_slam_amd as S
+from live_ekf_slam_amd.config import default_config
+from live_ekf_slam_amd.scenario import make_scenario
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+runs = fails = 0
+while time.time() < t_end:
+    L = int(rng.choice([3, 8, 20, 40, 60, 100, 150, 200]))
+    T = int(rng.integers(5, 400)) if L > 100 else int(rng.integers(5, 1000))
+    KP = int(rng.choice([4, 8, 16, 32]))
+    B = int(rng.integers(1, 24))
+    seed, sc = int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1 << 30))
+    fused = str(rng.choice(["-1", "0", "2", "3", "4"])); lst = str(rng.choice(["1", "1", "0"])); groups = int(rng.choice([0, 0, 2, 3]))
+    lanes = str(rng.choice(["4", "4", "1", "2"]))
+    os.environ["SLAM_PGS_FUSED"] = fused; os.environ["SLAM_PGS_LIST"] = lst; os.environ["SLAM_PGS_LANES"] = lanes
+    lm, cmds = make_scenario(sc, L, T)
+    cfg = default_config()
+    r = O.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8)
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+    if groups: pg.set_groups(groups)
+    pg.set_map(lm); pg.set_seed(seed); pg.init(0.0, 0.0, 0.0)
+    pg.run_sim(cmds); pg.solvePoseGraph()
+    st = pg.stats()
+    ok = (np.array_equal(st["flags"], r["flags"]) and np.array_equal(st["iterations"], r["iterations"]) and np.array_equal(st["trials"], r["trials"]))
+    err = 0.0
+    for b in range(B):
+        g1 = pg.get_graph(b, 1); M = r["M"][b]
+        ok = ok and g1["M"] == M
+        if g1["M"] == M:
+            err = max(err, float(np.abs(g1["poses"] - r["pose_res"][b]).max()), float(np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max()) if M else 0.0)
+    ok = ok and err < 1e-7
+    pg.close()
+    runs += 1
+    if not ok:
+        fails += 1
+        print(f"MISMATCH L={L} T={T} KP={KP} B={B} seed={seed} scenario={sc} fused={fused} list={lst} groups={groups} lanes={lanes}: max err {err:.3e}, "
+              f"iterations {st['iterations'].tolist()} vs {r['iterations'].tolist()}, trials {st['trials'].tolist()} vs {r['trials'].tolist()}, flags {st['flags'].tolist()} vs {r['flags'].tolist()}", flush=True)
+print(f"{runs} random pose-graph configurations in {budget:.0f} s, {fails} mismatches")
+sys.exit(1 if fails else 0)
