@@ -182,7 +182,9 @@ int slam_track_instance(slam_handle* h, int instance);
 int slam_get_poses(slam_handle* h, double* poses);
 int slam_get_landmark_counts(slam_handle* h, int32_t* M);            /* [batch] */
 int slam_get_truth(slam_handle* h, double* truth_poses);             /* [batch][3], sim_node.py x_v */
-/* Measurements the generator produced in the last slam_step_sim: meas [batch][k_stride][3], count [batch]. */
+/* Measurements the generator produced in the last slam_step_sim: meas [batch][k_stride][3], count [batch].  The generator only
+ * keeps a copy of its messages once somebody has asked: the FIRST call (or one with a larger k_stride) switches the dump on and
+ * returns count = 0 for every instance; call it once before the steps whose messages are wanted. */
 int slam_get_last_meas(slam_handle* h, float* meas, int32_t* meas_count, int k_stride);
 /* compute_average_error (plotting_node.py:195-218): mean over steps so far of the Euclidean position error of
  * the estimate at timestep t against the true pose of step t, per instance: [batch]. */

@@ -18,6 +18,7 @@ def fresh():
 # record K steps of generated measurements on a throw-away filter (the measurement dump switches the multi-step paths off)
 frec = fresh()
 rec = []
+frec.last_meas(KS)   # the first call only switches the dump on
 for t in range(20, 20 + K):
     frec.update_sim(cmds[t]); rec.append(frec.last_meas(KS))
 frec.close()
