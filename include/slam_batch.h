@@ -92,7 +92,8 @@ int slam_config_load(slam_config* cfg, const char* yaml_path);
 /* Replaces the filter factory `std::make_unique<EKF|UKF>()` + `filter->readParams(config)`
  * (localization_node.cpp:33-47).  batch = number of instances on THIS device, L_max = landmark capacity
  * (EKF_SLAM: <= 200 in fp64 [size classes 20 / 50 / 100 / 200], <= 50 in fp32 storage; UKF_SLAM: <= 50; UKF_LOC: ignored, the
- * state holds no landmarks).  The reference grows the state without limit (ekf.cpp:144-146); here the limit is what one
+ * state holds no landmarks - its map may have any size, one message up to 50 detections [20 while the map has <= 20 landmarks]; a
+ * longer one raises SLAM_INST_CAPACITY and loses the surplus).  The reference grows the state without limit (ekf.cpp:144-146); here the limit is what one
  * workgroup keeps in the 160 KB of LDS of a CU.
  * dtype SLAM_F32 (fp32 storage of x and P, fp64 arithmetic) is available for EKF_SLAM. */
 int slam_create(const slam_config* cfg, int filter_kind, int batch, int L_max, int dtype, int device,

@@ -1075,7 +1075,10 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
-    const int nmax = 4 + 2 * p.L_max;
+    // The size class also sets how many detections of one message the kernel holds (20 or 50).  UKF_LOC has a 4-state filter but
+    // sees a map of any size: with more than 20 landmarks it takes the large class (found by tools/gpu_soak_ekf.py: SLAM_INST_CAPACITY
+    // and dropped detections on a 35-landmark map where the reference - ukf.cpp:146-154 - uses every one).
+    const int nmax = (p.loc && p.L > 20) ? 104 : 4 + 2 * p.L_max;
     if (nmax <= 44) {
         switch (env_tpb(1, 128)) {
             case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;

@@ -243,3 +243,21 @@ def test_bench_scenario_raises_no_flags(S, L):
     sw = f.sweep_stats()
     assert int(sw[1]) == B * T and 2.0 <= sw[0] / sw[1] <= 8.0
     f.close()
+
+
+def test_ukf_loc_on_a_map_larger_than_the_small_size_class(S, oracle):
+    """UKF_LOC keeps a 4-state filter whatever the map: a map of 35 landmarks with the whole of it in view (35 detections per
+    message) must use every detection (ukf.cpp:146-154).  The step kernel's small size class holds 20 detections per message; the
+    launcher now takes the large one for maps of more than 20 landmarks (tools/gpu_soak_ekf.py found SLAM_INST_CAPACITY here)."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 35, 60, 9
+    lm, cmds = make_scenario(31, L, T)
+    cfg = S.default_config(); cfg.range_max = 1e9; cfg.fov_min = -4.0; cfg.fov_max = 4.0
+    f = S.BatchedUKFLoc(B).readParams(cfg); f.set_map(lm); f.set_seed(3); f.set_instance_offset(17); f.init(0, 0, 0)
+    f.run_sim(cmds[:25]); f.run_sim(cmds[25:])
+    r = oracle.run_ukf_batch(lm, cmds, B, 1, seed=3, inst0=17, nthreads=4, cfg=cfg, loc=True)
+    assert not f.status().any() and not r["flags"].any()
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
+    for b in range(B):
+        _eq(f.get_state(b), dict(M=0, ids=r["ids"][b, :0], x=r["x"][b, :4], P=r["P"][b, :16].reshape(4, 4)))
+    f.close()

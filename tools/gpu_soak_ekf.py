@@ -46,16 +46,40 @@ while time.time() < t_end:
     if wide:
         cfg.range_max = 1e9; cfg.fov_min = -4.0; cfg.fov_max = 4.0
     if split < 0: split = int(rng.integers(0, T + 1))
+    # extras (a second RNG so that SOAK_REPLAY lines of the plain mode stay valid): config switches, a sensor schedule with blind /
+    # wide / normal stretches, now and then a batch of more workgroups than the device holds at once, UKF localisation
+    xr = np.random.default_rng(seed ^ 0x5bd1e995)
+    extras = os.environ.get("SOAK_PLAIN") is None and xr.random() < 0.5
+    vis = None; loc = False
+    if extras:
+        cfg.replicate_vw_quirk = int(xr.random() < 0.7); cfg.ukf_float_trig = int(xr.random() < 0.7)
+        if xr.random() < 0.4: cfg.w_r, cfg.w_b, cfg.v_d, cfg.v_th = (float(v) for v in xr.normal(0, [0.01, 0.003, 0.002, 0.002]))
+        if xr.random() < 0.3: cfg.min_landmark_separation = float(xr.choice([0.05, 0.2, 0.5]))
+        if xr.random() < 0.6:
+            vis = np.tile([cfg.range_max, cfg.fov_min, cfg.fov_max], (T, 1)); t0 = 0
+            while t0 < T:
+                n = int(xr.integers(1, 40)); kind = xr.choice(["normal", "blind", "wide", "narrow"])
+                vis[t0:t0 + n] = {"normal": [3.0, -1.57, 1.57], "blind": [1e-6, -1.57, 1.57], "wide": [1e9, -4.0, 4.0], "narrow": [1.5, -0.5, 0.5]}[kind]
+                t0 += n
+        if L <= 20 and xr.random() < 0.15: B = int(xr.integers(300, 3000))
+        loc = ukf and xr.random() < 0.25
     if ukf:
-        f = S.BatchedUKF(B, L).readParams(cfg)
+        f = (S.BatchedUKFLoc(B) if loc else S.BatchedUKF(B, L)).readParams(cfg)
     else:
         f = S.BatchedEKF(B, L, dtype=S.F32 if f32 else S.F64).readParams(cfg)
     f.set_map(lm); f.set_seed(seed); f.set_instance_offset(inst0); f.init(0, 0, 0)
-    f.run_sim(cmds[:split]); f.run_sim(cmds[split:])
+    if vis is None:
+        f.run_sim(cmds[:split]); f.run_sim(cmds[split:])
+    else:   # the sensor limits are per launch: one run_sim per stretch of equal limits (and the split)
+        t0 = 0
+        while t0 < T:
+            t1 = t0 + 1
+            while t1 < T and t1 != split and np.array_equal(vis[t1], vis[t0]): t1 += 1
+            f.set_vision(*vis[t0]); f.run_sim(cmds[t0:t1]); t0 = t1
     if ukf:
-        r = O.run_ukf_batch(lm, cmds, B, L, seed=seed, inst0=inst0, nthreads=8, cfg=cfg)
+        r = O.run_ukf_batch(lm, cmds, B, 1 if loc else L, seed=seed, inst0=inst0, nthreads=8, cfg=cfg, vision=vis, loc=loc)
     else:
-        r = O.run_ekf_batch(lm, cmds, B, L, seed=seed, inst0=inst0, nthreads=8, cfg=cfg, mode=O.MODE_FAST | (O.STORAGE_F32 if f32 else 0))
+        r = O.run_ekf_batch(lm, cmds, B, L, seed=seed, inst0=inst0, nthreads=8, cfg=cfg, mode=O.MODE_FAST | (O.STORAGE_F32 if f32 else 0), vision=vis)
     why = []
     if not np.array_equal(f.status(), r["flags"]): why.append(f"flags {f.status().tolist()} vs {r['flags'].tolist()}")
     clean = r["flags"] == 0        # a flagged instance (capacity, singular S, ...) is only required to carry the same flag
@@ -67,7 +91,7 @@ while time.time() < t_end:
     for b in range(B):
         if not clean[b]:
             continue
-        n = (4 if ukf else 3) + 2 * r["M"][b]
+        n = (4 if ukf else 3) + 2 * (0 if loc else r["M"][b])
         sg = f.get_state(b)
         if sg["M"] != r["M"][b]:
             ok = False; continue
@@ -78,6 +102,6 @@ while time.time() < t_end:
     runs += 1
     if not ok:
         fails += 1
-        print(f"MISMATCH {desc} split={split}: {'; '.join(why)} max |diff| {worst:.3e}, oracle flags {r['flags'].tolist()}", flush=True)
+        print(f"MISMATCH {desc} split={split} extras={extras} loc={loc} B={B} vis={'yes' if vis is not None else 'no'}: {'; '.join(why)} max |diff| {worst:.3e}, oracle flags {r['flags'].tolist()}", flush=True)
 print(f"{runs} random filter configurations in {budget:.0f} s, {fails} mismatches")
 sys.exit(1 if fails else 0)
