@@ -2,7 +2,7 @@
 """Soak test of the pose-graph solver against the CPU oracle: random map sizes, pose counts, factor slots, batch sizes, seeds
 and launch shapes (slot list on / off, chain + SYRK fused with 2 / 3 / 4 workgroups per instance, two launches, solve
 groups) for a given number of seconds.  Same criteria as tests/test_parity_pgs_gpu.py (identical LM iteration / trial
-counts and flags, 1e-7 m on poses and landmarks).  usage: gpu_soak_pgs.py [seconds] [seed]"""
+counts and flags, 1e-7 m on poses and landmarks).  usage: gpu_soak_pgs.py [seconds] [seed] [big]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,6 +13,7 @@ from live_ekf_slam_amd.scenario import make_scenario
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 t_end = time.time() + budget
 runs = fails = 0
 while time.time() < t_end:
@@ -20,6 +21,8 @@ while time.time() < t_end:
     T = int(rng.integers(5, 400)) if L > 100 else int(rng.integers(5, 1000))
     KP = int(rng.choice([4, 8, 16, 32]))
     B = int(rng.integers(1, 24))
+    if big:   # BASELINE-size graphs in batches that reach every per-trial launch shape (<= 64 / 85 / 128 / more running slots)
+        L = int(rng.choice([120, 170, 200])); T = int(rng.integers(300, 1000)); KP = int(rng.choice([16, 32])); B = int(rng.choice([6, 40, 75, 110, 150]))
     seed, sc = int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1 << 30))
     fused = str(rng.choice(["-1", "0", "2", "3", "4"])); lst = str(rng.choice(["1", "1", "0"])); groups = int(rng.choice([0, 0, 2, 3]))
     lanes = str(rng.choice(["4", "4", "1", "2"]))
