@@ -43,14 +43,16 @@ enum slam_instance_flags {
     SLAM_INST_OK = 0,
     SLAM_INST_NONFINITE = 1,     /* x or P became non-finite                                                    */
     SLAM_INST_S_SINGULAR = 2,    /* zero pivot while inverting the 2x2 innovation covariance (ekf.cpp:135)      */
-    SLAM_INST_INDEX_OOR = 4,     /* landmark index outside x_t (ekf.cpp:115 under the duplicate/unknown-id quirk) */
+    SLAM_INST_INDEX_OOR = 4,     /* landmark index outside x_t (ekf.cpp:115 under the duplicate/unknown-id quirk): a message repeats a
+                                    NEW id that it has itself just inserted (a repeat of an id that found no room is skipped again, a
+                                    repeat of a mapped id is a second update - as the reference's loop does, detection by detection) */
     SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146), or a
                                     message held more detections than the landmark capacity of the handle's size class (20 / 50 /
                                     100 / 200), which takes repeated ids; the surplus was dropped                      */
     SLAM_INST_SQRT_FAILED = 16,  /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
     SLAM_INST_WATCHDOG = 32      /* EKF: a polling loop of the step kernel's intra-workgroup protocol exceeded its budget (~0.1 s);
-                                    the instance is frozen with an undefined state instead of hanging the GPU.  Never seen on a
-                                    correct build (tests/test_ring_protocol_model.py checks the protocol exhaustively)            */
+                                    the instance is frozen with an undefined state instead of hanging the GPU.  A defect if it ever
+                                    shows (round 3's random soak raised it once: tests/test_ring_protocol_model.py)   */
 };
 
 /* Flat mirror of the YAML keys the hot path reads (ekf_ws/src/base_pkg/config/params.yaml; key names kept).

@@ -403,37 +403,50 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
             const int kn = kraw < KCAP ? kraw : KCAP;
             // lanes scan lm_IDs in parallel for each detection (first match wins, ekf.cpp:102-107); lane l % 64 then keeps the
             // result of detection l.  The message is walked 64 detections at a time (ekf.cpp:73 loops over any number of them).
-            int cnt = 0;                    // new ids so far in this message
-            bool anydup = false;
+            // What the reference's loop does with a NEW id (ekf.cpp:99-108,141-173), per detection in message order: the first
+            // occurrence is inserted while there is room, else skipped (no capacity there; here SLAM_INST_CAPACITY); a LATER
+            // occurrence of an id this message inserted is found among the pushed ids and indexes x_t out of range (ekf.cpp:115 ->
+            // eigen_assert -> exception, filter.h:5: the reference dies, we freeze in the pre-step state); a later occurrence of a
+            // SKIPPED id is skipped again.  So: the first `room` distinct new ids are inserted in order of first occurrence, the
+            // step freezes at the first repeat of one of those, and the capacity flag is raised by a skip BEFORE that point only.
+            // (Until round 3 any repeated new id froze the instance and the capacity flag ignored the order: found by
+            // tools/gpu_soak_adversarial.py on messages no AprilTag front-end sends.)
+            const int room = (p.L_max < LMAX ? p.L_max : LMAX) - M;
+            int nins = 0;                   // insertions of this message
+            bool frz = false, capf = false;
             if (kn <= 64 && M <= 64) {
                 // the common case in registers: lane l holds the id of detection l and lm_IDs[l]; the id of detection l reaches the
                 // others by v_readlane, a match is one ballot (one LDS round trip for the whole message instead of two per detection)
                 const int myid = lane < kn ? (int)meas[3 * lane] : -1;
                 const int sid = lane < M ? s_ids[lane] : -2;
-                int idx = -1;
-                bool isnew = false, dup = false;
+                int idx = -1, firstl = lane;
+                bool isnew = false;
 #pragma unroll 1
                 for (int l = 0; l < kn; ++l) {
                     const int id = __builtin_amdgcn_readlane(myid, l);
                     const unsigned long long m = __ballot(sid == id);                    // first match wins (ekf.cpp:102-107)
-                    const unsigned long long e = __ballot(lane < l && myid == id);       // an earlier detection of this message has the id
-                    if (lane == l) { idx = m ? __ffsll((long long)m) - 1 : -1; isnew = m == 0ull; dup = isnew && e != 0ull; }
+                    const unsigned long long e = __ballot(lane < l && myid == id);       // earlier detections of this message with the id
+                    if (lane == l) { idx = m ? __ffsll((long long)m) - 1 : -1; isnew = m == 0ull; firstl = e ? __ffsll((long long)e) - 1 : l; }
                 }
-                anydup = __ballot(dup) != 0ull;
-                const unsigned long long nmask = __ballot(isnew);
-                const int rank = __popcll(nmask & ((1ull << lane) - 1ull));
-                if (isnew) idx = (M + rank < p.L_max && M + rank < LMAX) ? M + rank : -1;
+                const bool isfirst = isnew && firstl == lane;
+                const unsigned long long fmask = __ballot(isfirst);
+                const int rankf = __popcll(fmask & ((1ull << firstl) - 1ull));           // rank of my id's first occurrence among the new ids
+                const bool insf = rankf < room;
+                const unsigned long long fz = __ballot(isnew && !isfirst && insf);
+                const unsigned long long cm = __ballot(isnew && !insf);
+                const unsigned long long before = fz ? ((1ull << (__ffsll((long long)fz) - 1)) - 1ull) : ~0ull;
+                frz = fz != 0ull;
+                capf = (cm & before) != 0ull;
+                if (isnew) idx = (isfirst && insf) ? M + rankf : -1;
                 if (lane < kn) didx[lane] = idx;
-                cnt = __popcll(nmask);
-            } else
+                nins = __popcll(fmask);
+                nins = nins < room ? nins : (room > 0 ? room : 0);
+            } else {
+                // long messages / large maps: one detection at a time, the wavefront scans lm_IDs and the earlier part of the message
+                // 64 entries per ballot; didx of an earlier detection tells what became of its id
+                int nfirst = 0;
 #pragma unroll 1
-            for (int c0 = 0; c0 < kn; c0 += 64) {
-                int idx = -1;
-                bool isnew = false, dup = false;
-                const int lend = kn - c0 < 64 ? kn - c0 : 64;
-#pragma unroll 1
-                for (int ll = 0; ll < lend; ++ll) {
-                    const int l = c0 + ll;
+                for (int l = 0; l < kn && !frz; ++l) {
                     const int id = (int)meas[3 * l];
                     int found = -1;
 #pragma unroll 1
@@ -442,30 +455,35 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         const unsigned long long m = __ballot(j < M && s_ids[j] == id);
                         if (m != 0ull) found = j0 + (__ffsll((long long)m) - 1);
                     }
-                    // among the NEW ids: has an earlier detection of this message the same id?
-                    bool e = false;
+                    int code = found;
+                    if (found < 0) {
+                        int first = -1;       // first earlier detection of this message with the same id
 #pragma unroll 1
-                    for (int q0 = 0; q0 < l && !e; q0 += 64) {
-                        const int q = q0 + lane;
-                        e = __ballot(q < l && (int)meas[3 * (q < l ? q : 0)] == id) != 0ull;
+                        for (int q0 = 0; q0 < l && first < 0; q0 += 64) {
+                            const int q = q0 + lane;
+                            const unsigned long long m = __ballot(q < l && (int)meas[3 * (q < l ? q : 0)] == id);
+                            if (m != 0ull) first = q0 + (__ffsll((long long)m) - 1);
+                        }
+                        if (first < 0) {                          // first occurrence: inserted while there is room
+                            code = nfirst < room ? M + nfirst : -1;
+                            capf = capf || nfirst >= room;
+                            nfirst += 1;
+                        } else if (didx[first] >= M) {            // its first occurrence was inserted by this message: out of range
+                            frz = true;
+                        } else {                                  // its first occurrence was skipped: skipped again
+                            code = -1;
+                            capf = true;
+                        }
                     }
-                    if (lane == ll) { idx = found; isnew = found < 0; dup = isnew && e; }
+                    if (lane == 0) didx[l] = code;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // didx[l] is read back (uniformly) by later detections
                 }
-                // a repeated NEW id would be found among the ids pushed this step and index x_t out of range
-                // (ekf.cpp:115 -> eigen_assert -> exception, filter.h:5): the reference dies, we freeze.
-                anydup = anydup || __ballot(dup) != 0ull;
-                const unsigned long long nmask = __ballot(isnew);
-                const int rank = cnt + __popcll(nmask & ((1ull << lane) - 1ull));
-                if (isnew) idx = (M + rank < p.L_max && M + rank < LMAX) ? M + rank : -1;
-                if (lane < lend) didx[c0 + lane] = idx;
-                cnt += __popcll(nmask);
+                nins = nfirst < room ? nfirst : (room > 0 ? room : 0);
             }
             if (lane == 0) {
-                const unsigned long long dmask = anydup ? 1ull : 0ull;
-                const int room = (p.L_max < LMAX ? p.L_max : LMAX) - M;
-                nx[3] = cnt > room ? 1 : 0;           // capacity overflow
-                nx[1] = cnt > room ? room : cnt;      // insertions
-                nx[2] = dmask != 0ull ? 1 : 0;        // freeze
+                nx[3] = capf ? 1 : 0;       // capacity overflow (before the freeze point, if any)
+                nx[1] = nins;               // insertions
+                nx[2] = frz ? 1 : 0;        // freeze
             }
         }
     };
