@@ -3,7 +3,7 @@
 instance gets its OWN random external messages - repeated ids inside a message, ids beyond the landmark capacity, more
 detections than one wavefront associates at once (> 64), empty messages, tiny and huge ranges - in known-id and unknown-id mode,
 fp64 / fp32 storage, random queue depths and getters in between (Filter::update through slam_step; ekf.cpp:65-146).
-usage: gpu_soak_adversarial.py [seconds] [seed]"""
+usage: gpu_soak_adversarial.py [seconds] [seed] [ekf|ukf|both]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,12 +12,14 @@ import live_ekf_slam_amd as S
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+which = sys.argv[3] if len(sys.argv) > 3 else "ekf"
 t_end = time.time() + budget
 runs = fails = 0
 cat = {}
 while time.time() < t_end:
-    L = int(rng.choice([3, 8, 20, 50, 100]))
-    f32 = L <= 50 and rng.random() < 0.3
+    ukf = which == "ukf" or (which == "both" and rng.random() < 0.35)
+    L = int(rng.choice([3, 8, 20, 50] if ukf else [3, 8, 20, 50, 100]))
+    f32 = (not ukf) and L <= 50 and rng.random() < 0.3
     T = int(rng.integers(3, 50))
     B = int(rng.integers(1, 10))
     idknown = int(rng.random() < 0.75)
@@ -25,18 +27,20 @@ while time.time() < t_end:
     kcap = min(kcap, 20 if L <= 20 else (50 if L <= 50 else 100))   # a message holds at most the size class's landmark count (include/slam_batch.h: the surplus is dropped, SLAM_INST_CAPACITY)
     idmax = int(rng.choice([max(2, L // 2), L, 2 * L, 400]))
     seed = int(rng.integers(1, 1 << 30))
-    if os.environ.get("SOAK_REPLAY"):   # "L T B f32 idknown kcap idmax seed"
+    if os.environ.get("SOAK_REPLAY"):   # "ekf|ukf L T B f32 idknown kcap idmax seed"
         a = os.environ["SOAK_REPLAY"].split()
+        ukf = a[0] == "ukf"; a = a[1:]
         L, T, B = int(a[0]), int(a[1]), int(a[2]); f32 = a[3] == "True"; idknown, kcap, idmax, seed = int(a[4]), int(a[5]), int(a[6]), int(a[7]); t_end = 0
-    desc = f"L={L} T={T} B={B} f32={f32} idknown={idknown} kcap={kcap} idmax={idmax} seed={seed}"
+    desc = f"{'ukf' if ukf else 'ekf'} L={L} T={T} B={B} f32={f32} idknown={idknown} kcap={kcap} idmax={idmax} seed={seed}"
     if os.environ.get("SOAK_VERBOSE"): print("RUN", desc, flush=True)
     mr = np.random.default_rng(seed)
     cfg = S.default_config(); cfg.landmark_id_is_known = idknown
-    f = S.BatchedEKF(B, L, dtype=S.F32 if f32 else S.F64).readParams(cfg); f.init(0.0, 0.0, 0.0)
-    if mr.random() < 0.5: f.set_lazy_steps(int(mr.choice([1, 3, 32])))
+    f = (S.BatchedUKF(B, L) if ukf else S.BatchedEKF(B, L, dtype=S.F32 if f32 else S.F64)).readParams(cfg); f.init(0.0, 0.0, 0.0)
+    if not ukf and mr.random() < 0.5: f.set_lazy_steps(int(mr.choice([1, 3, 32])))
     es = []
     for b in range(B):
-        e = O.OracleEKF(cfg, L_max=L, mode=O.MODE_FAST | (O.STORAGE_F32 if f32 else 0)); e.init(0, 0, 0); es.append(e)
+        e = O.OracleUKF(cfg, L_max=L) if ukf else O.OracleEKF(cfg, L_max=L, mode=O.MODE_FAST | (O.STORAGE_F32 if f32 else 0))
+        e.init(0, 0, 0); es.append(e)
     oflags = np.zeros(B, dtype=np.int64)
     for t in range(T):
         cmd = np.array([mr.uniform(0, 0.1), mr.uniform(-0.05, 0.05)], dtype=np.float32)
