@@ -14,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tool,args", [("gpu_soak_ekf.py", ["both"]), ("gpu_soak_pgs.py", []), ("gpu_soak_api.py", []), ("gpu_soak_adversarial.py", [])])
+@pytest.mark.parametrize("tool,args", [("gpu_soak_ekf.py", ["both"]), ("gpu_soak_pgs.py", []), ("gpu_soak_api.py", []), ("gpu_soak_adversarial.py", ["both"]), ("gpu_soak_pgs_api.py", [])])
 def test_a_few_seconds_of_random_configurations(tool, args):
     seed = str(1 + time.gmtime().tm_yday)
     cmd = [sys.executable, os.path.join(ROOT, "tools", tool), "8", seed] + args
