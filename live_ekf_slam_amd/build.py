@@ -21,8 +21,9 @@ HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", 
 EKF_DEFAULT_VARIANTS = [(43, 2, 5, 4, 0, 1), (43, 2, 4, 4, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 4, 4, 0, 1),
                         (203, 4, 5, 4, 0, 1), (203, 4, 4, 4, 0, 1), (403, 4, 4, 4, 0, 1),
                         (43, 2, 4, 4, 1, 1), (103, 4, 4, 2, 1, 1)]
-# (43, 1, 2, 4, 0, 1), the one-wavefront variant, left the release build in round 3: it fails tools/gpu_soak_ekf.py when a second
-# multi-step launch continues a run (vehicle row of P; the decoupled loop of the W >= 2 kernels does not take that path)
+# (43, 1, 2, 4, 0, 1), the one-wavefront variant, left the release build in round 3: it fails tools/gpu_soak_ekf.py when a multi-step
+# launch continues a run with prediction-only timesteps and then updates a mapped landmark (five steps without detections, then one of
+# landmark 3: the vehicle row of P differs from the sixth step on; the W >= 2 kernels pass the same case in both of their paths)
 EKF_SWEEP_VARIANTS = [(43, 1, 2, 4, 0, 1), (103, 4, 5, 4, 0, 2), (103, 4, 5, 2, 0, 2), (103, 4, 4, 4, 0, 2), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1), (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 4, 5, 2, 1, 1), (103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
                       (103, 2, 4, 4, 0, 1), (103, 8, 4, 2, 0, 1), (103, 8, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1), (103, 4, 2, 4, 0, 1),
                       (103, 4, 4, 4, 1, 0), (103, 4, 4, 8, 1, 1), (103, 4, 4, 4, 1, 1), (103, 2, 4, 4, 1, 1), (103, 8, 4, 2, 1, 1),
