@@ -36,10 +36,17 @@ while time.time() < t_end:
         ukf = a[0] == "ukf"; L, T, B, seed, sc, inst0 = (int(v) for v in a[1:7]); f32 = a[7] == "True"; idknown = int(a[8]); wide = a[9] == "True"
         chunk, var, split = int(a[10]), int(a[11]), int(a[12]); t_end = 0
     os.environ["SLAM_RUN_CHUNK"] = str(chunk)
+    # UKF: the thread-count variants of its two kernels (SLAM_UKF_TPB = sqrt threads * 10000 + step threads), drawn from a second RNG
+    tr = np.random.default_rng(seed ^ 0x2545f491)
+    if ukf and os.environ.get("SOAK_PLAIN") is None and tr.random() < 0.4:
+        sq, stp = ((256, 128, 64), (128, 64, 256, 192)) if L <= 20 else ((1024, 512, 256), (1024, 256, 512))
+        os.environ["SLAM_UKF_TPB"] = str(int(tr.choice(sq)) * 10000 + int(tr.choice(stp)))
+    else:
+        os.environ.pop("SLAM_UKF_TPB", None)
     if var: os.environ["SLAM_WAVES_PER_FILTER"] = str(var)
     else: os.environ.pop("SLAM_WAVES_PER_FILTER", None)
     desc = (f"{'ukf' if ukf else 'ekf'} L={L} T={T} B={B} seed={seed} scenario={sc} inst0={inst0} f32={f32} idknown={idknown} wide={wide} chunk={chunk} "
-            f"variant={var}")
+            f"variant={var} ukf_tpb={os.environ.get('SLAM_UKF_TPB', '-')}")
     if os.environ.get("SOAK_VERBOSE"): print("RUN", desc, flush=True)
     lm, cmds = make_scenario(sc, L, T)
     cfg = S.default_config(); cfg.landmark_id_is_known = idknown
