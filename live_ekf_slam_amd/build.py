@@ -15,20 +15,18 @@ SOURCES = ["ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp",
 HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h",
            "capi_internal.h", "../../include/slam_batch.h", "../../include/slam_pgs.h", "../../include/slam_scenario.hpp",
            "../../include/slam_filter.hpp", "../../include/slam_multi.h", "host/filter_driver.cpp", "host/config_parse.h", "host/stream_parse.h"]
-# Instantiations of the EKF step kernel: (NMAX, W, KG, UNR, f32 storage, PIPE); variant code = PIPE*1000 + W*100 + KG*10 + UNR
-# (ekf_kernel.h).  The release library holds the defaults only (they must match SLAM_DEF_* in ekf_kernel.hip); the sweep
-# set is for tuning sessions: SLAM_SWEEP=1 python -m live_ekf_slam_amd.build --force
+# Instantiations of the EKF step kernel: (NMAX, W, KG, UNR, f32 storage, PIPE[, KP]); variant code = KP*10000 + PIPE*1000 + W*100 +
+# KG*10 + UNR (ekf_kernel.h; KP = 0 / absent: derived from KG).  The release library holds the defaults only (they must match
+# SLAM_DEF_* in ekf_kernel.hip) plus the one-wavefront lockstep-only variant the tests force; the sweep set is for tuning
+# sessions: SLAM_SWEEP=1 python -m live_ekf_slam_amd.build --force
 EKF_DEFAULT_VARIANTS = [(43, 2, 5, 4, 0, 1), (43, 2, 4, 4, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 4, 4, 0, 1),
                         (203, 4, 5, 4, 0, 1), (203, 4, 4, 4, 0, 1), (403, 4, 4, 4, 0, 1),
-                        (43, 2, 4, 4, 1, 1), (103, 4, 4, 2, 1, 1)]
-# (43, 1, 2, 4, 0, 1), the one-wavefront variant, left the release build in round 3: it fails tools/gpu_soak_ekf.py when a multi-step
-# launch continues a run with prediction-only timesteps and then updates a mapped landmark (five steps without detections, then one of
-# landmark 3: the vehicle row of P differs from the sixth step on; the W >= 2 kernels pass the same case in both of their paths)
-EKF_SWEEP_VARIANTS = [(43, 1, 2, 4, 0, 1), (103, 4, 5, 4, 0, 2), (103, 4, 5, 2, 0, 2), (103, 4, 4, 4, 0, 2), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1), (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 4, 5, 2, 1, 1), (103, 4, 4, 4, 0, 0), (103, 4, 4, 8, 0, 0), (103, 4, 4, 8, 0, 1), (103, 4, 4, 2, 0, 1), (103, 2, 4, 8, 0, 1),
-                      (103, 2, 4, 4, 0, 1), (103, 8, 4, 2, 0, 1), (103, 8, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1), (103, 4, 2, 4, 0, 1),
-                      (103, 4, 4, 4, 1, 0), (103, 4, 4, 8, 1, 1), (103, 4, 4, 4, 1, 1), (103, 2, 4, 4, 1, 1), (103, 8, 4, 2, 1, 1),
-                      (103, 2, 4, 2, 1, 1), (103, 3, 4, 2, 1, 1), (43, 2, 4, 2, 1, 1), (43, 2, 4, 2, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 6, 2, 1, 1), (103, 3, 4, 4, 0, 1), (103, 3, 4, 2, 0, 1),
-                      (43, 2, 4, 4, 0, 0), (43, 1, 2, 4, 0, 0), (43, 4, 4, 4, 0, 1), (43, 1, 4, 8, 0, 1), (43, 2, 4, 8, 0, 1), (43, 2, 2, 4, 0, 1)]
+                        (43, 2, 4, 4, 1, 1), (103, 4, 4, 2, 1, 1),
+                        (43, 1, 2, 4, 0, 1)]   # one wavefront per filter: no decoupled loop, every step through the synchronised path
+EKF_SWEEP_VARIANTS = [(103, 3, 4, 4, 0, 1, 2), (103, 3, 5, 4, 0, 1, 2), (103, 2, 3, 4, 0, 1, 2), (103, 2, 4, 4, 0, 1, 2), (103, 3, 6, 4, 0, 1, 2),
+                      (103, 4, 4, 4, 0, 1, 2), (103, 4, 5, 4, 0, 1, 2), (103, 3, 4, 4, 0, 1, 3), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1),
+                      (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 2, 4, 4, 0, 1), (103, 3, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1),
+                      (43, 2, 4, 2, 0, 1), (43, 4, 4, 4, 0, 1), (43, 2, 4, 8, 0, 1), (43, 2, 2, 4, 0, 1)]
 # EKF_FLAGS, -disable-machine-licm: with the register budget these kernels run at (128 VGPRs at four waves per SIMD), hoisting the
 # materialisation of fp64 constants out of loops pins registers the loops need; the compiler then SPILLED the hoisted constants
 # (det_atan's hi / lo table) to scratch and every atan2 of the EKF chain waited for three scratch loads.  Without the pass the
@@ -57,10 +55,13 @@ def build_extension(force=False, verbose=False):
     # in AGPRs and copied all of them in and out around every k-block of the covariance contraction)
     per_file = {"ukf_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     variants = list(EKF_DEFAULT_VARIANTS) + (EKF_SWEEP_VARIANTS if os.environ.get("SLAM_SWEEP") else [])
-    for (nmax, w, kg, unr, f32, pipe) in variants:
-        tag = f"ekf_inst_{nmax}_{pipe}{w}{kg}{unr}{'_f32' if f32 else ''}"
+    variants = list(dict.fromkeys(variants))
+    for v in variants:
+        nmax, w, kg, unr, f32, pipe = v[:6]
+        kp = v[6] if len(v) > 6 else 0
+        tag = f"ekf_inst_{nmax}_{kp if kp else ''}{pipe}{w}{kg}{unr}{'_f32' if f32 else ''}"
         jobs.append((tag, os.path.join(CSRC, tag + ".o"),
-                     [f"-DV_NMAX={nmax}", f"-DV_W={w}", f"-DV_KG={kg}", f"-DV_UNR={unr}", f"-DV_F32={f32}", f"-DV_PIPE={pipe}"]))
+                     [f"-DV_NMAX={nmax}", f"-DV_W={w}", f"-DV_KG={kg}", f"-DV_UNR={unr}", f"-DV_F32={f32}", f"-DV_PIPE={pipe}", f"-DV_KP={kp}"]))
     for f in os.listdir(CSRC):   # objects of variants that are no longer part of the build
         if f.startswith("ekf_inst_") and f.endswith(".o") and os.path.join(CSRC, f) not in [j[1] for j in jobs]:
             os.remove(os.path.join(CSRC, f))

@@ -142,21 +142,40 @@ int slam_multi_error_stats(slam_multi* m, double* out, int mode) {
     }
     // ---- mode 1: device-to-device all-gather with RCCL (one communicator per device in this process) ----
     if (!m->rccl) {
-        m->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!m->rccl) m->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!m->rccl) return slam_internal_fail(SLAM_ERR_UNSUPPORTED, "librccl.so cannot be loaded: %s", dlerror());
-        nccl_comm_init_all_t init_all = (nccl_comm_init_all_t)dlsym(m->rccl, "ncclCommInitAll");
-        if (!init_all) return slam_internal_fail(SLAM_ERR_UNSUPPORTED, "librccl.so has no ncclCommInitAll");
-        m->comms.assign(n, nullptr);
-        if (init_all(m->comms.data(), n, m->dev.data()) != 0) return slam_internal_fail(SLAM_ERR_HIP, "ncclCommInitAll failed");
-        m->pad = 0;
-        for (int s = 0; s < n; ++s) m->pad = m->count[s] > m->pad ? m->count[s] : m->pad;   // equal-sized contributions (ragged shards are padded)
-        m->cstream.assign(n, nullptr); m->dsend.assign(n, nullptr); m->drecv.assign(n, nullptr);
-        for (int s = 0; s < n; ++s) {
-            if (hipSetDevice(m->dev[s]) != hipSuccess || hipStreamCreateWithFlags(&m->cstream[s], hipStreamNonBlocking) != hipSuccess ||
-                hipMalloc(&m->dsend[s], sizeof(double) * m->pad) != hipSuccess || hipMalloc(&m->drecv[s], sizeof(double) * m->pad * n) != hipSuccess)
-                return slam_internal_fail(SLAM_ERR_HIP, "allocating the gather buffers failed");
+        // transactional: the communicators, streams and buffers are built in locals and committed together with the library handle
+        // only when every step succeeded; a failure tears down what exists, so a later call starts from scratch instead of indexing
+        // half-filled vectors
+        void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return slam_internal_fail(SLAM_ERR_UNSUPPORTED, "librccl.so cannot be loaded: %s", dlerror());
+        nccl_comm_init_all_t init_all = (nccl_comm_init_all_t)dlsym(lib, "ncclCommInitAll");
+        nccl_comm_destroy_t comm_destroy = (nccl_comm_destroy_t)dlsym(lib, "ncclCommDestroy");
+        if (!init_all) { dlclose(lib); return slam_internal_fail(SLAM_ERR_UNSUPPORTED, "librccl.so has no ncclCommInitAll"); }
+        std::vector<void*> comms(n, nullptr);
+        if (init_all(comms.data(), n, m->dev.data()) != 0) { dlclose(lib); return slam_internal_fail(SLAM_ERR_HIP, "ncclCommInitAll failed"); }
+        int64_t pad = 0;
+        for (int s = 0; s < n; ++s) pad = m->count[s] > pad ? m->count[s] : pad;   // equal-sized contributions (ragged shards are padded)
+        std::vector<hipStream_t> cstream(n, nullptr);
+        std::vector<double*> dsend(n, nullptr), drecv(n, nullptr);
+        bool ok = true;
+        for (int s = 0; s < n && ok; ++s)
+            ok = hipSetDevice(m->dev[s]) == hipSuccess && hipStreamCreateWithFlags(&cstream[s], hipStreamNonBlocking) == hipSuccess &&
+                 hipMalloc(&dsend[s], sizeof(double) * pad) == hipSuccess && hipMalloc(&drecv[s], sizeof(double) * pad * n) == hipSuccess;
+        if (!ok) {
+            for (int s = 0; s < n; ++s) {
+                hipSetDevice(m->dev[s]);
+                if (dsend[s]) hipFree(dsend[s]);
+                if (drecv[s]) hipFree(drecv[s]);
+                if (cstream[s]) hipStreamDestroy(cstream[s]);
+                if (comm_destroy && comms[s]) comm_destroy(comms[s]);
+            }
+            (void)hipGetLastError();
+            dlclose(lib);
+            return slam_internal_fail(SLAM_ERR_HIP, "allocating the gather buffers failed");
         }
+        m->comms.swap(comms); m->cstream.swap(cstream); m->dsend.swap(dsend); m->drecv.swap(drecv);
+        m->pad = pad;
+        m->rccl = lib;
     }
     nccl_all_gather_t all_gather = (nccl_all_gather_t)dlsym(m->rccl, "ncclAllGather");
     nccl_group_t gstart = (nccl_group_t)dlsym(m->rccl, "ncclGroupStart"), gend = (nccl_group_t)dlsym(m->rccl, "ncclGroupEnd");

@@ -324,7 +324,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     env = getenv("SLAM_DEBUG_FLAGS");   // 4 / 32: phase and per-step timers.  The ablation bits (1, 2, 16: WRONG results) are
     if (env) h->dbg = atoi(env);        // compiled out of the release kernels (-DSLAM_ABLATE builds only)
 #ifndef SLAM_ABLATE
-    h->dbg &= (4 | 32 | 128);
+    h->dbg &= (4 | 32);   // (the fault-injection bit 128 is reachable through slam_set_debug_flags only: no environment variable can plant it)
 #endif
     env = getenv("SLAM_UKF_SPLIT_MIN");   // batch size from which UKF run_sim splits the batch over two streams
     if (env) h->ukf_split_min = atoi(env);
@@ -511,6 +511,10 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
         HIP_TRY(hipStreamWaitEvent(h->shadow->stream, h->shadow_ev, 0));
         const int rs = slam_step_dev(h->shadow, cmd, d_meas + (size_t)h->tracked * k_stride * 3, d_count + h->tracked, k_stride);
         if (rs) return rs;
+        // ... and the other way round: the shadow reads the CALLER's buffers on its own stream, and the header promises that they
+        // may be overwritten by work enqueued on the handle's stream after this call returns
+        HIP_TRY(hipEventRecord(h->shadow_ev, h->shadow->stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->shadow_ev, 0));
     }
     // Device buffers on the caller's stream: queueing is OPT-IN here (slam_set_lazy_steps / SLAM_LAZY_STEPS), because a queued
     // call enqueues only its device-to-device copy on the stream, not the step itself
@@ -1072,6 +1076,28 @@ int slam_load_state(slam_handle* h, const char* path) {
         fclose(f);
         return fail(SLAM_ERR_ARG, "%s holds kind %d, batch %d, L_max %d, dtype %d; the handle is kind %d, batch %d, L_max %d, dtype %d", path, hd.kind, hd.B, hd.L_max,
                     hd.dtype, h->kind, h->B, h->L_max, h->dtype);
+    }
+    if (hd.n_max != h->n_max) { fclose(f); return fail(SLAM_ERR_ARG, "%s was written for a state capacity of %d, the handle has %d", path, hd.n_max, h->n_max); }
+    // The step kernels trust the per-instance counters (n = 3 + 2 M sizes every loop over LDS and the instance's slab), so a
+    // corrupted or hand-made file must be refused BEFORE anything reaches the device: landmark counts, the size of the UKF's
+    // stored square root and the timesteps are checked on the host first.
+    {
+        const std::vector<CkptItem> items = ckpt_items(h);
+        std::vector<size_t> off(items.size() + 1, sizeof(hd));
+        for (size_t i = 0; i < items.size(); ++i) off[i + 1] = off[i] + items[i].bytes;
+        std::vector<int32_t> col((size_t)h->B);
+        auto column = [&](size_t item, const char* what, int lo, int hi) -> int {
+            if (fseek(f, (long)off[item], SEEK_SET) != 0 || fread(col.data(), sizeof(int32_t), col.size(), f) != col.size()) return fail(SLAM_ERR_IO, "%s is truncated", path);
+            for (size_t b = 0; b < col.size(); ++b)
+                if (col[b] < lo || col[b] > hi) return fail(SLAM_ERR_ARG, "%s: %s of instance %zu is %d, outside [%d, %d]", path, what, b, col[b], lo, hi);
+            return SLAM_OK;
+        };
+        int rc = column(2, "the landmark count", 0, h->L_max);
+        if (!rc) rc = column(5, "the timestep", 0, INT32_MAX);
+        if (!rc && h->kind != SLAM_EKF_SLAM) rc = column(9, "the size of the stored square root", 0, h->n_max);
+        if (!rc && h->kind != SLAM_EKF_SLAM) rc = column(12, "the age of the warm-start eigenvectors", 0, INT32_MAX);
+        if (rc) { fclose(f); return rc; }
+        if (fseek(f, (long)sizeof(hd), SEEK_SET) != 0) { fclose(f); return fail(SLAM_ERR_IO, "cannot rewind %s", path); }
     }
     std::vector<char> buf((size_t)64 << 20);
     for (const CkptItem& it : ckpt_items(h))
