@@ -23,7 +23,7 @@ EKF_DEFAULT_VARIANTS = [(43, 2, 5, 4, 0, 1), (43, 2, 4, 4, 0, 1), (103, 4, 6, 4,
                         (203, 4, 5, 4, 0, 1), (203, 4, 4, 4, 0, 1), (403, 4, 4, 4, 0, 1),
                         (43, 2, 4, 4, 1, 1), (103, 4, 4, 2, 1, 1),
                         (43, 1, 2, 4, 0, 1)]   # one wavefront per filter: no decoupled loop, every step through the synchronised path
-EKF_SWEEP_VARIANTS = [(103, 3, 4, 4, 0, 1, 2), (103, 3, 5, 4, 0, 1, 2), (103, 2, 3, 4, 0, 1, 2), (103, 2, 4, 4, 0, 1, 2), (103, 3, 6, 4, 0, 1, 2),
+EKF_SWEEP_VARIANTS = [(103, 3, 6, 4, 0, 1), (103, 3, 5, 4, 0, 1), (103, 3, 4, 4, 0, 1, 2), (103, 3, 5, 4, 0, 1, 2), (103, 2, 3, 4, 0, 1, 2), (103, 2, 4, 4, 0, 1, 2), (103, 3, 6, 4, 0, 1, 2),
                       (103, 4, 4, 4, 0, 1, 2), (103, 4, 5, 4, 0, 1, 2), (103, 3, 4, 4, 0, 1, 3), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1),
                       (203, 4, 6, 4, 0, 1), (103, 4, 5, 2, 0, 1), (103, 2, 4, 4, 0, 1), (103, 3, 4, 4, 0, 1), (103, 4, 3, 4, 0, 1),
                       (43, 2, 4, 2, 0, 1), (43, 4, 4, 4, 0, 1), (43, 2, 4, 8, 0, 1), (43, 2, 2, 4, 0, 1)]

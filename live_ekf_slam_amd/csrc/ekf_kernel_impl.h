@@ -119,6 +119,12 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
 #ifndef SLAM_SD
 #define SLAM_SD 3         // timesteps the measurement generator may run ahead of the filter (ring of messages in LDS)
 #endif
+#ifndef SLAM_CTRL_ILP
+#define SLAM_CTRL_ILP 1   // control wavefront of the decoupled loop: thin downdate with batched LDS requests (thin_downdate_ctl)
+#endif
+#ifndef SLAM_CTRL_SG
+#define SLAM_CTRL_SG 3    // ... thin slots per batch (operands of SG slots and 2 SG NU elements in flight per lane)
+#endif
 #ifndef SLAM_PRIO_THIN
 #define SLAM_PRIO_THIN 2
 #endif
@@ -595,6 +601,56 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                     const int i = sl * LDP + j;
                     s_R[i] = s_R[i] - (kt.x * hj.x + kt.y * hj.y);   // P[T_s][j]
                     s_C[i] = s_C[i] - (kj.x * ht.x + kj.y * ht.y);   // P[j][T_s]
+                }
+            }
+        }
+    };
+
+    // ---- the same downdate for the CONTROL wavefront of the decoupled loop (round 4), written for memory-level parallelism: the loop
+    //      above makes two DEPENDENT LDS round trips per slot and state index (slot table -> operands -> element), 18 of them per
+    //      update at n = 103, and that latency was 15 % of the control wavefront's timeline.  Here the slot table is read once (one
+    //      batch), a lane's own K[j] / (H P)[j] arrive in registers from the phase that computed them, and the slots are walked in
+    //      groups of SG: the group's operands K[T_s], (H P)[T_s] and its elements of R and C are requested together, then updated and
+    //      stored.  Same expression per element, so not a bit changes; it wants registers (W = 3 variants: 168 VGPRs). ----
+    constexpr int NU = (LDP + 63) / 64;   // state indices per lane of ONE wavefront
+    auto thin_downdate_ctl = [&](int nTd, int nd, const double2* __restrict__ Ku, const double2* __restrict__ HPu, const double2 (&kj)[NU],
+                                 const double2 (&hj)[NU]) {
+        constexpr int SG = SLAM_CTRL_SG;
+        int tsv[TS];
+#pragma unroll
+        for (int sl = 0; sl < TS; ++sl) tsv[sl] = s_T[sl];
+#pragma unroll
+        for (int s0 = 0; s0 < TS; s0 += SG) {
+            if (s0 >= nTd) break;   // wave-uniform
+            double2 kt[SG], ht[SG];
+            double rv[SG][NU], cv[SG][NU];
+            bool ok[SG];
+#pragma unroll
+            for (int g = 0; g < SG; ++g) {
+                const int sl = s0 + g < TS ? s0 + g : TS - 1;
+                const int t_s = tsv[sl];
+                ok[g] = s0 + g < nTd && (unsigned)t_s < (unsigned)nd;   // wave-uniform
+                const int tc = ok[g] ? t_s : 0;
+                kt[g] = Ku[tc]; ht[g] = HPu[hpi(tc)];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int j = lane + 64 * u;
+                    const int i = sl * LDP + (j < LDP ? j : 0);
+                    rv[g][u] = s_R[i]; cv[g][u] = s_C[i];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < SG; ++g) {
+                if (!ok[g]) continue;
+                const int sl = s0 + g;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int j = lane + 64 * u;
+                    if (j < nd) {
+                        const int i = sl * LDP + j;
+                        s_R[i] = rv[g][u] - (kt[g].x * hj[u].x + kt[g].y * hj[u].y);   // P[T_s][j]
+                        s_C[i] = cv[g][u] - (kj[u].x * ht[g].x + kj[u].y * ht[g].y);   // P[j][T_s]
+                    }
                 }
             }
         }
@@ -1159,6 +1215,9 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         const int slot = pub % KG;
                         double2* __restrict__ HPu = s_HP + slot * HPW;
                         double2* __restrict__ Ku = s_K + slot * LDP;
+                        double2 kreg[NU], hreg[NU];   // this lane's K[j], (H P)[j], j = lane + 64 u: the thin downdate takes them from here
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) { kreg[u] = make_double2(0.0, 0.0); hreg[u] = make_double2(0.0, 0.0); }
                         if (!SLAM_DBG(p.dbg & 512)) {   // (ablation 512: timing without H P / K / x)
                             const double h00 = H[0], h01 = H[1], h03 = H[2], h04 = H[3], h10 = H[4], h11 = H[5], h12 = -1.0, h13 = H[6], h14 = H[7];
                             const double* Ri = s_R + si * LDP;
@@ -1183,6 +1242,7 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                                     s_xp[c] = xv;
                                 }
                                 if (c < LDP) { HPu[hpi(c)] = hp; Ku[c] = kk; }
+                                kreg[u] = kk; hreg[u] = hp;
                             }
                         }
                         if (!kWide && lane == 0) s_wend[slot] = (l == lastu) ? 1 : 0;
@@ -1191,7 +1251,13 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(cons
                         if (lane == 0) st_i(&s_ring[0], pub);
                         SLAM_STAMP(22);  // H P, K, x_pred
                         // thin copies follow the same downdate  P -= K (H P)
-                        if (!SLAM_DBG(p.dbg & 256)) thin_downdate(lane, 64, 0, 1, nTq, n, Ku, HPu);   // (ablation 256: timing without the thin downdates)
+                        if (!SLAM_DBG(p.dbg & 256)) {   // (ablation 256: timing without the thin downdates)
+#if SLAM_CTRL_ILP
+                            thin_downdate_ctl(nTq, n, Ku, HPu, kreg, hreg);
+#else
+                            thin_downdate(lane, 64, 0, 1, nTq, n, Ku, HPu);
+#endif
+                        }
                     }
                     l0q = l1q;
                     } while (l0q < kq && !ld_i(&s_ring[2]));

@@ -28,6 +28,10 @@
 
 typedef double dbl4_t __attribute__((ext_vector_type(4)));   // C/D of v_mfma_f64_16x16x4_f64
 
+#ifndef SLAM_UKF_SQRT_WG
+#define SLAM_UKF_SQRT_WG 6   // workgroups of ukf_sqrt_kernel<44, 256> the compiler must leave room for on a CU (25 KB of LDS each allow six; 80 VGPRs)
+#endif
+
 namespace slam {
 
 namespace {
@@ -130,7 +134,8 @@ __global__ void ukf_rot_table_kernel(uint4* tab) {
             e.x = (unsigned)(8 * (pq * (pq + 1) / 2 + pq)) | ((unsigned)(8 * (qq * (qq + 1) / 2 + qq)) << 16);
             e.y = (unsigned)(8 * (qq * (qq + 1) / 2 + pq));
         }
-        const int tp = kUkfRotThreads / m, iv = tid / tp;   // V^T rows of pair iv
+        // V^T rows of pair iv: wavefronts 1 .. 3 apply the V rotations (wavefront 0 computes the next round's parameters meanwhile)
+        const int tp = (kUkfRotThreads - 64) / m, iv = tid >= 64 ? (tid - 64) / tp : m;
         if (iv < m) {
             int vp, vq;
             rr_pair(iv, t, n, vp, vq);
@@ -155,13 +160,14 @@ hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream) {
 // PROF = true compiles the phase timers in (a separate instantiation, launched only when the debug buffer is attached:
 // as a run-time option they cost the production kernel 20 VGPRs = one wavefront per SIMD of occupancy, -9 % steps/s).
 template <int NMAX, int TPB, bool PROF = false>
-__global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
+__global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF_SQRT_WG : 1) void ukf_sqrt_kernel(const UkfStepParams p) {
     constexpr int MMAX = NMAX / 2;
     __shared__ double sA[NMAX * (NMAX + 1) / 2];   // packed lower triangle: A(r,c), r >= c, at r(r+1)/2 + c
-    __shared__ double sVt[NMAX * NMAX];            // V transposed: Vt[p*n + k] = V(k, p)
+    __shared__ __attribute__((aligned(16))) double sVt[NMAX * NMAX];   // V transposed: Vt[p*n + k] = V(k, p)
     __shared__ double s_cs[MMAX], s_sn[MMAX], s_tn[MMAX], s_sd[NMAX];
     __shared__ int s_pp[MMAX], s_qq[MMAX];
-    __shared__ double2 s_csn[MMAX];               // (c, s) of this round's rotations, one 16-byte read per consumer
+    __shared__ double2 s_csn[2 * MMAX];           // (c, s) of this round's rotations, one 16-byte read per consumer (table path: [round parity][pair])
+    __shared__ double s_tn2[2 * MMAX];            // table path: tan of the rotations, [round parity][pair]
     __shared__ double s_red[TPB / 64];
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
@@ -311,15 +317,51 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
     constexpr int ITB = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB;   // pair-block / diagonal items per thread (they are the first items)
     constexpr bool kFast = ITB <= 2;                               // n <= 103 with 1024 threads: two per thread
     constexpr int ITV = kFast ? (NMAX + (TPB / MMAX) - 1) / (TPB / MMAX) : 1;
-    const int tp = TPB / m;                 // threads per pair (V rows)
-    const int iv = tid / tp, subk = tid - iv * tp;
+    // Round 4: a thread takes its V entries as 16-byte PAIRS of consecutive k (n is even, rows of V^T start on 16-byte boundaries), pair
+    // index subk + tp * u: half the LDS instructions and address arithmetic of the V update, and the lanes of a pair read consecutive 16-byte
+    // words (the 8-byte elements at stride tp = 11 were behind the 39 % bank-conflict share of this kernel's LDS cycles).
+    constexpr int ITP = (ITV + 1) / 2;
+    // table path (round 4): the V rotations of round t run in the shadow of the parameter phase of round t + 1 - wavefront 0 computes
+    // the parameters, wavefronts 1 .. 3 rotate V (V is read by nobody until the decomposition ends, and A does not depend on it)
+    constexpr bool kTab = ITB <= 2 && NMAX == 44 && TPB == kUkfRotThreads;
+    constexpr int VT0 = kTab ? 64 : 0;      // first thread that rotates V
+    const int tp = (TPB - VT0) / m;         // threads per pair (V rows)
+    const int iv = tid >= VT0 ? (tid - VT0) / tp : m, subk = tid - VT0 - iv * tp;
     const bool vvalid = iv < m;
+    constexpr int ITPT = kTab ? (MMAX + ((TPB - VT0) / MMAX) - 1) / ((TPB - VT0) / MMAX) : 1;   // 16-byte pairs of V per thread there
     // schedule table (see ukf_rot_table_kernel): this thread's column of the table for state size n, or NULL
-    constexpr bool kTab = kFast && NMAX == 44 && TPB == kUkfRotThreads;
     const uint4* const tabn = kTab ? p.rot_tab + (size_t)(n / 2) * kUkfRotRounds * kUkfRotThreads + tid : nullptr;   // the launcher checks rot_tab
     bool converged = false;
     uint4 te_next = make_uint4(0u, 0u, 0u, 0u);
     if constexpr (kTab) te_next = tabn[0];
+    // table path: V rotations of the previous round, pending (row offsets, parity of their parameters)
+    unsigned vz_prev = 0u;
+    bool vpend = false;
+    int par = 0;
+    auto v_rotate = [&](unsigned vz, const double2* csn) {   // V <- V J of one round, this thread's pair iv
+        if (!vvalid) return;
+        const double2 vcs = csn[iv];
+        if (vcs.y == 0.0) return;           // identity rotation: the V row pairs are unchanged
+        char* const sVb = reinterpret_cast<char*>(sVt);
+        const unsigned vpo = vz & 0xffffu, vqo = vz >> 16;
+        double2 xp[ITPT], xq[ITPT];
+#pragma unroll
+        for (int u = 0; u < ITPT; ++u) {
+            const int k = 2 * (subk + tp * u);
+            const int kk = k < n ? k : 0;
+            xp[u] = *reinterpret_cast<const double2*>(sVb + vpo + 8 * kk);
+            xq[u] = *reinterpret_cast<const double2*>(sVb + vqo + 8 * kk);
+        }
+        const double c = vcs.x, sn = vcs.y;
+#pragma unroll
+        for (int u = 0; u < ITPT; ++u) {
+            const int k = 2 * (subk + tp * u);
+            if (k < n) {
+                *reinterpret_cast<double2*>(sVb + vpo + 8 * k) = make_double2(fma(c, xp[u].x, -(sn * xq[u].x)), fma(c, xp[u].y, -(sn * xq[u].y)));
+                *reinterpret_cast<double2*>(sVb + vqo + 8 * k) = make_double2(fma(sn, xp[u].x, c * xq[u].x), fma(sn, xp[u].y, c * xq[u].y));
+            }
+        }
+    };
 #pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: every off-diagonal element is exactly zero OR would only be zeroed by the small-element rule
@@ -384,30 +426,29 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                         s = tt * c;
                     }
                 }
-                s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
-                s_csn[k] = make_double2(c, s);
+                if constexpr (kTab) {
+                    s_tn2[par * MMAX + k] = tt;
+                    s_csn[par * MMAX + k] = make_double2(c, s);
+                } else {
+                    s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
+                    s_csn[k] = make_double2(c, s);
+                }
+            }
+            if constexpr (kTab) {
+                // ... and in its shadow the V rotations of the PREVIOUS round (wavefronts 1 .. 3; parameters of the other parity)
+                if (vpend && tid >= VT0) v_rotate(vz_prev, s_csn + (par ^ 1) * MMAX);
             }
             __syncthreads();
-            SQ_STAMP(2);   // rotation parameters (22 lanes of wavefront 0) + barrier
+            SQ_STAMP(2);   // rotation parameters (22 lanes of wavefront 0) [+ V rotations of the round before] + barrier
             if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
             if constexpr (kTab) {
-                // ---- the same round with every operand address taken from the schedule table ----
+                // ---- A <- J^T A J with every operand address taken from the schedule table ----
                 char* const sAb = reinterpret_cast<char*>(sA);
-                char* const sVb = reinterpret_cast<char*>(sVt);
-                const unsigned vpo = te.z & 0xffffu, vqo = te.z >> 16;
-                const double2 vcs = s_csn[vvalid ? iv : 0];
-                double xp[ITV], xq[ITV];
-#pragma unroll
-                for (int u = 0; u < ITV; ++u) {
-                    const int k = subk + tp * u;
-                    const int kk = k < n ? k : 0;
-                    xp[u] = *reinterpret_cast<const double*>(sVb + vpo + 8 * kk);
-                    xq[u] = *reinterpret_cast<const double*>(sVb + vqo + 8 * kk);
-                }
+                const double2* const csn = s_csn + par * MMAX;
                 const int d = desc[0];
                 const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
                 if (kind == 0) {
-                    const double2 csi = s_csn[i], csj = s_csn[j];
+                    const double2 csi = csn[i], csj = csn[j];
                     double* const e00 = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
                     double* const e01 = reinterpret_cast<double*>(sAb + (te.x >> 16));
                     double* const e10 = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
@@ -424,34 +465,24 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                     double* const epp = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
                     double* const eqq = reinterpret_cast<double*>(sAb + (te.x >> 16));
                     double* const epq = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
-                    const double tn = s_tn[i];
+                    const double tn = s_tn2[par * MMAX + i];
                     const double app = *epp, aqq = *eqq, apq = *epq;
                     *epp = fma(-tn, apq, app);
                     *eqq = fma(tn, apq, aqq);
                     if (apq != 0.0) *epq = 0.0;
                 }
-                if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
-                    const double c = vcs.x, sn = vcs.y;
-#pragma unroll
-                    for (int u = 0; u < ITV; ++u) {
-                        const int k = subk + tp * u;
-                        if (k < n) {
-                            *reinterpret_cast<double*>(sVb + vpo + 8 * k) = fma(c, xp[u], -(sn * xq[u]));
-                            *reinterpret_cast<double*>(sVb + vqo + 8 * k) = fma(sn, xp[u], c * xq[u]);
-                        }
-                    }
-                }
+                vz_prev = te.z; vpend = true; par ^= 1;   // this round's V rotations run beside the next parameter phase
             } else if constexpr (kFast) {
                 // ---- V row-pairs of pair iv: operands first ----
                 int vpi, vqi;
                 rr_pair(vvalid ? iv : 0, t, n, vpi, vqi);
                 const double2 vcs = s_csn[vvalid ? iv : 0];
-                double xp[ITV], xq[ITV];
+                double2 xp[ITP], xq[ITP];
 #pragma unroll
-                for (int u = 0; u < ITV; ++u) {
-                    const int k = subk + tp * u;
+                for (int u = 0; u < ITP; ++u) {
+                    const int k = 2 * (subk + tp * u);
                     const int kk = k < n ? k : 0;
-                    xp[u] = sVt[vpi * n + kk]; xq[u] = sVt[vqi * n + kk];
+                    xp[u] = *reinterpret_cast<const double2*>(&sVt[vpi * n + kk]); xq[u] = *reinterpret_cast<const double2*>(&sVt[vqi * n + kk]);
                 }
                 // ---- the thread's pair-blocks / diagonal blocks (items are independent: any order, any owner, same bits) ----
 #pragma unroll
@@ -488,11 +519,11 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
                 if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
                     const double c = vcs.x, sn = vcs.y;
 #pragma unroll
-                    for (int u = 0; u < ITV; ++u) {
-                        const int k = subk + tp * u;
+                    for (int u = 0; u < ITP; ++u) {
+                        const int k = 2 * (subk + tp * u);
                         if (k < n) {
-                            sVt[vpi * n + k] = fma(c, xp[u], -(sn * xq[u]));
-                            sVt[vqi * n + k] = fma(sn, xp[u], c * xq[u]);
+                            *reinterpret_cast<double2*>(&sVt[vpi * n + k]) = make_double2(fma(c, xp[u].x, -(sn * xq[u].x)), fma(c, xp[u].y, -(sn * xq[u].y)));
+                            *reinterpret_cast<double2*>(&sVt[vqi * n + k]) = make_double2(fma(sn, xp[u].x, c * xq[u].x), fma(sn, xp[u].y, c * xq[u].y));
                         }
                     }
                 }
@@ -533,6 +564,12 @@ __global__ __launch_bounds__(TPB) void ukf_sqrt_kernel(const UkfStepParams p) {
             }
             __syncthreads();
             SQ_STAMP(3);   // rotation phase + barrier
+        }
+    }
+    if constexpr (kTab) {
+        if (vpend) {   // the V rotations of the last round (nobody has read V since)
+            if (tid >= VT0) v_rotate(vz_prev, s_csn + (par ^ 1) * MMAX);
+            __syncthreads();
         }
     }
     if (!converged) {

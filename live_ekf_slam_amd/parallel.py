@@ -96,6 +96,15 @@ class ShardedRun:
             wall = float(tw.item())
         return wall
 
+    def max_over_ranks(self, v):
+        """MAX over the ranks of a per-rank scalar (e.g. a HIP-event duration): one small all-reduce, outside any timed region."""
+        if not self.dist:
+            return float(v)
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
     def error_statistics(self, engine):
         """(global per-instance errors, mean, std, count): the end-of-run gather + reduce (RCCL on the GPU box)."""
         err = engine.error_stats()

@@ -98,6 +98,21 @@ def test_bad_arguments_return_error_codes():
     assert L.slam_destroy(None) == 0
 
 
+def test_multi_handle_rejects_a_device_listed_twice():
+    """include/slam_multi.h: 'a device may appear once' - two shards on one device would share nothing but fight for it; the call must
+    fail loudly BEFORE any handle is created (no GPU needed to see it)."""
+    L = _lib.lib()
+    c = default_config()
+    m = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    L.slam_multi_create.restype = C.c_int
+    assert L.slam_multi_create(C.byref(c), 1, C.c_int64(64), 20, 0, devs, 2, C.byref(m)) == -1
+    assert b"listed twice" in L.slam_last_error()
+    assert not m.value
+    one = (C.c_int * 1)(0)
+    assert L.slam_multi_create(C.byref(c), 1, C.c_int64(0), 20, 0, one, 1, C.byref(m)) == -1   # fewer instances than devices
+
+
 def test_no_gpu_fails_loudly_not_silently():
     """Without a HIP device the product must raise, never fall back to a CPU path."""
     import torch

@@ -53,6 +53,21 @@ def test_parallel_new_id_rule_equals_the_reference_loop():
         assert parallel(known, msg, L_max) == sequential(known, msg, L_max), (known, msg, L_max)
 
 
+def test_negative_ids_are_ordinary_ids():
+    """ekf.cpp:99-108 compares ints: -1 and -2 are ids like any other (the register path of the pre-step once padded the unused lanes of
+    lm_IDs with -2 and matched without a lane guard: a detection with id -2 'found' landmark M)."""
+    rng = np.random.default_rng(11)
+    for _ in range(5000):
+        L_max = int(rng.integers(1, 9))
+        M = int(rng.integers(0, L_max + 1))
+        known = [int(v) for v in rng.choice(np.arange(-4, 12), size=M, replace=False)]
+        k = int(rng.integers(0, 10))
+        msg = [int(v) for v in rng.integers(-4, 12, k)]
+        assert parallel(known, msg, L_max) == sequential(known, msg, L_max), (known, msg, L_max)
+    assert sequential([5], [-2], 4) == ([1], 1, False, False) == parallel([5], [-2], 4)
+    assert sequential([5, -2], [-2, -1], 4) == ([1, 2], 1, False, False) == parallel([5, -2], [-2, -1], 4)
+
+
 def test_the_cases_the_soak_found():
     # a repeat of an id that found no room is skipped again: capacity, no freeze (the old rule froze)
     assert sequential([1, 2], [7, 7], 2) == ([-1, -1], 0, False, True) == parallel([1, 2], [7, 7], 2)

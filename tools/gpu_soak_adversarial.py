@@ -26,12 +26,14 @@ while time.time() < t_end:
     kcap = int(rng.choice([2, 6, 20, 70]))
     kcap = min(kcap, 20 if L <= 20 else (50 if L <= 50 else 100))   # a message holds at most the size class's landmark count (include/slam_batch.h: the surplus is dropped, SLAM_INST_CAPACITY)
     idmax = int(rng.choice([max(2, L // 2), L, 2 * L, 400]))
+    idmin = int(rng.choice([0, 0, -3, -40]))   # any int is an id for the reference (ekf.cpp:99-108), negative ones included (-1 / -2 were sentinels once)
     seed = int(rng.integers(1, 1 << 30))
-    if os.environ.get("SOAK_REPLAY"):   # "ekf|ukf L T B f32 idknown kcap idmax seed"
+    if os.environ.get("SOAK_REPLAY"):   # "ekf|ukf L T B f32 idknown kcap idmax seed [idmin]"
         a = os.environ["SOAK_REPLAY"].split()
         ukf = a[0] == "ukf"; a = a[1:]
         L, T, B = int(a[0]), int(a[1]), int(a[2]); f32 = a[3] == "True"; idknown, kcap, idmax, seed = int(a[4]), int(a[5]), int(a[6]), int(a[7]); t_end = 0
-    desc = f"{'ukf' if ukf else 'ekf'} L={L} T={T} B={B} f32={f32} idknown={idknown} kcap={kcap} idmax={idmax} seed={seed}"
+        idmin = int(a[8]) if len(a) > 8 else 0
+    desc = f"{'ukf' if ukf else 'ekf'} L={L} T={T} B={B} f32={f32} idknown={idknown} kcap={kcap} idmax={idmax} seed={seed} idmin={idmin}"
     if os.environ.get("SOAK_VERBOSE"): print("RUN", desc, flush=True)
     mr = np.random.default_rng(seed)
     cfg = S.default_config(); cfg.landmark_id_is_known = idknown
@@ -50,7 +52,7 @@ while time.time() < t_end:
         meas = np.zeros((B, K, 3), dtype=np.float32)
         for b in range(B):
             k = int(ks[b])
-            ids = mr.integers(0, idmax, k)
+            ids = mr.integers(idmin, idmax, k)
             if k > 1 and mr.random() < 0.3: ids[mr.integers(0, k)] = ids[mr.integers(0, k)]      # a repeated id
             meas[b, :k, 0] = ids
             meas[b, :k, 1] = mr.choice([mr.uniform(0.05, 5.0, k), mr.uniform(1e-4, 1e-2, k), mr.uniform(50, 500, k)][:1 + int(mr.random() < 0.2) * 2])
