@@ -28,6 +28,9 @@
 
 typedef double dbl4_t __attribute__((ext_vector_type(4)));   // C/D of v_mfma_f64_16x16x4_f64
 
+#ifndef SLAM_UKF_PRIO
+#define SLAM_UKF_PRIO 2
+#endif
 #ifndef SLAM_UKF_SQRT_WG
 #define SLAM_UKF_SQRT_WG 6   // workgroups of ukf_sqrt_kernel<44, 256> the compiler must leave room for on a CU (25 KB of LDS each allow six; 80 VGPRs)
 #endif
@@ -112,39 +115,66 @@ __device__ __forceinline__ void rr_pair(int k, int t, int n, int& p, int& q) {
 // indices (p, q) of pair k for the parameter phase.  One 16-byte load per thread and round, issued before the parameter
 // phase.  Same addresses, same arithmetic: not a bit changes.
 // ------------------------------------------------------------------------------------------------------------------
+// Round 4: the item -> thread mapping of the table path puts everything the NEXT round's rotation parameters depend on into
+// wavefront 0.  Going from round t to t + 1 every index but 0 moves one slot along the circle, so pair k of round t + 1 is (top of
+// pair k + 1, bottom of pair k - 1) of round t: its pivot element lies in pair-block (k + 1, k - 1) - (1, 0) for k = 0, (m - 1, m - 2)
+// for k = m - 1 - and its diagonal elements in the diagonal blocks.  Threads 0 .. m-1 own the diagonal blocks, threads m .. 2m-1 those
+// m "critical" pair-blocks, the other threads the remaining pair-blocks in lexicographic order.  Wavefront 0 (2 m <= 44 threads of it)
+// can therefore rotate its items and go straight on to the parameters of round t + 1 - the LDS executes one wavefront's accesses in
+// order - while wavefronts 1 .. 3 finish the other pair-blocks and rotate V: ONE barrier per round instead of two, and the parameter
+// chain (sqrt, div, sqrt: the longest dependent chain of a round) runs beside the bulk of the round's work instead of before it.
+__host__ __device__ inline bool ukf_block_is_critical(int i, int j, int m) {
+    return (i == 1 && j == 0) || (j == i - 2) || (i == m - 1 && j == m - 2);
+}
+__host__ __device__ inline int ukf_item_of_thread(int tid, int m) {   // (kind << 16) | (i << 8) | j; kind 0 pair-block, 1 diagonal block, 3 none
+    if (tid < m) return (1 << 16) | (tid << 8);
+    if (tid < 2 * m) {
+        const int c = tid - m;
+        if (c == 0) return (1 << 8) | 0;
+        if (c <= m - 2) return ((c + 1) << 8) | (c - 1);
+        return m >= 3 ? ((m - 1) << 8) | (m - 2) : (3 << 16);   // m == 2: (1, 0) is the only pair-block
+    }
+    int r = tid - 2 * m;   // rank among the other pair-blocks
+    for (int i = 1; i < m; ++i)
+        for (int j = 0; j < i; ++j) {
+            if (ukf_block_is_critical(i, j, m)) continue;
+            if (r == 0) return (i << 8) | j;
+            --r;
+        }
+    return 3 << 16;
+}
 __global__ void ukf_rot_table_kernel(uint4* tab) {
     const int n = 2 * blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     uint4 e = make_uint4(0u, 0u, 0u, 0u);
     if (n >= 4 && t < n - 1) {
-        const int m = n / 2, nb = m * (m - 1) / 2;
+        const int m = n / 2;
         auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
-        if (tid < nb) {            // pair-block (i, j), i > j: same decoding as the kernel's desc[]
-            int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)tid)) * 0.5f);
-            while (i * (i - 1) / 2 > tid) --i;
-            while ((i + 1) * i / 2 <= tid) ++i;
-            const int j = tid - i * (i - 1) / 2;
+        const int d = ukf_item_of_thread(tid, m), kind = d >> 16, i = (d >> 8) & 0xff, j = d & 0xff;
+        if (kind == 0) {           // pair-block (i, j), i > j
             int pi, qi, pj, qj;
             rr_pair(i, t, n, pi, qi);
             rr_pair(j, t, n, pj, qj);
             e.x = (unsigned)(8 * idx(pi, pj)) | ((unsigned)(8 * idx(pi, qj)) << 16);
             e.y = (unsigned)(8 * idx(qi, pj)) | ((unsigned)(8 * idx(qi, qj)) << 16);
-        } else if (tid < nb + m) { // diagonal block of pair i
+        } else if (kind == 1) {    // diagonal block of pair i
             int pq, qq;
-            rr_pair(tid - nb, t, n, pq, qq);
+            rr_pair(i, t, n, pq, qq);
             e.x = (unsigned)(8 * (pq * (pq + 1) / 2 + pq)) | ((unsigned)(8 * (qq * (qq + 1) / 2 + qq)) << 16);
             e.y = (unsigned)(8 * (qq * (qq + 1) / 2 + pq));
         }
-        // V^T rows of pair iv: wavefronts 1 .. 3 apply the V rotations (wavefront 0 computes the next round's parameters meanwhile)
+        // V^T rows of pair iv: wavefronts 1 .. 3 apply the V rotations
         const int tp = (kUkfRotThreads - 64) / m, iv = tid >= 64 ? (tid - 64) / tp : m;
         if (iv < m) {
             int vp, vq;
             rr_pair(iv, t, n, vp, vq);
             e.z = (unsigned)(8 * vp * n) | ((unsigned)(8 * vq * n) << 16);
         }
-        if (tid < m) {             // parameter phase: pair k = tid
+        if (tid < m) {             // parameter phase: indices (p, q) of pair k = tid in THIS round
             int pp, qq;
             rr_pair(tid, t, n, pp, qq);
             e.w = (unsigned)pp | ((unsigned)qq << 16);
+        } else {
+            e.w = (unsigned)d;     // the thread's item (the same in every round)
         }
     }
     tab[((size_t)blockIdx.y * kUkfRotRounds + t) * kUkfRotThreads + tid] = e;
@@ -168,7 +198,6 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     __shared__ int s_pp[MMAX], s_qq[MMAX];
     __shared__ double2 s_csn[2 * MMAX];           // (c, s) of this round's rotations, one 16-byte read per consumer (table path: [round parity][pair])
     __shared__ double s_tn2[2 * MMAX];            // table path: tan of the rotations, [round parity][pair]
-    __shared__ double s_red[TPB / 64];
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     const int M = p.M[b];
@@ -334,10 +363,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     bool converged = false;
     uint4 te_next = make_uint4(0u, 0u, 0u, 0u);
     if constexpr (kTab) te_next = tabn[0];
-    // table path: V rotations of the previous round, pending (row offsets, parity of their parameters)
-    unsigned vz_prev = 0u;
-    bool vpend = false;
-    int par = 0;
+    int par = 0;                            // table path: parity of the parameter buffers the current round reads
     auto v_rotate = [&](unsigned vz, const double2* csn) {   // V <- V J of one round, this thread's pair iv
         if (!vvalid) return;
         const double2 vcs = csn[iv];
@@ -362,6 +388,53 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             }
         }
     };
+    // rotation parameters (c, s, t = tan) of the pair (pidx, qidx) from the current A; sw: the sweep the rotation belongs to
+    auto jacobi_param = [&](double app, double aqq, double apq, int sw, double& c, double& s, double& tt) {
+        c = 1.0; s = 0.0; tt = 0.0;
+        // small-element rule (classical Jacobi): after three sweeps an off-diagonal element that cannot change
+        // either diagonal neighbour in fp64 is set to zero instead of being rotated away
+        const double g = 100.0 * fabs(apq);
+        const bool tiny = sw >= tiny_from && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq));
+        if (apq != 0.0 && !tiny) {
+            // t = tan(theta) of the rotation that annihilates a_pq: the smaller root of t^2 + 2 tau t - 1 = 0 with
+            // tau = (a_qq - a_pp) / (2 a_pq), written without tau so that the dependent chain is sqrt, div, sqrt instead
+            // of div, sqrt, div, sqrt, div: with d = a_qq - a_pp, h = hypot(d, 2 a_pq), w = |d| + h:
+            // t = 2 a_pq / (+-w) (sign of d), c = 1 / sqrt(1 + t^2) = sqrt(w / (2 h)), s = t c.
+            const double d = aqq - app, b2 = 2.0 * apq;
+            const double h = sqrt(fma(d, d, b2 * b2));
+            if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
+                const double w = fabs(d) + h;
+                // sign of t = sign of tau = d / (2 a_pq), +1 at d = 0 exactly (equal diagonal entries are common: every
+                // landmark enters P with the same W block; letting the sign follow a_pq there made clusters of equal
+                // eigenvalues cycle at the rounding level instead of settling)
+                const bool pos = (d == 0.0) || ((d > 0.0) == (b2 > 0.0));
+                tt = (pos ? fabs(b2) : -fabs(b2)) / w;
+                c = sqrt(w / (2.0 * h));
+                s = tt * c;
+            }
+        }
+    };
+    constexpr int NSC = kTab ? (NMAX * (NMAX - 1) / 2 + TPB - 1) / TPB : 1;   // strictly-lower elements per thread in the convergence scan
+    const int nlow = n * (n - 1) / 2;
+    unsigned scan_a[NSC], scan_b[NSC];      // byte offsets: element | A(c, c) << 16, A(r, r)
+    if constexpr (kTab) {
+#pragma unroll
+        for (int u = 0; u < NSC; ++u) {
+            const int e = tid + TPB * u < nlow ? tid + TPB * u : 0;
+            int r = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);   // row r >= 1 holds the elements r (r - 1) / 2 .. r (r + 1) / 2 - 1
+            while (r * (r - 1) / 2 > e) --r;
+            while ((r + 1) * r / 2 <= e) ++r;
+            const int c = e - r * (r - 1) / 2;
+            scan_a[u] = (unsigned)(8 * (r * (r + 1) / 2 + c)) | ((unsigned)(8 * (c * (c + 1) / 2 + c)) << 16);
+            scan_b[u] = (unsigned)(8 * (r * (r + 1) / 2 + r));
+        }
+    }
+    if constexpr (kTab) {
+        // wavefront 0 carries the longest dependent chain of a round (its items, then the next parameters): let it issue ahead
+        if (tid < 64) __builtin_amdgcn_s_setprio(SLAM_UKF_PRIO);
+    }
+    int desc_tab = 3 << 16;                 // table path: this thread's item (diagonal block of pair tid, or the table's word)
+    if constexpr (kTab) desc_tab = tid < m ? ((1 << 16) | (tid << 8)) : (int)te_next.w;
 #pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: every off-diagonal element is exactly zero OR would only be zeroed by the small-element rule
@@ -369,6 +442,26 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         // untouched and merely writes the zeros, so it can be skipped without changing sqtP by a single bit (the oracle
         // runs that last sweep and arrives at the same V and diagonal).
         int live = 0;
+        if constexpr (kTab) {
+            // the thread's (at most four) strictly-lower elements, addresses decoded once per launch: every read of the scan is issued at
+            // once (the two-threads-per-row walk below left two thirds of the workgroup idle and each lane 22 dependent round trips)
+            const char* const sAc = reinterpret_cast<const char*>(sA);
+            double v[NSC], dp[NSC], dq[NSC];
+#pragma unroll
+            for (int u = 0; u < NSC; ++u) {
+                v[u] = *reinterpret_cast<const double*>(sAc + (scan_a[u] & 0xffffu));
+                dp[u] = *reinterpret_cast<const double*>(sAc + (scan_a[u] >> 16));
+                dq[u] = *reinterpret_cast<const double*>(sAc + scan_b[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NSC; ++u) {
+                if (tid + TPB * u < nlow && v[u] != 0.0) {
+                    const double g = 100.0 * fabs(v[u]);
+                    const double app = fabs(dp[u]), aqq = fabs(dq[u]);
+                    if (!(sweep >= tiny_from && (app + g == app) && (aqq + g == aqq))) live = 1;
+                }
+            }
+        } else
         for (int r = tid / 2; r < n; r += TPB / 2)          // two threads per row, strictly-lower part
             for (int c = (tid & 1); c < r; c += 2) {
                 const double v = sA[r * (r + 1) / 2 + c];
@@ -391,63 +484,24 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             // here put an L2 round trip at the head of every round); the next round's is requested now
             const uint4 te = te_next;
             if constexpr (kTab) te_next = tabn[(size_t)(t + 1 < n - 1 ? t + 1 : 0) * kUkfRotThreads];
-            if (tid < m) {  // rotation parameters of this round's pairs (round-robin: position 0 fixed)
-                const int k = tid;
-                int pidx, qidx;
-                if constexpr (kTab) {
-                    pidx = (int)(te.w & 0xffffu); qidx = (int)(te.w >> 16);
-                } else {
-                    const int a = (k == 0) ? 0 : 1 + ((k - 1 + t) % (n - 1));
-                    const int k2 = n - 1 - k;
-                    const int bq = 1 + ((k2 - 1 + t) % (n - 1));
-                    pidx = a < bq ? a : bq; qidx = a < bq ? bq : a;
-                }
-                const double app = AT(pidx, pidx), aqq = AT(qidx, qidx), apq = AT(qidx, pidx);
-                double c = 1.0, s = 0.0, tt = 0.0;
-                // small-element rule (classical Jacobi): after three sweeps an off-diagonal element that cannot change
-                // either diagonal neighbour in fp64 is set to zero instead of being rotated away
-                const double g = 100.0 * fabs(apq);
-                const bool tiny = sweep >= tiny_from && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq));
-                if (apq != 0.0 && !tiny) {
-                    // t = tan(theta) of the rotation that annihilates a_pq: the smaller root of t^2 + 2 tau t - 1 = 0 with
-                    // tau = (a_qq - a_pp) / (2 a_pq), written without tau so that the dependent chain is sqrt, div, sqrt instead
-                    // of div, sqrt, div, sqrt, div: with d = a_qq - a_pp, h = hypot(d, 2 a_pq), w = |d| + h:
-                    // t = 2 a_pq / (+-w) (sign of d), c = 1 / sqrt(1 + t^2) = sqrt(w / (2 h)), s = t c.
-                    const double d = aqq - app, b2 = 2.0 * apq;
-                    const double h = sqrt(fma(d, d, b2 * b2));
-                    if (h > 0.0) {   // h == 0: d and a_pq below 1e-154, nothing to rotate (the element is zeroed)
-                        const double w = fabs(d) + h;
-                        // sign of t = sign of tau = d / (2 a_pq), +1 at d = 0 exactly (equal diagonal entries are common: every
-                        // landmark enters P with the same W block; letting the sign follow a_pq there made clusters of equal
-                        // eigenvalues cycle at the rounding level instead of settling)
-                        const bool pos = (d == 0.0) || ((d > 0.0) == (b2 > 0.0));
-                        tt = (pos ? fabs(b2) : -fabs(b2)) / w;
-                        c = sqrt(w / (2.0 * h));
-                        s = tt * c;
+            if constexpr (kTab) {
+                // ---- table path: ONE barrier per round (see ukf_item_of_thread) ----
+                if (sweep == 0 && t == 0) {   // parameters of the very first round (every later round's are computed a round ahead)
+                    if (tid < m) {
+                        double c, sn, tt;
+                        const char* const sAc = reinterpret_cast<const char*>(sA);   // (a diagonal thread's table words ARE the three addresses)
+                        jacobi_param(*reinterpret_cast<const double*>(sAc + (te.x & 0xffffu)), *reinterpret_cast<const double*>(sAc + (te.x >> 16)),
+                                     *reinterpret_cast<const double*>(sAc + (te.y & 0xffffu)), 0, c, sn, tt);
+                        s_tn2[par * MMAX + tid] = tt;
+                        s_csn[par * MMAX + tid] = make_double2(c, sn);
                     }
+                    __syncthreads();
                 }
-                if constexpr (kTab) {
-                    s_tn2[par * MMAX + k] = tt;
-                    s_csn[par * MMAX + k] = make_double2(c, s);
-                } else {
-                    s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
-                    s_csn[k] = make_double2(c, s);
-                }
-            }
-            if constexpr (kTab) {
-                // ... and in its shadow the V rotations of the PREVIOUS round (wavefronts 1 .. 3; parameters of the other parity)
-                if (vpend && tid >= VT0) v_rotate(vz_prev, s_csn + (par ^ 1) * MMAX);
-            }
-            __syncthreads();
-            SQ_STAMP(2);   // rotation parameters (22 lanes of wavefront 0) [+ V rotations of the round before] + barrier
-            if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
-            if constexpr (kTab) {
-                // ---- A <- J^T A J with every operand address taken from the schedule table ----
                 char* const sAb = reinterpret_cast<char*>(sA);
                 const double2* const csn = s_csn + par * MMAX;
-                const int d = desc[0];
-                const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
-                if (kind == 0) {
+                const int d = desc_tab;
+                const int kind = d >> 16, i = (d >> 8) & 0xff, j = d & 0xff;
+                if (kind == 0) {           // A <- J^T A J on pair-block (i, j); operand addresses from the schedule table
                     const double2 csi = csn[i], csj = csn[j];
                     double* const e00 = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
                     double* const e01 = reinterpret_cast<double*>(sAb + (te.x >> 16));
@@ -461,7 +515,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                         *e00 = fma(t00, cj, -(t01 * sj)); *e01 = fma(t00, sj, t01 * cj);
                         *e10 = fma(t10, cj, -(t11 * sj)); *e11 = fma(t10, sj, t11 * cj);
                     }
-                } else if (kind == 1) {
+                } else if (kind == 1) {    // diagonal block of pair i
                     double* const epp = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
                     double* const eqq = reinterpret_cast<double*>(sAb + (te.x >> 16));
                     double* const epq = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
@@ -471,8 +525,37 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                     *eqq = fma(tn, apq, aqq);
                     if (apq != 0.0) *epq = 0.0;
                 }
-                vz_prev = te.z; vpend = true; par ^= 1;   // this round's V rotations run beside the next parameter phase
-            } else if constexpr (kFast) {
+                if (tid < m) {
+                    // wavefront 0: the parameters of the NEXT round (the first round of the next sweep after the last one), from the
+                    // elements this wavefront has just written (the LDS executes a wavefront's accesses in order)
+                    double c, sn, tt;
+                    jacobi_param(*reinterpret_cast<const double*>(sAb + (te_next.x & 0xffffu)), *reinterpret_cast<const double*>(sAb + (te_next.x >> 16)),
+                                 *reinterpret_cast<const double*>(sAb + (te_next.y & 0xffffu)), t + 1 < n - 1 ? sweep : sweep + 1, c, sn, tt);
+                    s_tn2[(par ^ 1) * MMAX + tid] = tt;
+                    s_csn[(par ^ 1) * MMAX + tid] = make_double2(c, sn);
+                }
+                if (tid >= VT0) v_rotate(te.z, csn);   // wavefronts 1 .. 3: V <- V J of this round
+                __syncthreads();
+                SQ_STAMP(3);   // one round (one barrier)
+                if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
+                par ^= 1;
+                continue;
+            }
+            if (tid < m) {  // rotation parameters of this round's pairs (round-robin: position 0 fixed)
+                const int k = tid;
+                const int a = (k == 0) ? 0 : 1 + ((k - 1 + t) % (n - 1));
+                const int k2 = n - 1 - k;
+                const int bq = 1 + ((k2 - 1 + t) % (n - 1));
+                const int pidx = a < bq ? a : bq, qidx = a < bq ? bq : a;
+                double c, s, tt;
+                jacobi_param(AT(pidx, pidx), AT(qidx, qidx), AT(qidx, pidx), sweep, c, s, tt);
+                s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
+                s_csn[k] = make_double2(c, s);
+            }
+            __syncthreads();
+            SQ_STAMP(2);   // rotation parameters (lanes of wavefront 0) + barrier
+            if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
+            if constexpr (kFast) {
                 // ---- V row-pairs of pair iv: operands first ----
                 int vpi, vqi;
                 rr_pair(vvalid ? iv : 0, t, n, vpi, vqi);
@@ -564,12 +647,6 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             }
             __syncthreads();
             SQ_STAMP(3);   // rotation phase + barrier
-        }
-    }
-    if constexpr (kTab) {
-        if (vpend) {   // the V rotations of the last round (nobody has read V since)
-            if (tid >= VT0) v_rotate(vz_prev, s_csn + (par ^ 1) * MMAX);
-            __syncthreads();
         }
     }
     if (!converged) {

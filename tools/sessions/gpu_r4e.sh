@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4, session e: UKF sqrt kernel with ONE barrier per round (critical items + next round's parameters in wavefront 0): parity, A/B, phases
+mkdir -p gpurun_out/r4e
+L=live_ekf_slam_amd/libslam_hip.so
+timeout 1200 python -m pytest tests/test_parity_ukf_gpu.py -q -m gpu -x 2>&1 | tail -5 | tee gpurun_out/r4e/pytest_ukf.txt
+bash tools/gpu_ab_ukf.sh tools/lib_ukf_r4d.so $L 2>&1 | tee gpurun_out/r4e/ab_ukf.txt
+python tools/gpu_ukf_sqrt_phases.py 20 2>&1 | tee gpurun_out/r4e/phases.txt
