@@ -24,7 +24,9 @@ while time.time() < t_end:
     B = int(rng.integers(1, 10))
     idknown = int(rng.random() < 0.75)
     kcap = int(rng.choice([2, 6, 20, 70]))
-    kcap = min(kcap, 20 if L <= 20 else (50 if L <= 50 else 100))   # a message holds at most the size class's landmark count (include/slam_batch.h: the surplus is dropped, SLAM_INST_CAPACITY)
+    # a message holds at most the size class's landmark count (include/slam_batch.h: the surplus is dropped, SLAM_INST_CAPACITY); the oracle
+    # restates that limit under a switch (set_message_capacity), so over-long messages are drawn too and the flags compared exactly
+    class_cap = (20 if L <= 20 else 50) if ukf else (20 if L <= 20 else (50 if L <= 50 else (100 if L <= 100 else 200)))
     idmax = int(rng.choice([max(2, L // 2), L, 2 * L, 400]))
     idmin = int(rng.choice([0, 0, -3, -40]))   # any int is an id for the reference (ekf.cpp:99-108), negative ones included (-1 / -2 were sentinels once)
     seed = int(rng.integers(1, 1 << 30))
@@ -42,6 +44,7 @@ while time.time() < t_end:
     es = []
     for b in range(B):
         e = O.OracleUKF(cfg, L_max=L) if ukf else O.OracleEKF(cfg, L_max=L, mode=O.MODE_FAST | (O.STORAGE_F32 if f32 else 0))
+        e.set_message_capacity(class_cap)
         e.init(0, 0, 0); es.append(e)
     oflags = np.zeros(B, dtype=np.int64)
     for t in range(T):
