@@ -48,7 +48,8 @@ enum slam_instance_flags {
                                     repeat of a mapped id is a second update - as the reference's loop does, detection by detection) */
     SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146), or a
                                     message held more detections than the landmark capacity of the handle's size class (20 / 50 /
-                                    100 / 200), which takes repeated ids; the surplus was dropped                      */
+                                    100 / 200), which takes repeated ids; the surplus was dropped.  (The HBM-streamed EKF class,
+                                    L_max > 200, walks a message of any length where it lies, like ekf.cpp:73.)        */
     SLAM_INST_SQRT_FAILED = 16,  /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
     SLAM_INST_WATCHDOG = 32      /* EKF: a polling loop of the step kernel's intra-workgroup protocol exceeded its budget (~0.1 s);
                                     the instance is frozen with an undefined state instead of hanging the GPU.  A defect if it ever
@@ -93,10 +94,12 @@ int slam_config_load(slam_config* cfg, const char* yaml_path);
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
 /* Replaces the filter factory `std::make_unique<EKF|UKF>()` + `filter->readParams(config)`
  * (localization_node.cpp:33-47).  batch = number of instances on THIS device, L_max = landmark capacity
- * (EKF_SLAM: <= 200 in fp64 [size classes 20 / 50 / 100 / 200], <= 50 in fp32 storage; UKF_SLAM: <= 50; UKF_LOC: ignored, the
+ * (EKF_SLAM: <= 1000 in fp64 [LDS size classes 20 / 50 / 100 / 200; beyond 200 the HBM-streamed class: the same EKF::update with
+ * the covariance streamed through HBM in every phase, one launch per timestep, bit-identical but slow - the state of the reference
+ * grows without a limit, ekf.cpp:144-146]; <= 50 in fp32 storage; UKF_SLAM: <= 50; UKF_LOC: ignored, the
  * state holds no landmarks - its map may have any size, one message up to 50 detections [20 while the map has <= 20 landmarks]; a
- * longer one raises SLAM_INST_CAPACITY and loses the surplus).  The reference grows the state without limit (ekf.cpp:144-146); here the limit is what one
- * workgroup keeps in the 160 KB of LDS of a CU.
+ * longer one raises SLAM_INST_CAPACITY and loses the surplus).  The reference grows the state without limit (ekf.cpp:144-146); here the limit of the
+ * fast classes is what one workgroup keeps in the 160 KB of LDS of a CU, and of the streamed class 2 x n x n doubles per instance in HBM.
  * dtype SLAM_F32 (fp32 storage of x and P, fp64 arithmetic) is available for EKF_SLAM. */
 int slam_create(const slam_config* cfg, int filter_kind, int batch, int L_max, int dtype, int device,
                 slam_handle** out);

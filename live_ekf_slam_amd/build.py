@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslam_hip.so")
-SOURCES = ["ekf_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp", "scenario_capi.cpp", "multi_capi.cpp"]
+SOURCES = ["ekf_kernel.hip", "ekf_big_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp", "scenario_capi.cpp", "multi_capi.cpp"]
 HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h",
            "capi_internal.h", "../../include/slam_batch.h", "../../include/slam_pgs.h", "../../include/slam_scenario.hpp",
            "../../include/slam_filter.hpp", "../../include/slam_multi.h", "host/filter_driver.cpp", "host/config_parse.h", "host/stream_parse.h"]
@@ -72,7 +72,7 @@ def build_extension(force=False, verbose=False):
         while pending and len(running) < maxpar:
             name, obj, defs = pending.pop(0)
             src = os.path.join(CSRC, name if not defs else "ekf_inst.hip")
-            cmd = [hipcc] + FLAGS + (EKF_FLAGS if (defs or name == "ekf_kernel.hip") else []) + extra + per_file.get(name, []) + defs + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + (EKF_FLAGS if (defs or name in ("ekf_kernel.hip", "ekf_big_kernel.hip")) else []) + extra + per_file.get(name, []) + defs + ["-c", src, "-o", obj]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 print(" ".join(cmd), flush=True)

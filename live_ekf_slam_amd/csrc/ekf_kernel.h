@@ -68,10 +68,13 @@ static constexpr int kEkfProfSlots = 128;   // per-block slots of EkfStepParams:
 static constexpr int kEkfTrafficSlot = 10;  // khist[10..13]: bytes moved by the P-stream passes (read + write), other global bytes
                                             // (thin gathers, vehicle rows / columns, state vectors), passes, updates applied by passes
 
-// Largest landmark capacity of the instantiated variants (n = 3+2L <= 403: 145 KB of the CU's 160 KB of LDS, one workgroup per CU;
-// n <= 203: 72 KB, two per CU; the limit is LDS, not registers).
-// fp32 storage is instantiated up to 50 landmarks.
-static constexpr int kEkfMaxLandmarks = 200;
+// Largest landmark capacity of the LDS size classes of the fused kernel (n = 3+2L <= 403: 145 KB of the CU's 160 KB of LDS, one workgroup
+// per CU; n <= 203: 72 KB, two per CU; the limit is LDS, not registers).  Beyond it ekf_big_kernel.hip takes over (round 4): the same
+// EKF::update with the covariance streamed through HBM / L2 in every phase, one launch per timestep, fp64 storage only - slow, but the
+// reference's state grows without a limit (ekf.cpp:144-146) and 200 landmarks was one.  Its own limit is the LDS for x, K and H P
+// (6 n doubles) and the 2 x n^2 doubles of an instance in HBM.  fp32 storage is instantiated up to 50 landmarks.
+static constexpr int kEkfLdsMaxLandmarks = 200;
+static constexpr int kEkfMaxLandmarks = 1000;
 static constexpr int kEkfMaxLandmarksF32 = 50;
 
 // Tuning variants of the step kernel.  Every instantiation unit (ekf_inst.hip compiled with -DV_NMAX=.. -DV_W=.. -DV_KG=..
@@ -103,6 +106,10 @@ int ekf_variant_available(int L_max, int f32_storage, int variant);
 hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage, hipStream_t stream);
 // the instantiation launch_ekf_step would pick for (L_max, batch, variant, storage); multi = multi-step launch
 hipError_t ekf_kernel_info(int L_max, int B, int variant, int f32_storage, int multi, EkfKernelInfo* out);
+
+// the size class beyond the LDS classes (ekf_big_kernel.hip): p.T timesteps as p.T launches
+hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream);
+hipError_t ekf_big_kernel_info(EkfKernelInfo* out);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)
 hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, int elem_bytes, double* out, hipStream_t stream);

@@ -306,7 +306,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (dtype != SLAM_F64 && !(dtype == SLAM_F32 && kind == SLAM_EKF_SLAM))
         return fail(SLAM_ERR_UNSUPPORTED, "fp32 state storage is implemented for EKF_SLAM only");
     if (L_max > (kind != SLAM_EKF_SLAM ? slam::kUkfMaxLandmarks : (dtype == SLAM_F32 ? slam::kEkfMaxLandmarksF32 : slam::kEkfMaxLandmarks)))
-        return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the limit of this filter kind / storage type (EKF fp64 %d, EKF fp32 %d, UKF %d): the per-instance thin rows and update slots must fit the 160 KB of LDS of one CU", L_max, slam::kEkfMaxLandmarks, slam::kEkfMaxLandmarksF32, slam::kUkfMaxLandmarks);
+        return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the limit of this filter kind / storage type (EKF fp64 %d, EKF fp32 %d, UKF %d): EKF fp64 beyond %d landmarks runs the HBM-streamed size class; fp32 storage and the UKF keep the per-instance working set in the 160 KB of LDS of one CU", L_max, slam::kEkfMaxLandmarks, slam::kEkfMaxLandmarksF32, slam::kUkfMaxLandmarks, slam::kEkfLdsMaxLandmarks);
     HIP_TRY(hipSetDevice(device));
     slam_handle* h = new slam_handle();
     h->cfg = *cfg; h->kind = kind; h->B = batch; h->L_max = L_max; h->dtype = dtype; h->device = device;

@@ -617,6 +617,72 @@ def test_state_of_200_landmarks(S, oracle):
     f.close()
 
 
+def test_state_of_400_landmarks(S, oracle):
+    """n = 803: beyond the LDS size classes (the reference's state grows without limit, ekf.cpp:144-146; up to round 3 slam_create
+    answered SLAM_ERR_UNSUPPORTED above 200 landmarks).  The HBM-streamed class (ekf_big_kernel.hip): a first look at all 400
+    landmarks in one message, a second full look (400 updates in one message), ordinary steps, single-step and multi-step calls;
+    bit-identical to the oracle, error statistics and true poses included."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 400, 24, 3
+    lm, cmds = make_scenario(77, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1))
+    vis[0] = [1e9, -4.0, 4.0]; vis[9] = [1e9, -4.0, 4.0]; vis[15] = [6.0, -3.2, 3.2]
+    f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(8); f.init(0, 0, 0)
+    assert f.kernel_info()["name"] == "ekf_big_step_kernel"
+    t = 0
+    for t1 in (1, 9, 10, 15, 16, T):
+        f.set_vision(*vis[t])
+        if t1 - t == 1: f.update_sim(cmds[t])
+        else: f.run_sim(cmds[t:t1])
+        t = t1
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=8, nthreads=3, vision=vis)
+    assert np.all(r["M"] == L) and np.array_equal(f.landmark_counts(), r["M"]) and np.array_equal(f.status(), r["flags"])
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
+    for b in range(B):
+        n = 3 + 2 * L
+        _assert_state_equal(f.get_state(b), dict(M=L, ids=r["ids"][b, :L], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    f.close()
+
+
+@pytest.mark.parametrize("idknown", [1, 0])
+def test_streamed_class_walks_messages_of_any_length(S, oracle, idknown):
+    """The HBM-streamed class follows the reference's loop detection by detection (ekf.cpp:73): per-instance external messages with
+    repeated ids, ids beyond the capacity (SLAM_INST_CAPACITY), MORE detections than landmarks (no per-message limit here), a repeat
+    of an id the message itself inserted (the reference dies: frozen in the pre-step state); known and unknown ids."""
+    L, B, T = 230, 4, 10
+    cfg = S.default_config(); cfg.landmark_id_is_known = idknown
+    f = S.BatchedEKF(B, L).readParams(cfg); f.init(0.0, 0.0, 0.0)
+    es = []
+    for b in range(B):
+        e = oracle.OracleEKF(cfg, L_max=L); e.init(0, 0, 0); es.append(e)
+    rng = np.random.default_rng(5 + idknown)
+    of = np.zeros(B, dtype=np.int64)
+    for t in range(T):
+        cmd = np.array([rng.uniform(0, 0.1), rng.uniform(-0.05, 0.05)], dtype=np.float32)
+        ks = rng.integers(0, 300, B)
+        if t == 0: ks[:] = 250                      # a first look at more ids than the capacity
+        if t == 3: ks[0] = 0
+        K = max(1, int(ks.max()))
+        meas = np.zeros((B, K, 3), dtype=np.float32)
+        for b in range(B):
+            k = int(ks[b])
+            ids = rng.integers(0, 260, k)
+            if t == 0: ids = rng.permutation(260)[:k]   # distinct at first (no freeze at the first step) ...
+            if t == 6 and b == 1 and k > 3: ids[:3] = [900, 901, 900]   # ... later a repeat of a new id
+            meas[b, :k, 0] = ids
+            meas[b, :k, 1] = rng.uniform(0.5, 6.0, k)
+            meas[b, :k, 2] = rng.uniform(-3.1, 3.1, k)
+        f.update(cmd, meas, ks.astype(np.int32))
+        for b in range(B):
+            of[b] |= es[b].update(cmd[0], cmd[1], meas[b, :ks[b]])
+    assert np.array_equal(f.status().astype(np.int64), of)
+    for b in range(B):
+        so, sg = es[b].state(), f.get_state(b)
+        assert sg["M"] == so["M"] and np.array_equal(sg["ids"], so["ids"])
+        assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"]), b
+    f.close()
+
+
 @pytest.mark.parametrize("kind", ["ekf", "ekf_f32", "ukf"])
 def test_checkpoint_and_resume_are_bit_identical(S, tmp_path, kind):
     """slam_save_state / slam_load_state (the reference keeps the filter only in memory): a run continued from a checkpoint

@@ -18,15 +18,15 @@ runs = fails = 0
 cat = {}
 while time.time() < t_end:
     ukf = which == "ukf" or (which == "both" and rng.random() < 0.35)
-    L = int(rng.choice([3, 8, 20, 50] if ukf else [3, 8, 20, 50, 100]))
+    L = int(rng.choice([3, 8, 20, 50] if ukf else [3, 8, 20, 50, 100, 230]))   # 230: the HBM-streamed EKF class (no per-message limit)
     f32 = (not ukf) and L <= 50 and rng.random() < 0.3
-    T = int(rng.integers(3, 50))
+    T = int(rng.integers(3, 50 if L <= 200 else 12))
     B = int(rng.integers(1, 10))
     idknown = int(rng.random() < 0.75)
-    kcap = int(rng.choice([2, 6, 20, 70]))
+    kcap = int(rng.choice([2, 6, 20, 70] + ([300] if L > 200 else [])))
     # a message holds at most the size class's landmark count (include/slam_batch.h: the surplus is dropped, SLAM_INST_CAPACITY); the oracle
     # restates that limit under a switch (set_message_capacity), so over-long messages are drawn too and the flags compared exactly
-    class_cap = (20 if L <= 20 else 50) if ukf else (20 if L <= 20 else (50 if L <= 50 else (100 if L <= 100 else 200)))
+    class_cap = (20 if L <= 20 else 50) if ukf else (20 if L <= 20 else (50 if L <= 50 else (100 if L <= 100 else (200 if L <= 200 else 0))))
     idmax = int(rng.choice([max(2, L // 2), L, 2 * L, 400]))
     idmin = int(rng.choice([0, 0, -3, -40]))   # any int is an id for the reference (ekf.cpp:99-108), negative ones included (-1 / -2 were sentinels once)
     seed = int(rng.integers(1, 1 << 30))
