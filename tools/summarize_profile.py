@@ -14,7 +14,7 @@ res = {"steps": K, "warmup": W}
 
 
 def is_multi(name):
-    return "ekf_step_kernel" in name and (", true>" in name or "Lb1" in name)
+    return "ekf_step_kernel" in name and (", true>" in name or ", true," in name or "Lb1" in name)
 
 
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
