@@ -315,8 +315,9 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     # BENCH_SHARE_GPU=1 (testing only): every rank uses GPU 0 and the collectives run over gloo, so that the N > 1 control flow
     # (shard plan, barriers, gather) can be exercised on a one-GPU box; the figures of such a run mean nothing.
-    share = os.environ.get("BENCH_SHARE_GPU") == "1"
-    if share:
+    share_mode = os.environ.get("BENCH_SHARE_GPU", "")
+    share = share_mode == "1"
+    if share_mode in ("1", "nccl"):   # "nccl" (testing only): all ranks on GPU 0 but the collectives over RCCL, if it accepts two ranks per device
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -34,8 +34,12 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// (The runtime's "last error" is sticky and per thread: a launcher that ends in hipGetLastError() would report an error some OTHER library
+// of the process left behind - PyTorch creating a stream right before slam_init did exactly that in a test.  It is cleared before every
+// call; our own calls are all checked through their return values.)
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
+        (void)hipGetLastError();                                                                   \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return fail(SLAM_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
     } while (0)

@@ -61,3 +61,23 @@ def test_two_ranks_strong_scaling_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["global_batch"] == 8192 and d["config"]["batch_per_gpu"] == 4096
     assert d["config"]["state_rmse_vs_oracle"] == 0.0 and d["config"]["instances_flagged"] == 0
+
+
+def test_two_ranks_over_rccl_on_one_gpu_or_the_reason_why_not():
+    """the RCCL branch of bench.py (init_process_group("nccl"), the barrier-bracketed timing, the end-of-run
+    all-gather / all-reduce of the error statistics) has only ever run with one rank.  Two ranks on GPU 0 over the nccl backend
+    exercise it on a one-GPU box IF RCCL accepts two ranks per device; if it refuses (NCCL's duplicate-GPU check) the refusal itself
+    is asserted, so that this test says which of the two happened instead of passing vacuously."""
+    env = dict(os.environ, BENCH_SHARE_GPU="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--batch", "8192", "--no-long-runs", "--no-cpu-baseline", "--no-once-per-step"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    if out.returncode == 0:
+        d = _last_json(out.stdout)
+        assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["config"]["state_rmse_vs_oracle"] == 0.0
+        return
+    txt = (out.stdout + out.stderr)
+    assert ("Duplicate GPU" in txt) or ("duplicate" in txt.lower()) or ("invalid usage" in txt.lower()), txt[-3000:]
+    pytest.skip("RCCL refuses two ranks on one device (duplicate-GPU check): the nccl branch needs a multi-GPU node; "
+                "the gloo path (test_two_ranks_strong_scaling_on_one_gpu) covers the control flow")

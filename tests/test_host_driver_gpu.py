@@ -207,3 +207,76 @@ def test_publish_state_every_tick_from_the_tracked_instance(oracle):
     r = oracle.run_ekf_batch(lm, cmds, 128, 20, seed=9, inst0=1000, nthreads=8)
     assert np.array_equal(f.error_stats(), r["avg_err"])
     f.close()
+
+
+def test_tracked_instance_reads_the_callers_device_buffers_before_they_are_reused(oracle):
+    """slam_step_dev with a tracked instance runs the shadow's step on the shadow's OWN stream, reading the caller's
+    d_meas / d_count.  The header allows the caller to overwrite those buffers by work enqueued on the handle's stream right after
+    the call - so the handle's stream must wait for the shadow's read.  Here the buffers are scrubbed on the stream immediately
+    after every call; the tracked instance must still equal the oracle (and the batch) at every tick.  (Device buffers through the
+    HIP runtime libslam_hip.so itself links, not through torch: two HIP runtimes in one process do not share stream handles.)"""
+    import ctypes as C
+    import live_ekf_slam_amd as S
+    g = load_golden("sim_seed1234_L50_T400.npz")
+    L, B, T, inst, ks = 50, 4096, 60, 4000, 8
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    stream, d_meas, d_cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    assert hip.hipMalloc(C.byref(d_meas), B * ks * 3 * 4) == 0 and hip.hipMalloc(C.byref(d_cnt), B * 4) == 0
+    f = S.BatchedEKF(B, L).readParams(); f.set_stream(stream.value); f.init(0, 0, 0)
+    f.track_instance(inst)
+    o = oracle.OracleEKF(L_max=L); o.init(0, 0, 0)
+    for t in range(T):
+        k = int(g["meas_count"][t])
+        m = np.zeros((ks, 3), dtype=np.float32); m[:k] = g["meas"][t, :k]
+        hm = np.ascontiguousarray(np.broadcast_to(m, (B, ks, 3))); hc = np.full(B, k, dtype=np.int32)
+        assert hip.hipMemcpyAsync(d_meas, hm.ctypes.data_as(C.c_void_p), hm.nbytes, 1, stream) == 0
+        assert hip.hipMemcpyAsync(d_cnt, hc.ctypes.data_as(C.c_void_p), hc.nbytes, 1, stream) == 0
+        assert hip.hipStreamSynchronize(stream) == 0            # (pageable host arrays: the copies are done before they go out of scope)
+        f.update_dev(g["cmds"][t], d_meas.value, d_cnt.value, ks)
+        # the caller reuses its buffers at once, on the handle's stream: 0x41 bytes = ids / ranges / bearings of 12.08, counts of 1 094 795 585
+        assert hip.hipMemsetAsync(d_meas, 0x41, B * ks * 3 * 4, stream) == 0 and hip.hipMemsetAsync(d_cnt, 0x41, B * 4, stream) == 0
+        o.update(g["cmds"][t, 0], g["cmds"][t, 1], g["meas"][t, :k])
+        sg, so = f.get_state(inst), o.state()                   # answered by the shadow
+        assert sg["M"] == so["M"] and np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"]), t
+    f.track_instance(-1)
+    sg, so = f.get_state(inst), o.state()                       # the batch's own copy of the instance
+    assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"])
+    f.close()
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipFree(d_meas); hip.hipFree(d_cnt)
+
+
+def test_a_corrupted_checkpoint_is_refused_before_it_reaches_the_device(tmp_path):
+    """slam_load_state used to check the header only; a landmark count beyond L_max (or a state capacity that does
+    not match) made the next step kernel index past the instance's slab.  Now the per-instance counters are validated on the
+    host and the handle keeps its state."""
+    import live_ekf_slam_amd as S
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B = 20, 16
+    lm, cmds = make_scenario(5, L, 30)
+    f = S.BatchedEKF(B, L).readParams(); f.set_map(lm); f.set_seed(3); f.init(0, 0, 0); f.run_sim(cmds[:20])
+    good = tmp_path / "good.ckpt"; f.save_state(good)
+    raw = bytearray(open(good, "rb").read())
+    # locate the landmark-count column: the only run of B int32 equal to landmark_counts()
+    M = f.landmark_counts().astype(np.int32)
+    pos = bytes(raw).find(M.tobytes())
+    assert pos > 0
+    bad = bytearray(raw); bad[pos + 4 * 3:pos + 4 * 4] = np.int32(L + 7).tobytes()
+    p_bad = tmp_path / "bad.ckpt"; open(p_bad, "wb").write(bad)
+    before = f.get_state(3)
+    with pytest.raises(S.SlamError, match="landmark count"):
+        f.load_state(p_bad)
+    neg = bytearray(raw); neg[pos:pos + 4] = np.int32(-1).tobytes()
+    p_neg = tmp_path / "neg.ckpt"; open(p_neg, "wb").write(neg)
+    with pytest.raises(S.SlamError, match="landmark count"):
+        f.load_state(p_neg)
+    after = f.get_state(3)
+    assert np.array_equal(before["x"], after["x"]) and np.array_equal(before["P"], after["P"])   # nothing was copied
+    f.load_state(good); f.run_sim(cmds[20:]); assert np.all(f.status() == 0)
+    f.close()
