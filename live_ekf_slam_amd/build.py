@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslam_hip.so")
-SOURCES = ["ekf_kernel.hip", "ekf_big_kernel.hip", "ukf_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp", "scenario_capi.cpp", "multi_capi.cpp"]
+SOURCES = ["ekf_kernel.hip", "ekf_big_kernel.hip", "ukf_kernel.hip", "ukf_big_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp", "scenario_capi.cpp", "multi_capi.cpp"]
 HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h",
            "capi_internal.h", "../../include/slam_batch.h", "../../include/slam_pgs.h", "../../include/slam_scenario.hpp",
            "../../include/slam_filter.hpp", "../../include/slam_multi.h", "host/filter_driver.cpp", "host/config_parse.h", "host/stream_parse.h"]
@@ -53,7 +53,7 @@ def build_extension(force=False, verbose=False):
     jobs = [(src, os.path.join(CSRC, src + ".o"), []) for src in SOURCES]
     # per-file code generation options: the UKF step kernel keeps its MFMA accumulators in VGPRs (the compiler's default put them
     # in AGPRs and copied all of them in and out around every k-block of the covariance contraction)
-    per_file = {"ukf_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+    per_file = {"ukf_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}   # (ukf_big_kernel.hip has no MFMA)
     variants = list(EKF_DEFAULT_VARIANTS) + (EKF_SWEEP_VARIANTS if os.environ.get("SLAM_SWEEP") else [])
     variants = list(dict.fromkeys(variants))
     for v in variants:

@@ -340,8 +340,10 @@ size_t big_lds_bytes(int L_max, int L_map) {
 hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream) {
     const size_t lds = big_lds_bytes(p.L_max, p.sim ? p.L : 1);
     if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
-    // (per device: a single-process multi-GPU host launches this on several)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_big_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 64 * 1024) {   // (per device and per launch: a single-process multi-GPU host launches this on several)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_big_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     const int multi = (p.cmds != nullptr && p.T > 1) ? 1 : 0;
     const int T = multi ? p.T : 1;
     for (int t = 0; t < T; ++t) {   // one launch per timestep: the kernel keeps nothing on chip between steps

@@ -116,6 +116,9 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
                           // ring of KG = 5 slots that leaves one free for the control wavefront during a pass (KG = 5 with passes at five pending:
                           // 20 % fewer passes and bytes but the stall is back, 72 vs 78 M steps/s; fp32 storage gains nothing from a fifth slot)
 #endif
+#ifndef SLAM_W1_WAVES
+#define SLAM_W1_WAVES 3   // one-wavefront variant: wavefronts per SIMD the register allocation leaves room for
+#endif
 #ifndef SLAM_SD
 #define SLAM_SD 3         // timesteps the measurement generator may run ahead of the filter (ring of messages in LDS)
 #endif
@@ -178,7 +181,7 @@ __device__ __forceinline__ unsigned hi_abs(double v) {
 // MULTI = false: one timestep per launch (slam_step / slam_step_dev / slam_step_sim); MULTI = true: p.T timesteps per
 // launch with the per-instance state resident on chip (slam_run_sim).  Same code, the loop is compiled out for T = 1.
 template <int NMAX, int W, int KG_, int UNR_, class ST, int PIPE, bool MULTI, int KP_ = 0>
-__global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : 3)) void ekf_step_kernel(const EkfStepParams p) {
+__global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : SLAM_W1_WAVES)) void ekf_step_kernel(const EkfStepParams p) {
     using G = EkfGeom<NMAX, W, KG_, UNR_, KP_>;
     constexpr int TPB = G::TPB, LDP = G::LDP, KCAP = G::KCAP, LMAX = G::LMAX, KG = G::KG, KP = G::KP, KLOOP = G::KLOOP, TS = G::TS, UNR = G::UNR;
 

@@ -139,6 +139,7 @@ struct slam_handle {
     double* dsq = nullptr; int32_t* dnsq = nullptr;   // UKF: matrix square root scratch + its dimension
     double* dxprev = nullptr;                         // UKF: x_t the last sigma points were drawn around
     double* dvt = nullptr; int32_t* dvage = nullptr;  // UKF: V^T of the last eigen-decomposition + warm-start age
+    double* dbigws = nullptr;                         // UKF beyond the LDS size classes: [B][2 * pstride] scratch (ukf_big_kernel.hip)
     uint4* drot = nullptr;                            // UKF (n <= 44): Jacobi schedule table of the fast sqrt kernel
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr}; hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // UKF run_sim: the other parts of the batch
     int ukf_parts = 2;                                                               // streams the UKF batch is split over (SLAM_UKF_PARTS, 1..4)
@@ -197,6 +198,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
     p.rot_tab = h->drot;
     p.khist = h->dkhist;
+    p.big_ws = h->dbigws;
     p.prof = (h->dbg & 4) ? h->dprof : nullptr;
 }
 
@@ -310,7 +312,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (dtype != SLAM_F64 && !(dtype == SLAM_F32 && kind == SLAM_EKF_SLAM))
         return fail(SLAM_ERR_UNSUPPORTED, "fp32 state storage is implemented for EKF_SLAM only");
     if (L_max > (kind != SLAM_EKF_SLAM ? slam::kUkfMaxLandmarks : (dtype == SLAM_F32 ? slam::kEkfMaxLandmarksF32 : slam::kEkfMaxLandmarks)))
-        return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the limit of this filter kind / storage type (EKF fp64 %d, EKF fp32 %d, UKF %d): EKF fp64 beyond %d landmarks runs the HBM-streamed size class; fp32 storage and the UKF keep the per-instance working set in the 160 KB of LDS of one CU", L_max, slam::kEkfMaxLandmarks, slam::kEkfMaxLandmarksF32, slam::kUkfMaxLandmarks, slam::kEkfLdsMaxLandmarks);
+        return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the limit of this filter kind / storage type (EKF fp64 %d, EKF fp32 %d, UKF %d): EKF fp64 beyond %d landmarks and the UKF beyond 50 run the HBM-streamed size classes; fp32 storage keeps the per-instance working set in the 160 KB of LDS of one CU", L_max, slam::kEkfMaxLandmarks, slam::kEkfMaxLandmarksF32, slam::kUkfMaxLandmarks, slam::kEkfLdsMaxLandmarks);
     HIP_TRY(hipSetDevice(device));
     slam_handle* h = new slam_handle();
     h->cfg = *cfg; h->kind = kind; h->B = batch; h->L_max = L_max; h->dtype = dtype; h->device = device;
@@ -362,6 +364,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dnsq, sizeof(int32_t) * B) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dxprev, sizeof(double) * B * h->xstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvt, sizeof(double) * B * h->pstride) : hipSuccess,
+        (kind == SLAM_UKF_SLAM && L_max > slam::kUkfLdsMaxLandmarks) ? hipMalloc(&h->dbigws, sizeof(double) * B * 2 * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvage, sizeof(int32_t) * B) : hipSuccess,
         (kind != SLAM_EKF_SLAM && h->n_max <= 44) ? hipMalloc(&h->drot, sizeof(uint4) * slam::kUkfRotTabEntries) : hipSuccess,
     };
@@ -418,7 +421,7 @@ int slam_destroy(slam_handle* h) {
         if (s.copied) hipEventDestroy(s.copied);
         if (s.used) hipEventDestroy(s.used);
     }
-    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage, h->dkhist, h->drot};
+    void* bufs[] = {h->dP, h->dP2, h->dx, h->dM, h->dids, h->dflags, h->dts, h->dtruth, h->derr, h->dmap, h->dmeas, h->dcount, h->dscalar, h->dprof, h->dsq, h->dnsq, h->dscratch, h->dmapf, h->dcmds, h->dxprev, h->dvt, h->dvage, h->dkhist, h->drot, h->dbigws};
     for (void* q : bufs)
         if (q) hipFree(q);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);

@@ -54,6 +54,9 @@ struct UkfStepParams {
     // workload statistics (optional): [0..7] instance-steps by detections in the message (7 = seven or more), [8] Jacobi sweeps
     // that rotated something, [9] eigen-decompositions (slam_k_histogram / slam_ukf_sweep_stats)
     unsigned long long* khist;
+    // the size class beyond LDS (ukf_big_kernel.hip, n = 4 + 2 L_max > 104): [B][2 * pstride] doubles of scratch per instance (the scaled
+    // symmetrised matrix and the warm-start product of the sqrt kernel, then P_pred of the step kernel); NULL for the LDS classes
+    double* big_ws;
 };
 
 // Schedule table for ukf_sqrt_kernel<44, 256>: kUkfRotTabEntries uint4 entries (4 MB); see UkfStepParams::rot_tab.
@@ -61,7 +64,10 @@ static constexpr int kUkfRotRounds = 43, kUkfRotThreads = 256, kUkfRotSizes = 23
 static constexpr size_t kUkfRotTabEntries = (size_t)kUkfRotSizes * kUkfRotRounds * kUkfRotThreads;
 hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream);
 
-static constexpr int kUkfMaxLandmarks = 50;   // n = 4 + 2L <= 104
+static constexpr int kUkfLdsMaxLandmarks = 50;   // n = 4 + 2L <= 104: the fast kernels keep A, V^T and sqtP of an instance in LDS
+static constexpr int kUkfMaxLandmarks = 200;     // beyond: ukf_big_kernel.hip, every n x n object in HBM / L2 (slow, bit-identical)
+hipError_t launch_ukf_big_sqrt(const UkfStepParams& p, hipStream_t stream);
+hipError_t launch_ukf_big_step(const UkfStepParams& p, hipStream_t stream);
 
 hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream);
 hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream);

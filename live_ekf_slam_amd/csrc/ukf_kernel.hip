@@ -1183,7 +1183,7 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
                 break;
         }
     } else {
-        return hipErrorInvalidValue;
+        return launch_ukf_big_sqrt(p, stream);   // every n x n object in HBM / L2 (ukf_big_kernel.hip)
     }
     return hipGetLastError();
 }
@@ -1213,7 +1213,7 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
                 break;
         }
     } else {
-        return hipErrorInvalidValue;
+        return launch_ukf_big_step(p, stream);   // every n x n object in HBM / L2 (ukf_big_kernel.hip)
     }
     return hipGetLastError();
 }

@@ -261,3 +261,51 @@ def test_ukf_loc_on_a_map_larger_than_the_small_size_class(S, oracle):
     for b in range(B):
         _eq(f.get_state(b), dict(M=0, ids=r["ids"][b, :0], x=r["x"][b, :4], P=r["P"][b, :16].reshape(4, 4)))
     f.close()
+
+
+def test_ukf_state_of_100_landmarks(S, oracle):
+    """n = 204: beyond the LDS size classes of the UKF kernels (up to round 3: SLAM_ERR_UNSUPPORTED above 50 landmarks; the reference's
+    state grows without a limit, ukf.cpp:357,371).  The HBM-streamed class (ukf_big_kernel.hip): a first look at all 100 landmarks
+    (100 insertions in one message), a full second look (100 updates), ordinary steps with warm-started decompositions; device-generated
+    messages (per-instance noise) and an external message with a repeated new id and more detections than landmarks.  Bit-identical
+    to the oracle, error statistics and true poses included."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 100, 14, 3
+    lm, cmds = make_scenario(31, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]; vis[6] = [1e9, -4.0, 4.0]
+    f = S.BatchedUKF(B, L).readParams(); f.set_map(lm); f.set_seed(12); f.init(0, 0, 0)
+    for t in range(T):
+        f.set_vision(*vis[t]); f.update_sim(cmds[t])
+    r = oracle.run_ukf_batch(lm, cmds, B, L, seed=12, nthreads=3, vision=vis)
+    assert np.all(r["M"] == L) and np.array_equal(f.landmark_counts(), r["M"]) and np.array_equal(f.status(), r["flags"])
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
+    n = 4 + 2 * L
+    for b in range(B):
+        _eq(f.get_state(b), dict(M=L, ids=r["ids"][b], x=r["x"][b], P=r["P"][b].reshape(n, n)))
+    f.close()
+    # external messages, one oracle per instance: growth over several steps, a repeated NEW id (two insertions, ukf.cpp:279-287),
+    # ids beyond the capacity, 130 detections in one message
+    L2, B2 = 60, 2
+    f = S.BatchedUKF(B2, L2).readParams(); f.init(0.0, 0.0, 0.0)
+    es = [oracle.OracleUKF(L_max=L2) for _ in range(B2)]
+    for e in es: e.init(0, 0, 0)
+    rng = np.random.default_rng(4)
+    of = np.zeros(B2, dtype=np.int64)
+    for t in range(6):
+        cmd = np.array([rng.uniform(0, 0.1), rng.uniform(-0.05, 0.05)], dtype=np.float32)
+        ks = np.array([130 if t == 3 else int(rng.integers(0, 25)) for _ in range(B2)])
+        K = max(1, int(ks.max()))
+        meas = np.zeros((B2, K, 3), dtype=np.float32)
+        for b in range(B2):
+            kk = int(ks[b])
+            ids = rng.integers(0, 70, kk)
+            if t == 1 and kk > 2: ids[:3] = [500, 501, 500]
+            meas[b, :kk, 0] = ids; meas[b, :kk, 1] = rng.uniform(0.5, 6.0, kk); meas[b, :kk, 2] = rng.uniform(-3.1, 3.1, kk)
+        f.update(cmd, meas, ks.astype(np.int32))
+        for b in range(B2):
+            of[b] |= es[b].update(cmd[0], cmd[1], meas[b, :ks[b]])
+    assert np.array_equal(f.status().astype(np.int64), of)
+    for b in range(B2):
+        so = es[b].state()
+        _eq(f.get_state(b), dict(M=so["M"], ids=so["ids"], x=so["x"], P=so["P"]))
+    f.close()

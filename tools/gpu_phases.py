@@ -11,9 +11,7 @@ from live_ekf_slam_amd.scenario import make_scenario
 names = {0: "init loads", 1: "pre-step(0)", 2: "wait for pre-step", 3: "group formation", 9: "pre-flush pass", 4: "thin gather", 5: "predict",
          6: "detections", 7: "pass / end barrier", 10: "end of step", 8: "epilogue",
          16: "C: loop overhead", 17: "C: group formation", 18: "C: flush wait + gather", 19: "C: prediction", 20: "C: scalar chain / upd",
-         21: "C: ring slot wait", 22: "C: H P, K, x", 23: "C: thin downdates", 24: "C: end of step", 25: "C: pre-step(t+1)", 26: "C: wait for generator",
-         40: "A: work", 41: "A: wait for command entry", 42: "A: wait for B (gather/exit)", 43: "A: wait for generator", 44: "A: pre-step",
-         50: "B: other work", 51: "B: wait for command", 52: "B: decode", 53: "B: wait for ring slot", 54: "B: H P, K, x", 55: "B: thin downdates"}
+         21: "C: ring slot wait", 22: "C: H P, K, x", 23: "C: thin downdates", 24: "C: end of step", 25: "C: pre-step(t+1)", 26: "C: wait for generator"}
 dt = sys.argv[1] if len(sys.argv) > 1 else "f64"
 if len(sys.argv) > 2:
     os.environ["SLAM_WAVES_PER_FILTER"] = sys.argv[2]

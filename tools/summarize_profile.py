@@ -30,7 +30,15 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recurs
         res["kernel"] = rows[-1]["Kernel_Name"]
         res["timed_launch_ns"] = durs[-1]
         res["ns_per_timestep"] = durs[-1] / K
-        res["vgpr"] = rows[-1].get("VGPR_Count"); res["lds_bytes"] = rows[-1].get("LDS_Block_Size")
+        # the profiler reports the ARCHITECTURAL and the ACCUMULATION registers separately; the allocation that bounds occupancy (and what
+        # slam_kernel_info / bench.py's roofline.vgprs report from hipFuncGetAttributes) is their sum, rounded up to the allocation granule
+        def _int(v):
+            try: return int(v)
+            except (TypeError, ValueError): return None
+        res["arch_vgpr"] = _int(rows[-1].get("VGPR_Count")); res["accum_vgpr"] = _int(rows[-1].get("Accum_VGPR_Count"))
+        res["total_vgpr"] = (res["arch_vgpr"] or 0) + (res["accum_vgpr"] or 0)
+        res["sgpr"] = _int(rows[-1].get("SGPR_Count")); res["scratch_bytes"] = _int(rows[-1].get("Scratch_Size") or rows[-1].get("Private_Segment_Size"))
+        res["lds_bytes"] = rows[-1].get("LDS_Block_Size")
         if len(durs) >= 2:
             res["warmup_launch_ns"] = durs[-2]
         print(f"== timed launch ({K} timesteps): {durs[-1] / 1e6:.3f} ms = {durs[-1] / K / 1e6:.4f} ms per timestep")
