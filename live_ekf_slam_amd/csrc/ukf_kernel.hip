@@ -345,19 +345,22 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     // pair, ITV rows each.  Items are independent, so the mapping does not change a single bit.
     constexpr int ITB = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB;   // pair-block / diagonal items per thread (they are the first items)
     constexpr bool kFast = ITB <= 2;                               // n <= 103 with 1024 threads: two per thread
-    constexpr int ITV = kFast ? (NMAX + (TPB / MMAX) - 1) / (TPB / MMAX) : 1;
     // Round 4: a thread takes its V entries as 16-byte PAIRS of consecutive k (n is even, rows of V^T start on 16-byte boundaries), pair
     // index subk + tp * u: half the LDS instructions and address arithmetic of the V update, and the lanes of a pair read consecutive 16-byte
     // words (the 8-byte elements at stride tp = 11 were behind the 39 % bank-conflict share of this kernel's LDS cycles).
-    constexpr int ITP = (ITV + 1) / 2;
     // table path (round 4): the V rotations of round t run in the shadow of the parameter phase of round t + 1 - wavefront 0 computes
     // the parameters, wavefronts 1 .. 3 rotate V (V is read by nobody until the decomposition ends, and A does not depend on it)
     constexpr bool kTab = ITB <= 2 && NMAX == 44 && TPB == kUkfRotThreads;
-    constexpr int VT0 = kTab ? 64 : 0;      // first thread that rotates V
+    // the other fast variants (no schedule table; L = 50 runs <104, 1024>, ONE workgroup per CU - nothing overlaps its phases unless the
+    // workgroup does it itself): the V rotations of round t run in the shadow of the parameter phase of round t + 1 there too
+    // (Measured and dropped in round 4: advancing the round-robin indices in registers instead of deriving them with rr_pair every round -
+    // bit-exact, the pair-block phase 931 -> 802 ns per round at L = 50, but 17 more VGPRs and the V phase 792 -> 1015 ns: 254.9 -> 246.5 k steps/s.)
+    constexpr bool kShadow = ITB <= 2 && !kTab && TPB >= 128;
+    constexpr int VT0 = (kTab || kShadow) ? 64 : 0;      // first thread that rotates V
     const int tp = (TPB - VT0) / m;         // threads per pair (V rows)
     const int iv = tid >= VT0 ? (tid - VT0) / tp : m, subk = tid - VT0 - iv * tp;
     const bool vvalid = iv < m;
-    constexpr int ITPT = kTab ? (MMAX + ((TPB - VT0) / MMAX) - 1) / ((TPB - VT0) / MMAX) : 1;   // 16-byte pairs of V per thread there
+    constexpr int ITPT = ITB <= 2 ? (MMAX + ((TPB - VT0) / MMAX) - 1) / ((TPB - VT0) / MMAX) : 1;   // 16-byte pairs of V per thread
     // schedule table (see ukf_rot_table_kernel): this thread's column of the table for state size n, or NULL
     const uint4* const tabn = kTab ? p.rot_tab + (size_t)(n / 2) * kUkfRotRounds * kUkfRotThreads + tid : nullptr;   // the launcher checks rot_tab
     bool converged = false;
@@ -388,6 +391,31 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             }
         }
     };
+    auto v_rotate_rr = [&](int tr, const double2* csn) {   // the same with the rows taken from the round-robin schedule of round tr
+        if (!vvalid) return;
+        const double2 vcs = csn[iv];
+        if (vcs.y == 0.0) return;
+        int vpi, vqi;
+        rr_pair(iv, tr, n, vpi, vqi);
+        double2 xp[ITPT], xq[ITPT];
+#pragma unroll
+        for (int u = 0; u < ITPT; ++u) {
+            const int k = 2 * (subk + tp * u);
+            const int kk = k < n ? k : 0;
+            xp[u] = *reinterpret_cast<const double2*>(&sVt[vpi * n + kk]); xq[u] = *reinterpret_cast<const double2*>(&sVt[vqi * n + kk]);
+        }
+        const double c = vcs.x, sn = vcs.y;
+#pragma unroll
+        for (int u = 0; u < ITPT; ++u) {
+            const int k = 2 * (subk + tp * u);
+            if (k < n) {
+                *reinterpret_cast<double2*>(&sVt[vpi * n + k]) = make_double2(fma(c, xp[u].x, -(sn * xq[u].x)), fma(c, xp[u].y, -(sn * xq[u].y)));
+                *reinterpret_cast<double2*>(&sVt[vqi * n + k]) = make_double2(fma(sn, xp[u].x, c * xq[u].x), fma(sn, xp[u].y, c * xq[u].y));
+            }
+        }
+    };
+    bool vpend = false;   // kShadow: the V rotations of round t_prev are pending (they run beside the next parameter phase)
+    int t_prev = 0;
     // rotation parameters (c, s, t = tan) of the pair (pidx, qidx) from the current A; sw: the sweep the rotation belongs to
     auto jacobi_param = [&](double app, double aqq, double apq, int sw, double& c, double& s, double& tt) {
         c = 1.0; s = 0.0; tt = 0.0;
@@ -550,22 +578,30 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                 double c, s, tt;
                 jacobi_param(AT(pidx, pidx), AT(qidx, qidx), AT(qidx, pidx), sweep, c, s, tt);
                 s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
-                s_csn[k] = make_double2(c, s);
+                s_csn[par * MMAX + k] = make_double2(c, s);
+                s_tn2[par * MMAX + k] = tt;
+            }
+            if constexpr (kShadow) {
+                if (vpend && tid >= VT0) v_rotate_rr(t_prev, s_csn + (par ^ 1) * MMAX);   // V <- V J of the round before, beside the parameters
             }
             __syncthreads();
-            SQ_STAMP(2);   // rotation parameters (lanes of wavefront 0) + barrier
+            SQ_STAMP(2);   // rotation parameters (lanes of wavefront 0) [+ V rotations of the round before] + barrier
             if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
             if constexpr (kFast) {
-                // ---- V row-pairs of pair iv: operands first ----
-                int vpi, vqi;
-                rr_pair(vvalid ? iv : 0, t, n, vpi, vqi);
-                const double2 vcs = s_csn[vvalid ? iv : 0];
-                double2 xp[ITP], xq[ITP];
+                const double2* const csn = s_csn + par * MMAX;
+                // ---- V row-pairs of pair iv: operands first (kShadow: V is rotated beside the NEXT parameter phase instead) ----
+                int vpi = 0, vqi = 0;
+                double2 vcs = make_double2(1.0, 0.0);
+                double2 xp[ITPT], xq[ITPT];
+                if constexpr (!kShadow) {
+                    rr_pair(vvalid ? iv : 0, t, n, vpi, vqi);
+                    vcs = csn[vvalid ? iv : 0];
 #pragma unroll
-                for (int u = 0; u < ITP; ++u) {
-                    const int k = 2 * (subk + tp * u);
-                    const int kk = k < n ? k : 0;
-                    xp[u] = *reinterpret_cast<const double2*>(&sVt[vpi * n + kk]); xq[u] = *reinterpret_cast<const double2*>(&sVt[vqi * n + kk]);
+                    for (int u = 0; u < ITPT; ++u) {
+                        const int k = 2 * (subk + tp * u);
+                        const int kk = k < n ? k : 0;
+                        xp[u] = *reinterpret_cast<const double2*>(&sVt[vpi * n + kk]); xq[u] = *reinterpret_cast<const double2*>(&sVt[vqi * n + kk]);
+                    }
                 }
                 // ---- the thread's pair-blocks / diagonal blocks (items are independent: any order, any owner, same bits) ----
 #pragma unroll
@@ -576,7 +612,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                         int pi, qi, pj, qj;
                         rr_pair(i, t, n, pi, qi);
                         rr_pair(j, t, n, pj, qj);
-                        const double2 csi = s_csn[i], csj = s_csn[j];
+                        const double2 csi = csn[i], csj = csn[j];
                         auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
                         const int a00 = idx(pi, pj), a01 = idx(pi, qj), a10 = idx(qi, pj), a11 = idx(qi, qj);
                         const double b00 = sA[a00], b01 = sA[a01], b10 = sA[a10], b11 = sA[a11];
@@ -591,7 +627,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                         int pq, qq;
                         rr_pair(i, t, n, pq, qq);
                         const int app_i = pq * (pq + 1) / 2 + pq, aqq_i = qq * (qq + 1) / 2 + qq, apq_i = qq * (qq + 1) / 2 + pq;
-                        const double tn = s_tn[i];
+                        const double tn = s_tn2[par * MMAX + i];
                         const double app = sA[app_i], aqq = sA[aqq_i], apq = sA[apq_i];
                         sA[app_i] = fma(-tn, apq, app);
                         sA[aqq_i] = fma(tn, apq, aqq);
@@ -599,10 +635,12 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                     }
                 }
                 // ---- V <- V J ----
-                if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
+                if constexpr (kShadow) {
+                    vpend = true; t_prev = t; par ^= 1;   // this round's V rotations run beside the next parameter phase
+                } else if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
                     const double c = vcs.x, sn = vcs.y;
 #pragma unroll
-                    for (int u = 0; u < ITP; ++u) {
+                    for (int u = 0; u < ITPT; ++u) {
                         const int k = 2 * (subk + tp * u);
                         if (k < n) {
                             *reinterpret_cast<double2*>(&sVt[vpi * n + k]) = make_double2(fma(c, xp[u].x, -(sn * xq[u].x)), fma(c, xp[u].y, -(sn * xq[u].y)));
@@ -647,6 +685,12 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             }
             __syncthreads();
             SQ_STAMP(3);   // rotation phase + barrier
+        }
+    }
+    if constexpr (kShadow) {
+        if (vpend) {   // the V rotations of the last round (nobody has read V since)
+            if (tid >= VT0) v_rotate_rr(t_prev, s_csn + (par ^ 1) * MMAX);
+            __syncthreads();
         }
     }
     if (!converged) {
