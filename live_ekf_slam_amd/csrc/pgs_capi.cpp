@@ -53,6 +53,7 @@ struct pgs_handle {
     std::vector<hipEvent_t> gevents;
     int32_t* h_active = nullptr;               // pinned host: per-group active counts
     int p_notrim = 0;
+    int chol_ll = 1;                           // SLAM_PGS_CHOL_LL=0: the right-looking Cholesky of rounds 1-3
     int chol_threads = 0, chol_switch = 256;   // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces; else 256 while > chol_switch instances are active
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
     double path_ms[2] = {0.0, 0.0};           // profiled solve: ms in the separate SYRK launches / in the fused chain + SYRK launches
@@ -134,6 +135,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_GROUPS")) h->groups = atoi(e);
     if (const char* e = getenv("SLAM_PGS_CHOL_THREADS")) h->chol_threads = atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0);
     if (const char* e = getenv("SLAM_PGS_CHOL_SWITCH")) h->chol_switch = atoi(e);
+    if (const char* e = getenv("SLAM_PGS_CHOL_LL")) h->chol_ll = atoi(e) != 0;
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
@@ -340,6 +342,7 @@ int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lan
     active_hint *= p.lanes;   // the kernel variants below are chosen by the number of slots that run (an upper bound), not of instances
     p.syrk_notrim = h->p_notrim;
     p.chol_threads = h->chol_threads ? h->chol_threads : (active_hint > h->chol_switch ? 256 : 1024);
+    p.chol_ll = h->chol_ll;
     // 32x32 wavefront tiles by default; the 64x64 variant (more operand reuse, 4x fewer wavefronts) is kept for tuning
     p.syrk_wave_tile = h->syrk_tile ? h->syrk_tile : (active_hint >= h->syrk_switch ? 64 : 32);
     // instance-resident accumulators (tile code 1) from syrk_inst_switch active instances; its staging registers are sized for LD <= 448

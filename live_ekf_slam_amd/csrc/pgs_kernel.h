@@ -16,6 +16,7 @@ struct PgsParams {
     int32_t N;                         // poses in the graph now (timestep + 1), the same for every instance
     int32_t b_off, b_cnt;              // LM kernels: the launch covers instances [b_off, b_off + b_cnt) (one solve group)
     int32_t chol_threads;              // 1024 or 256: workgroup size of the dense Cholesky of the next trial
+    int32_t chol_ll;                   // 1: the 1024-thread Cholesky runs left-looking (pgs_chol_ll_kernel), 0: right-looking
     int32_t syrk_notrim;               // experiment: do not trim the k range (tiles of an instance then march in step)
     int32_t syrk_wave_tile;            // 64 or 32: SYRK variant of the next trial (chosen by the host from the active count)
     int32_t fused;                     // 0: chain and SYRK are two launches; 2 | 3 | 4: one (pgs_chain_syrk_kernel), that many workgroups per instance

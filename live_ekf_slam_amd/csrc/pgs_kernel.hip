@@ -1432,6 +1432,199 @@ __global__ __launch_bounds__(CTPB) void pgs_chol_kernel(const PgsParams p) {
 #undef PGS_STAMP
 }
 
+// The same factorisation LEFT-LOOKING (round 4).  The right-looking kernel above reads, updates and writes back the whole trailing matrix
+// at every panel step: ~22 dependent read-modify-write round trips through L2 per element, a panel solve that must wait for the trailing
+// update before it, and 0.18 of the 0.50 ms of a trial in that update alone.  Here panel j is formed when it is needed,
+//     C(rows >= j0, 16 columns)  =  S  -  L[rows, 0 : j0] L[j0 : j0+16, 0 : j0]^T ,
+// as ONE chain of v_mfma_f64_16x16x4_f64 per 16 x 16 tile (the rows of L it reads were written panels ago; the 16 block rows are staged in
+// LDS once per panel for all tiles), stays on chip through the factorisation of its diagonal block and its panel solve, and is written to
+// memory once, as L.  Per element the arithmetic is the SAME chain of fused multiply-adds in ascending k as before (the right-looking
+// kernel rounds to fp64 between panels exactly where this chain does), the diagonal block and the panel solve are the same code: the
+// factor is bit-identical to the right-looking kernel's (SLAM_PGS_CHOL_LL=0 keeps the old one for the comparison).
+#ifndef SLAM_PGS_LL_KU
+#define SLAM_PGS_LL_KU 4
+#endif
+__global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
+    constexpr int CTPB = 1024, NB = 16, NBL = 4, NW = CTPB / 64;
+    extern __shared__ double s_dyn[];
+    __shared__ double s_diag[NB], s_rdiag[NB];
+    __shared__ int s_fail;
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int LD = p.LD, m2 = 2 * p.M[b];
+    if (m2 == 0) return;
+    double* Sb = p.S + (size_t)b * LD * LD;
+    // dynamic LDS: the panel C [rows j0 .. m2][NB + 1] (its first 16 rows are the diagonal block), then the block rows of L [16][ldb]
+    double* const s_c = s_dyn;
+    double* const s_b = s_dyn + (size_t)(LD + 16) * (NB + 1);
+    double* const s_y = s_dyn;           // backward phase: y / x [m2]
+    auto SD = [&](int r, int c) -> double& { return s_c[r * (NB + 1) + c]; };
+    if (tid == 0) s_fail = 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
+#define PGS_STAMP(i) do { if (p.prof && tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } while (0)
+    const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
+    __syncthreads();
+    for (int j0 = 0; j0 < m2; j0 += NB) {
+        const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
+        const int R = m2 + 1 - j0;                 // rows of the panel: the block rows, the rows below, the rhs row
+        const int nt = (R + 15) >> 4;
+        int ldb = (j0 + 3) & ~3;                   // row length of the staged block rows: a multiple of 4 with an odd quotient (bank spread)
+        if (((ldb >> 2) & 1) == 0) ldb += 4;
+        // ---- stage L[j0 .. j0+15][0 .. j0) (rows beyond m2: clamped, their products are never stored) ----
+        for (int e = tid; e < 16 * j0; e += CTPB) {
+            const int r = e / j0, k = e - r * j0;
+            const int rr = j0 + r <= m2 ? j0 + r : m2;
+            s_b[r * ldb + k] = Sb[(size_t)rr * LD + k];
+        }
+        __syncthreads();
+        // ---- C tiles: acc = S - sum_k L[row][k] L[j0 + col][k], one wavefront per tile at a time.  A lane fetches FOUR consecutive k of
+        //      its row with one 32-byte request (the four k-lanes of a row together read one whole 128-byte line; 8-byte requests at
+        //      k0 + 4 q + kq touched every line four times and the L2 traffic of this phase was what it cost), so MFMA step q of a
+        //      16-k block takes k = k0 + 4 kq + q from lane kq: within a block the sum runs over k in the order (0, 4, 8, 12), (1, 5, 9,
+        //      13), ... instead of ascending - a different (fixed) rounding order than the right-looking kernel's. ----
+        typedef double dbl4v_t __attribute__((ext_vector_type(4)));
+        constexpr int KU = SLAM_PGS_LL_KU;                      // 16-k blocks in flight per lane
+        for (int tr = w; tr < nt; tr += NW) {
+            const int r0 = j0 + 16 * tr;
+            dbl4_t acc;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = r0 + kq + 4 * r4, c = j0 + cl;
+                acc[r4] = (r <= m2 && c <= r && c < m2) ? Sb[(size_t)r * LD + c] : 0.0;
+            }
+            const int ar = r0 + cl <= m2 ? r0 + cl : m2;        // A-operand row of this lane (clamped)
+            const double* __restrict__ arow = Sb + (size_t)ar * LD + 4 * kq;
+            const double* __restrict__ brow = s_b + cl * ldb + 4 * kq;
+            int k0 = 0;
+#pragma unroll 1
+            for (; k0 + 16 * KU <= j0; k0 += 16 * KU) {
+                dbl4v_t av[KU];
+#pragma unroll
+                for (int u = 0; u < KU; ++u) av[u] = *reinterpret_cast<const dbl4v_t*>(arow + k0 + 16 * u);
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][q], brow[k0 + 16 * u + q], acc, 0, 0, 0);
+            }
+#pragma unroll 1
+            for (; k0 < j0; k0 += 16) {
+                const dbl4v_t a1 = *reinterpret_cast<const dbl4v_t*>(arow + k0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[q], brow[k0 + q], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rl = 16 * tr + kq + 4 * r4;             // row of the panel
+                if (rl < R) SD(rl, cl) = acc[r4];
+            }
+        }
+        __syncthreads();
+        PGS_STAMP(3);   // panel formation (the trailing update of the right-looking kernel)
+        {   // factor the diagonal block (rows 0 .. nb-1 of the panel) on an NB x NB thread grid: column by column, two barriers each
+            const int r = tid >> NBL, c2 = tid & (NB - 1);
+            for (int c = 0; c < nb; ++c) {
+                if (tid < NB * NB && c2 == c && r >= c && r < nb) {
+                    const double d = SD(c, c);
+                    if (r == c) {
+                        if (!(d > 0.0)) s_fail = 1;
+                        const double sd = sqrt(d > 0.0 ? d : 1.0);
+                        s_diag[c] = sd; s_rdiag[c] = 1.0 / sd;
+                    } else {
+                        SD(r, c) = SD(r, c) / sqrt(d > 0.0 ? d : 1.0);
+                    }
+                }
+                __syncthreads();
+                if (tid < NB * NB && r > c && c2 > c && c2 <= r && r < nb) SD(r, c2) = SD(r, c2) - SD(r, c) * SD(c2, c);
+                __syncthreads();
+            }
+            if (tid < nb) SD(tid, tid) = s_diag[tid];
+        }
+        __syncthreads();
+        {   // the factored block goes to memory
+            const int r = tid >> NBL, c = tid & (NB - 1);
+            if (r < nb && c <= r) Sb[(size_t)(j0 + r) * LD + j0 + c] = SD(r, c);
+        }
+        PGS_STAMP(1);
+        for (int rr = nb + tid; rr < R; rr += CTPB) {   // panel solve: row <- row * L_block^-T, written to memory as L
+            double x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[c] = c < nb ? SD(rr, c) : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c < nb) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        if (k < c) v -= x[k] * SD(c, k);
+                    x[c] = v * s_rdiag[c];
+                }
+                asm volatile("" ::: "memory");   // keep the LDS reads of later columns from being hoisted (register pressure)
+            }
+            double* row = Sb + (size_t)(j0 + rr) * LD + j0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c < nb) row[c] = x[c];
+        }
+        __syncthreads();   // L of this panel is in memory before the next panel's tiles read it; s_c / s_b are free again
+        PGS_STAMP(2);
+    }
+    if (s_fail) { if (tid == 0) p.solve_ok[b] = 0; return; }
+    // backward substitution  L^T x = y  (y = row 2M of the factored matrix), blocks from the bottom.  Nothing a block step loads depends on
+    // the solution so far, so the loads leave the dependent chain: the 16 rows of L a thread needs for the update of its y[c] are requested
+    // BEFORE the block's 16-step solve and used after it, the next block's diagonal block one iteration ahead (the right-looking kernel's
+    // loop paid two memory round trips per block: 5.9 of its 6 us); the solve multiplies by reciprocals of the diagonal formed in parallel.
+    __shared__ double s_d[NB][NB + 1];
+    for (int c = tid; c < m2; c += CTPB) s_y[c] = Sb[(size_t)m2 * LD + c];
+    const int nblk = (m2 + NB - 1) / NB;
+    double dreg = 0.0;
+    {
+        const int j0 = (nblk - 1) * NB, nb = m2 - j0;
+        const int r = tid >> NBL, c = tid & (NB - 1);
+        if (tid < NB * NB && r < nb && c <= r) dreg = Sb[(size_t)(j0 + r) * LD + j0 + c];
+    }
+    __syncthreads();
+    for (int bi = nblk - 1; bi >= 0; --bi) {
+        const int j0 = bi * NB;
+        const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
+        {
+            const int r = tid >> NBL, c = tid & (NB - 1);
+            if (tid < NB * NB && r < nb && c <= r) s_d[r][c] = dreg;
+        }
+        double lrow[NB];                       // L[j0 + k][c] for this thread's column c < j0 (m2 <= CTPB: one column per thread)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) lrow[k] = (tid < j0 && k < nb) ? Sb[(size_t)(j0 + k) * LD + tid] : 0.0;
+        if (bi > 0) {                          // the next block's diagonal block
+            const int r = tid >> NBL, c = tid & (NB - 1);
+            dreg = (tid < NB * NB && c <= r) ? Sb[(size_t)(j0 - NB + r) * LD + j0 - NB + c] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {   // lane k owns y[j0 + k]; x_c is broadcast from lane c
+            double yk = tid < nb ? s_y[j0 + tid] : 0.0;
+            const double rd = tid < nb ? 1.0 / s_d[tid][tid] : 0.0;
+            for (int c = nb - 1; c >= 0; --c) {
+                const double xc = __shfl(yk, c, 64) * __shfl(rd, c, 64);
+                if (tid == c) yk = xc;
+                if (tid < c) yk -= s_d[c][tid] * xc;
+            }
+            if (tid < nb) s_y[j0 + tid] = yk;
+        }
+        __syncthreads();
+        if (tid < j0) {   // y[c] -= sum_k L[j0+k][c] x[j0+k]
+            double v = s_y[tid];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v -= lrow[k] * s_y[j0 + (k < nb ? k : 0)];
+            s_y[tid] = v;
+        }
+        __syncthreads();
+    }
+    PGS_STAMP(4);
+    double* dlb = p.dl + (size_t)b * p.L_max * 2;
+    for (int c = tid; c < m2; c += CTPB) dlb[c] = s_y[c];
+    if (p.prof && tid == 0)
+        for (int i = 0; i < 6; ++i) p.prof[(size_t)b * 8 + i] = tacc[i];
+#undef PGS_STAMP
+}
+
 // Pose step: H_pp dp = gp - E dl through the chain factor: forward  z_i = v_i - M_i z_{i-1}  (v = Linv u, M = Linv G),
 // backward  d_i = w_i - N_i d_{i+1}  (w = Linv^T z, N = Linv^T G_{i+1}^T).  Both are affine recurrences in a 3-vector,
 // so they are evaluated as a SCAN instead of 2 x N dependent steps: every thread prepares (v, M) of its poses, then one
@@ -1844,6 +2037,13 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
             (void)hipFuncSetAttribute((const void*)pgs_chol_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         });
         if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(nslot), dim3(256), lds, s, p); break; }
+        if (p.chol_ll && p.LD <= 448) {   // left-looking: the panel [LD + 16][17] and the staged block rows [16][<= LD + 8] (its staging registers are sized for LD <= 448)
+            const size_t lds_ll = lds + sizeof(double) * 16 * (size_t)(p.LD + 8);
+            static std::once_flag attr_ll;
+            std::call_once(attr_ll, []() { (void)hipFuncSetAttribute((const void*)pgs_chol_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+            hipLaunchKernelGGL(pgs_chol_ll_kernel, dim3(nslot), dim3(1024), lds_ll, s, p);
+            break;
+        }
         hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(nslot), dim3(1024), lds, s, p);
         break;
     }
