@@ -1463,88 +1463,145 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
 #define PGS_STAMP(i) do { if (p.prof && tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } while (0)
     const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
+    typedef double dbl4v_t __attribute__((ext_vector_type(4)));
+    constexpr int KU = SLAM_PGS_LL_KU;                      // 16-k blocks in flight per lane
+    constexpr int NTW = NW - 1, TPW = 2;                    // wavefronts that own tiles (1 .. 15), tiles per wavefront (nt <= 30: LD <= 448)
+    // PIPELINE over the panels.  A panel step is: complete the tiles (the last 16 k), factor the 16 x 16 diagonal block, solve the rows
+    // below, write L.  The factorisation of the diagonal block is a 16-step dependent chain - one wavefront's work (wave-synchronous on LDS,
+    // no workgroup barrier inside; it had thirty-two of them with sixteen wavefronts waiting at each) - and meanwhile wavefronts 1 .. 15 form
+    // the NEXT panel's tiles over every k that is final already (all columns before this panel's), so that when this panel's L is written
+    // only four MFMAs per tile are missing.  accn[] carries those partial sums (S minus the sum over k < j0) from one iteration to the next;
+    // per element the products are subtracted in the same order as without the pipeline.
+    dbl4_t accn[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) accn[q] = dbl4_t{0.0, 0.0, 0.0, 0.0};
+    // tile t of the panel that starts at row jb: S entries (lower triangle, columns < m2, rows <= m2) as an MFMA accumulator
+    auto tile_init = [&](int jb, int t) -> dbl4_t {
+        dbl4_t a;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = jb + 16 * t + kq + 4 * r4, c = jb + cl;
+            a[r4] = (r <= m2 && c <= r && c < m2) ? Sb[(size_t)r * LD + c] : 0.0;
+        }
+        return a;
+    };
+    if (w >= 1) {   // the first panel has no k range: its tiles are S itself
+        const int nt0 = (m2 + 1 + 15) >> 4;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) { const int t = (w - 1) + NTW * q; if (t < nt0) accn[q] = tile_init(0, t); }
+    }
     __syncthreads();
     for (int j0 = 0; j0 < m2; j0 += NB) {
         const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
         const int R = m2 + 1 - j0;                 // rows of the panel: the block rows, the rows below, the rhs row
         const int nt = (R + 15) >> 4;
+        // ---- phase F: the tiles of this panel get the last 16 k (columns j0-16 .. j0-1, written by the previous panel's solve) ----
+        if (w >= 1) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int t = (w - 1) + NTW * q;
+                if (t >= nt) continue;
+                dbl4_t acc = accn[q];
+                if (j0 > 0) {
+                    const int ar = j0 + 16 * t + cl <= m2 ? j0 + 16 * t + cl : m2, br = j0 + cl <= m2 ? j0 + cl : m2;
+                    const dbl4v_t a1 = *reinterpret_cast<const dbl4v_t*>(Sb + (size_t)ar * LD + j0 - 16 + 4 * kq);
+                    const dbl4v_t b1 = *reinterpret_cast<const dbl4v_t*>(Sb + (size_t)br * LD + j0 - 16 + 4 * kq);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[qq], b1[qq], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = 16 * t + kq + 4 * r4;
+                    if (rl < R) SD(rl, cl) = acc[r4];
+                }
+            }
+        }
+        __syncthreads();
+        PGS_STAMP(3);   // completion of the panel
+        // ---- phases D1 / D2: wavefront 0 factors the diagonal block (columns 0 .. 7, then 8 .. 15); wavefronts 1 .. 15 stage the NEXT
+        //      panel's block rows L[j0+16 .. j0+31][0 .. j0) (D1) and run its tiles over k < j0 (D2) ----
+        const int jn = j0 + NB;                    // next panel
+        const bool has_next = jn < m2;
+        const int ntn = has_next ? (m2 + 1 - jn + 15) >> 4 : 0;
         int ldb = (j0 + 3) & ~3;                   // row length of the staged block rows: a multiple of 4 with an odd quotient (bank spread)
         if (((ldb >> 2) & 1) == 0) ldb += 4;
-        // ---- stage L[j0 .. j0+15][0 .. j0) (rows beyond m2: clamped, their products are never stored) ----
-        for (int e = tid; e < 16 * j0; e += CTPB) {
-            const int r = e / j0, k = e - r * j0;
-            const int rr = j0 + r <= m2 ? j0 + r : m2;
-            s_b[r * ldb + k] = Sb[(size_t)rr * LD + k];
-        }
-        __syncthreads();
-        // ---- C tiles: acc = S - sum_k L[row][k] L[j0 + col][k], one wavefront per tile at a time.  A lane fetches FOUR consecutive k of
-        //      its row with one 32-byte request (the four k-lanes of a row together read one whole 128-byte line; 8-byte requests at
-        //      k0 + 4 q + kq touched every line four times and the L2 traffic of this phase was what it cost), so MFMA step q of a
-        //      16-k block takes k = k0 + 4 kq + q from lane kq: within a block the sum runs over k in the order (0, 4, 8, 12), (1, 5, 9,
-        //      13), ... instead of ascending - a different (fixed) rounding order than the right-looking kernel's. ----
-        typedef double dbl4v_t __attribute__((ext_vector_type(4)));
-        constexpr int KU = SLAM_PGS_LL_KU;                      // 16-k blocks in flight per lane
-        for (int tr = w; tr < nt; tr += NW) {
-            const int r0 = j0 + 16 * tr;
-            dbl4_t acc;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int r = r0 + kq + 4 * r4, c = j0 + cl;
-                acc[r4] = (r <= m2 && c <= r && c < m2) ? Sb[(size_t)r * LD + c] : 0.0;
-            }
-            const int ar = r0 + cl <= m2 ? r0 + cl : m2;        // A-operand row of this lane (clamped)
-            const double* __restrict__ arow = Sb + (size_t)ar * LD + 4 * kq;
-            const double* __restrict__ brow = s_b + cl * ldb + 4 * kq;
-            int k0 = 0;
-#pragma unroll 1
-            for (; k0 + 16 * KU <= j0; k0 += 16 * KU) {
-                dbl4v_t av[KU];
-#pragma unroll
-                for (int u = 0; u < KU; ++u) av[u] = *reinterpret_cast<const dbl4v_t*>(arow + k0 + 16 * u);
-#pragma unroll
-                for (int u = 0; u < KU; ++u)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][q], brow[k0 + 16 * u + q], acc, 0, 0, 0);
-            }
-#pragma unroll 1
-            for (; k0 < j0; k0 += 16) {
-                const dbl4v_t a1 = *reinterpret_cast<const dbl4v_t*>(arow + k0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[q], brow[k0 + q], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int rl = 16 * tr + kq + 4 * r4;             // row of the panel
-                if (rl < R) SD(rl, cl) = acc[r4];
-            }
-        }
-        __syncthreads();
-        PGS_STAMP(3);   // panel formation (the trailing update of the right-looking kernel)
-        {   // factor the diagonal block (rows 0 .. nb-1 of the panel) on an NB x NB thread grid: column by column, two barriers each
-            const int r = tid >> NBL, c2 = tid & (NB - 1);
-            for (int c = 0; c < nb; ++c) {
-                if (tid < NB * NB && c2 == c && r >= c && r < nb) {
-                    const double d = SD(c, c);
-                    if (r == c) {
-                        if (!(d > 0.0)) s_fail = 1;
-                        const double sd = sqrt(d > 0.0 ? d : 1.0);
-                        s_diag[c] = sd; s_rdiag[c] = 1.0 / sd;
-                    } else {
-                        SD(r, c) = SD(r, c) / sqrt(d > 0.0 ? d : 1.0);
-                    }
+        auto diag_cols = [&](int c_lo, int c_hi) {   // wavefront 0, wave-synchronous: lane = (row r, column group g: columns g, g+4, g+8, g+12)
+            const int r = lane & 15, g = lane >> 4;
+            for (int c = c_lo; c < c_hi && c < nb; ++c) {
+                const double d = SD(c, c);
+                const double sd = sqrt(d > 0.0 ? d : 1.0);
+                if (r == c && g == (c & 3)) {
+                    if (!(d > 0.0)) s_fail = 1;
+                    s_diag[c] = sd; s_rdiag[c] = 1.0 / sd;
                 }
-                __syncthreads();
-                if (tid < NB * NB && r > c && c2 > c && c2 <= r && r < nb) SD(r, c2) = SD(r, c2) - SD(r, c) * SD(c2, c);
-                __syncthreads();
+                if (g == (c & 3) && r > c && r < nb) SD(r, c) = SD(r, c) / sd;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const double lrc = SD(r, c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c2 = g + 4 * i;
+                    if (r > c && c2 > c && c2 <= r && r < nb) SD(r, c2) = SD(r, c2) - lrc * SD(c2, c);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            if (tid < nb) SD(tid, tid) = s_diag[tid];
+        };
+        if (w == 0) {
+            diag_cols(0, 8);
+        } else if (has_next) {
+            for (int e = tid - 64; e < 16 * j0; e += CTPB - 64) {
+                const int r = e / j0, k = e - r * j0;
+                const int rr = jn + r <= m2 ? jn + r : m2;
+                s_b[r * ldb + k] = Sb[(size_t)rr * LD + k];
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) { const int t = (w - 1) + NTW * q; if (t < ntn) accn[q] = tile_init(jn, t); }
         }
         __syncthreads();
-        {   // the factored block goes to memory
-            const int r = tid >> NBL, c = tid & (NB - 1);
-            if (r < nb && c <= r) Sb[(size_t)(j0 + r) * LD + j0 + c] = SD(r, c);
+        if (w == 0) {
+            diag_cols(8, 16);
+            if (lane < nb) SD(lane, lane) = s_diag[lane];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < NB * NB; e += 64) {   // the factored block goes to memory
+                const int r = e >> NBL, c = e & (NB - 1);
+                if (r < nb && c <= r) Sb[(size_t)(j0 + r) * LD + j0 + c] = SD(r, c);
+            }
+        } else if (has_next) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int t = (w - 1) + NTW * q;
+                if (t >= ntn) continue;
+                dbl4_t acc = accn[q];
+                const int ar = jn + 16 * t + cl <= m2 ? jn + 16 * t + cl : m2;   // A-operand row of this lane (clamped)
+                const double* __restrict__ arow = Sb + (size_t)ar * LD + 4 * kq;
+                const double* __restrict__ brow = s_b + cl * ldb + 4 * kq;
+                int k0 = 0;
+#pragma unroll 1
+                for (; k0 + 16 * KU <= j0; k0 += 16 * KU) {
+                    dbl4v_t av[KU];
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) av[u] = *reinterpret_cast<const dbl4v_t*>(arow + k0 + 16 * u);
+#pragma unroll
+                    for (int u = 0; u < KU; ++u)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][qq], brow[k0 + 16 * u + qq], acc, 0, 0, 0);
+                }
+#pragma unroll 1
+                for (; k0 < j0; k0 += 16) {
+                    const dbl4v_t a1 = *reinterpret_cast<const dbl4v_t*>(arow + k0);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[qq], brow[k0 + qq], acc, 0, 0, 0);
+                }
+                accn[q] = acc;
+            }
         }
-        PGS_STAMP(1);
+        __syncthreads();
+        PGS_STAMP(1);   // diagonal block (+ the next panel's tiles beside it)
+        // (Measured and dropped: the panel solve as 4 MFMAs per tile against the INVERSE of the diagonal block, and the backward substitution
+        // as a product with it - panel solve 105 -> 18 us, backward 67 -> 44 us per factorisation, but forming the inverse costs wavefront 0,
+        // already the long pole of the diagonal phase, 5 us per block: 414 -> 457 us in all.)
         for (int rr = nb + tid; rr < R; rr += CTPB) {   // panel solve: row <- row * L_block^-T, written to memory as L
             double x[NB];
 #pragma unroll
@@ -1565,7 +1622,7 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
             for (int c = 0; c < NB; ++c)
                 if (c < nb) row[c] = x[c];
         }
-        __syncthreads();   // L of this panel is in memory before the next panel's tiles read it; s_c / s_b are free again
+        __syncthreads();   // L of this panel is in memory before the next panel's tiles read its columns; s_c is free again
         PGS_STAMP(2);
     }
     if (s_fail) { if (tid == 0) p.solve_ok[b] = 0; return; }
