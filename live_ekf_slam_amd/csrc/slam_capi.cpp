@@ -197,6 +197,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.b_off = 0; p.b_cnt = h->B;
     p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
     p.rot_tab = h->drot;
+    p.quad_tab = h->drot ? h->drot + slam::kUkfRotTabEntries : nullptr;
     p.khist = h->dkhist;
     p.big_ws = h->dbigws;
     p.prof = (h->dbg & 4) ? h->dprof : nullptr;
@@ -366,7 +367,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvt, sizeof(double) * B * h->pstride) : hipSuccess,
         (kind == SLAM_UKF_SLAM && L_max > slam::kUkfLdsMaxLandmarks) ? hipMalloc(&h->dbigws, sizeof(double) * B * 2 * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvage, sizeof(int32_t) * B) : hipSuccess,
-        (kind != SLAM_EKF_SLAM && h->n_max <= 44) ? hipMalloc(&h->drot, sizeof(uint4) * slam::kUkfRotTabEntries) : hipSuccess,
+        (kind != SLAM_EKF_SLAM && h->n_max <= 44) ? hipMalloc(&h->drot, sizeof(uint4) * (slam::kUkfRotTabEntries + slam::kUkfQuadTabEntries)) : hipSuccess,
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -388,6 +389,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         h->dnsq ? hipMemsetAsync(h->dnsq, 0, sizeof(int32_t) * B, h->stream) : hipSuccess,
         h->dprof ? hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * slam::kEkfProfSlots * B, h->stream) : hipSuccess,
         h->drot ? slam::launch_ukf_rot_table(h->drot, h->stream) : hipSuccess,
+        h->drot ? slam::launch_ukf_quad_table(h->drot + slam::kUkfRotTabEntries, h->stream) : hipSuccess,
     };
     for (hipError_t ee : zs)
         if (ee != hipSuccess) {

@@ -11,6 +11,7 @@
 #include "ukf_kernel.h"
 
 #include "../../include/slam_batch.h"
+#include "jacobi_schedule.h"
 #include "sim_device.h"
 #include "slam_math.h"
 #include "slam_rng.h"
@@ -114,11 +115,9 @@ __global__ __launch_bounds__(kTpb) void ukf_big_sqrt_kernel(const UkfStepParams 
         if (!__syncthreads_or(live)) { converged = true; sweeps_done = sweep; break; }
 #pragma unroll 1
         for (int t = 0; t < n - 1; ++t) {
-            for (int k = tid; k < m; k += kTpb) {   // rotation parameters of this round's pairs (round-robin: position 0 fixed)
-                const int a = (k == 0) ? 0 : 1 + ((k - 1 + t) % (n - 1));
-                const int k2 = n - 1 - k;
-                const int bq = 1 + ((k2 - 1 + t) % (n - 1));
-                const int pi = a < bq ? a : bq, qi = a < bq ? bq : a;
+            for (int k = tid; k < m; k += kTpb) {   // rotation parameters of this round's pairs (jacobi_schedule.h)
+                int pi, qi;
+                jacobi_pair(k, t, n, pi, qi);
                 const double app = A[(size_t)pi * n + pi], aqq = A[(size_t)qi * n + qi], apq = A[(size_t)qi * n + pi];
                 double c = 1.0, s = 0.0, tt = 0.0;
                 const double g = 100.0 * fabs(apq);

@@ -51,6 +51,9 @@ struct UkfStepParams {
     // offsets of every operand a thread touches in round t at state size n (built once by launch_ukf_rot_table); NULL = the
     // kernel derives them from the round-robin schedule itself, as the other variants do
     const uint4* rot_tab;
+    // the same for the state sizes divisible by four, whose schedule (jacobi_schedule.h) the kernel walks in PASSES of two rounds
+    // (three in the first pass of a sweep): [n / 4][pass < 21][thread 256] x 32 bytes (launch_ukf_quad_table)
+    const uint4* quad_tab;
     // workload statistics (optional): [0..7] instance-steps by detections in the message (7 = seven or more), [8] Jacobi sweeps
     // that rotated something, [9] eigen-decompositions (slam_k_histogram / slam_ukf_sweep_stats)
     unsigned long long* khist;
@@ -63,6 +66,10 @@ struct UkfStepParams {
 static constexpr int kUkfRotRounds = 43, kUkfRotThreads = 256, kUkfRotSizes = 23;   // n = 0, 2, ..., 44
 static constexpr size_t kUkfRotTabEntries = (size_t)kUkfRotSizes * kUkfRotRounds * kUkfRotThreads;
 hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream);
+// Pass table for ukf_sqrt_kernel<44, 256> at n = 4, 8, ..., 44: kUkfQuadTabEntries uint4 entries (2 MB), built on the host
+static constexpr int kUkfQuadPasses = 21, kUkfQuadSizes = 12;   // block rounds T = 0 .. n / 2 - 2; n / 4 = 0 .. 11
+static constexpr size_t kUkfQuadTabEntries = (size_t)kUkfQuadSizes * kUkfQuadPasses * kUkfRotThreads * 2;
+hipError_t launch_ukf_quad_table(uint4* tab, hipStream_t stream);
 
 static constexpr int kUkfLdsMaxLandmarks = 50;   // n = 4 + 2L <= 104: the fast kernels keep A, V^T and sqtP of an instance in LDS
 static constexpr int kUkfMaxLandmarks = 200;     // beyond: ukf_big_kernel.hip, every n x n object in HBM / L2 (slow, bit-identical)

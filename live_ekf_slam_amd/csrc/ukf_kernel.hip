@@ -21,7 +21,10 @@
 
 #include <stdlib.h>
 
+#include <vector>
+
 #include "../../include/slam_batch.h"
+#include "jacobi_schedule.h"
 #include "sim_device.h"
 #include "slam_math.h"
 #include "slam_rng.h"
@@ -77,6 +80,15 @@ __device__ __forceinline__ float yaw_of(double c, double s) {  // (float) remain
     return (float)remainder(det_atan2(s, c), kTwoPi);
 }
 
+// a double from another lane of the same group of four (DPP quad_perm; every lane of the group must be active)
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double block_max(double v, double* s_red, int tid, int tpb) {
     for (int o = 32; o > 0; o >>= 1) {
         const double w = __shfl_down(v, o);
@@ -88,19 +100,6 @@ __device__ __forceinline__ double block_max(double v, double* s_red, int tid, in
     double r = s_red[0];
     for (int i = 1; i < tpb / 64; ++i) r = r > s_red[i] ? r : s_red[i];
     return r;
-}
-
-// round-robin schedule of the parallel-order Jacobi: indices (p < q) of pair k in round t of a sweep (position 0 fixed)
-__device__ __forceinline__ void rr_pair(int k, int t, int n, int& p, int& q) {
-    const int nm1 = n - 1;
-    int x = k - 1 + t;
-    if (x >= nm1) x -= nm1;
-    const int a = (k == 0) ? 0 : 1 + x;
-    int y = nm1 - k - 1 + t;
-    if (y >= nm1) y -= nm1;
-    const int bq = 1 + y;
-    p = a < bq ? a : bq;
-    q = a < bq ? bq : a;
 }
 
 }  // namespace
@@ -185,18 +184,105 @@ hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Pass table of the state sizes divisible by four (round 4).  jacobi_schedule.h pairs the n / 2 blocks of two consecutive
+// indices by the circle method; a block round ("pass") T holds n / 4 QUADRUPLES (a, b | c, d) and two rounds of the schedule
+// - (a, c) (b, d), then (a, d) (b, c); pass 0 also the in-block round (a, b) (c, d) before them - which touch nothing outside the
+// quadruple's four rows / columns.  The kernel therefore reads every element of A and V once per PASS, not per round:
+//   * the 4 x 4 block of A between quadruples I > J belongs to four adjacent lanes, lane 2 i + j holding rows (pair i of I) x
+//     columns (pair j of J); between the two rounds the lanes swap three of their four elements by DPP quad_perm;
+//   * a V item is (quadruple, 16-byte pair of columns k): four rows of V^T through all the rotations of the pass;
+//   * the diagonal 4 x 4 block of a quadruple belongs to two PARAMETER lanes, one per pair of the round: parameters from its pair's
+//     three elements, the pair's diagonal block, then (lane 1) the cross block with both rotations, round after round through LDS
+//     (one wavefront's LDS accesses execute in order).  As in the round-robin table path this runs a pass ahead, in wavefront 0,
+//     which also owns the "critical" blocks - the ones that hold the next pass's pivots: the cross block of next quadruple (X, Y)
+//     lies in the block between the current quadruples of X and of Y.  One barrier per pass.
+// Entry (32 bytes = w[0..7]) of thread tid in pass T at size n:
+//   w7 = kind (0 none, 1 block lane) | I << 8 | J << 16 | i << 24 | j << 25
+//   block lane: w0 w1 = LDS byte offsets of its four elements in the first round of the pass (e00 | e01 << 16, e10 | e11 << 16),
+//               w2 w3 = in the second round, w4 w5 = in the in-block round (pass 0)
+//   w6 = blocks X | Y << 8 of the thread's two V items (second item << 16), 0xff = none (threads 64 ..); lanes 2 q + u < n / 2 of
+//        wavefront 0: the blocks of quadruple q, whose parameter lanes they are
+// ------------------------------------------------------------------------------------------------------------------
+hipError_t launch_ukf_quad_table(uint4* tab, hipStream_t stream) {
+    std::vector<uint32_t> h(kUkfQuadTabEntries * 4, 0u);
+    auto idx = [](int r, int c) { return (unsigned)(8 * (r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r)); };
+    for (int n = 4; n <= 4 * (kUkfQuadSizes - 1); n += 4) {
+        const int m = n / 2, mq = n / 4;
+        for (int T = 0; T < m - 1; ++T) {
+            int X[kUkfQuadSizes], Y[kUkfQuadSizes], quad_of[2 * kUkfQuadSizes];
+            for (int q = 0; q < mq; ++q) { rr_pair(q, T, m, X[q], Y[q]); quad_of[X[q]] = q; quad_of[Y[q]] = q; }
+            // owner lanes of the off-diagonal blocks: critical ones in wavefront 0 (lanes 16 + 4 c), the others from thread 64 on
+            int owner[kUkfQuadSizes][kUkfQuadSizes];
+            for (int i = 0; i < mq; ++i) for (int j = 0; j < mq; ++j) owner[i][j] = -1;
+            const int Tn = T + 1 < m - 1 ? T + 1 : 0;
+            int ncrit = 0;
+            for (int q = 0; q < mq && mq > 1; ++q) {
+                int xn, yn;
+                rr_pair(q, Tn, m, xn, yn);
+                int I = quad_of[xn], J = quad_of[yn];
+                if (I < J) { const int t = I; I = J; J = t; }
+                if (I != J && owner[I][J] < 0) owner[I][J] = 4 * ncrit++;
+            }
+            int nother = 0;
+            for (int I = 1; I < mq; ++I) for (int J = 0; J < I; ++J) if (owner[I][J] < 0) owner[I][J] = 64 + 4 * nother++;
+            if (4 * ncrit > 64 || 64 + 4 * nother > kUkfRotThreads) return hipErrorInvalidValue;
+            uint32_t* const base = h.data() + ((size_t)(n / 4) * kUkfQuadPasses + T) * kUkfRotThreads * 8;
+            for (int tid = 0; tid < kUkfRotThreads; ++tid) { base[8 * tid + 6] = 0xffffffffu; }
+            for (int q = 0; q < mq; ++q)   // parameter lanes 2 q + u (they are block lanes as well): the blocks of their quadruple
+                for (int u = 0; u < 2; ++u) base[8 * (2 * q + u) + 6] = 0xffff0000u | (unsigned)X[q] | ((unsigned)Y[q] << 8);
+            for (int I = 1; I < mq; ++I)
+                for (int J = 0; J < I; ++J) {
+                    const int row[4] = {2 * X[I], 2 * X[I] + 1, 2 * Y[I], 2 * Y[I] + 1};
+                    const int col[4] = {2 * X[J], 2 * X[J] + 1, 2 * Y[J], 2 * Y[J] + 1};
+                    for (int i = 0; i < 2; ++i)
+                        for (int j = 0; j < 2; ++j) {
+                            uint32_t* w = base + 8 * (owner[I][J] + 2 * i + j);
+                            auto four = [&](int r0, int r1, int c0, int c1, uint32_t* o) {
+                                o[0] = idx(row[r0], col[c0]) | (idx(row[r0], col[c1]) << 16);
+                                o[1] = idx(row[r1], col[c0]) | (idx(row[r1], col[c1]) << 16);
+                            };
+                            four(i, i + 2, j, j + 2, w + 0);
+                            four(i, 3 - i, j, 3 - j, w + 2);
+                            four(2 * i, 2 * i + 1, 2 * j, 2 * j + 1, w + 4);
+                            w[7] = 1u | ((unsigned)I << 8) | ((unsigned)J << 16) | ((unsigned)i << 24) | ((unsigned)j << 25);
+                        }
+                }
+            for (int tid = 64; tid < kUkfRotThreads; ++tid) {   // V items: (quadruple, pair of columns), n / 2 pairs per quadruple
+                uint32_t v = 0xffffffffu;
+                for (int u = 1; u >= 0; --u) {
+                    const int it = tid - 64 + (kUkfRotThreads - 64) * u, Q = it / m;
+                    v = (v << 16) | (Q < mq ? ((unsigned)X[Q] | ((unsigned)Y[Q] << 8)) : 0xffffu);
+                }
+                base[8 * tid + 6] = v;
+            }
+        }
+    }
+    hipError_t e = hipMemcpyAsync(tab, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // h is a pageable host array that goes out of scope
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // nearestSPD + sqrt
 // ------------------------------------------------------------------------------------------------------------------
 // PROF = true compiles the phase timers in (a separate instantiation, launched only when the debug buffer is attached:
 // as a run-time option they cost the production kernel 20 VGPRs = one wavefront per SIMD of occupancy, -9 % steps/s).
-template <int NMAX, int TPB, bool PROF = false>
+// SCHED (the variant with the schedule tables, <44, 256>): 1 = only the instances whose state size is divisible by four (pass table),
+// 2 = only the others (round-robin table), 0 = every instance.  Two launches per step, each instance runs in one of them: the two
+// table paths in ONE kernel need 101 VGPRs, apart 84 and 76 - and six workgroups per CU have 80.
+template <int NMAX, int TPB, bool PROF = false, int SCHED = 0>
 __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF_SQRT_WG : 1) void ukf_sqrt_kernel(const UkfStepParams p) {
     constexpr int MMAX = NMAX / 2;
+    if constexpr (SCHED == 1) { if (p.M[blockIdx.x + p.b_off] & 1) return; }   // n = 4 + 2 M
+    if constexpr (SCHED == 2) { if (!(p.M[blockIdx.x + p.b_off] & 1)) return; }
     __shared__ double sA[NMAX * (NMAX + 1) / 2];   // packed lower triangle: A(r,c), r >= c, at r(r+1)/2 + c
     __shared__ __attribute__((aligned(16))) double sVt[NMAX * NMAX];   // V transposed: Vt[p*n + k] = V(k, p)
     __shared__ double s_cs[MMAX], s_sn[MMAX], s_tn[MMAX], s_sd[NMAX];
     __shared__ int s_pp[MMAX], s_qq[MMAX];
-    __shared__ double2 s_csn[2 * MMAX];           // (c, s) of this round's rotations, one 16-byte read per consumer (table path: [round parity][pair])
+    constexpr bool kQuadLds = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB <= 2;   // the variants that walk the sizes divisible by four in passes of two rounds (kFast below)
+    __shared__ double2 s_csn[(kQuadLds ? 6 : 2) * MMAX];   // (c, s) of this round's rotations, one 16-byte read per consumer (table path: [round parity][pair]; pass table: [pass parity][round of the pass][pair])
+    __shared__ int s_qflag[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];   // passes: [pass parity][quadruple] any rotation of the pass that is not the identity
+    __shared__ int s_xy[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];      // passes without the table: [pass parity][quadruple] its blocks X | Y << 8
     __shared__ double s_tn2[2 * MMAX];            // table path: tan of the rotations, [round parity][pair]
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
@@ -362,10 +448,14 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     const bool vvalid = iv < m;
     constexpr int ITPT = ITB <= 2 ? (MMAX + ((TPB - VT0) / MMAX) - 1) / ((TPB - VT0) / MMAX) : 1;   // 16-byte pairs of V per thread
     // schedule table (see ukf_rot_table_kernel): this thread's column of the table for state size n, or NULL
+    const bool quad = kTab && (SCHED == 1 || (SCHED == 0 && (n & 3) == 0));   // state sizes divisible by four walk the schedule in passes (launch_ukf_quad_table)
     const uint4* const tabn = kTab ? p.rot_tab + (size_t)(n / 2) * kUkfRotRounds * kUkfRotThreads + tid : nullptr;   // the launcher checks rot_tab
     bool converged = false;
     uint4 te_next = make_uint4(0u, 0u, 0u, 0u);
-    if constexpr (kTab) te_next = tabn[0];
+    // (one pointer and one set of prefetch registers for both table paths: an instance walks one of them)
+    const uint4* const qtab = kTab ? (quad ? p.quad_tab + ((size_t)(n >> 2) * kUkfQuadPasses * kUkfRotThreads + tid) * 2 : tabn) : nullptr;   // + 2 * 256 * pass
+    uint4 qnb = make_uint4(0u, 0u, 0u, 0u);   // pass table: the thread's entry of the NEXT pass is (te_next, qnb), requested a pass ahead
+    if constexpr (kTab) { te_next = qtab[0]; if (quad) qnb = qtab[1]; }
     int par = 0;                            // table path: parity of the parameter buffers the current round reads
     auto v_rotate = [&](unsigned vz, const double2* csn) {   // V <- V J of one round, this thread's pair iv
         if (!vvalid) return;
@@ -396,7 +486,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         const double2 vcs = csn[iv];
         if (vcs.y == 0.0) return;
         int vpi, vqi;
-        rr_pair(iv, tr, n, vpi, vqi);
+        jacobi_pair(iv, tr, n, vpi, vqi);
         double2 xp[ITPT], xq[ITPT];
 #pragma unroll
         for (int u = 0; u < ITPT; ++u) {
@@ -445,7 +535,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     constexpr int NSC = kTab ? (NMAX * (NMAX - 1) / 2 + TPB - 1) / TPB : 1;   // strictly-lower elements per thread in the convergence scan
     const int nlow = n * (n - 1) / 2;
     unsigned scan_a[NSC], scan_b[NSC];      // byte offsets: element | A(c, c) << 16, A(r, r)
-    if constexpr (kTab) {
+    auto scan_addresses = [&]() {
 #pragma unroll
         for (int u = 0; u < NSC; ++u) {
             const int e = tid + TPB * u < nlow ? tid + TPB * u : 0;
@@ -456,13 +546,94 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             scan_a[u] = (unsigned)(8 * (r * (r + 1) / 2 + c)) | ((unsigned)(8 * (c * (c + 1) / 2 + c)) << 16);
             scan_b[u] = (unsigned)(8 * (r * (r + 1) / 2 + r));
         }
-    }
+    };
     if constexpr (kTab) {
         // wavefront 0 carries the longest dependent chain of a round (its items, then the next parameters): let it issue ahead
         if (tid < 64) __builtin_amdgcn_s_setprio(SLAM_UKF_PRIO);
     }
     int desc_tab = 3 << 16;                 // table path: this thread's item (diagonal block of pair tid, or the table's word)
     if constexpr (kTab) desc_tab = tid < m ? ((1 << 16) | (tid << 8)) : (int)te_next.w;
+    // ---- pass-table path: the thread's V items (quadruple, 16-byte pair of columns); fixed for the launch ----
+    int vitem[2] = {-1, -1};   // quadruple | pair of columns << 8, -1 = none
+    if constexpr (kTab) {
+        if (quad && tid >= 64) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = tid - 64 + (kUkfRotThreads - 64) * u, q = it / m;
+                if (q < (n >> 2)) vitem[u] = q | ((it - q * m) << 8);
+            }
+        }
+    }
+    // ---- pieces of the quadruple ("pass") paths, n divisible by four (launch_ukf_quad_table; jacobi_schedule.h) ----
+    constexpr int MQ = (MMAX + 1) / 2;
+    char* const sAb = reinterpret_cast<char*>(sA);
+    char* const sVb = reinterpret_cast<char*>(sVt);
+    auto ldA = [&](unsigned off) -> double { return *reinterpret_cast<const double*>(sAb + off); };
+    auto stA = [&](unsigned off, double v) { *reinterpret_cast<double*>(sAb + off) = v; };
+    // B' = R_i^T B R_j on a pair-block (rows: the pair with the higher index)
+    auto rot_block = [&](double& b00, double& b01, double& b10, double& b11, const double2 ri, const double2 rj) {
+        // (no test for identity rotations here: the oracle has none either, and a pass in which a whole quadruple rests is skipped as one)
+        const double ci = ri.x, si = ri.y, cj = rj.x, sj = rj.y;
+        const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
+        const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
+        b00 = fma(t00, cj, -(t01 * sj)); b01 = fma(t00, sj, t01 * cj);
+        b10 = fma(t10, cj, -(t11 * sj)); b11 = fma(t10, sj, t11 * cj);
+    };
+    // Parameter lane 2 q + u of wavefront 0, pair u of quadruple q = blocks (X, Y) of the pass that comes next: the pass's rounds
+    // one after the other on the quadruple's diagonal 4 x 4 block (a, b | c, d) = (2X, 2X+1 | 2Y, 2Y+1) IN LDS - parameters from the
+    // pair's three elements, the pair's diagonal block, then lane 1 the cross block (rows: pair 1) with both rotations.
+    //   round 0 (first pass of a sweep): pairs (a,b) (c,d), cross (c,d) x (a,b);  1: (a,c) (b,d), cross (b,d) x (a,c);  2: (a,d) (b,c), cross (b,c) x (a,d)
+    auto param_phase = [&](const unsigned xy, const bool first, const int parw, const int sweep) {
+        const int u = tid & 1, q = tid >> 1;
+        const unsigned a = 2u * (xy & 0xffu), c = 2u * ((xy >> 8) & 0xffu);
+        const unsigned ta = 4u * a * (a + 1u), tb = ta + 8u * (a + 1u), tc = 4u * c * (c + 1u), td = tc + 8u * (c + 1u);   // 8 * row (row + 1) / 2
+        const unsigned aa = ta + 8u * a, ba = tb + 8u * a, bb = ba + 8u, ca = tc + 8u * a, cb = ca + 8u, cc = tc + 8u * c;
+        const unsigned da = td + 8u * a, db = da + 8u, dc = td + 8u * c, dd = dc + 8u;
+        bool any = false;
+        auto round_of_pass = [&](const unsigned pp, const unsigned qq, const unsigned pq,
+                                 const unsigned x00, const unsigned x01, const unsigned x10, const unsigned x11, const int s) {
+            const double app = ldA(pp), aqq = ldA(qq), apq = ldA(pq);
+            double cr, sr, tr;
+            jacobi_param(app, aqq, apq, sweep, cr, sr, tr);
+            s_csn[(parw * 3 + s) * MMAX + tid] = make_double2(cr, sr);
+            stA(pp, fma(-tr, apq, app)); stA(qq, fma(tr, apq, aqq));
+            if (apq != 0.0) stA(pq, 0.0);
+            any = any || sr != 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // lane 1 reads lane 0's rotation
+            if (u == 1) {
+                const double2 r0 = s_csn[(parw * 3 + s) * MMAX + tid - 1];
+                double b00 = ldA(x00), b01 = ldA(x01), b10 = ldA(x10), b11 = ldA(x11);
+                rot_block(b00, b01, b10, b11, make_double2(cr, sr), r0);
+                stA(x00, b00); stA(x01, b01); stA(x10, b10); stA(x11, b11);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the next round reads what this one wrote
+        };
+        if (first) round_of_pass(u ? cc : aa, u ? dd : bb, u ? dc : ba, ca, cb, da, db, 0);
+        round_of_pass(u ? bb : aa, u ? dd : cc, u ? db : ca, ba, cb, da, dc, 1);
+        round_of_pass(u ? bb : aa, u ? cc : dd, u ? cb : da, ba, db, ca, dc, 2);
+        // any rotation of the quadruple in this pass that is not the identity?  (both lanes of the quadruple: lane ^ 1)
+        const int mine = any ? 1 : 0;
+        const int both = mine | __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xf, 0xf, true);
+        if (u == 0) s_qflag[parw * MQ + q] = both;
+    };
+    // V <- V J for a pass: rows a, b, c, d of V^T (quadruple Q = blocks xy), the 16-byte pair kp of columns, through every rotation of the pass
+    auto v_item = [&](const int Q, const int kp, const unsigned xy, const bool first, const double2* const cs) {
+        char* const ra = sVb + 16 * kp + 16 * n * (int)(xy & 0xffu);
+        char* const rc = sVb + 16 * kp + 16 * n * (int)(xy >> 8);
+        double2 va = *reinterpret_cast<const double2*>(ra), vb = *reinterpret_cast<const double2*>(ra + 8 * n);
+        double2 vc = *reinterpret_cast<const double2*>(rc), vd = *reinterpret_cast<const double2*>(rc + 8 * n);
+        auto rot_v = [&](double2& xp, double2& xq, const double2 r) {
+            const double c = r.x, sn = r.y;
+            const double2 np = make_double2(fma(c, xp.x, -(sn * xq.x)), fma(c, xp.y, -(sn * xq.y)));
+            xq = make_double2(fma(sn, xp.x, c * xq.x), fma(sn, xp.y, c * xq.y));
+            xp = np;
+        };
+        if (first) { rot_v(va, vb, cs[2 * Q]); rot_v(vc, vd, cs[2 * Q + 1]); }
+        rot_v(va, vc, cs[MMAX + 2 * Q]); rot_v(vb, vd, cs[MMAX + 2 * Q + 1]);
+        rot_v(va, vd, cs[2 * MMAX + 2 * Q]); rot_v(vb, vc, cs[2 * MMAX + 2 * Q + 1]);
+        *reinterpret_cast<double2*>(ra) = va; *reinterpret_cast<double2*>(ra + 8 * n) = vb;
+        *reinterpret_cast<double2*>(rc) = vc; *reinterpret_cast<double2*>(rc + 8 * n) = vd;
+    };
 #pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: every off-diagonal element is exactly zero OR would only be zeroed by the small-element rule
@@ -475,6 +646,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             // once (the two-threads-per-row walk below left two thirds of the workgroup idle and each lane 22 dependent round trips)
             const char* const sAc = reinterpret_cast<const char*>(sA);
             double v[NSC], dp[NSC], dq[NSC];
+            scan_addresses();   // (once per sweep: kept across the sweep they were eight registers of a kernel that has 80)
 #pragma unroll
             for (int u = 0; u < NSC; ++u) {
                 v[u] = *reinterpret_cast<const double*>(sAc + (scan_a[u] & 0xffffu));
@@ -506,12 +678,133 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             if (tid == 0 && p.khist) { atomicAdd(&p.khist[8], (unsigned long long)sweep); atomicAdd(&p.khist[9], 1ull); }
             break;
         }
+        if constexpr (kTab) {
+            if (quad) {
+                // ======== pass-table path (n divisible by four): n / 2 - 1 passes of two rounds, the in-block round inside pass 0 ========
+                const int mq = n >> 2;
+#pragma unroll 1
+                for (int T = -1; T < m - 1; ++T) {   // T = -1: only the parameters of pass 0 (every later pass gets its own a pass ahead)
+                    const uint4 ea = te_next, eb = qnb;
+                    if (T >= 0) {
+                        const int Tn = T + 1 < m - 1 ? T + 1 : 0;
+                        te_next = qtab[(size_t)Tn * (2 * kUkfRotThreads)]; qnb = qtab[(size_t)Tn * (2 * kUkfRotThreads) + 1];
+                        const bool first = T == 0;
+                        const double2* const cs = s_csn + par * 3 * MMAX;
+                        const int* const qf = s_qflag + par * MQ;
+                        if ((eb.w & 3u) == 1u) {   // a lane of the 4 x 4 block between quadruples I > J
+                            const int I = (eb.w >> 8) & 0xff, J = (eb.w >> 16) & 0xff;
+                            const int si = 2 * I + (int)((eb.w >> 24) & 1u), sj = 2 * J + (int)((eb.w >> 25) & 1u);
+                            if (qf[I] | qf[J]) {   // (the same for the four lanes of the block)
+                                if (first) {
+                                    double g00 = ldA(eb.x & 0xffffu), g01 = ldA(eb.x >> 16), g10 = ldA(eb.y & 0xffffu), g11 = ldA(eb.y >> 16);
+                                    rot_block(g00, g01, g10, g11, cs[si], cs[sj]);
+                                    stA(eb.x & 0xffffu, g00); stA(eb.x >> 16, g01); stA(eb.y & 0xffffu, g10); stA(eb.y >> 16, g11);
+                                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the lanes of the block read each other's results below
+                                }
+                                double e00 = ldA(ea.x & 0xffffu), e01 = ldA(ea.x >> 16), e10 = ldA(ea.y & 0xffffu), e11 = ldA(ea.y >> 16);
+                                rot_block(e00, e01, e10, e11, cs[MMAX + si], cs[MMAX + sj]);
+                                // rows (i, i+2) x columns (j, j+2) -> rows (i, 3-i) x columns (j, 3-j): three of the four elements come from the other lanes
+                                e01 = dpp_quad<0xB1>(e01); e10 = dpp_quad<0x4E>(e10); e11 = dpp_quad<0x1B>(e11);
+                                rot_block(e00, e01, e10, e11, cs[2 * MMAX + si], cs[2 * MMAX + sj]);
+                                stA(ea.z & 0xffffu, e00); stA(ea.z >> 16, e01); stA(ea.w & 0xffffu, e10); stA(ea.w >> 16, e11);
+                            }
+                        }
+#pragma unroll 1
+                        for (int u = 0; u < 2; ++u) {   // V <- V J: four rows of V^T, a 16-byte pair of columns (one item at a time: registers)
+                            const int vi = u ? vitem[1] : vitem[0];
+                            if (vi < 0) continue;
+                            const int Q = vi & 0xff, kp = vi >> 8;
+                            if (!qf[Q]) continue;
+                            v_item(Q, kp, (eb.z >> (16 * u)) & 0xffffu, first, cs);
+                        }
+                    }
+                    // wavefront 0: the next pass's parameters, from what it has just written (its lanes < n / 2 carry their quadruple's blocks in w6)
+                    if (tid < 2 * mq && T + 1 < m - 1) param_phase(T < 0 ? eb.z : qnb.z, T < 0, par ^ 1, sweep);
+                    __syncthreads();
+                    SQ_STAMP(3);   // one pass (one barrier)
+                    if constexpr (PROF) { if (tid == 0 && T >= 0) sacc[5] += 2; }   // rounds
+                    par ^= 1;
+                }
+                continue;
+            }
+        }
+        if constexpr (kFast && !kTab) {
+            if ((n & 3) == 0) {
+                // ======== passes without the table (the other fast variants; L = 50 runs <104, 1024>): two barriers per pass ========
+                //   parameters of pass T (lanes 2 q + u of wavefront 0, on the diagonal 4 x 4 blocks in LDS) beside the V items of pass T - 1,
+                //   barrier, the 4 x 4 blocks of pass T (four adjacent lanes each, operand addresses from the quadruples' blocks), barrier
+                const int mq = n >> 2, nblk = mq * (mq - 1) / 2;
+                constexpr int NBU = (4 * (MQ * (MQ - 1) / 2) + TPB - 1) / TPB;                 // block-lane slots per thread
+                constexpr int NVU = (MQ * MMAX + (TPB - VT0) - 1) / (TPB - VT0);               // V item slots per thread (threads VT0 ..)
+                auto v_pass = [&](const int pv, const bool first) {
+                    if (tid < VT0) return;
+                    const double2* const cs = s_csn + pv * 3 * MMAX;
+#pragma unroll 1
+                    for (int u = 0; u < NVU; ++u) {
+                        const int it = tid - VT0 + (TPB - VT0) * u, Q = it / m;
+                        if (Q >= mq) break;
+                        if (!s_qflag[pv * MQ + Q]) continue;
+                        v_item(Q, it - Q * m, (unsigned)s_xy[pv * MQ + Q], first, cs);
+                    }
+                };
+                bool vp = false;
+#pragma unroll 1
+                for (int T = 0; T < m - 1; ++T) {
+                    const bool first = T == 0;
+                    if (tid < 2 * mq) {
+                        int X, Y;
+                        rr_pair(tid >> 1, T, m, X, Y);
+                        const unsigned xy = (unsigned)X | ((unsigned)Y << 8);
+                        if (!(tid & 1)) s_xy[par * MQ + (tid >> 1)] = (int)xy;
+                        param_phase(xy, first, par, sweep);
+                    }
+                    if (vp) v_pass(par ^ 1, T == 1);
+                    __syncthreads();
+                    SQ_STAMP(2);
+                    const double2* const cs = s_csn + par * 3 * MMAX;
+                    const int* const qf = s_qflag + par * MQ;
+#pragma unroll
+                    for (int ub = 0; ub < NBU; ++ub) {
+                        const int it = tid + TPB * ub, blk = it >> 2;
+                        if (blk >= nblk) continue;
+                        int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)blk)) * 0.5f);   // block (I, J), I > J: blk = I (I - 1) / 2 + J
+                        while (I * (I - 1) / 2 > blk) --I;
+                        while ((I + 1) * I / 2 <= blk) ++I;
+                        const int J = blk - I * (I - 1) / 2;
+                        if (!(qf[I] | qf[J])) continue;   // (the same for the four lanes of the block)
+                        const int li = (it >> 1) & 1, lj = it & 1, si = 2 * I + li, sj = 2 * J + lj;
+                        const unsigned xi = (unsigned)s_xy[par * MQ + I], xj = (unsigned)s_xy[par * MQ + J];
+                        const int rX = 2 * (int)(xi & 0xffu), rY = 2 * (int)(xi >> 8), cX = 2 * (int)(xj & 0xffu), cY = 2 * (int)(xj >> 8);
+                        if (first) {   // the in-block round: rows (2 i, 2 i + 1) x columns (2 j, 2 j + 1) of the block
+                            const int r0 = li ? rY : rX, c0 = lj ? cY : cX;
+                            double& g00 = AT(r0, c0); double& g01 = AT(r0, c0 + 1); double& g10 = AT(r0 + 1, c0); double& g11 = AT(r0 + 1, c0 + 1);
+                            double b00 = g00, b01 = g01, b10 = g10, b11 = g11;
+                            rot_block(b00, b01, b10, b11, cs[si], cs[sj]);
+                            g00 = b00; g01 = b01; g10 = b10; g11 = b11;
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the lanes of the block read each other's results below
+                        }
+                        double e00 = AT(rX + li, cX + lj), e01 = AT(rX + li, cY + lj), e10 = AT(rY + li, cX + lj), e11 = AT(rY + li, cY + lj);
+                        rot_block(e00, e01, e10, e11, cs[MMAX + si], cs[MMAX + sj]);
+                        e01 = dpp_quad<0xB1>(e01); e10 = dpp_quad<0x4E>(e10); e11 = dpp_quad<0x1B>(e11);   // rows (i, i+2) x columns (j, j+2) -> (i, 3-i) x (j, 3-j)
+                        rot_block(e00, e01, e10, e11, cs[2 * MMAX + si], cs[2 * MMAX + sj]);
+                        AT(rX + li, cX + lj) = e00; AT(rX + li, cY + 1 - lj) = e01; AT(rY + 1 - li, cX + lj) = e10; AT(rY + 1 - li, cY + 1 - lj) = e11;
+                    }
+                    __syncthreads();
+                    SQ_STAMP(3);
+                    if constexpr (PROF) { if (tid == 0) sacc[5] += 2; }   // rounds
+                    vp = true;
+                    par ^= 1;
+                }
+                if (vp) { v_pass(par ^ 1, m - 1 == 1); __syncthreads(); }   // the V items of the last pass (nobody has read V since)
+                continue;
+            }
+        }
 #pragma unroll 1
         for (int t = 0; t < n - 1; ++t) {
             // the table entry of this round was requested a round ago (the parameter lanes need it at once: waiting for it
             // here put an L2 round trip at the head of every round); the next round's is requested now
             const uint4 te = te_next;
-            if constexpr (kTab) te_next = tabn[(size_t)(t + 1 < n - 1 ? t + 1 : 0) * kUkfRotThreads];
+            if constexpr (kTab) te_next = qtab[(size_t)(t + 1 < n - 1 ? t + 1 : 0) * kUkfRotThreads];
             if constexpr (kTab) {
                 // ---- table path: ONE barrier per round (see ukf_item_of_thread) ----
                 if (sweep == 0 && t == 0) {   // parameters of the very first round (every later round's are computed a round ahead)
@@ -569,12 +862,10 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                 par ^= 1;
                 continue;
             }
-            if (tid < m) {  // rotation parameters of this round's pairs (round-robin: position 0 fixed)
+            if (tid < m) {  // rotation parameters of this round's pairs (jacobi_schedule.h)
                 const int k = tid;
-                const int a = (k == 0) ? 0 : 1 + ((k - 1 + t) % (n - 1));
-                const int k2 = n - 1 - k;
-                const int bq = 1 + ((k2 - 1 + t) % (n - 1));
-                const int pidx = a < bq ? a : bq, qidx = a < bq ? bq : a;
+                int pidx, qidx;
+                jacobi_pair(k, t, n, pidx, qidx);
                 double c, s, tt;
                 jacobi_param(AT(pidx, pidx), AT(qidx, qidx), AT(qidx, pidx), sweep, c, s, tt);
                 s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
@@ -594,7 +885,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                 double2 vcs = make_double2(1.0, 0.0);
                 double2 xp[ITPT], xq[ITPT];
                 if constexpr (!kShadow) {
-                    rr_pair(vvalid ? iv : 0, t, n, vpi, vqi);
+                    jacobi_pair(vvalid ? iv : 0, t, n, vpi, vqi);
                     vcs = csn[vvalid ? iv : 0];
 #pragma unroll
                     for (int u = 0; u < ITPT; ++u) {
@@ -610,8 +901,8 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                     const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
                     if (kind == 0) {
                         int pi, qi, pj, qj;
-                        rr_pair(i, t, n, pi, qi);
-                        rr_pair(j, t, n, pj, qj);
+                        jacobi_pair(i, t, n, pi, qi);
+                        jacobi_pair(j, t, n, pj, qj);
                         const double2 csi = csn[i], csj = csn[j];
                         auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
                         const int a00 = idx(pi, pj), a01 = idx(pi, qj), a10 = idx(qi, pj), a11 = idx(qi, qj);
@@ -625,7 +916,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                         }
                     } else if (kind == 1) {
                         int pq, qq;
-                        rr_pair(i, t, n, pq, qq);
+                        jacobi_pair(i, t, n, pq, qq);
                         const int app_i = pq * (pq + 1) / 2 + pq, aqq_i = qq * (qq + 1) / 2 + qq, apq_i = qq * (qq + 1) / 2 + pq;
                         const double tn = s_tn2[par * MMAX + i];
                         const double app = sA[app_i], aqq = sA[aqq_i], apq = sA[apq_i];
@@ -1212,9 +1503,12 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
             case 128: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 128>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;
             case 64: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 64>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
             default:
-                if (p.rot_tab == nullptr) return hipErrorInvalidValue;   // <44, 256> takes its operand addresses from the schedule table
+                if (p.rot_tab == nullptr || p.quad_tab == nullptr) return hipErrorInvalidValue;   // <44, 256> takes its operand addresses from the schedule tables
                 if (p.prof) hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, true>), dim3(p.b_cnt), dim3(256), 0, stream, p);
-                else hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p);
+                else {   // each instance runs in one of the two (see SCHED)
+                    hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, false, 1>), dim3(p.b_cnt), dim3(256), 0, stream, p);
+                    hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, false, 2>), dim3(p.b_cnt), dim3(256), 0, stream, p);
+                }
                 break;
         }
     } else if (nmax <= 104) {

@@ -42,6 +42,30 @@ constexpr int kUkfWarmMaxAge = 100;   // consecutive warm starts before a cold o
 // tau = (a_qq - a_pp) / (2 a_pq), t = sign(tau) / (|tau| + sqrt(tau^2 + 1)), c = 1 / sqrt(t^2 + 1), s = t c.  The default mode
 // (false) evaluates the same mathematics the way the kernel does (fused products, tau-free parameters) so that GPU == oracle
 // is a bit-exact statement; tests/test_oracle_ukf.py bounds the difference between the two over long trajectories.
+// The schedule: which index pairs (p < q) rotate together in round t = 0 .. n - 2 of a sweep (pair k = 0 .. n / 2 - 1; the pairs of a
+// round are disjoint, a sweep visits every pair once).  An implementation choice shared with the kernels, like the Jacobi iteration itself.
+//   rr_pair      the circle method over the n indices (position 0 fixed, the others move one slot per round).
+//   jacobi_pair  n divisible by four: the circle method over the n / 2 BLOCKS of two consecutive indices.  A block round T pairs the
+//                blocks into quadruples (a, b | c, d) and takes two rounds: (a, c) (b, d), then (a, d) (b, c); round 0 of the sweep
+//                rotates inside the blocks, (a, b) (c, d), indexed by the quadruples of block round 0.  Two consecutive rounds then
+//                stay inside the same 4 x 4 blocks of the matrix and the same four columns of V, which the kernel keeps in registers
+//                across both (half the passes over LDS).  Pair 2 kb + u belongs to quadruple kb.
+//                n = 2 (mod 4): rr_pair.
+static inline void rr_pair(int k, int t, int n, int& p, int& q) {
+    auto at = [&](int kk) { return kk == 0 ? 0 : 1 + ((kk - 1 + t) % (n - 1)); };
+    const int a = at(k), b = at(n - 1 - k);
+    p = std::min(a, b); q = std::max(a, b);
+}
+static inline void jacobi_pair(int k, int t, int n, int& p, int& q) {
+    if (n & 2) { rr_pair(k, t, n, p, q); return; }
+    const int kb = k >> 1, u = k & 1;
+    int X, Y;
+    rr_pair(kb, t == 0 ? 0 : (t - 1) >> 1, n / 2, X, Y);
+    if (t == 0) { p = 2 * (u ? Y : X); q = p + 1; return; }
+    const int s = (t - 1) & 1;
+    p = 2 * X + u;
+    q = 2 * Y + (s ? 1 - u : u);
+}
 static inline double mul_add(bool refmode, double a, double b, double c) { return refmode ? a * b + c : std::fma(a, b, c); }
 int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = false, bool refmode = false) {
     const int m = n / 2;
@@ -59,11 +83,8 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
             for (int j = 0; j < i; ++j) off = std::max(off, fabs(A[(size_t)i * n + j]));
         if (off == 0.0) return sweep;
         for (int t = 0; t < n - 1; ++t) {
-            // round-robin pairing: position 0 is fixed, positions 1..n-1 rotate
-            auto at = [&](int k) { return k == 0 ? 0 : 1 + ((k - 1 + t) % (n - 1)); };
             for (int k = 0; k < m; ++k) {
-                const int a = at(k), b = at(n - 1 - k);
-                pp[k] = std::min(a, b); qq[k] = std::max(a, b);
+                jacobi_pair(k, t, n, pp[k], qq[k]);
                 const double app = A[(size_t)pp[k] * n + pp[k]], aqq = A[(size_t)qq[k] * n + qq[k]], apq = A[(size_t)qq[k] * n + pp[k]];
                 double c = 1.0, s = 0.0, tt = 0.0;
                 // small-element rule (classical Jacobi): after three sweeps an off-diagonal element that cannot change
