@@ -283,6 +283,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     __shared__ double2 s_csn[(kQuadLds ? 6 : 2) * MMAX];   // (c, s) of this round's rotations, one 16-byte read per consumer (table path: [round parity][pair]; pass table: [pass parity][round of the pass][pair])
     __shared__ int s_qflag[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];   // passes: [pass parity][quadruple] any rotation of the pass that is not the identity
     __shared__ int s_xy[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];      // passes without the table: [pass parity][quadruple] its blocks X | Y << 8
+    __shared__ int s_pass_flag;                                    // passes without the table: wavefront 1 -> wavefront 0, "critical blocks of pass # written"
     __shared__ double s_tn2[2 * MMAX];            // table path: tan of the rotations, [round parity][pair]
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
@@ -451,6 +452,8 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     const bool quad = kTab && (SCHED == 1 || (SCHED == 0 && (n & 3) == 0));   // state sizes divisible by four walk the schedule in passes (launch_ukf_quad_table)
     const uint4* const tabn = kTab ? p.rot_tab + (size_t)(n / 2) * kUkfRotRounds * kUkfRotThreads + tid : nullptr;   // the launcher checks rot_tab
     bool converged = false;
+    int pass_seq = 1;                       // passes without the table: number of the pass (s_pass_flag)
+    if (tid == 0) s_pass_flag = 0;          // (the barriers of the prologue come before its first use)
     uint4 te_next = make_uint4(0u, 0u, 0u, 0u);
     // (one pointer and one set of prefetch registers for both table paths: an instance walks one of them)
     const uint4* const qtab = kTab ? (quad ? p.quad_tab + ((size_t)(n >> 2) * kUkfQuadPasses * kUkfRotThreads + tid) * 2 : tabn) : nullptr;   // + 2 * 256 * pass
@@ -566,6 +569,47 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     }
     // ---- pieces of the quadruple ("pass") paths, n divisible by four (launch_ukf_quad_table; jacobi_schedule.h) ----
     constexpr int MQ = (MMAX + 1) / 2;
+    // passes without the table: the thread's block lanes (block (I, J) of quadruple positions, I > J: I << 8 | J) and V items (quadruple | pair of
+    // columns << 8).  As in the table path the "critical" blocks - (1, 0), (k + 1, k - 1), (mq - 1, mq - 2): the ones that hold the next pass's pivots -
+    // belong to the first lanes of the workgroup (wavefront 0, and wavefront 1 when there are more than sixteen), the others start at thread QOT0.
+    constexpr bool kQuadGen = ITB <= 2 && !kTab;
+    constexpr int QOT0 = 4 * MQ > 64 ? 128 : 64;
+    constexpr int QNB = kQuadGen ? 1 + (4 * (MQ * (MQ - 1) / 2) + (TPB - QOT0) - 1) / (TPB - QOT0) : 1, QNV = kQuadGen ? (MQ * MMAX + (TPB - VT0) - 1) / (TPB - VT0) : 1;
+    int qb_desc[QNB], qv_desc[QNV];
+    if constexpr (kQuadGen) {
+        const int mq_ = n >> 2;
+#pragma unroll
+        for (int ub = 0; ub < QNB; ++ub) qb_desc[ub] = -1;
+        if (mq_ >= 2 && tid < 4 * mq_) {   // slot 0 of the first lanes: critical block tid / 4
+            const int c = tid >> 2;
+            qb_desc[0] = c == 0 ? (1 << 8) : (c <= mq_ - 2 ? (((c + 1) << 8) | (c - 1)) : (mq_ >= 3 ? (((mq_ - 1) << 8) | (mq_ - 2)) : -1));
+        }
+        if (tid >= QOT0) {
+#pragma unroll
+            for (int ub = 1; ub < QNB; ++ub) {
+                // rank r among the other blocks, lexicographic.  Row I = 2 .. mq - 2 holds I - 1 of them (every J < I but I - 2), row mq - 1 the
+                // mq - 3 with J < mq - 3: the rows before the last are a triangle, decoded in closed form
+                const int r = ((tid - QOT0) + (TPB - QOT0) * (ub - 1)) >> 2;
+                const int ntri = mq_ >= 3 ? (mq_ - 2) * (mq_ - 3) / 2 : 0;
+                int d = -1;
+                if (r < ntri) {
+                    int Ip = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)r)) * 0.5f);
+                    while (Ip * (Ip - 1) / 2 > r) --Ip;
+                    while ((Ip + 1) * Ip / 2 <= r) ++Ip;
+                    const int Jp = r - Ip * (Ip - 1) / 2, I = Ip + 1;
+                    d = (I << 8) | (Jp < I - 2 ? Jp : Jp + 1);
+                } else if (mq_ >= 4 && r - ntri <= mq_ - 4) {
+                    d = ((mq_ - 1) << 8) | (r - ntri);
+                }
+                qb_desc[ub] = d;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QNV; ++u) {
+            const int it = tid - VT0 + (TPB - VT0) * u, Q = it / m;
+            qv_desc[u] = (tid >= VT0 && Q < mq_) ? (Q | ((it - Q * m) << 8)) : -1;
+        }
+    }
     char* const sAb = reinterpret_cast<char*>(sA);
     char* const sVb = reinterpret_cast<char*>(sVt);
     auto ldA = [&](unsigned off) -> double { return *reinterpret_cast<const double*>(sAb + off); };
@@ -730,72 +774,86 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         }
         if constexpr (kFast && !kTab) {
             if ((n & 3) == 0) {
-                // ======== passes without the table (the other fast variants; L = 50 runs <104, 1024>): two barriers per pass ========
-                //   parameters of pass T (lanes 2 q + u of wavefront 0, on the diagonal 4 x 4 blocks in LDS) beside the V items of pass T - 1,
-                //   barrier, the 4 x 4 blocks of pass T (four adjacent lanes each, operand addresses from the quadruples' blocks), barrier
-                const int mq = n >> 2, nblk = mq * (mq - 1) / 2;
-                constexpr int NBU = (4 * (MQ * (MQ - 1) / 2) + TPB - 1) / TPB;                 // block-lane slots per thread
-                constexpr int NVU = (MQ * MMAX + (TPB - VT0) - 1) / (TPB - VT0);               // V item slots per thread (threads VT0 ..)
-                auto v_pass = [&](const int pv, const bool first) {
-                    if (tid < VT0) return;
-                    const double2* const cs = s_csn + pv * 3 * MMAX;
+                // ======== passes without the table (the other fast variants; L = 50 runs <104, 1024>, one workgroup per CU) ========
+                // One barrier per pass, as in the table path: wavefront 0 (and 1) rotate the critical blocks first, then wavefront 0 goes on to the
+                // parameters of the NEXT pass (two rounds of sqrt / div / sqrt chains on the diagonal 4 x 4 blocks in LDS: ~1 us, the longest thing in
+                // a pass) while the other wavefronts do the rest of the blocks and the V items.  Critical blocks beyond wavefront 0's sixteen are
+                // wavefront 1's: it raises s_pass_flag after writing them and wavefront 0 waits for that before it reads the pivots.
+                const int mq = n >> 2;
+                const bool crit_in_w1 = 4 * mq > 64;
 #pragma unroll 1
-                    for (int u = 0; u < NVU; ++u) {
-                        const int it = tid - VT0 + (TPB - VT0) * u, Q = it / m;
-                        if (Q >= mq) break;
-                        if (!s_qflag[pv * MQ + Q]) continue;
-                        v_item(Q, it - Q * m, (unsigned)s_xy[pv * MQ + Q], first, cs);
-                    }
-                };
-                bool vp = false;
-#pragma unroll 1
-                for (int T = 0; T < m - 1; ++T) {
-                    const bool first = T == 0;
-                    if (tid < 2 * mq) {
-                        int X, Y;
-                        rr_pair(tid >> 1, T, m, X, Y);
-                        const unsigned xy = (unsigned)X | ((unsigned)Y << 8);
-                        if (!(tid & 1)) s_xy[par * MQ + (tid >> 1)] = (int)xy;
-                        param_phase(xy, first, par, sweep);
-                    }
-                    if (vp) v_pass(par ^ 1, T == 1);
-                    __syncthreads();
-                    SQ_STAMP(2);
-                    const double2* const cs = s_csn + par * 3 * MMAX;
-                    const int* const qf = s_qflag + par * MQ;
+                for (int T = -1; T < m - 1; ++T) {   // T = -1: only the parameters of pass 0
+                    if (T >= 0) {
+                        const bool first = T == 0;
+                        const double2* const cs = s_csn + par * 3 * MMAX;
+                        const int* const qf = s_qflag + par * MQ;
 #pragma unroll
-                    for (int ub = 0; ub < NBU; ++ub) {
-                        const int it = tid + TPB * ub, blk = it >> 2;
-                        if (blk >= nblk) continue;
-                        int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)blk)) * 0.5f);   // block (I, J), I > J: blk = I (I - 1) / 2 + J
-                        while (I * (I - 1) / 2 > blk) --I;
-                        while ((I + 1) * I / 2 <= blk) ++I;
-                        const int J = blk - I * (I - 1) / 2;
-                        if (!(qf[I] | qf[J])) continue;   // (the same for the four lanes of the block)
-                        const int li = (it >> 1) & 1, lj = it & 1, si = 2 * I + li, sj = 2 * J + lj;
-                        const unsigned xi = (unsigned)s_xy[par * MQ + I], xj = (unsigned)s_xy[par * MQ + J];
-                        const int rX = 2 * (int)(xi & 0xffu), rY = 2 * (int)(xi >> 8), cX = 2 * (int)(xj & 0xffu), cY = 2 * (int)(xj >> 8);
-                        if (first) {   // the in-block round: rows (2 i, 2 i + 1) x columns (2 j, 2 j + 1) of the block
-                            const int r0 = li ? rY : rX, c0 = lj ? cY : cX;
-                            double& g00 = AT(r0, c0); double& g01 = AT(r0, c0 + 1); double& g10 = AT(r0 + 1, c0); double& g11 = AT(r0 + 1, c0 + 1);
-                            double b00 = g00, b01 = g01, b10 = g10, b11 = g11;
-                            rot_block(b00, b01, b10, b11, cs[si], cs[sj]);
-                            g00 = b00; g01 = b01; g10 = b10; g11 = b11;
-                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the lanes of the block read each other's results below
+                        for (int ub = 0; ub < QNB; ++ub) {
+                            const int bd = qb_desc[ub];   // block (I, J), I > J: I << 8 | J
+                            if (bd < 0) continue;
+                            const int I = bd >> 8, J = bd & 0xff;
+                            if (!(qf[I] | qf[J])) continue;   // (the same for the four lanes of the block)
+                            const int li = (tid >> 1) & 1, lj = tid & 1, si = 2 * I + li, sj = 2 * J + lj;
+                            const unsigned xi = (unsigned)s_xy[par * MQ + I], xj = (unsigned)s_xy[par * MQ + J];
+                            // the blocks (two consecutive indices each) behind the lane's rows and columns; an element (r, c) of the packed lower triangle sits
+                            // at tri(max) + min, and which of r, c is larger is a property of the two BLOCKS (four comparisons for all twelve elements)
+                            const int bX = (int)(xi & 0xffu), bY = (int)(xi >> 8), dX = (int)(xj & 0xffu), dY = (int)(xj >> 8);
+                            auto off = [&](const int r, const int c, const bool r_gt_c) -> unsigned {   // byte offset of A(r, c)
+                                const int hi = r_gt_c ? r : c, lo = r_gt_c ? c : r;
+                                return (unsigned)(4 * hi * (hi + 1) + 8 * lo);
+                            };
+                            const bool gXX = bX > dX, gXY = bX > dY, gYX = bY > dX, gYY = bY > dY;
+                            if (first) {   // the in-block round: rows (2 i, 2 i + 1) x columns (2 j, 2 j + 1) of the block
+                                const int r0 = 2 * (li ? bY : bX), c0 = 2 * (lj ? dY : dX);
+                                const bool g = li ? (lj ? gYY : gYX) : (lj ? gXY : gXX);
+                                const unsigned a00 = off(r0, c0, g), a01 = off(r0, c0 + 1, g), a10 = off(r0 + 1, c0, g), a11 = off(r0 + 1, c0 + 1, g);
+                                double b00 = ldA(a00), b01 = ldA(a01), b10 = ldA(a10), b11 = ldA(a11);
+                                rot_block(b00, b01, b10, b11, cs[si], cs[sj]);
+                                stA(a00, b00); stA(a01, b01); stA(a10, b10); stA(a11, b11);
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the lanes of the block read each other's results below
+                            }
+                            const int rA = 2 * bX + li, rB = 2 * bY + li, cA = 2 * dX + lj, cB = 2 * dY + lj;
+                            double e00 = ldA(off(rA, cA, gXX)), e01 = ldA(off(rA, cB, gXY)), e10 = ldA(off(rB, cA, gYX)), e11 = ldA(off(rB, cB, gYY));
+                            rot_block(e00, e01, e10, e11, cs[MMAX + si], cs[MMAX + sj]);
+                            e01 = dpp_quad<0xB1>(e01); e10 = dpp_quad<0x4E>(e10); e11 = dpp_quad<0x1B>(e11);   // rows (i, i+2) x columns (j, j+2) -> (i, 3-i) x (j, 3-j)
+                            rot_block(e00, e01, e10, e11, cs[2 * MMAX + si], cs[2 * MMAX + sj]);
+                            const int rC = 2 * bY + 1 - li, cC = 2 * dY + 1 - lj;
+                            stA(off(rA, cA, gXX), e00); stA(off(rA, cC, gXY), e01); stA(off(rC, cA, gYX), e10); stA(off(rC, cC, gYY), e11);
                         }
-                        double e00 = AT(rX + li, cX + lj), e01 = AT(rX + li, cY + lj), e10 = AT(rY + li, cX + lj), e11 = AT(rY + li, cY + lj);
-                        rot_block(e00, e01, e10, e11, cs[MMAX + si], cs[MMAX + sj]);
-                        e01 = dpp_quad<0xB1>(e01); e10 = dpp_quad<0x4E>(e10); e11 = dpp_quad<0x1B>(e11);   // rows (i, i+2) x columns (j, j+2) -> (i, 3-i) x (j, 3-j)
-                        rot_block(e00, e01, e10, e11, cs[2 * MMAX + si], cs[2 * MMAX + sj]);
-                        AT(rX + li, cX + lj) = e00; AT(rX + li, cY + 1 - lj) = e01; AT(rY + 1 - li, cX + lj) = e10; AT(rY + 1 - li, cY + 1 - lj) = e11;
+                        if (crit_in_w1 && tid >= 64 && tid < 128) {   // wavefront 1: its critical blocks are written (a wavefront's LDS accesses execute in order)
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (tid == 64) *reinterpret_cast<volatile int*>(&s_pass_flag) = pass_seq;
+                        }
+                        if (tid >= VT0) {
+#pragma unroll
+                            for (int u = 0; u < QNV; ++u) {
+                                const int vd = qv_desc[u];   // quadruple | pair of columns << 8
+                                if (vd < 0) continue;
+                                const int Q = vd & 0xff;
+                                if (!qf[Q]) continue;
+                                v_item(Q, vd >> 8, (unsigned)s_xy[par * MQ + Q], first, cs);
+                            }
+                        }
+                    }
+                    if (tid < 64 && T + 1 < m - 1) {   // wavefront 0: the next pass's parameters, from what the critical lanes have just written
+                        if (T >= 0 && crit_in_w1) {
+                            while (*reinterpret_cast<volatile int*>(&s_pass_flag) != pass_seq) __builtin_amdgcn_s_sleep(1);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        }
+                        if (tid < 2 * mq) {
+                            int X, Y;
+                            rr_pair(tid >> 1, T + 1, m, X, Y);
+                            const unsigned xy = (unsigned)X | ((unsigned)Y << 8);
+                            if (!(tid & 1)) s_xy[(par ^ 1) * MQ + (tid >> 1)] = (int)xy;
+                            param_phase(xy, T < 0, par ^ 1, sweep);
+                        }
                     }
                     __syncthreads();
-                    SQ_STAMP(3);
-                    if constexpr (PROF) { if (tid == 0) sacc[5] += 2; }   // rounds
-                    vp = true;
+                    SQ_STAMP(3);   // one pass (one barrier)
+                    if constexpr (PROF) { if (tid == 0 && T >= 0) sacc[5] += 2; }   // rounds
                     par ^= 1;
+                    pass_seq += 1;
                 }
-                if (vp) { v_pass(par ^ 1, m - 1 == 1); __syncthreads(); }   // the V items of the last pass (nobody has read V since)
                 continue;
             }
         }
