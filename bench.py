@@ -137,7 +137,7 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=10.0
                        "parity": "bit-exact vs the CPU oracle (tests/test_parity_ukf_gpu.py); the oracle's eigen-decomposition is pinned to LAPACK at 1e-12 and to a numpy transliteration of ukf.cpp, not to the reference binary (Eigen/ROS absent)"},
             "roofline": {"bound": "fp64-valu", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
                          "frac": round(flops / (step_ms * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
-                         "note": "algorithmic FLOPs (warm-start transform + the counted Jacobi sweeps + sqtP + weighted covariance on v_mfma_f64_16x16x4_f64 + the counted updates) / step time of both kernels; sqrt kernel VALU-issue bound (69 % VALU utilisation, profiles/r01n_ukf/pmc_summary.txt)"}}
+                         "note": "algorithmic FLOPs (warm-start transform + the counted Jacobi sweeps + sqtP + weighted covariance on v_mfma_f64_16x16x4_f64 + the counted updates) / step time of both kernels; sqrt kernel VALU-issue bound (82 % VALU utilisation at six workgroups per CU, profiles/r04_ukf/pmc_summary_quad.txt)"}}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         Tc = min(T, 131)

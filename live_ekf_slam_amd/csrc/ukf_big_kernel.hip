@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kTpb) void ukf_big_sqrt_kernel(const UkfStepParams 
         int live = 0;   // convergence: every off-diagonal element is exactly zero
         for (int e = tid; e < n * n; e += kTpb) {
             const int r = e / n, c = e - r * n;
-            if (c < r && A[e] != 0.0) live = 1;
+            if (c < r && A[e] != 0.0 && A[e] == A[e]) live = 1;   // (NaNs are passed over, as by the oracle's std::max)
         }
         if (!__syncthreads_or(live)) { converged = true; sweeps_done = sweep; break; }
 #pragma unroll 1

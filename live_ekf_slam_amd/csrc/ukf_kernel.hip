@@ -2,13 +2,13 @@
 // (ekf_ws/src/localization_pkg/src/ukf.cpp:161-372) as two kernels per timestep, one workgroup per instance.
 //
 //  ukf_sqrt_kernel  nearestSPD + principal matrix square root (ukf.cpp:106-123,208).  The reference calls Eigen's
-//                   SelfAdjointEigenSolver and MatrixFunctions sqrt; here: cyclic Jacobi in PARALLEL (round-robin)
-//                   ORDER entirely in LDS — A packed lower-triangular (exact symmetry by construction), V^T full —
-//                   n/2 disjoint rotations per round, every pair-block B' = R_i^T B R_j and every V row-pair an
-//                   independent work item.  This O(n^3 * sweeps) fp64 phase dominates the UKF (70 % of its GPU time); it
-//                   is not HBM bound but VALU-ISSUE bound: 69 % VALU utilisation, most of it index arithmetic and selects
-//                   around ~70 fp64 operations per wavefront-round (counters: profiles/r01n_ukf/pmc_summary.txt,
-//                   DESIGN.md §4.2 and §7 item 3).
+//                   SelfAdjointEigenSolver and MatrixFunctions sqrt; here: cyclic Jacobi in PARALLEL ORDER entirely in LDS
+//                   - A packed lower-triangular (exact symmetry by construction), V^T full - n/2 disjoint rotations per
+//                   round (jacobi_schedule.h), every pair-block B' = R_i^T B R_j and every V row-pair an independent work
+//                   item.  State sizes divisible by four walk the schedule in PASSES of two rounds that stay inside
+//                   quadruples of indices: the 4 x 4 blocks of A and four rows of V^T in registers across both, one barrier
+//                   per pass.  This O(n^3 * sweeps) fp64 phase dominates the UKF (70 % of its GPU time); it is bound by
+//                   VALU issue (82 % utilisation at six workgroups per CU, profiles/r04_ukf/).
 //  ukf_step_kernel  sigma points through the motion model, weighted mean and covariance (sequential in the sigma
 //                   index exactly like the reference's accumulation loops), all landmark updates (the reference never
 //                   redraws sigma points, so K and S of every update are independent of P), insertions, and ONE
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             }
 #pragma unroll
             for (int u = 0; u < NSC; ++u) {
-                if (tid + TPB * u < nlow && v[u] != 0.0) {
+                if (tid + TPB * u < nlow && v[u] != 0.0 && v[u] == v[u]) {   // (a NaN is not "live": the oracle's max() passes over it, see below)
                     const double g = 100.0 * fabs(v[u]);
                     const double app = fabs(dp[u]), aqq = fabs(dq[u]);
                     if (!(sweep >= tiny_from && (app + g == app) && (aqq + g == aqq))) live = 1;
@@ -709,7 +709,9 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         for (int r = tid / 2; r < n; r += TPB / 2)          // two threads per row, strictly-lower part
             for (int c = (tid & 1); c < r; c += 2) {
                 const double v = sA[r * (r + 1) / 2 + c];
-                if (v != 0.0) {
+                // (NaN: the oracle's convergence test is max |a_ij| == 0 with std::max, which passes over NaNs - an instance whose P went
+                // non-finite is flagged SLAM_INST_NONFINITE by the step kernel either way; it must not ALSO end as "no convergence" here only)
+                if (v != 0.0 && v == v) {
                     const double g = 100.0 * fabs(v);
                     const double app = fabs(sA[c * (c + 1) / 2 + c]), aqq = fabs(sA[r * (r + 1) / 2 + r]);
                     if (!(sweep >= tiny_from && (app + g == app) && (aqq + g == aqq))) live = 1;

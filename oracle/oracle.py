@@ -59,6 +59,8 @@ def lib():
         L.orc_ukf_update.argtypes = [C.c_void_p, C.c_float, C.c_float, _fp, C.c_int]
         L.orc_ukf_get.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip]
         L.orc_ukf_sqrt_probe.argtypes = [_dp, C.c_int, C.c_double, _dp]
+        L.orc_ukf_jacobi_pair.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_ukf_jacobi_pair.restype = None
         L.orc_ukf_set_loc_map.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_run_ukf_batch.restype = C.c_double
         L.orc_run_ukf_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int, C.c_uint64,
@@ -230,6 +232,13 @@ class OracleUKF:
         n = 4 + 2 * M.value
         return dict(x=x[:n].copy(), P=P[:n * n].reshape(n, n).copy(), M=M.value, ids=ids[:M.value].copy(),
                     timestep=ts.value, sweeps=sw.value)
+
+
+def ukf_jacobi_pair(k, t, n):
+    """Pair k of round t of a Jacobi sweep at state size n (the schedule the oracle and the kernels share)."""
+    p = C.c_int(0); q = C.c_int(0)
+    lib().orc_ukf_jacobi_pair(k, t, n, C.byref(p), C.byref(q))
+    return p.value, q.value
 
 
 def ukf_sqrt_probe(P, scale):

@@ -12,8 +12,9 @@
 //
 // Two places where the reference delegates to Eigen routines whose rounding cannot be reproduced:
 //  * SelfAdjointEigenSolver + MatrixFunctions .sqrt() (ukf.cpp:116-122,208).  Mathematically sqtP = Qv sqrt(D+) Qv^T
-//    is unique; here it is computed with a cyclic Jacobi eigen-iteration in PARALLEL (round-robin) ORDER on the
-//    exactly-symmetric matrix, the same schedule the GPU kernel runs, so GPU == oracle bit for bit.  From the second
+//    is unique; here it is computed with a cyclic Jacobi eigen-iteration in PARALLEL ORDER (n / 2 disjoint rotations per round;
+//    jacobi_pair below: the circle method over the indices, or over blocks of two when n is divisible by four) on the
+//    exactly-symmetric matrix, the same schedule the GPU kernels run, so GPU == oracle bit for bit.  From the second
 //    timestep on the iteration is WARM-STARTED in the previous step's eigenbasis (B = V0^T (A V0), V starts at V0,
 //    small-element rule from the first sweep; cold start every 100 steps) — an implementation choice shared with the
 //    kernel that halves the sweeps; the eigen-decomposition it converges to is the same mathematical object.
@@ -28,7 +29,7 @@
 namespace {
 using namespace orc;
 
-// ---- symmetric eigen-decomposition: cyclic Jacobi, round-robin parallel ordering -------------------------------
+// ---- symmetric eigen-decomposition: cyclic Jacobi, parallel ordering (jacobi_pair) -----------------------------
 // A: n x n row-major, exactly symmetric on entry and kept so (only pair-blocks i >= j are computed, then mirrored).
 // V: n x n, columns = eigenvectors.  n is even (n = 4 + 2M).  Returns the number of sweeps, or -1 if not converged.
 // All rotations of a round read the matrix as it was at the start of the round (disjoint index pairs).
@@ -452,6 +453,9 @@ void orc_ukf_get(void* h, double* x, double* P, int* M, int* ids, int* timestep,
     if (sweeps) *sweeps = u->last_sweeps;
 }
 // matrix square root probe: sqtP of nearestSPD(scale * P) for a given symmetric-ish P (n x n row-major)
+// the Jacobi schedule (tests: every pair once per sweep, disjoint rounds, the same pairs as the kernels' jacobi_schedule.h)
+void orc_ukf_jacobi_pair(int k, int t, int n, int* p, int* q) { jacobi_pair(k, t, n, *p, *q); }
+
 int orc_ukf_sqrt_probe(const double* P, int n, double scale, double* out) {
     std::vector<double> Y((size_t)n * n), V((size_t)n * n);
     for (int r = 0; r < n; ++r)
