@@ -208,6 +208,7 @@ hipError_t launch_ukf_quad_table(uint4* tab, hipStream_t stream) {
     auto idx = [](int r, int c) { return (unsigned)(8 * (r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r)); };
     for (int n = 4; n <= 4 * (kUkfQuadSizes - 1); n += 4) {
         const int m = n / 2, mq = n / 4;
+        int owner0[kUkfQuadSizes][kUkfQuadSizes];
         for (int T = 0; T < m - 1; ++T) {
             int X[kUkfQuadSizes], Y[kUkfQuadSizes], quad_of[2 * kUkfQuadSizes];
             for (int q = 0; q < mq; ++q) { rr_pair(q, T, m, X[q], Y[q]); quad_of[X[q]] = q; quad_of[Y[q]] = q; }
@@ -226,6 +227,12 @@ hipError_t launch_ukf_quad_table(uint4* tab, hipStream_t stream) {
             int nother = 0;
             for (int I = 1; I < mq; ++I) for (int J = 0; J < I; ++J) if (owner[I][J] < 0) owner[I][J] = 64 + 4 * nother++;
             if (4 * ncrit > 64 || 64 + 4 * nother > kUkfRotThreads) return hipErrorInvalidValue;
+            // the critical blocks sit at the same quadruple POSITIONS in every pass (circle method: next pair k = top of k + 1, bottom of k - 1),
+            // so a lane owns the same block (I, J) throughout: the kernel reads w7 once per launch
+            for (int I = 1; I < mq; ++I) for (int J = 0; J < I; ++J) {
+                if (T == 0) owner0[I][J] = owner[I][J];
+                else if (owner0[I][J] != owner[I][J]) return hipErrorInvalidValue;
+            }
             uint32_t* const base = h.data() + ((size_t)(n / 4) * kUkfQuadPasses + T) * kUkfRotThreads * 8;
             for (int tid = 0; tid < kUkfRotThreads; ++tid) { base[8 * tid + 6] = 0xffffffffu; }
             for (int q = 0; q < mq; ++q)   // parameter lanes 2 q + u (they are block lanes as well): the blocks of their quadruple
@@ -457,8 +464,9 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     uint4 te_next = make_uint4(0u, 0u, 0u, 0u);
     // (one pointer and one set of prefetch registers for both table paths: an instance walks one of them)
     const uint4* const qtab = kTab ? (quad ? p.quad_tab + ((size_t)(n >> 2) * kUkfQuadPasses * kUkfRotThreads + tid) * 2 : tabn) : nullptr;   // + 2 * 256 * pass
-    uint4 qnb = make_uint4(0u, 0u, 0u, 0u);   // pass table: the thread's entry of the NEXT pass is (te_next, qnb), requested a pass ahead
-    if constexpr (kTab) { te_next = qtab[0]; if (quad) qnb = qtab[1]; }
+    unsigned qnz = 0u;   // pass table: the words of the NEXT pass's entry that every pass needs - (te_next = w0..w3, qnz = w6) - requested a pass ahead
+    unsigned qw7 = 0u;   // w7 (the same in every pass)
+    if constexpr (kTab) { te_next = qtab[0]; if (quad) { qnz = qtab[1].z; qw7 = qtab[1].w; } }
     int par = 0;                            // table path: parity of the parameter buffers the current round reads
     auto v_rotate = [&](unsigned vz, const double2* csn) {   // V <- V J of one round, this thread's pair iv
         if (!vvalid) return;
@@ -557,6 +565,17 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     int desc_tab = 3 << 16;                 // table path: this thread's item (diagonal block of pair tid, or the table's word)
     if constexpr (kTab) desc_tab = tid < m ? ((1 << 16) | (tid << 8)) : (int)te_next.w;
     // ---- pass-table path: the thread's V items (quadruple, 16-byte pair of columns); fixed for the launch ----
+    // pass table: the thread's block lane, fixed for the launch (w7 of any pass): parameter slots 2 I + i | (2 J + j) << 8 | I << 16 | J << 24, -1 = none
+    int qrole = -1;
+    if constexpr (kTab) {
+        if (quad) {
+            const unsigned w7 = qw7;
+            if ((w7 & 3u) == 1u) {
+                const int I = (w7 >> 8) & 0xff, J = (w7 >> 16) & 0xff;
+                qrole = (2 * I + (int)((w7 >> 24) & 1u)) | ((2 * J + (int)((w7 >> 25) & 1u)) << 8) | (I << 16) | (J << 24);
+            }
+        }
+    }
     int vitem[2] = {-1, -1};   // quadruple | pair of columns << 8, -1 = none
     if constexpr (kTab) {
         if (quad && tid >= 64) {
@@ -730,21 +749,22 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                 const int mq = n >> 2;
 #pragma unroll 1
                 for (int T = -1; T < m - 1; ++T) {   // T = -1: only the parameters of pass 0 (every later pass gets its own a pass ahead)
-                    const uint4 ea = te_next, eb = qnb;
+                    const uint4 ea = te_next;
+                    const unsigned ez = qnz;
                     if (T >= 0) {
                         const int Tn = T + 1 < m - 1 ? T + 1 : 0;
-                        te_next = qtab[(size_t)Tn * (2 * kUkfRotThreads)]; qnb = qtab[(size_t)Tn * (2 * kUkfRotThreads) + 1];
+                        te_next = qtab[(size_t)Tn * (2 * kUkfRotThreads)]; qnz = qtab[(size_t)Tn * (2 * kUkfRotThreads) + 1].z;
                         const bool first = T == 0;
                         const double2* const cs = s_csn + par * 3 * MMAX;
                         const int* const qf = s_qflag + par * MQ;
-                        if ((eb.w & 3u) == 1u) {   // a lane of the 4 x 4 block between quadruples I > J
-                            const int I = (eb.w >> 8) & 0xff, J = (eb.w >> 16) & 0xff;
-                            const int si = 2 * I + (int)((eb.w >> 24) & 1u), sj = 2 * J + (int)((eb.w >> 25) & 1u);
+                        if (qrole >= 0) {   // a lane of the 4 x 4 block between quadruples I > J
+                            const int I = (qrole >> 16) & 0xff, J = qrole >> 24, si = qrole & 0xff, sj = (qrole >> 8) & 0xff;
                             if (qf[I] | qf[J]) {   // (the same for the four lanes of the block)
                                 if (first) {
-                                    double g00 = ldA(eb.x & 0xffffu), g01 = ldA(eb.x >> 16), g10 = ldA(eb.y & 0xffffu), g11 = ldA(eb.y >> 16);
+                                    const uint2 e0 = *reinterpret_cast<const uint2*>(qtab + 1);   // w4 w5 of pass 0: once per sweep, on demand
+                                    double g00 = ldA(e0.x & 0xffffu), g01 = ldA(e0.x >> 16), g10 = ldA(e0.y & 0xffffu), g11 = ldA(e0.y >> 16);
                                     rot_block(g00, g01, g10, g11, cs[si], cs[sj]);
-                                    stA(eb.x & 0xffffu, g00); stA(eb.x >> 16, g01); stA(eb.y & 0xffffu, g10); stA(eb.y >> 16, g11);
+                                    stA(e0.x & 0xffffu, g00); stA(e0.x >> 16, g01); stA(e0.y & 0xffffu, g10); stA(e0.y >> 16, g11);
                                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the lanes of the block read each other's results below
                                 }
                                 double e00 = ldA(ea.x & 0xffffu), e01 = ldA(ea.x >> 16), e10 = ldA(ea.y & 0xffffu), e11 = ldA(ea.y >> 16);
@@ -761,11 +781,11 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                             if (vi < 0) continue;
                             const int Q = vi & 0xff, kp = vi >> 8;
                             if (!qf[Q]) continue;
-                            v_item(Q, kp, (eb.z >> (16 * u)) & 0xffffu, first, cs);
+                            v_item(Q, kp, (ez >> (16 * u)) & 0xffffu, first, cs);
                         }
                     }
                     // wavefront 0: the next pass's parameters, from what it has just written (its lanes < n / 2 carry their quadruple's blocks in w6)
-                    if (tid < 2 * mq && T + 1 < m - 1) param_phase(T < 0 ? eb.z : qnb.z, T < 0, par ^ 1, sweep);
+                    if (tid < 2 * mq && T + 1 < m - 1) param_phase(T < 0 ? ez : qnz, T < 0, par ^ 1, sweep);
                     __syncthreads();
                     SQ_STAMP(3);   // one pass (one barrier)
                     if constexpr (PROF) { if (tid == 0 && T >= 0) sacc[5] += 2; }   // rounds
