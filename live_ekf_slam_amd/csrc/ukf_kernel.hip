@@ -1622,13 +1622,15 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
                 break;
         }
     } else if (nmax <= 104) {
-        switch (env_tpb(1, 1024)) {
+        // 512 threads (220 VGPRs) since round 4: with 1024 the compiler has 128 VGPRs and spills 82 of them; 345 -> 350 k steps/s at L = 50
+        // once the sqrt kernel's passes left the step kernel a quarter of the step (1024 had measured best against the round-3 sqrt kernel)
+        switch (p.prof ? 1024 : env_tpb(1, 512)) {
             case 256: hipLaunchKernelGGL((ukf_step_kernel<104, 256, 8>), dim3(p.b_cnt), dim3(256), 0, stream, p); break;
-            case 512: hipLaunchKernelGGL((ukf_step_kernel<104, 512, 8>), dim3(p.b_cnt), dim3(512), 0, stream, p); break;
-            default:
+            case 1024:
                 if (p.prof) hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8, true>), dim3(p.b_cnt), dim3(1024), 0, stream, p);
                 else hipLaunchKernelGGL((ukf_step_kernel<104, 1024, 8>), dim3(p.b_cnt), dim3(1024), 0, stream, p);
                 break;
+            default: hipLaunchKernelGGL((ukf_step_kernel<104, 512, 8>), dim3(p.b_cnt), dim3(512), 0, stream, p); break;
         }
     } else {
         return launch_ukf_big_step(p, stream);   // every n x n object in HBM / L2 (ukf_big_kernel.hip)

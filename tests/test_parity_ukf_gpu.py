@@ -71,7 +71,8 @@ def test_ukf_sim_step_parity(S, oracle, L, T, B):
 @pytest.mark.parametrize("code,L,T,B", [
     (1280256, 20, 70, 16),   # sqrt 128 threads (generic rotation path), step 256 threads (2 x 4 covariance tiles)
     (640064, 20, 70, 12),    # one wavefront per instance in both kernels
-    (5120512, 50, 50, 8),    # n = 104: sqrt 512, step 512 (217 VGPRs, no spill; the 1024-thread default spills 69)
+    (5120512, 50, 50, 8),    # n = 104: sqrt 512, step 512 (the step kernel's default since round 4: 220 VGPRs, no spill)
+    (10241024, 50, 50, 8),   # n = 104: sqrt 1024 (the default), step 1024 (128 VGPRs, 82 spilled; the default until round 4)
     (2560256, 50, 50, 6),    # n = 104: sqrt 256 (256 VGPRs), step 256
 ])
 def test_ukf_thread_count_variants_bit_exact(S, oracle, monkeypatch, code, L, T, B):
