@@ -140,7 +140,7 @@ struct slam_handle {
     double* dxprev = nullptr;                         // UKF: x_t the last sigma points were drawn around
     double* dvt = nullptr; int32_t* dvage = nullptr;  // UKF: V^T of the last eigen-decomposition + warm-start age
     double* dbigws = nullptr;                         // UKF beyond the LDS size classes: [B][2 * pstride] scratch (ukf_big_kernel.hip)
-    uint4* drot = nullptr;                            // UKF (n <= 44): Jacobi schedule table of the fast sqrt kernel
+    uint4* drot = nullptr;                            // UKF (n <= 44): pass table of the fast sqrt kernel (launch_ukf_quad_table)
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr}; hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // UKF run_sim: the other parts of the batch
     int ukf_parts = 2;                                                               // streams the UKF batch is split over (SLAM_UKF_PARTS, 1..4)
     int ukf_split_min = 1024;                                                        // batch size from which it is used
@@ -196,8 +196,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.B = h->B; p.L_max = h->L_max; p.pstride = h->pstride; p.xstride = h->xstride;
     p.b_off = 0; p.b_cnt = h->B;
     p.loc = h->kind == SLAM_UKF_LOC; p.mapf = h->dmapf;
-    p.rot_tab = h->drot;
-    p.quad_tab = h->drot ? h->drot + slam::kUkfRotTabEntries : nullptr;
+    p.quad_tab = h->drot;
     p.khist = h->dkhist;
     p.big_ws = h->dbigws;
     p.prof = (h->dbg & 4) ? h->dprof : nullptr;
@@ -367,7 +366,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvt, sizeof(double) * B * h->pstride) : hipSuccess,
         (kind == SLAM_UKF_SLAM && L_max > slam::kUkfLdsMaxLandmarks) ? hipMalloc(&h->dbigws, sizeof(double) * B * 2 * h->pstride) : hipSuccess,
         kind != SLAM_EKF_SLAM ? hipMalloc(&h->dvage, sizeof(int32_t) * B) : hipSuccess,
-        (kind != SLAM_EKF_SLAM && h->n_max <= 44) ? hipMalloc(&h->drot, sizeof(uint4) * (slam::kUkfRotTabEntries + slam::kUkfQuadTabEntries)) : hipSuccess,
+        (kind != SLAM_EKF_SLAM && h->n_max <= 44) ? hipMalloc(&h->drot, sizeof(uint4) * slam::kUkfQuadTabEntries) : hipSuccess,
     };
     for (hipError_t ee : errs)
         if (ee != hipSuccess) {
@@ -388,8 +387,7 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
         hipMemsetAsync(h->dkhist, 0, sizeof(unsigned long long) * 16, h->stream),
         h->dnsq ? hipMemsetAsync(h->dnsq, 0, sizeof(int32_t) * B, h->stream) : hipSuccess,
         h->dprof ? hipMemsetAsync(h->dprof, 0, sizeof(unsigned long long) * slam::kEkfProfSlots * B, h->stream) : hipSuccess,
-        h->drot ? slam::launch_ukf_rot_table(h->drot, h->stream) : hipSuccess,
-        h->drot ? slam::launch_ukf_quad_table(h->drot + slam::kUkfRotTabEntries, h->stream) : hipSuccess,
+        h->drot ? slam::launch_ukf_quad_table(h->drot, h->stream) : hipSuccess,
     };
     for (hipError_t ee : zs)
         if (ee != hipSuccess) {

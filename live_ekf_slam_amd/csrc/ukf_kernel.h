@@ -47,12 +47,9 @@ struct UkfStepParams {
     int32_t loc;          // 1 = FilterChoice::UKF_LOC: every detection updates against the known map (ukf.cpp:146-154)
     unsigned long long* prof;   // optional [B][16] phase timers of the step kernel (debug), NULL otherwise
     const float* mapf;    // [L][3] float32 {id, x, y}: `filter->map` as it arrives on /truth/landmarks
-    // Jacobi schedule table of the fast sqrt kernel (<44, 256>): [n / 2][round t < 43][thread 256] x 16 bytes, the LDS byte
-    // offsets of every operand a thread touches in round t at state size n (built once by launch_ukf_rot_table); NULL = the
-    // kernel derives them from the round-robin schedule itself, as the other variants do
-    const uint4* rot_tab;
-    // the same for the state sizes divisible by four, whose schedule (jacobi_schedule.h) the kernel walks in PASSES of two rounds
-    // (three in the first pass of a sweep): [n / 4][pass < 21][thread 256] x 32 bytes (launch_ukf_quad_table)
+    // Pass table of the fast sqrt kernel (<44, 256>): [nj / 4][pass < 21][thread 256] x 32 bytes, the LDS byte offsets of every operand a thread
+    // touches in a pass of two Jacobi rounds at the padded state size nj = 4, 8, .., 44 (built once by launch_ukf_quad_table); the other
+    // variants derive them from the schedule themselves
     const uint4* quad_tab;
     // workload statistics (optional): [0..7] instance-steps by detections in the message (7 = seven or more), [8] Jacobi sweeps
     // that rotated something, [9] eigen-decompositions (slam_k_histogram / slam_ukf_sweep_stats)
@@ -62,11 +59,8 @@ struct UkfStepParams {
     double* big_ws;
 };
 
-// Schedule table for ukf_sqrt_kernel<44, 256>: kUkfRotTabEntries uint4 entries (4 MB); see UkfStepParams::rot_tab.
-static constexpr int kUkfRotRounds = 43, kUkfRotThreads = 256, kUkfRotSizes = 23;   // n = 0, 2, ..., 44
-static constexpr size_t kUkfRotTabEntries = (size_t)kUkfRotSizes * kUkfRotRounds * kUkfRotThreads;
-hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream);
-// Pass table for ukf_sqrt_kernel<44, 256> at n = 4, 8, ..., 44: kUkfQuadTabEntries uint4 entries (2 MB), built on the host
+static constexpr int kUkfRotThreads = 256;   // threads of the variant with the pass table
+// Pass table for ukf_sqrt_kernel<44, 256> at the padded sizes nj = 4, 8, ..., 44: kUkfQuadTabEntries uint4 entries (2 MB), built on the host
 static constexpr int kUkfQuadPasses = 21, kUkfQuadSizes = 12;   // block rounds T = 0 .. n / 2 - 2; n / 4 = 0 .. 11
 static constexpr size_t kUkfQuadTabEntries = (size_t)kUkfQuadSizes * kUkfQuadPasses * kUkfRotThreads * 2;
 hipError_t launch_ukf_quad_table(uint4* tab, hipStream_t stream);

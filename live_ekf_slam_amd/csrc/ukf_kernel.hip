@@ -105,86 +105,7 @@ __device__ __forceinline__ double block_max(double v, double* s_red, int tid, in
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// Jacobi schedule table.  In the fast rotation phase a thread's work is fixed (pair-block (i, j) or diagonal block i, and a
-// few V^T rows of pair iv); what changes from round to round is only WHICH matrix rows / columns its pairs hold (the
-// round-robin schedule).  Deriving the operand addresses from the schedule costs ~100 integer instructions per thread and
-// round against ~60 fp64 operations (the kernel is VALU-issue bound); they depend on (n, t, thread) only, so they are
-// tabulated once: entry = {a00 | a01 << 16, a10 | a11 << 16, vp | vq << 16, p | q << 16} as LDS byte offsets (pair-block:
-// the four elements; diagonal block: A_pp, A_qq, A_qp; V^T rows p, q of the thread's pair) and, for thread k < n / 2, the
-// indices (p, q) of pair k for the parameter phase.  One 16-byte load per thread and round, issued before the parameter
-// phase.  Same addresses, same arithmetic: not a bit changes.
-// ------------------------------------------------------------------------------------------------------------------
-// Round 4: the item -> thread mapping of the table path puts everything the NEXT round's rotation parameters depend on into
-// wavefront 0.  Going from round t to t + 1 every index but 0 moves one slot along the circle, so pair k of round t + 1 is (top of
-// pair k + 1, bottom of pair k - 1) of round t: its pivot element lies in pair-block (k + 1, k - 1) - (1, 0) for k = 0, (m - 1, m - 2)
-// for k = m - 1 - and its diagonal elements in the diagonal blocks.  Threads 0 .. m-1 own the diagonal blocks, threads m .. 2m-1 those
-// m "critical" pair-blocks, the other threads the remaining pair-blocks in lexicographic order.  Wavefront 0 (2 m <= 44 threads of it)
-// can therefore rotate its items and go straight on to the parameters of round t + 1 - the LDS executes one wavefront's accesses in
-// order - while wavefronts 1 .. 3 finish the other pair-blocks and rotate V: ONE barrier per round instead of two, and the parameter
-// chain (sqrt, div, sqrt: the longest dependent chain of a round) runs beside the bulk of the round's work instead of before it.
-__host__ __device__ inline bool ukf_block_is_critical(int i, int j, int m) {
-    return (i == 1 && j == 0) || (j == i - 2) || (i == m - 1 && j == m - 2);
-}
-__host__ __device__ inline int ukf_item_of_thread(int tid, int m) {   // (kind << 16) | (i << 8) | j; kind 0 pair-block, 1 diagonal block, 3 none
-    if (tid < m) return (1 << 16) | (tid << 8);
-    if (tid < 2 * m) {
-        const int c = tid - m;
-        if (c == 0) return (1 << 8) | 0;
-        if (c <= m - 2) return ((c + 1) << 8) | (c - 1);
-        return m >= 3 ? ((m - 1) << 8) | (m - 2) : (3 << 16);   // m == 2: (1, 0) is the only pair-block
-    }
-    int r = tid - 2 * m;   // rank among the other pair-blocks
-    for (int i = 1; i < m; ++i)
-        for (int j = 0; j < i; ++j) {
-            if (ukf_block_is_critical(i, j, m)) continue;
-            if (r == 0) return (i << 8) | j;
-            --r;
-        }
-    return 3 << 16;
-}
-__global__ void ukf_rot_table_kernel(uint4* tab) {
-    const int n = 2 * blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    uint4 e = make_uint4(0u, 0u, 0u, 0u);
-    if (n >= 4 && t < n - 1) {
-        const int m = n / 2;
-        auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
-        const int d = ukf_item_of_thread(tid, m), kind = d >> 16, i = (d >> 8) & 0xff, j = d & 0xff;
-        if (kind == 0) {           // pair-block (i, j), i > j
-            int pi, qi, pj, qj;
-            rr_pair(i, t, n, pi, qi);
-            rr_pair(j, t, n, pj, qj);
-            e.x = (unsigned)(8 * idx(pi, pj)) | ((unsigned)(8 * idx(pi, qj)) << 16);
-            e.y = (unsigned)(8 * idx(qi, pj)) | ((unsigned)(8 * idx(qi, qj)) << 16);
-        } else if (kind == 1) {    // diagonal block of pair i
-            int pq, qq;
-            rr_pair(i, t, n, pq, qq);
-            e.x = (unsigned)(8 * (pq * (pq + 1) / 2 + pq)) | ((unsigned)(8 * (qq * (qq + 1) / 2 + qq)) << 16);
-            e.y = (unsigned)(8 * (qq * (qq + 1) / 2 + pq));
-        }
-        // V^T rows of pair iv: wavefronts 1 .. 3 apply the V rotations
-        const int tp = (kUkfRotThreads - 64) / m, iv = tid >= 64 ? (tid - 64) / tp : m;
-        if (iv < m) {
-            int vp, vq;
-            rr_pair(iv, t, n, vp, vq);
-            e.z = (unsigned)(8 * vp * n) | ((unsigned)(8 * vq * n) << 16);
-        }
-        if (tid < m) {             // parameter phase: indices (p, q) of pair k = tid in THIS round
-            int pp, qq;
-            rr_pair(tid, t, n, pp, qq);
-            e.w = (unsigned)pp | ((unsigned)qq << 16);
-        } else {
-            e.w = (unsigned)d;     // the thread's item (the same in every round)
-        }
-    }
-    tab[((size_t)blockIdx.y * kUkfRotRounds + t) * kUkfRotThreads + tid] = e;
-}
-hipError_t launch_ukf_rot_table(uint4* tab, hipStream_t stream) {
-    hipLaunchKernelGGL(ukf_rot_table_kernel, dim3(kUkfRotRounds, kUkfRotSizes), dim3(kUkfRotThreads), 0, stream, tab);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Pass table of the state sizes divisible by four (round 4).  jacobi_schedule.h pairs the n / 2 blocks of two consecutive
+// Pass table (round 4; one per padded state size nj = 4, 8, .., 44).  jacobi_schedule.h pairs the nj / 2 blocks of two consecutive
 // indices by the circle method; a block round ("pass") T holds n / 4 QUADRUPLES (a, b | c, d) and two rounds of the schedule
 // - (a, c) (b, d), then (a, d) (b, c); pass 0 also the in-block round (a, b) (c, d) before them - which touch nothing outside the
 // quadruple's four rows / columns.  The kernel therefore reads every element of A and V once per PASS, not per round:
@@ -274,14 +195,9 @@ hipError_t launch_ukf_quad_table(uint4* tab, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------------------------
 // PROF = true compiles the phase timers in (a separate instantiation, launched only when the debug buffer is attached:
 // as a run-time option they cost the production kernel 20 VGPRs = one wavefront per SIMD of occupancy, -9 % steps/s).
-// SCHED (the variant with the schedule tables, <44, 256>): 1 = only the instances whose state size is divisible by four (pass table),
-// 2 = only the others (round-robin table), 0 = every instance.  Two launches per step, each instance runs in one of them: the two
-// table paths in ONE kernel need 101 VGPRs, apart 84 and 76 - and six workgroups per CU have 80.
-template <int NMAX, int TPB, bool PROF = false, int SCHED = 0>
+template <int NMAX, int TPB, bool PROF = false>
 __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF_SQRT_WG : 1) void ukf_sqrt_kernel(const UkfStepParams p) {
     constexpr int MMAX = NMAX / 2;
-    if constexpr (SCHED == 1) { if (p.M[blockIdx.x + p.b_off] & 1) return; }   // n = 4 + 2 M
-    if constexpr (SCHED == 2) { if (!(p.M[blockIdx.x + p.b_off] & 1)) return; }
     __shared__ double sA[NMAX * (NMAX + 1) / 2];   // packed lower triangle: A(r,c), r >= c, at r(r+1)/2 + c
     __shared__ __attribute__((aligned(16))) double sVt[NMAX * NMAX];   // V transposed: Vt[p*n + k] = V(k, p)
     __shared__ double s_cs[MMAX], s_sn[MMAX], s_tn[MMAX], s_sd[NMAX];
@@ -404,10 +320,20 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         __syncthreads();
     }
     const int tiny_from = warm ? 0 : 3;
+    // The Jacobi iteration runs on the state size padded to a multiple of four, nj = n or n + 2, so that every size walks the schedule over
+    // quadruples (jacobi_schedule.h; the oracle pads likewise): two more rows of A (packed: the elements n (n + 1) / 2 ..) and of V^T, all zero.
+    // Every rotation with one of the two extra indices is the identity (a_pq = 0), their partners rest in those rounds, the arithmetic on the
+    // n x n part is that of the oracle's padded matrix; the columns >= n of V^T are never formed (they would stay zero / one).
+    const int nj = (n + 3) & ~3, mj = nj >> 1;
+    if (nj != n) {
+        for (int e = n * (n + 1) / 2 + tid; e < nj * (nj + 1) / 2; e += TPB) sA[e] = 0.0;
+        for (int e = n * n + tid; e < nj * n; e += TPB) sVt[e] = 0.0;
+        __syncthreads();
+    }
     SQ_STAMP(0);   // load, symmetrise, warm-start transform
 
-    const int nb = m * (m - 1) / 2;
-    const int items = nb + m + m * n;
+    const int nb = mj * (mj - 1) / 2;       // (the item loop of the variants without passes: pair-blocks, diagonal blocks, V rows of the PADDED size)
+    const int items = nb + mj + mj * n;
     // The work items a thread owns are the same in every round: decode them once.
     //   kind 0: pair-block (i, j), i > j      B' = R_i^T B R_j
     //   kind 1: diagonal block of pair i
@@ -423,100 +349,30 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             while (i * (i - 1) / 2 > it) --i;
             while ((i + 1) * i / 2 <= it) ++i;
             d = (i << 8) | (it - i * (i - 1) / 2);
-        } else if (it < nb + m) {
+        } else if (it < nb + mj) {
             d = (1 << 16) | ((it - nb) << 8);
         } else if (it < items) {
-            const int e = it - nb - m;
+            const int e = it - nb - mj;
             const int i = e / n;
             d = (2 << 16) | (i << 8) | (e - i * n);
         }
         desc[u] = d;
     }
-    // Fast rotation phase (every pair-block / diagonal item is some thread's FIRST item): all LDS operands of a thread's
-    // work in a round have addresses that follow from the round-robin schedule alone (rr_pair), so they are issued
-    // together and the round costs ONE LDS round trip instead of three dependent ones per item (rotation parameters ->
-    // indices -> data).  The V row-pairs are mapped so that a thread's rows all belong to one pair: TPB / m threads per
-    // pair, ITV rows each.  Items are independent, so the mapping does not change a single bit.
-    constexpr int ITB = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB;   // pair-block / diagonal items per thread (they are the first items)
-    constexpr bool kFast = ITB <= 2;                               // n <= 103 with 1024 threads: two per thread
-    // Round 4: a thread takes its V entries as 16-byte PAIRS of consecutive k (n is even, rows of V^T start on 16-byte boundaries), pair
-    // index subk + tp * u: half the LDS instructions and address arithmetic of the V update, and the lanes of a pair read consecutive 16-byte
-    // words (the 8-byte elements at stride tp = 11 were behind the 39 % bank-conflict share of this kernel's LDS cycles).
-    // table path (round 4): the V rotations of round t run in the shadow of the parameter phase of round t + 1 - wavefront 0 computes
-    // the parameters, wavefronts 1 .. 3 rotate V (V is read by nobody until the decomposition ends, and A does not depend on it)
+    // The variants with at most two pair-block items per thread walk the schedule in PASSES of two rounds (below); <44, 256> takes the LDS
+    // addresses of a pass from the pass table, the others derive them from the quadruples' block numbers.
+    constexpr int ITB = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB;
+    constexpr bool kFast = ITB <= 2;
     constexpr bool kTab = ITB <= 2 && NMAX == 44 && TPB == kUkfRotThreads;
-    // the other fast variants (no schedule table; L = 50 runs <104, 1024>, ONE workgroup per CU - nothing overlaps its phases unless the
-    // workgroup does it itself): the V rotations of round t run in the shadow of the parameter phase of round t + 1 there too
-    // (Measured and dropped in round 4: advancing the round-robin indices in registers instead of deriving them with rr_pair every round -
-    // bit-exact, the pair-block phase 931 -> 802 ns per round at L = 50, but 17 more VGPRs and the V phase 792 -> 1015 ns: 254.9 -> 246.5 k steps/s.)
-    constexpr bool kShadow = ITB <= 2 && !kTab && TPB >= 128;
-    constexpr int VT0 = (kTab || kShadow) ? 64 : 0;      // first thread that rotates V
-    const int tp = (TPB - VT0) / m;         // threads per pair (V rows)
-    const int iv = tid >= VT0 ? (tid - VT0) / tp : m, subk = tid - VT0 - iv * tp;
-    const bool vvalid = iv < m;
-    constexpr int ITPT = ITB <= 2 ? (MMAX + ((TPB - VT0) / MMAX) - 1) / ((TPB - VT0) / MMAX) : 1;   // 16-byte pairs of V per thread
-    // schedule table (see ukf_rot_table_kernel): this thread's column of the table for state size n, or NULL
-    const bool quad = kTab && (SCHED == 1 || (SCHED == 0 && (n & 3) == 0));   // state sizes divisible by four walk the schedule in passes (launch_ukf_quad_table)
-    const uint4* const tabn = kTab ? p.rot_tab + (size_t)(n / 2) * kUkfRotRounds * kUkfRotThreads + tid : nullptr;   // the launcher checks rot_tab
+    constexpr int VT0 = kFast ? 64 : 0;      // first thread that has V items (wavefront 0 carries the parameter chain)
     bool converged = false;
     int pass_seq = 1;                       // passes without the table: number of the pass (s_pass_flag)
     if (tid == 0) s_pass_flag = 0;          // (the barriers of the prologue come before its first use)
     uint4 te_next = make_uint4(0u, 0u, 0u, 0u);
-    // (one pointer and one set of prefetch registers for both table paths: an instance walks one of them)
-    const uint4* const qtab = kTab ? (quad ? p.quad_tab + ((size_t)(n >> 2) * kUkfQuadPasses * kUkfRotThreads + tid) * 2 : tabn) : nullptr;   // + 2 * 256 * pass
+    const uint4* const qtab = kTab ? p.quad_tab + ((size_t)(nj >> 2) * kUkfQuadPasses * kUkfRotThreads + tid) * 2 : nullptr;   // + 2 * 256 * pass
     unsigned qnz = 0u;   // pass table: the words of the NEXT pass's entry that every pass needs - (te_next = w0..w3, qnz = w6) - requested a pass ahead
     unsigned qw7 = 0u;   // w7 (the same in every pass)
-    if constexpr (kTab) { te_next = qtab[0]; if (quad) { qnz = qtab[1].z; qw7 = qtab[1].w; } }
+    if constexpr (kTab) { te_next = qtab[0]; qnz = qtab[1].z; qw7 = qtab[1].w; }
     int par = 0;                            // table path: parity of the parameter buffers the current round reads
-    auto v_rotate = [&](unsigned vz, const double2* csn) {   // V <- V J of one round, this thread's pair iv
-        if (!vvalid) return;
-        const double2 vcs = csn[iv];
-        if (vcs.y == 0.0) return;           // identity rotation: the V row pairs are unchanged
-        char* const sVb = reinterpret_cast<char*>(sVt);
-        const unsigned vpo = vz & 0xffffu, vqo = vz >> 16;
-        double2 xp[ITPT], xq[ITPT];
-#pragma unroll
-        for (int u = 0; u < ITPT; ++u) {
-            const int k = 2 * (subk + tp * u);
-            const int kk = k < n ? k : 0;
-            xp[u] = *reinterpret_cast<const double2*>(sVb + vpo + 8 * kk);
-            xq[u] = *reinterpret_cast<const double2*>(sVb + vqo + 8 * kk);
-        }
-        const double c = vcs.x, sn = vcs.y;
-#pragma unroll
-        for (int u = 0; u < ITPT; ++u) {
-            const int k = 2 * (subk + tp * u);
-            if (k < n) {
-                *reinterpret_cast<double2*>(sVb + vpo + 8 * k) = make_double2(fma(c, xp[u].x, -(sn * xq[u].x)), fma(c, xp[u].y, -(sn * xq[u].y)));
-                *reinterpret_cast<double2*>(sVb + vqo + 8 * k) = make_double2(fma(sn, xp[u].x, c * xq[u].x), fma(sn, xp[u].y, c * xq[u].y));
-            }
-        }
-    };
-    auto v_rotate_rr = [&](int tr, const double2* csn) {   // the same with the rows taken from the round-robin schedule of round tr
-        if (!vvalid) return;
-        const double2 vcs = csn[iv];
-        if (vcs.y == 0.0) return;
-        int vpi, vqi;
-        jacobi_pair(iv, tr, n, vpi, vqi);
-        double2 xp[ITPT], xq[ITPT];
-#pragma unroll
-        for (int u = 0; u < ITPT; ++u) {
-            const int k = 2 * (subk + tp * u);
-            const int kk = k < n ? k : 0;
-            xp[u] = *reinterpret_cast<const double2*>(&sVt[vpi * n + kk]); xq[u] = *reinterpret_cast<const double2*>(&sVt[vqi * n + kk]);
-        }
-        const double c = vcs.x, sn = vcs.y;
-#pragma unroll
-        for (int u = 0; u < ITPT; ++u) {
-            const int k = 2 * (subk + tp * u);
-            if (k < n) {
-                *reinterpret_cast<double2*>(&sVt[vpi * n + k]) = make_double2(fma(c, xp[u].x, -(sn * xq[u].x)), fma(c, xp[u].y, -(sn * xq[u].y)));
-                *reinterpret_cast<double2*>(&sVt[vqi * n + k]) = make_double2(fma(sn, xp[u].x, c * xq[u].x), fma(sn, xp[u].y, c * xq[u].y));
-            }
-        }
-    };
-    bool vpend = false;   // kShadow: the V rotations of round t_prev are pending (they run beside the next parameter phase)
-    int t_prev = 0;
     // rotation parameters (c, s, t = tan) of the pair (pidx, qidx) from the current A; sw: the sweep the rotation belongs to
     auto jacobi_param = [&](double app, double aqq, double apq, int sw, double& c, double& s, double& tt) {
         c = 1.0; s = 0.0; tt = 0.0;
@@ -562,27 +418,22 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         // wavefront 0 carries the longest dependent chain of a round (its items, then the next parameters): let it issue ahead
         if (tid < 64) __builtin_amdgcn_s_setprio(SLAM_UKF_PRIO);
     }
-    int desc_tab = 3 << 16;                 // table path: this thread's item (diagonal block of pair tid, or the table's word)
-    if constexpr (kTab) desc_tab = tid < m ? ((1 << 16) | (tid << 8)) : (int)te_next.w;
-    // ---- pass-table path: the thread's V items (quadruple, 16-byte pair of columns); fixed for the launch ----
     // pass table: the thread's block lane, fixed for the launch (w7 of any pass): parameter slots 2 I + i | (2 J + j) << 8 | I << 16 | J << 24, -1 = none
     int qrole = -1;
     if constexpr (kTab) {
-        if (quad) {
-            const unsigned w7 = qw7;
-            if ((w7 & 3u) == 1u) {
-                const int I = (w7 >> 8) & 0xff, J = (w7 >> 16) & 0xff;
-                qrole = (2 * I + (int)((w7 >> 24) & 1u)) | ((2 * J + (int)((w7 >> 25) & 1u)) << 8) | (I << 16) | (J << 24);
-            }
+        const unsigned w7 = qw7;
+        if ((w7 & 3u) == 1u) {
+            const int I = (w7 >> 8) & 0xff, J = (w7 >> 16) & 0xff;
+            qrole = (2 * I + (int)((w7 >> 24) & 1u)) | ((2 * J + (int)((w7 >> 25) & 1u)) << 8) | (I << 16) | (J << 24);
         }
     }
     int vitem[2] = {-1, -1};   // quadruple | pair of columns << 8, -1 = none
     if constexpr (kTab) {
-        if (quad && tid >= 64) {
+        if (tid >= 64) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int it = tid - 64 + (kUkfRotThreads - 64) * u, q = it / m;
-                if (q < (n >> 2)) vitem[u] = q | ((it - q * m) << 8);
+                const int it = tid - 64 + (kUkfRotThreads - 64) * u, q = it / mj, kp = it - q * mj;   // (the table numbers nj / 2 pairs of columns per quadruple)
+                if (q < (nj >> 2) && kp < m) vitem[u] = q | (kp << 8);                                 // the columns >= n of V^T are not formed
             }
         }
     }
@@ -596,7 +447,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     constexpr int QNB = kQuadGen ? 1 + (4 * (MQ * (MQ - 1) / 2) + (TPB - QOT0) - 1) / (TPB - QOT0) : 1, QNV = kQuadGen ? (MQ * MMAX + (TPB - VT0) - 1) / (TPB - VT0) : 1;
     int qb_desc[QNB], qv_desc[QNV];
     if constexpr (kQuadGen) {
-        const int mq_ = n >> 2;
+        const int mq_ = nj >> 2;
 #pragma unroll
         for (int ub = 0; ub < QNB; ++ub) qb_desc[ub] = -1;
         if (mq_ >= 2 && tid < 4 * mq_) {   // slot 0 of the first lanes: critical block tid / 4
@@ -744,15 +595,15 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             break;
         }
         if constexpr (kTab) {
-            if (quad) {
-                // ======== pass-table path (n divisible by four): n / 2 - 1 passes of two rounds, the in-block round inside pass 0 ========
-                const int mq = n >> 2;
+            {
+                // ======== pass-table path: nj / 2 - 1 passes of two rounds, the in-block round inside pass 0 ========
+                const int mq = nj >> 2;
 #pragma unroll 1
-                for (int T = -1; T < m - 1; ++T) {   // T = -1: only the parameters of pass 0 (every later pass gets its own a pass ahead)
+                for (int T = -1; T < mj - 1; ++T) {   // T = -1: only the parameters of pass 0 (every later pass gets its own a pass ahead)
                     const uint4 ea = te_next;
                     const unsigned ez = qnz;
                     if (T >= 0) {
-                        const int Tn = T + 1 < m - 1 ? T + 1 : 0;
+                        const int Tn = T + 1 < mj - 1 ? T + 1 : 0;
                         te_next = qtab[(size_t)Tn * (2 * kUkfRotThreads)]; qnz = qtab[(size_t)Tn * (2 * kUkfRotThreads) + 1].z;
                         const bool first = T == 0;
                         const double2* const cs = s_csn + par * 3 * MMAX;
@@ -785,7 +636,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                         }
                     }
                     // wavefront 0: the next pass's parameters, from what it has just written (its lanes < n / 2 carry their quadruple's blocks in w6)
-                    if (tid < 2 * mq && T + 1 < m - 1) param_phase(T < 0 ? ez : qnz, T < 0, par ^ 1, sweep);
+                    if (tid < 2 * mq && T + 1 < mj - 1) param_phase(T < 0 ? ez : qnz, T < 0, par ^ 1, sweep);
                     __syncthreads();
                     SQ_STAMP(3);   // one pass (one barrier)
                     if constexpr (PROF) { if (tid == 0 && T >= 0) sacc[5] += 2; }   // rounds
@@ -795,16 +646,16 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             }
         }
         if constexpr (kFast && !kTab) {
-            if ((n & 3) == 0) {
+            {
                 // ======== passes without the table (the other fast variants; L = 50 runs <104, 1024>, one workgroup per CU) ========
                 // One barrier per pass, as in the table path: wavefront 0 (and 1) rotate the critical blocks first, then wavefront 0 goes on to the
                 // parameters of the NEXT pass (two rounds of sqrt / div / sqrt chains on the diagonal 4 x 4 blocks in LDS: ~1 us, the longest thing in
                 // a pass) while the other wavefronts do the rest of the blocks and the V items.  Critical blocks beyond wavefront 0's sixteen are
                 // wavefront 1's: it raises s_pass_flag after writing them and wavefront 0 waits for that before it reads the pivots.
-                const int mq = n >> 2;
+                const int mq = nj >> 2;
                 const bool crit_in_w1 = 4 * mq > 64;
 #pragma unroll 1
-                for (int T = -1; T < m - 1; ++T) {   // T = -1: only the parameters of pass 0
+                for (int T = -1; T < mj - 1; ++T) {   // T = -1: only the parameters of pass 0
                     if (T >= 0) {
                         const bool first = T == 0;
                         const double2* const cs = s_csn + par * 3 * MMAX;
@@ -857,14 +708,14 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                             }
                         }
                     }
-                    if (tid < 64 && T + 1 < m - 1) {   // wavefront 0: the next pass's parameters, from what the critical lanes have just written
+                    if (tid < 64 && T + 1 < mj - 1) {   // wavefront 0: the next pass's parameters, from what the critical lanes have just written
                         if (T >= 0 && crit_in_w1) {
                             while (*reinterpret_cast<volatile int*>(&s_pass_flag) != pass_seq) __builtin_amdgcn_s_sleep(1);
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         }
                         if (tid < 2 * mq) {
                             int X, Y;
-                            rr_pair(tid >> 1, T + 1, m, X, Y);
+                            rr_pair(tid >> 1, T + 1, mj, X, Y);
                             const unsigned xy = (unsigned)X | ((unsigned)Y << 8);
                             if (!(tid & 1)) s_xy[(par ^ 1) * MQ + (tid >> 1)] = (int)xy;
                             param_phase(xy, T < 0, par ^ 1, sweep);
@@ -879,147 +730,23 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                 continue;
             }
         }
+        // ======== the variants without passes (more than two pair-block items per thread): round by round, two barriers each ========
+        if constexpr (!kFast) {
 #pragma unroll 1
-        for (int t = 0; t < n - 1; ++t) {
-            // the table entry of this round was requested a round ago (the parameter lanes need it at once: waiting for it
-            // here put an L2 round trip at the head of every round); the next round's is requested now
-            const uint4 te = te_next;
-            if constexpr (kTab) te_next = qtab[(size_t)(t + 1 < n - 1 ? t + 1 : 0) * kUkfRotThreads];
-            if constexpr (kTab) {
-                // ---- table path: ONE barrier per round (see ukf_item_of_thread) ----
-                if (sweep == 0 && t == 0) {   // parameters of the very first round (every later round's are computed a round ahead)
-                    if (tid < m) {
-                        double c, sn, tt;
-                        const char* const sAc = reinterpret_cast<const char*>(sA);   // (a diagonal thread's table words ARE the three addresses)
-                        jacobi_param(*reinterpret_cast<const double*>(sAc + (te.x & 0xffffu)), *reinterpret_cast<const double*>(sAc + (te.x >> 16)),
-                                     *reinterpret_cast<const double*>(sAc + (te.y & 0xffffu)), 0, c, sn, tt);
-                        s_tn2[par * MMAX + tid] = tt;
-                        s_csn[par * MMAX + tid] = make_double2(c, sn);
-                    }
-                    __syncthreads();
-                }
-                char* const sAb = reinterpret_cast<char*>(sA);
-                const double2* const csn = s_csn + par * MMAX;
-                const int d = desc_tab;
-                const int kind = d >> 16, i = (d >> 8) & 0xff, j = d & 0xff;
-                if (kind == 0) {           // A <- J^T A J on pair-block (i, j); operand addresses from the schedule table
-                    const double2 csi = csn[i], csj = csn[j];
-                    double* const e00 = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
-                    double* const e01 = reinterpret_cast<double*>(sAb + (te.x >> 16));
-                    double* const e10 = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
-                    double* const e11 = reinterpret_cast<double*>(sAb + (te.y >> 16));
-                    const double b00 = *e00, b01 = *e01, b10 = *e10, b11 = *e11;
-                    const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
-                    if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
-                        const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
-                        const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
-                        *e00 = fma(t00, cj, -(t01 * sj)); *e01 = fma(t00, sj, t01 * cj);
-                        *e10 = fma(t10, cj, -(t11 * sj)); *e11 = fma(t10, sj, t11 * cj);
-                    }
-                } else if (kind == 1) {    // diagonal block of pair i
-                    double* const epp = reinterpret_cast<double*>(sAb + (te.x & 0xffffu));
-                    double* const eqq = reinterpret_cast<double*>(sAb + (te.x >> 16));
-                    double* const epq = reinterpret_cast<double*>(sAb + (te.y & 0xffffu));
-                    const double tn = s_tn2[par * MMAX + i];
-                    const double app = *epp, aqq = *eqq, apq = *epq;
-                    *epp = fma(-tn, apq, app);
-                    *eqq = fma(tn, apq, aqq);
-                    if (apq != 0.0) *epq = 0.0;
-                }
-                if (tid < m) {
-                    // wavefront 0: the parameters of the NEXT round (the first round of the next sweep after the last one), from the
-                    // elements this wavefront has just written (the LDS executes a wavefront's accesses in order)
-                    double c, sn, tt;
-                    jacobi_param(*reinterpret_cast<const double*>(sAb + (te_next.x & 0xffffu)), *reinterpret_cast<const double*>(sAb + (te_next.x >> 16)),
-                                 *reinterpret_cast<const double*>(sAb + (te_next.y & 0xffffu)), t + 1 < n - 1 ? sweep : sweep + 1, c, sn, tt);
-                    s_tn2[(par ^ 1) * MMAX + tid] = tt;
-                    s_csn[(par ^ 1) * MMAX + tid] = make_double2(c, sn);
-                }
-                if (tid >= VT0) v_rotate(te.z, csn);   // wavefronts 1 .. 3: V <- V J of this round
-                __syncthreads();
-                SQ_STAMP(3);   // one round (one barrier)
-                if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
-                par ^= 1;
-                continue;
-            }
-            if (tid < m) {  // rotation parameters of this round's pairs (jacobi_schedule.h)
+        for (int t = 0; t < nj - 1; ++t) {
+            if (tid < mj) {  // rotation parameters of this round's pairs (jacobi_schedule.h)
                 const int k = tid;
                 int pidx, qidx;
-                jacobi_pair(k, t, n, pidx, qidx);
+                jacobi_pair(k, t, nj, pidx, qidx);
                 double c, s, tt;
                 jacobi_param(AT(pidx, pidx), AT(qidx, qidx), AT(qidx, pidx), sweep, c, s, tt);
                 s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
                 s_csn[par * MMAX + k] = make_double2(c, s);
                 s_tn2[par * MMAX + k] = tt;
             }
-            if constexpr (kShadow) {
-                if (vpend && tid >= VT0) v_rotate_rr(t_prev, s_csn + (par ^ 1) * MMAX);   // V <- V J of the round before, beside the parameters
-            }
             __syncthreads();
-            SQ_STAMP(2);   // rotation parameters (lanes of wavefront 0) [+ V rotations of the round before] + barrier
+            SQ_STAMP(2);   // rotation parameters (lanes of wavefront 0) + barrier
             if constexpr (PROF) { if (tid == 0) sacc[5] += 1; }   // rounds
-            if constexpr (kFast) {
-                const double2* const csn = s_csn + par * MMAX;
-                // ---- V row-pairs of pair iv: operands first (kShadow: V is rotated beside the NEXT parameter phase instead) ----
-                int vpi = 0, vqi = 0;
-                double2 vcs = make_double2(1.0, 0.0);
-                double2 xp[ITPT], xq[ITPT];
-                if constexpr (!kShadow) {
-                    jacobi_pair(vvalid ? iv : 0, t, n, vpi, vqi);
-                    vcs = csn[vvalid ? iv : 0];
-#pragma unroll
-                    for (int u = 0; u < ITPT; ++u) {
-                        const int k = 2 * (subk + tp * u);
-                        const int kk = k < n ? k : 0;
-                        xp[u] = *reinterpret_cast<const double2*>(&sVt[vpi * n + kk]); xq[u] = *reinterpret_cast<const double2*>(&sVt[vqi * n + kk]);
-                    }
-                }
-                // ---- the thread's pair-blocks / diagonal blocks (items are independent: any order, any owner, same bits) ----
-#pragma unroll
-                for (int ub = 0; ub < ITB; ++ub) {
-                    const int d = desc[ub];
-                    const int kind = d < 0 ? 3 : (d >> 16), i = (d >> 8) & 0xff, j = d & 0xff;
-                    if (kind == 0) {
-                        int pi, qi, pj, qj;
-                        jacobi_pair(i, t, n, pi, qi);
-                        jacobi_pair(j, t, n, pj, qj);
-                        const double2 csi = csn[i], csj = csn[j];
-                        auto idx = [](int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; };
-                        const int a00 = idx(pi, pj), a01 = idx(pi, qj), a10 = idx(qi, pj), a11 = idx(qi, qj);
-                        const double b00 = sA[a00], b01 = sA[a01], b10 = sA[a10], b11 = sA[a11];
-                        const double ci = csi.x, si = csi.y, cj = csj.x, sj = csj.y;
-                        if (!(si == 0.0 && sj == 0.0)) {   // both rotations the identity (c = 1 exactly): B' = B bit for bit
-                            const double t00 = fma(ci, b00, -(si * b10)), t01 = fma(ci, b01, -(si * b11));
-                            const double t10 = fma(si, b00, ci * b10), t11 = fma(si, b01, ci * b11);
-                            sA[a00] = fma(t00, cj, -(t01 * sj)); sA[a01] = fma(t00, sj, t01 * cj);
-                            sA[a10] = fma(t10, cj, -(t11 * sj)); sA[a11] = fma(t10, sj, t11 * cj);
-                        }
-                    } else if (kind == 1) {
-                        int pq, qq;
-                        jacobi_pair(i, t, n, pq, qq);
-                        const int app_i = pq * (pq + 1) / 2 + pq, aqq_i = qq * (qq + 1) / 2 + qq, apq_i = qq * (qq + 1) / 2 + pq;
-                        const double tn = s_tn2[par * MMAX + i];
-                        const double app = sA[app_i], aqq = sA[aqq_i], apq = sA[apq_i];
-                        sA[app_i] = fma(-tn, apq, app);
-                        sA[aqq_i] = fma(tn, apq, aqq);
-                        if (apq != 0.0) sA[apq_i] = 0.0;
-                    }
-                }
-                // ---- V <- V J ----
-                if constexpr (kShadow) {
-                    vpend = true; t_prev = t; par ^= 1;   // this round's V rotations run beside the next parameter phase
-                } else if (vvalid && vcs.y != 0.0) {   // identity rotation: the V row pairs are unchanged
-                    const double c = vcs.x, sn = vcs.y;
-#pragma unroll
-                    for (int u = 0; u < ITPT; ++u) {
-                        const int k = 2 * (subk + tp * u);
-                        if (k < n) {
-                            *reinterpret_cast<double2*>(&sVt[vpi * n + k]) = make_double2(fma(c, xp[u].x, -(sn * xq[u].x)), fma(c, xp[u].y, -(sn * xq[u].y)));
-                            *reinterpret_cast<double2*>(&sVt[vqi * n + k]) = make_double2(fma(sn, xp[u].x, c * xq[u].x), fma(sn, xp[u].y, c * xq[u].y));
-                        }
-                    }
-                }
-            } else
 #pragma unroll
             for (int u = 0; u < IT; ++u) {
                 const int d = desc[u];
@@ -1057,11 +784,6 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             __syncthreads();
             SQ_STAMP(3);   // rotation phase + barrier
         }
-    }
-    if constexpr (kShadow) {
-        if (vpend) {   // the V rotations of the last round (nobody has read V since)
-            if (tid >= VT0) v_rotate_rr(t_prev, s_csn + (par ^ 1) * MMAX);
-            __syncthreads();
         }
     }
     if (!converged) {
@@ -1583,12 +1305,9 @@ hipError_t launch_ukf_sqrt(const UkfStepParams& p, hipStream_t stream) {
             case 128: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 128>), dim3(p.b_cnt), dim3(128), 0, stream, p); break;
             case 64: hipLaunchKernelGGL((ukf_sqrt_kernel<44, 64>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;
             default:
-                if (p.rot_tab == nullptr || p.quad_tab == nullptr) return hipErrorInvalidValue;   // <44, 256> takes its operand addresses from the schedule tables
+                if (p.quad_tab == nullptr) return hipErrorInvalidValue;   // <44, 256> takes its operand addresses from the pass table
                 if (p.prof) hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, true>), dim3(p.b_cnt), dim3(256), 0, stream, p);
-                else {   // each instance runs in one of the two (see SCHED)
-                    hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, false, 1>), dim3(p.b_cnt), dim3(256), 0, stream, p);
-                    hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256, false, 2>), dim3(p.b_cnt), dim3(256), 0, stream, p);
-                }
+                else hipLaunchKernelGGL((ukf_sqrt_kernel<44, 256>), dim3(p.b_cnt), dim3(256), 0, stream, p);
                 break;
         }
     } else if (nmax <= 104) {

@@ -158,6 +158,27 @@ int jacobi_round_robin(double* A, double* V, int n, int max_sweeps, bool warm = 
     return -1;
 }
 
+// State sizes n = 2 (mod 4) in the LDS size classes of the kernels (L_max <= 50): the matrix is PADDED by a decoupled 2 x 2 zero block to
+// n + 2 (V by the identity), so that every size walks the schedule over quadruples; the rotations with the two extra indices are the
+// identity (a_pq = 0) and the sweep has two more rounds, in which their partners rest.  The kernels keep the two zero rows physically
+// (ukf_kernel.hip), the arithmetic on the n x n part is the same.  pad = false (the HBM-streamed class, ukf_big_kernel.hip, whose full
+// square matrices have no room for the extra rows): the circle method over the n indices, as before.
+int jacobi_parallel(double* A, double* V, int n, int max_sweeps, bool warm, bool refmode, bool pad) {
+    if (!(n & 2) || !pad) return jacobi_round_robin(A, V, n, max_sweeps, warm, refmode);
+    const int np = n + 2;
+    std::vector<double> Ap((size_t)np * np, 0.0), Vp((size_t)np * np, 0.0);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            Ap[(size_t)r * np + c] = A[(size_t)r * n + c];
+            if (warm) Vp[(size_t)r * np + c] = V[(size_t)r * n + c];
+        }
+    if (warm) { Vp[(size_t)n * np + n] = 1.0; Vp[(size_t)(n + 1) * np + n + 1] = 1.0; }
+    const int sweeps = jacobi_round_robin(Ap.data(), Vp.data(), np, max_sweeps, warm, refmode);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) { A[(size_t)r * n + c] = Ap[(size_t)r * np + c]; V[(size_t)r * n + c] = Vp[(size_t)r * np + c]; }
+    return sweeps;
+}
+
 struct Ukf {
     slam_config cfg;
     FilterNoise nz;
@@ -238,7 +259,7 @@ struct Ukf {
                     Y[(size_t)r * nn + c] = acc; Y[(size_t)c * nn + r] = acc;
                 }
         }
-        const int sweeps = jacobi_round_robin(Y.data(), V.data(), nn, 60, warm, refmode);
+        const int sweeps = jacobi_parallel(Y.data(), V.data(), nn, 60, warm, refmode, 4 + 2 * L_max <= 104);
         last_sweeps = sweeps;
         if (sweeps >= 0) { Vprev = V; v_age = warm ? v_age + 1 : 0; } else { v_age = -1; }
         if (sweeps < 0) {
@@ -460,7 +481,7 @@ int orc_ukf_sqrt_probe(const double* P, int n, double scale, double* out) {
     std::vector<double> Y((size_t)n * n), V((size_t)n * n);
     for (int r = 0; r < n; ++r)
         for (int c = 0; c < n; ++c) Y[(size_t)r * n + c] = (0.5 * (P[(size_t)r * n + c] + P[(size_t)c * n + r])) * scale;
-    const int sweeps = jacobi_round_robin(Y.data(), V.data(), n, 60);
+    const int sweeps = jacobi_parallel(Y.data(), V.data(), n, 60, false, false, n <= 104);
     if (sweeps < 0) return -1;
     for (int r = 0; r < n; ++r)
         for (int c = 0; c <= r; ++c) {
