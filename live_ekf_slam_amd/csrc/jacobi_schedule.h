@@ -23,8 +23,9 @@ __host__ __device__ inline void rr_pair(int k, int t, int n, int& p, int& q) {
 // blocks into quadruples (a, b | c, d) = (2X, 2X+1 | 2Y, 2Y+1), X < Y, and takes two rounds: t = 1 + 2T: (a, c) (b, d); t = 2 + 2T:
 // (a, d) (b, c).  Round 0 rotates inside the blocks, (a, b) (c, d), indexed by the quadruples of block round 0.  Pairs 2 kb and
 // 2 kb + 1 belong to quadruple kb.  Two consecutive rounds stay inside the same 4 x 4 blocks of A and the same four rows of V^T:
-// ukf_sqrt_kernel<44, 256> keeps them in registers across both (half the passes over LDS, half the barriers).
-// n = 2 (mod 4): the circle method over the indices.
+// the sqrt kernels of the LDS size classes keep them in registers across both (half the passes over LDS, half the barriers).
+// Those kernels (and the oracle for those classes) PAD a state size n = 2 (mod 4) by two all-zero rows to n + 2 and call this with the padded
+// size; n = 2 (mod 4) itself - the circle method over the indices - is what the HBM-streamed class (ukf_big_kernel.hip) still runs.
 __host__ __device__ inline void jacobi_pair(int k, int t, int n, int& p, int& q) {
     if (n & 2) { rr_pair(k, t, n, p, q); return; }
     const int kb = k >> 1, u = k & 1;

@@ -114,7 +114,7 @@ __device__ __forceinline__ double block_max(double v, double* s_red, int tid, in
 //   * a V item is (quadruple, 16-byte pair of columns k): four rows of V^T through all the rotations of the pass;
 //   * the diagonal 4 x 4 block of a quadruple belongs to two PARAMETER lanes, one per pair of the round: parameters from its pair's
 //     three elements, the pair's diagonal block, then (lane 1) the cross block with both rotations, round after round through LDS
-//     (one wavefront's LDS accesses execute in order).  As in the round-robin table path this runs a pass ahead, in wavefront 0,
+//     (one wavefront's LDS accesses execute in order).  This runs a pass ahead, in wavefront 0,
 //     which also owns the "critical" blocks - the ones that hold the next pass's pivots: the cross block of next quadruple (X, Y)
 //     lies in the block between the current quadruples of X and of Y.  One barrier per pass.
 // Entry (32 bytes = w[0..7]) of thread tid in pass T at size n:

@@ -44,6 +44,8 @@ def test_two_rounds_of_a_pass_stay_inside_quadruples(oracle, n):
 
 @pytest.mark.parametrize("n", [6, 10, 42])
 def test_other_sizes_use_the_circle_method_over_the_indices(oracle, n):
+    """(What the HBM-streamed class runs at n = 2 mod 4; the LDS classes pad such a size to n + 2 and walk the quadruples -
+    test_padded_sizes_give_the_square_root below.)"""
     for t, rnd in enumerate(sweep_pairs(oracle, n)):
         at = lambda k: 0 if k == 0 else 1 + ((k - 1 + t) % (n - 1))
         for k, (p, q) in enumerate(rnd):
@@ -65,3 +67,17 @@ def test_device_header_lists_the_same_pairs(oracle, tmp_path):
     out = np.array(subprocess.check_output([str(exe)]).split(), dtype=np.int64).reshape(-1, 2)
     ref = [oracle.ukf_jacobi_pair(k, t, n) for n in range(4, 206, 2) for t in range(n - 1) for k in range(n // 2)]
     assert np.array_equal(out, np.array(ref, dtype=np.int64))
+
+
+@pytest.mark.parametrize("n", [6, 10, 22, 42, 102])
+def test_padded_sizes_give_the_square_root(oracle, n):
+    """n = 2 (mod 4) runs padded by a decoupled 2 x 2 zero block (oracle and kernels alike): the n x n result is the principal square
+    root of the clamped matrix all the same (LAPACK, 1e-12)."""
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)); P = A @ A.T / n + np.diag(rng.uniform(1e-6, 1.0, n))
+    scale = float(np.float32(n) / np.float32(0.8))
+    out, sweeps = oracle.ukf_sqrt_probe(P, scale)
+    Y = 0.5 * (P + P.T) * scale
+    D, Q = np.linalg.eigh(Y)
+    ref = (Q * np.sqrt(np.maximum(D, 1e-8))) @ Q.T
+    assert sweeps >= 0 and np.abs(out.reshape(n, n) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
