@@ -203,11 +203,10 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     __shared__ double s_cs[MMAX], s_sn[MMAX], s_tn[MMAX], s_sd[NMAX];
     __shared__ int s_pp[MMAX], s_qq[MMAX];
     constexpr bool kQuadLds = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB <= 2;   // the variants that walk the sizes divisible by four in passes of two rounds (kFast below)
-    __shared__ double2 s_csn[(kQuadLds ? 6 : 2) * MMAX];   // (c, s) of this round's rotations, one 16-byte read per consumer (table path: [round parity][pair]; pass table: [pass parity][round of the pass][pair])
+    __shared__ double2 s_csn[(kQuadLds ? 6 : 2) * MMAX];   // (c, s) of the rotations, one 16-byte read per consumer: [pass parity][round of the pass][pair] (round-by-round variants: [pair])
     __shared__ int s_qflag[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];   // passes: [pass parity][quadruple] any rotation of the pass that is not the identity
     __shared__ int s_xy[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];      // passes without the table: [pass parity][quadruple] its blocks X | Y << 8
     __shared__ int s_pass_flag;                                    // passes without the table: wavefront 1 -> wavefront 0, "critical blocks of pass # written"
-    __shared__ double s_tn2[2 * MMAX];            // table path: tan of the rotations, [round parity][pair]
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     const int M = p.M[b];
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     unsigned qnz = 0u;   // pass table: the words of the NEXT pass's entry that every pass needs - (te_next = w0..w3, qnz = w6) - requested a pass ahead
     unsigned qw7 = 0u;   // w7 (the same in every pass)
     if constexpr (kTab) { te_next = qtab[0]; qnz = qtab[1].z; qw7 = qtab[1].w; }
-    int par = 0;                            // table path: parity of the parameter buffers the current round reads
+    int par = 0;                            // passes: parity of the parameter buffers the current pass reads
     // rotation parameters (c, s, t = tan) of the pair (pidx, qidx) from the current A; sw: the sweep the rotation belongs to
     auto jacobi_param = [&](double app, double aqq, double apq, int sw, double& c, double& s, double& tt) {
         c = 1.0; s = 0.0; tt = 0.0;
@@ -742,7 +741,6 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                 jacobi_param(AT(pidx, pidx), AT(qidx, qidx), AT(qidx, pidx), sweep, c, s, tt);
                 s_pp[k] = pidx; s_qq[k] = qidx; s_cs[k] = c; s_sn[k] = s; s_tn[k] = tt;
                 s_csn[par * MMAX + k] = make_double2(c, s);
-                s_tn2[par * MMAX + k] = tt;
             }
             __syncthreads();
             SQ_STAMP(2);   // rotation parameters (lanes of wavefront 0) + barrier
