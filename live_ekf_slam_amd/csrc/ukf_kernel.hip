@@ -496,7 +496,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     // one after the other on the quadruple's diagonal 4 x 4 block (a, b | c, d) = (2X, 2X+1 | 2Y, 2Y+1) IN LDS - parameters from the
     // pair's three elements, the pair's diagonal block, then lane 1 the cross block (rows: pair 1) with both rotations.
     //   round 0 (first pass of a sweep): pairs (a,b) (c,d), cross (c,d) x (a,b);  1: (a,c) (b,d), cross (b,d) x (a,c);  2: (a,d) (b,c), cross (b,c) x (a,d)
-    auto param_phase = [&](const unsigned xy, const bool first, const int parw, const int sweep) {
+    auto param_phase = [&](const unsigned xy, const bool first, const int parw, const int sweep) -> int {
         const int u = tid & 1, q = tid >> 1;
         const unsigned a = 2u * (xy & 0xffu), c = 2u * ((xy >> 8) & 0xffu);
         const unsigned ta = 4u * a * (a + 1u), tb = ta + 8u * (a + 1u), tc = 4u * c * (c + 1u), td = tc + 8u * (c + 1u);   // 8 * row (row + 1) / 2
@@ -528,6 +528,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         const int mine = any ? 1 : 0;
         const int both = mine | __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xf, 0xf, true);
         if (u == 0) s_qflag[parw * MQ + q] = both;
+        return both;
     };
     // V <- V J for a pass: rows a, b, c, d of V^T (quadruple Q = blocks xy), the 16-byte pair kp of columns, through every rotation of the pass
     auto v_item = [&](const int Q, const int kp, const unsigned xy, const bool first, const double2* const cs) {
@@ -573,6 +574,33 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                     const double app = fabs(dp[u]), aqq = fabs(dq[u]);
                     if (!(sweep >= tiny_from && (app + g == app) && (aqq + g == aqq))) live = 1;
                 }
+            }
+        } else if constexpr (kFast) {
+            // passes without the table: wavefront 0 forms the parameters of pass 0 (three rounds on the diagonal 4 x 4 blocks: the longest chain of
+            // a sweep, and nothing else of the workgroup can run beside it but this scan) while the other wavefronts scan.  The two touch the
+            // same elements - the pivots the parameter lanes zero or rotate, the diagonal entries they update - and the verdict is still
+            // exact: a rotation that is not the identity means an element was live at the start of the sweep and is reported by its lane
+            // (param_phase returns it); if every rotation is the identity, nothing the scan reads has changed (a_pp' = fma(-0, a_pq, a_pp)).
+            const int mq = nj >> 2;
+            if (tid < 64) {
+                if (tid < 2 * mq) {
+                    int X, Y;
+                    rr_pair(tid >> 1, 0, mj, X, Y);
+                    const unsigned xy = (unsigned)X | ((unsigned)Y << 8);
+                    if (!(tid & 1)) s_xy[(par ^ 1) * MQ + (tid >> 1)] = (int)xy;
+                    live = param_phase(xy, true, par ^ 1, sweep);
+                }
+            } else {
+                const int tt = tid - 64, tpr = (TPB - 64) / n > 0 ? (TPB - 64) / n : 1;   // threads per row of the strictly-lower part
+                for (int r = tt / tpr; r < n; r += (TPB - 64) / tpr)
+                    for (int c = tt - (tt / tpr) * tpr; c < r; c += tpr) {
+                        const double v = sA[r * (r + 1) / 2 + c];
+                        if (v != 0.0 && v == v) {   // (NaN: see below)
+                            const double g = 100.0 * fabs(v);
+                            const double app = fabs(sA[c * (c + 1) / 2 + c]), aqq = fabs(sA[r * (r + 1) / 2 + r]);
+                            if (!(sweep >= tiny_from && (app + g == app) && (aqq + g == aqq))) live = 1;
+                        }
+                    }
             }
         } else
         for (int r = tid / 2; r < n; r += TPB / 2)          // two threads per row, strictly-lower part
@@ -653,9 +681,10 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                 // wavefront 1's: it raises s_pass_flag after writing them and wavefront 0 waits for that before it reads the pivots.
                 const int mq = nj >> 2;
                 const bool crit_in_w1 = 4 * mq > 64;
+                par ^= 1;   // the parameters of pass 0 were formed beside the convergence scan
 #pragma unroll 1
-                for (int T = -1; T < mj - 1; ++T) {   // T = -1: only the parameters of pass 0
-                    if (T >= 0) {
+                for (int T = 0; T < mj - 1; ++T) {
+                    {
                         const bool first = T == 0;
                         const double2* const cs = s_csn + par * 3 * MMAX;
                         const int* const qf = s_qflag + par * MQ;
@@ -708,7 +737,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                         }
                     }
                     if (tid < 64 && T + 1 < mj - 1) {   // wavefront 0: the next pass's parameters, from what the critical lanes have just written
-                        if (T >= 0 && crit_in_w1) {
+                        if (crit_in_w1) {
                             while (*reinterpret_cast<volatile int*>(&s_pass_flag) != pass_seq) __builtin_amdgcn_s_sleep(1);
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         }
@@ -717,12 +746,12 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                             rr_pair(tid >> 1, T + 1, mj, X, Y);
                             const unsigned xy = (unsigned)X | ((unsigned)Y << 8);
                             if (!(tid & 1)) s_xy[(par ^ 1) * MQ + (tid >> 1)] = (int)xy;
-                            param_phase(xy, T < 0, par ^ 1, sweep);
+                            param_phase(xy, false, par ^ 1, sweep);
                         }
                     }
                     __syncthreads();
                     SQ_STAMP(3);   // one pass (one barrier)
-                    if constexpr (PROF) { if (tid == 0 && T >= 0) sacc[5] += 2; }   // rounds
+                    if constexpr (PROF) { if (tid == 0) sacc[5] += 2; }   // rounds
                     par ^= 1;
                     pass_seq += 1;
                 }
