@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kTpb) void ukf_big_sqrt_kernel(const UkfStepParams 
         const int r = e / n, c = e - r * n;
         if (c > r) continue;
         double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc = acc + (Vt[(size_t)k * n + r] * s_sd[k]) * Vt[(size_t)k * n + c];
+        for (int k = 0; k < n; ++k) acc = fma(Vt[(size_t)k * n + r] * s_sd[k], Vt[(size_t)k * n + c], acc);   // (fused, ascending k: as the oracle and the MFMA form of the LDS classes)
         Sq[(size_t)r * n + c] = acc;
         Sq[(size_t)c * n + r] = acc;
     }

@@ -830,16 +830,36 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         s_sd[k] = sqrt(d > 0.00000001 ? d : 0.00000001);   // cwiseMax(1e-8), then the principal square root
     }
     __syncthreads();
-    for (int e = tid; e < n * (n + 1) / 2; e += TPB) {
-        int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while (r * (r + 1) / 2 > e) --r;
-        while ((r + 1) * (r + 2) / 2 <= e) ++r;
-        const int c = e - r * (r + 1) / 2;
-        double acc = 0.0;
+    {   // sqtP = (V sqrt(D)) V^T on v_mfma_f64_16x16x4_f64 (round 4; as n^3 / 2 scalar multiply-adds out of LDS it was bound by LDS bandwidth: two
+        // reads per product): one 16 x 16 tile of the lower triangle per wavefront at a time, k in steps of four; per element the chain is
+        // acc = fma(V(r, k) sd_k, V(c, k), acc) in ascending k, which is what the oracle evaluates; rows, columns and k beyond n give zero operands
+        const int nt = (n + 15) >> 4, nk = (n + 3) >> 2;
+        const int wv = tid >> 6, ln = tid & 63, kq = ln >> 4, cl = ln & 15;
+#pragma unroll 1
+        for (int t = wv; t < nt * nt; t += TPB / 64) {
+            const int tr = t / nt, tc = t - tr * nt;
+            if (tc > tr) continue;                              // (wave-uniform)
+            const int ar = 16 * tr + cl, bc = 16 * tc + cl;     // A-operand: row ar of V sqrt(D); B-operand: column bc of V^T
+            const bool va = ar < n, vb = bc < n;
+            const int arc = va ? ar : 0, bcc = vb ? bc : 0;
+            dbl4_t acc = dbl4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-        for (int k = 0; k < n; ++k) acc = acc + (sVt[k * n + r] * s_sd[k]) * sVt[k * n + c];
-        Sq[(size_t)r * n + c] = acc;
-        Sq[(size_t)c * n + r] = acc;
+            for (int ks = 0; ks < nk; ++ks) {
+                const int k = 4 * ks + kq;
+                const bool vk = k < n;
+                const int kc = vk ? k : 0;
+                double a = sVt[kc * n + arc] * s_sd[kc];        // V(ar, k) sd_k   (row k of V^T = eigenvector k)
+                double bv = sVt[kc * n + bcc];                  // V(bc, k)
+                a = (va && vk) ? a : 0.0;
+                bv = (vb && vk) ? bv : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {   // C/D layout: row = (lane >> 4) + 4 * reg, column = lane & 15
+                const int r = 16 * tr + kq + 4 * r4, c = 16 * tc + cl;
+                if (r < n && c <= r) { Sq[(size_t)r * n + c] = acc[r4]; Sq[(size_t)c * n + r] = acc[r4]; }
+            }
+        }
     }
     if (tid == 0) p.n_sq[b] = n;
     SQ_STAMP(4);   // V^T store, sqrt(D), sqtP = V sqrt(D) V^T

@@ -277,7 +277,8 @@ struct Ukf {
             for (int r = 0; r < nn; ++r)
                 for (int c = 0; c <= r; ++c) {
                     double acc = 0.0;
-                    for (int k = 0; k < nn; ++k) acc = acc + (V[(size_t)r * nn + k] * sd[k]) * V[(size_t)c * nn + k];
+                    // (each term fused, ascending k: the kernels form this product on v_mfma_f64_16x16x4_f64 - refmode keeps the plain sum)
+                    for (int k = 0; k < nn; ++k) acc = mul_add(refmode, V[(size_t)r * nn + k] * sd[k], V[(size_t)c * nn + k], acc);
                     sqtP[(size_t)r * nn + c] = acc; sqtP[(size_t)c * nn + r] = acc;
                 }
         }
@@ -488,7 +489,7 @@ int orc_ukf_sqrt_probe(const double* P, int n, double scale, double* out) {
             double acc = 0.0;
             for (int k = 0; k < n; ++k) {
                 const double d = Y[(size_t)k * n + k];
-                acc = acc + (V[(size_t)r * n + k] * sqrt(d > 0.00000001 ? d : 0.00000001)) * V[(size_t)c * n + k];
+                acc = std::fma(V[(size_t)r * n + k] * sqrt(d > 0.00000001 ? d : 0.00000001), V[(size_t)c * n + k], acc);
             }
             out[(size_t)r * n + c] = acc; out[(size_t)c * n + r] = acc;
         }
