@@ -68,6 +68,30 @@ def test_ukf_sim_step_parity(S, oracle, L, T, B):
     f.close()
 
 
+@pytest.mark.parametrize("code,L", [(0, 20), (1280256, 20), (640064, 20), (0, 50), (5120512, 50), (2560256, 50)])
+def test_ukf_growing_state_walks_padded_sizes_bit_exact(S, oracle, monkeypatch, code, L):
+    """A map discovered landmark by landmark: the state passes through the sizes n = 2 (mod 4), which the sqrt kernels of the LDS classes
+    (and the oracle) pad by two zero rows to walk the quadruple schedule - in every thread-count variant (pass table, passes without the
+    table, round by round).  code 0 = the defaults."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    if code:
+        monkeypatch.setenv("SLAM_UKF_TPB", str(code))
+    T, B = 90, 4
+    lm, cmds = make_scenario(91, L, T)
+    f = S.BatchedUKF(B, L).readParams(); f.set_map(lm); f.set_seed(5); f.set_instance_offset(3); f.init(0, 0, 0)
+    seen = set()
+    for t0 in range(0, T, 15):
+        f.run_sim(cmds[t0:t0 + 15])
+        seen.update(int(m) for m in f.landmark_counts())
+    r = oracle.run_ukf_batch(lm, cmds, B, L, seed=5, inst0=3, nthreads=8)
+    assert any(m % 2 == 1 for m in seen), seen          # odd landmark counts = sizes n = 2 (mod 4) were walked
+    assert np.array_equal(f.landmark_counts(), r["M"]) and np.array_equal(f.status(), r["flags"])
+    assert np.array_equal(f.error_stats(), r["avg_err"])
+    for b in range(B):
+        m = int(r["M"][b]); n = 4 + 2 * m
+        _eq(f.get_state(b), dict(M=m, ids=r["ids"][b, :m], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+
+
 @pytest.mark.parametrize("code,L,T,B", [
     (1280256, 20, 70, 16),   # sqrt 128 threads (generic rotation path), step 256 threads (2 x 4 covariance tiles)
     (640064, 20, 70, 12),    # one wavefront per instance in both kernels
