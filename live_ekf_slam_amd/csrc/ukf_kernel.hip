@@ -5,7 +5,7 @@
 //                   SelfAdjointEigenSolver and MatrixFunctions sqrt; here: cyclic Jacobi in PARALLEL ORDER entirely in LDS
 //                   - A packed lower-triangular (exact symmetry by construction), V^T full - n/2 disjoint rotations per
 //                   round (jacobi_schedule.h), every pair-block B' = R_i^T B R_j and every V row-pair an independent work
-//                   item.  State sizes divisible by four walk the schedule in PASSES of two rounds that stay inside
+//                   item.  The state size, padded to a multiple of four, walks the schedule in PASSES of two rounds that stay inside
 //                   quadruples of indices: the 4 x 4 blocks of A and four rows of V^T in registers across both, one barrier
 //                   per pass.  This O(n^3 * sweeps) fp64 phase dominates the UKF (70 % of its GPU time); it is bound by
 //                   VALU issue (82 % utilisation at six workgroups per CU, profiles/r04_ukf/).
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     __shared__ __attribute__((aligned(16))) double sVt[NMAX * NMAX];   // V transposed: Vt[p*n + k] = V(k, p)
     __shared__ double s_cs[MMAX], s_sn[MMAX], s_tn[MMAX], s_sd[NMAX];
     __shared__ int s_pp[MMAX], s_qq[MMAX];
-    constexpr bool kQuadLds = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB <= 2;   // the variants that walk the sizes divisible by four in passes of two rounds (kFast below)
+    constexpr bool kQuadLds = (MMAX * (MMAX + 1) / 2 + TPB - 1) / TPB <= 2;   // the variants that walk the schedule in passes of two rounds (kFast below)
     __shared__ double2 s_csn[(kQuadLds ? 6 : 2) * MMAX];   // (c, s) of the rotations, one 16-byte read per consumer: [pass parity][round of the pass][pair] (round-by-round variants: [pair])
     __shared__ int s_qflag[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];   // passes: [pass parity][quadruple] any rotation of the pass that is not the identity
     __shared__ int s_xy[kQuadLds ? 2 * ((MMAX + 1) / 2) : 1];      // passes without the table: [pass parity][quadruple] its blocks X | Y << 8
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             }
         }
     }
-    // ---- pieces of the quadruple ("pass") paths, n divisible by four (launch_ukf_quad_table; jacobi_schedule.h) ----
+    // ---- pieces of the quadruple ("pass") paths (launch_ukf_quad_table; jacobi_schedule.h) ----
     constexpr int MQ = (MMAX + 1) / 2;
     // passes without the table: the thread's block lanes (block (I, J) of quadruple positions, I > J: I << 8 | J) and V items (quadruple | pair of
     // columns << 8).  As in the table path the "critical" blocks - (1, 0), (k + 1, k - 1), (mq - 1, mq - 2): the ones that hold the next pass's pivots -
