@@ -875,8 +875,11 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
 // ------------------------------------------------------------------------------------------------------------------
 // PROF: phase timers compiled in (own instantiation, launched only with the debug buffer attached; as a run-time option
 // the ten accumulators cost every variant 22 VGPRs of the production kernel).
+#ifndef SLAM_UKF_STEP_WG
+#define SLAM_UKF_STEP_WG 6   // workgroups of ukf_step_kernel<44, 128, 3> the compiler must leave room for on a CU (26 KB of LDS, 155 VGPRs: six)
+#endif
 template <int NMAX, int TPB, int KU, bool PROF = false>
-__global__ __launch_bounds__(TPB) void ukf_step_kernel(const UkfStepParams p) {
+__global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 128 && !PROF) ? SLAM_UKF_STEP_WG : 1) void ukf_step_kernel(const UkfStepParams p) {
     constexpr int LDN = NMAX + 2;
     constexpr int NS = 2 * NMAX + 1;
     constexpr int LMAX = (NMAX - 4) / 2;
@@ -1384,7 +1387,13 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
             case 192: hipLaunchKernelGGL((ukf_step_kernel<44, 192, 8>), dim3(p.b_cnt), dim3(192), 0, stream, p); break;   // one wavefront per tile row of the covariance
             default:   // measured best
                 if (p.prof) hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8, true>), dim3(p.b_cnt), dim3(128), 0, stream, p);
-                else hipLaunchKernelGGL((ukf_step_kernel<44, 128, 8>), dim3(p.b_cnt), dim3(128), 0, stream, p);
+                // KU = 3 updates kept for one pass over P (round 4; it was 8: 33 KB of LDS and 188 VGPRs = four workgroups per CU; 3: 26 KB, 155 =
+                // six; a message with more than three detections of mapped landmarks takes further passes, P back from HBM): 4.69 -> 4.92 M
+                // steps/s at L = 20 (KU = 4: 4.74, KU = 2: 4.74 - the mean is 1.3 - 2 detections per message)
+#ifndef SLAM_UKF_STEP_KU
+#define SLAM_UKF_STEP_KU 3
+#endif
+                else hipLaunchKernelGGL((ukf_step_kernel<44, 128, SLAM_UKF_STEP_KU>), dim3(p.b_cnt), dim3(128), 0, stream, p);
                 break;
         }
     } else if (nmax <= 104) {
