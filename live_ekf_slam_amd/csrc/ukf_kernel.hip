@@ -232,6 +232,9 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
         // of one element at a time: the ISA had vmcnt(0) after each pair of loads).  Four, not all eight: the whole batch
         // made this prologue the register peak of the kernel (100 VGPRs) and cost the 44/256 variant its fifth wavefront.
         constexpr int NE = (NMAX * NMAX + TPB - 1) / TPB, NB4 = 4;
+        // e / n for e < n^2 <= 10 816 as a multiplication: floor(e ceil(2^20 / n) / 2^20) is exact while e < 2^20 / n (one division per launch
+        // instead of two per element: the index arithmetic of this loop was 2 % of the <44, 256> kernel's VALU instructions)
+        const unsigned ninv = ((1u << 20) + (unsigned)n - 1u) / (unsigned)n;
 #pragma unroll 1
         for (int u0 = 0; u0 < NE; u0 += NB4) {
             double pa[NB4], pb[NB4], pv[NB4];
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             for (int u = 0; u < NB4; ++u) {
                 const int e = tid + TPB * (u0 + u);
                 const bool in = e < n * n;
-                const int r = in ? e / n : 0, c = in ? e - r * n : 0;
+                const int r = in ? (int)(((unsigned)e * ninv) >> 20) : 0, c = in ? e - r * n : 0;   // e / n (see ninv)
                 const bool lower = in && c <= r, wv = in && warm && r < n_v && c < n_v;
                 pa[u] = lower ? Pb[(size_t)r * n + c] : 0.0;
                 pb[u] = lower ? Pb[(size_t)c * n + r] : 0.0;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
             for (int u = 0; u < NB4; ++u) {
                 const int e = tid + TPB * (u0 + u);
                 if (e < n * n) {
-                    const int r = e / n, c = e - r * n;
+                    const int r = (int)(((unsigned)e * ninv) >> 20), c = e - r * n;
                     if (c <= r) sA[r * (r + 1) / 2 + c] = (0.5 * (pa[u] + pb[u])) * scale;
                     sVt[e] = (warm && r < n_v && c < n_v) ? pv[u] : ((r == c) ? 1.0 : 0.0);   // row r = eigenvector r
                 }
