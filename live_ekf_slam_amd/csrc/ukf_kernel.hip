@@ -441,6 +441,9 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
     }
     // ---- pieces of the quadruple ("pass") paths (launch_ukf_quad_table; jacobi_schedule.h) ----
     constexpr int MQ = (MMAX + 1) / 2;
+    // convergence scan of the passes without the table: threads 64 .. walk the strictly-lower triangle, scan_tpr of them per row
+    const int scan_tpr = (TPB - 64) / n > 0 ? (TPB - 64) / n : 1, scan_dr = (TPB - 64) / scan_tpr > 0 ? (TPB - 64) / scan_tpr : 1;
+    const int scan_r0 = (tid - 64) / scan_tpr, scan_c0 = (tid - 64) - scan_r0 * scan_tpr;
     // passes without the table: the thread's block lanes (block (I, J) of quadruple positions, I > J: I << 8 | J) and V items (quadruple | pair of
     // columns << 8).  As in the table path the "critical" blocks - (1, 0), (k + 1, k - 1), (mq - 1, mq - 2): the ones that hold the next pass's pivots -
     // belong to the first lanes of the workgroup (wavefront 0, and wavefront 1 when there are more than sixteen), the others start at thread QOT0.
@@ -594,9 +597,8 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 256 && !PROF) ? SLAM_UKF
                     live = param_phase(xy, true, par ^ 1, sweep);
                 }
             } else {
-                const int tt = tid - 64, tpr = (TPB - 64) / n > 0 ? (TPB - 64) / n : 1;   // threads per row of the strictly-lower part
-                for (int r = tt / tpr; r < n; r += (TPB - 64) / tpr)
-                    for (int c = tt - (tt / tpr) * tpr; c < r; c += tpr) {
+                for (int r = scan_r0; r < n; r += scan_dr)   // scan_tpr threads per row of the strictly-lower part (divisions: once per launch)
+                    for (int c = scan_c0; c < r; c += scan_tpr) {
                         const double v = sA[r * (r + 1) / 2 + c];
                         if (v != 0.0 && v == v) {   // (NaN: see below)
                             const double g = 100.0 * fabs(v);
