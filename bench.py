@@ -4,20 +4,26 @@
 A "step" (K of them are timed) is ONE pass of the hot path over the whole batch: for every instance, generate that
 instance's range-bearing measurements on the device (get_cmd, sim_node.py:209-250) and run EKF::update
 (ekf.cpp:37-179).  `value` = instance-steps per second = batch * K / seconds (all ranks).  The K timed steps go
-through slam_run_sim, which by default runs them in ONE launch of the fused kernel (every workgroup carries its
-instance through all K timesteps, keeping x_t, ids, the true pose and the thin rows of P on chip while P itself
-streams HBM -> HBM once per timestep); `--steps-per-launch 1` gives one launch per timestep instead.  The roofline
-object is per launch: algorithmic bytes of one launch = (steps in it) x sum_b 2(n_b^2+n_b)*8.
+through slam_run_sim, which by default runs them in ONE launch of the fused kernel: every workgroup carries its
+instance through all K timesteps, keeping x_t, ids, the true pose and the thin rows / columns of P on chip, and applies the
+rank-2 downdates of P in DEFERRED GROUPS (one in-place pass over P in HBM per group of up to KG updates, about every third
+timestep at this scenario's 1.7 detections per step).  `--steps-per-launch 1` gives one launch - and at most
+one pass over P - per timestep instead; `roofline.once_per_step` measures that regime on the same timesteps.  The roofline
+object is per launch: bytes the launch MOVED, counted on the device, over its duration from HIP events; SURVEY 8d's byte model
+(2(n_b^2+n_b)*8 per instance-step) is reported beside it as algorithmic_*.
 
 Workload construction (deterministic, everything resident in HBM before the timed region):
   scenario seed 1234 -> random map of L landmarks + TSP command sequence (live_ekf_slam_amd/scenario.py ==
   reference generator, tests/test_scenario.py); step 0 uses an unlimited sensor so every instance inserts all L
-  landmarks (steady state n = 3+2L for the whole batch, SURVEY.md §8d "steady state"), then PRE-ROLL steps with the
-  normal sensor (range 3.0, FOV ±1.57), then W warm-up steps, then the K timed steps.
+  landmarks (steady state n = 3+2L for the whole batch, SURVEY.md §8d "steady state"), then the pre-roll with the
+  normal sensor (range 3.0, FOV ±1.57) to the window (timestep 644), W warm-up steps, then the K timed steps.
 
 Launch: `python bench.py --gpus N --steps K --warmup W`; for N>1 under torch.distributed.run (one rank per GPU,
-RCCL).  Scaling is WEAK: every rank owns `--batch` instances with global instance ids rank*batch.. (no data-path
-collective; the only collective is the end-of-run gather of per-instance error statistics).
+RCCL).  Scaling is STRONG by default: the global `--batch` (65 536) is sharded contiguously over the ranks (8 192 per GPU at
+N = 8, BASELINE configs[3]) with global instance ids, so the result is the same for every N; `--scaling weak` keeps `--batch`
+instances on every rank.  No data-path collective; the only collective is the end-of-run gather of per-instance error
+statistics.  The headline line also carries `config.secondary_digest` and a few top-level scalars (`roofline.once_per_step_frac`,
+`config.steady_state_value`, ...) so that a record that keeps only scalars and short strings still shows every BASELINE config.
 """
 import argparse
 import json
@@ -343,7 +349,53 @@ def main():
     line = bench_ekf(args, torch, dist, rank, local_rank, world, dev)
     if world == 1 and line is not None and not args.no_secondary and args.dtype == "f64" and args.landmarks == 50 and args.batch == 65536:
         line["secondary"] = secondary_lines(args, torch, dist, rank, local_rank, world, dev)
+        line["config"]["secondary_digest"] = secondary_digest(line)
     return finish(line, dist, rank, world)
+
+
+def _short(v):
+    """A rate in three significant digits with a suffix: 5320000 -> 5.32M, 2849 -> 2849, 369000 -> 369k."""
+    v = float(v)
+    if v >= 1e6:
+        return f"{v / 1e6:.3g}M"
+    if v >= 1e4:
+        return f"{v / 1e3:.3g}k"
+    return f"{v:.0f}"
+
+
+def _pstr(pc, key):
+    """Parity of a leg's in-run oracle check as p<max abs difference> (p0 = bit-identical), p! = a structural mismatch, p- = not run."""
+    if not pc:
+        return "p-"
+    if pc.get("mismatch"):
+        return "p!"
+    d = pc.get(key)
+    if d is None:
+        return "p-"
+    if key == "max_abs_diff_m" and not pc.get("lm_iteration_and_trial_counts_equal", True):
+        return "p!"
+    return "p0" if d == 0 else f"p{d:.0e}".replace("e-0", "e-")
+
+
+def secondary_digest(line):
+    """One string <= 110 characters with value, roofline fraction and in-run parity of every secondary leg and of the once-per-step
+    leg, e.g. `ukf 5.32M f.196 p0|pgs 2849 f.185 p4e-11|f32 70.9M f.535 p0|L20 241M f.11 p0|1step 27.2M f.63` (the
+    driver's record keeps scalars and short strings of the headline line only)."""
+    tags = {"configs[2]": "ukf", "configs[4]": "pgs", "configs[3]": "f32", "configs[1]": "L20"}
+    parts = []
+    for leg in line.get("secondary", []):
+        tag = next((t for k, t in tags.items() if leg.get("name", "").startswith(k)), "?")
+        if "error" in leg:
+            parts.append(f"{tag} ERR")
+            continue
+        pc = leg.get("config", {}).get("parity_check")
+        key = "max_abs_diff_m" if tag == "pgs" else "max_abs_diff"
+        fr = f"{leg['roofline']['frac']:.3f}".lstrip("0")[:4]
+        parts.append(f"{tag} {_short(leg['value'])} f{fr} {_pstr(pc, key)}")
+    once = line["roofline"].get("once_per_step")
+    if once:
+        parts.append(f"1step {_short(once['value'])} f{once['frac']:.2f}".replace("f0.", "f."))
+    return "|".join(parts)[:110]
 
 
 def secondary_lines(args, torch, dist, rank, local_rank, world, dev):
@@ -583,6 +635,7 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
                "k_histogram": {str(k): int(v) for k, v in enumerate(khist) if v},
                "storage": args.dtype,
                "state_rmse_vs_oracle": None if parity is None else parity["state_rmse_vs_oracle"],
+               "max_abs_diff_vs_oracle": None if parity is None else parity["max_abs_diff"],
                "parity_check": parity,
                "parity": "bit-exact vs the CPU oracle (tests/test_parity_gpu.py, and the check above on the timed trajectory); "
                          "the oracle is unpinned vs the reference binary (Eigen/ROS absent), pinned to an independent numpy "
@@ -601,6 +654,10 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
                                             "frac": round(float(tc_long[0] + tc_long[1]) / wall_long / 1e9 / HBM_PEAK_GBS, 4),
                                             "algorithmic_equiv_frac": round(alg_bytes * LONG / wall_long / 1e9 / HBM_PEAK_GBS, 4)}
             cfg["full_run_from_init"] = full
+            # the same figures as scalars (a record that drops nested objects keeps these)
+            cfg["steady_state_value"] = cfg["steady_state_long_run"]["value"]
+            cfg["steady_state_frac"] = cfg["steady_state_long_run"]["frac"]
+            cfg["full_run_value"] = full["value"]
         # ---- roofline of the timed launches: the bytes the kernel MOVED (device-counted), never more than what fits the time ----
         traffic = float(tc[0] + tc[1]) / n_launch                      # bytes per launch
         achieved = traffic / (kernel_ms * 1e-3) / 1e9
@@ -621,7 +678,7 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "counted on the device in this run (slam_traffic_counters: bytes the passes of the P stream read "
                                            "+ wrote, plus thin gathers / vehicle rows / state vectors); rocprofv3 PMC cross-check of the "
-                                           "same command in profiles/r03*",
+                                           "same command: profiles/r05a/ (r04a, r03h, r03a for the earlier kernels)",
                          "limiter": "latency/occupancy, not bandwidth: one control wavefront per instance runs the dependent scalar chain "
                                     "of EKF::update while the other wavefronts of its workgroup stream P; the launch lasts "
                                     "(instances / resident workgroups) rounds x steps x time per workgroup-step",
@@ -636,6 +693,8 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
                          "traffic_over_algorithmic": round(traffic / launch_bytes, 4),
                          "algorithmic_equiv_GBps": round(launch_bytes / (kernel_ms * 1e-3) / 1e9, 1),
                          "once_per_step": once,
+                         "once_per_step_frac": None if once is None else once["frac"],
+                         "once_per_step_value": None if once is None else once["value"],
                          "note": "achieved / frac = bytes this launch moved (counted by the kernel: one pass over P per GROUP of deferred "
                                  "rank-2 updates, 2 n ld s bytes each) / launch duration from HIP events on the launch stream / 8 TB/s. "
                                  "SURVEY 8d's once-per-step model (algorithmic_bytes_*: 2(n^2+n)s per instance-step) describes the "

@@ -106,9 +106,11 @@ int pgs_set_profiling(pgs_handle* h, int on);
 int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]);
 /* The last solve run with profiling on, split by how the Schur complement was formed: out = {algorithmic SYRK FLOP of the trials
  * that ran the separate SYRK kernels, FLOP of the trials that ran the fused chain + SYRK kernel, ms spent in those SYRK
- * launches, ms spent in those fused launches}.  (Few running slots: the chain is replicated on 2-4 CUs per instance with the
- * SYRK tiles shared among them; between one and two rounds of that, chain and SYRK are two launches.) */
-int pgs_last_solve_paths(pgs_handle* h, double out[4]);
+ * launches, ms spent in those fused launches, FLOP of the trials of the SEGMENTED elimination (round 5: the pose chain cut at every
+ * SLAM_PGS_SEG-th pose, default 32; segments' interiors side by side, then the separators - the reference's solve,
+ * pose_graph.cpp:273-300, in another exact elimination order), ms in its SYRK launches, 1 if the solve ran that order (0: a
+ * segment of some instance sees more than 63 landmarks, or SLAM_PGS_SEG=0: the sequential chain of rounds 1-4), the segment length}. */
+int pgs_last_solve_paths(pgs_handle* h, double out[8]);
 int pgs_sync(pgs_handle* h);
 int pgs_timestep(const pgs_handle* h);
 

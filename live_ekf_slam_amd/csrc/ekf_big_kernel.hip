@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "../../include/slam_batch.h"
+#include "lds_attr.h"
 #include "sim_device.h"
 #include "slam_math.h"
 #include "slam_rng.h"
@@ -340,8 +341,8 @@ size_t big_lds_bytes(int L_max, int L_map) {
 hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream) {
     const size_t lds = big_lds_bytes(p.L_max, p.sim ? p.L : 1);
     if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
-    if (lds > 64 * 1024) {   // (per device and per launch: a single-process multi-GPU host launches this on several)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_big_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {   // once per device, to the kernel's maximum (lds_attr.h)
+        const hipError_t e = slam_allow_full_lds(reinterpret_cast<const void*>(&ekf_big_step_kernel));
         if (e != hipSuccess) return e;
     }
     const int multi = (p.cmds != nullptr && p.T > 1) ? 1 : 0;

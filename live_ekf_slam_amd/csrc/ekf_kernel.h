@@ -112,6 +112,8 @@ hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream);
 hipError_t ekf_big_kernel_info(EkfKernelInfo* out);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)
+// per-instance average position error (err_sum / timestep; zeros in [B, pad)) into a device buffer
+hipError_t launch_avg_error(const double* err_sum, const int32_t* timestep, int B, int pad, double* out, hipStream_t stream);
 hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, int elem_bytes, double* out, hipStream_t stream);
 
 // fill x/P/M/... for Filter::init (ekf.cpp:4-21,29-34)

@@ -112,6 +112,20 @@ hipError_t launch_algorithmic_bytes(const int32_t* M, int B, int base, int elem_
     return hipGetLastError();
 }
 
+// compute_average_error (plotting_node.py:195-218) on the device: sum of the position errors / timesteps per instance, zeros in the
+// padding of a ragged shard - what the RCCL gather of include/slam_multi.h sends, without a detour over the host
+__global__ void avg_err_kernel(const double* err_sum, const int32_t* timestep, int B, int pad, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pad) return;
+    double v = 0.0;
+    if (i < B) { const int ts = timestep[i]; v = ts > 0 ? err_sum[i] / (double)ts : 0.0; }
+    out[i] = v;
+}
+hipError_t launch_avg_error(const double* err_sum, const int32_t* timestep, int B, int pad, double* out, hipStream_t stream) {
+    hipLaunchKernelGGL(avg_err_kernel, dim3((pad + 255) / 256), dim3(256), 0, stream, err_sum, timestep, B, pad, out);
+    return hipGetLastError();
+}
+
 template <class ST>
 __global__ void ekf_init_kernel(const EkfInitParams p) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

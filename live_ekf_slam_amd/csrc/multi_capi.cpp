@@ -180,15 +180,9 @@ int slam_multi_error_stats(slam_multi* m, double* out, int mode) {
     nccl_all_gather_t all_gather = (nccl_all_gather_t)dlsym(m->rccl, "ncclAllGather");
     nccl_group_t gstart = (nccl_group_t)dlsym(m->rccl, "ncclGroupStart"), gend = (nccl_group_t)dlsym(m->rccl, "ncclGroupEnd");
     if (!all_gather || !gstart || !gend) return slam_internal_fail(SLAM_ERR_UNSUPPORTED, "librccl.so lacks ncclAllGather / ncclGroupStart / ncclGroupEnd");
-    std::vector<double> tmp((size_t)m->pad);
-    for (int s = 0; s < n; ++s) {   // per-shard statistic (sum / steps, computed by the library on the host side of slam_error_stats)
-        memset(tmp.data(), 0, sizeof(double) * tmp.size());
-        const int rc = slam_error_stats(m->h[s], tmp.data());
+    for (int s = 0; s < n; ++s) {   // every shard forms its statistic in its own send buffer, on its device (no host staging: VERDICT r04)
+        const int rc = slam_internal_error_stats_dev(m->h[s], m->dsend[s], (long long)m->pad);
         if (rc) return rc;
-        if (hipSetDevice(m->dev[s]) != hipSuccess ||
-            hipMemcpyAsync(m->dsend[s], tmp.data(), sizeof(double) * m->pad, hipMemcpyHostToDevice, m->cstream[s]) != hipSuccess ||
-            hipStreamSynchronize(m->cstream[s]) != hipSuccess)
-            return slam_internal_fail(SLAM_ERR_HIP, "staging the statistics failed");
     }
     gstart();
     for (int s = 0; s < n; ++s) {

@@ -56,7 +56,9 @@ struct pgs_handle {
     int chol_ll = 1;                           // SLAM_PGS_CHOL_LL=0: the right-looking Cholesky of rounds 1-3
     int chol_threads = 0, chol_switch = 256;   // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces; else 256 while > chol_switch instances are active
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
-    double path_ms[2] = {0.0, 0.0};           // profiled solve: ms in the separate SYRK launches / in the fused chain + SYRK launches
+    double path_ms[3] = {0.0, 0.0, 0.0};      // profiled solve: ms in the separate SYRK launches / in the fused chain + SYRK launches / in the segmented path's SYRK launches
+    int seg_len = 32;                         // SLAM_PGS_SEG: poses per segment of the segmented elimination (pgs_seg_impl.h), 0 = the sequential chain of rounds 1-4
+    bool seg_ok = false;                      // this solve runs the segmented elimination (decided in pgs_solve from the plan)
     bool fused_ok = false;                    // this solve's graphs fit the fused kernel (decided in pgs_solve from max M)
     int cus = 256;                            // compute units of the device
     bool use_list = true;                     // SLAM_PGS_LIST=0: full-size grids, inactive workgroups return (the round-2 launch shape)
@@ -130,6 +132,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
     h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
     if (const char* e = getenv("SLAM_PGS_FUSED")) h->fused_mode = atoi(e);
+    if (const char* e = getenv("SLAM_PGS_SEG")) { const int v = atoi(e); h->seg_len = v <= 0 ? 0 : (v < 2 ? 2 : (v > slam::kPgsSegMaxLen ? slam::kPgsSegMaxLen : v)); }
     if (const char* e = getenv("SLAM_PGS_LIST")) h->use_list = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PGS_NOTRIM")) h->p_notrim = atoi(e) ? atoi(e) : 1;
     if (const char* e = getenv("SLAM_PGS_GROUPS")) h->groups = atoi(e);
@@ -147,8 +150,9 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     // Every per-instance array has `lanes` slots per instance: slot b is instance b, slot j * B + b its j-th lambda lane (a
     // clone that pgs_solve fills from the instance; PgsParams::lanes_max).  Arrays only the instance itself uses keep B slots.
     {   // the lanes multiply the LM work space (Y alone is 3 N_max x LD doubles per slot): keep them within half of the free memory
-        const double per_slot = 8.0 * ((double)round_up(3 * N_max, 4) * h->LD + (double)h->LD * h->LD + (double)K * 17 + (double)N * 42 + (double)L * 12) +
-                                4.0 * ((double)K * 4 + (double)N + (double)L * 5);
+        const double nsegx = h->seg_len > 0 ? (double)((N_max - 2) / h->seg_len + 1) : 0.0;
+        const double per_slot = 8.0 * (((double)round_up(3 * N_max, 4) + 10.0 * nsegx) * h->LD + (double)h->LD * h->LD + (double)K * 17 + (double)N * 51 + (double)L * 12 + nsegx * 48) +
+                                4.0 * ((double)K * 4 + (double)N + (double)L * 6 + nsegx * (3.0 * L + 1));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             while (h->lanes > 1 && per_slot * (double)B * h->lanes > 0.5 * (double)free_b) h->lanes -= 1;
@@ -172,11 +176,22 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     A(&p.A, S * N * 9); A(&p.C, S * N * 9); A(&p.gp, S * N * 3); A(&p.E, S * K * 6); A(&p.Wl, S * K * 5);
     AC(&p.evt_start, L + 1); AC(&p.evt_pose, K); AC(&p.slot_pos, K); A(&p.Elm, S * K * 6);
     A(&p.D, S * L * 3); A(&p.gl, S * L * 2); A(&p.Linv, S * N * 6); A(&p.G, S * N * 9);
-    p.y_stride = (int64_t)round_up(3 * N_max, 4) * h->LD;
+    // segmented elimination: the segments' contributions to their separators' right-hand sides and the separators' rows of Y live
+    // behind the pose rows of Y (pgs_kernel.h: yr_rc, yr_sep)
+    p.seg_len = h->seg_len; p.seg_on = 0; p.syrk_rows = -1; p.syrk_row0 = 0; p.syrk_first = nullptr;
+    p.nseg_max = h->seg_len > 0 ? (N_max - 2) / h->seg_len + 1 : 1;
+    p.yr_rc = round_up(3 * N_max, 4);
+    p.yr_sep = p.yr_rc + 6 * (int64_t)p.nseg_max;
+    p.y_stride = (int64_t)(p.yr_sep + round_up(3 * p.nseg_max, 4)) * h->LD;
+    if (h->seg_len > 0) {
+        const size_t G = (size_t)p.nseg_max;
+        AC(&p.seg_ncol, G); AC(&p.seg_lm, G * L); AC(&p.seg_inv, G * L); AC(&p.seg_evt, G * L); AC(&p.sep_first, L); A(&p.seg_umax, B);
+        A(&p.Gs, S * N * 9); A(&p.segout, S * G * 32); A(&p.sepfac, S * G * 16);
+    }
     A(&p.Y, S * (size_t)p.y_stride); A(&p.S, S * (size_t)h->LD * h->LD);
     A(&p.dl, S * L * 2); A(&p.dp, S * N * 3);
     A(&p.lambda, S); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
-    A(&p.iters, B); A(&p.trials, B); A(&p.state, S); AC(&p.solve_ok, 1); A(&p.n_active, 64); A(&p.alist, S); A(&p.inst_flop, B); A(&p.work, 2);
+    A(&p.iters, B); A(&p.trials, B); A(&p.state, S); AC(&p.solve_ok, 1); A(&p.n_active, 64); A(&p.alist, S); A(&p.inst_flop, B); A(&p.work, 3);
     A(&p.nl, B); A(&p.nlin, S); A(&p.nerr, S); A(&p.nok, S);
     A(&h->dcount, B); A(&h->dsec, B * 3); A(&h->dout, B);
     if (getenv("SLAM_PGS_PROF")) { A(&p.prof, S * 24); }   // [S][8] chol phase timers, then [S][2][8] per-workgroup stamps of the fused chain
@@ -369,10 +384,26 @@ int pgs_solve(pgs_handle* h) {
     if (!h->inited) return fail(SLAM_ERR_STATE, "pgs_init must be called before pgs_solve");
     h->p.N = h->timestep + 1;
     h->p.b_off = 0; h->p.b_cnt = h->B;
+    {   // Segmented elimination of the pose chain (pgs_seg_impl.h): the plan kernel lists the landmarks every segment's interior poses
+        // see; the path runs when no segment of any instance sees more than kPgsSegMaxLm of them (its columns fit the segment kernels)
+        // and the separators fit the separator kernel's staging.  Otherwise - dense visibility on a big map - the sequential chain.
+        h->seg_ok = false; h->p.seg_on = 0;
+        const int NS = h->seg_len > 0 && h->p.N >= 2 ? (h->p.N - 2) / h->seg_len : 0;
+        if (h->seg_len > 0 && NS <= slam::kPgsSegMaxSep) {
+            HIP_TRY(slam::pgs_launch_seg_plan(h->p, h->stream));
+            std::vector<int32_t> U((size_t)h->B);
+            HIP_TRY(hipMemcpyAsync(U.data(), h->p.seg_umax, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            int mx = 0;
+            for (int32_t u : U) mx = u > mx ? u : mx;
+            h->seg_ok = mx <= slam::kPgsSegMaxLm;
+            h->p.seg_on = h->seg_ok ? 1 : 0;
+        }
+    }
     {   // chain + SYRK in one launch (Y stays in LDS) is possible while the lower triangle of every instance fits the 72 wavefront
         // tiles of pgs_chain_syrk_kernel, a column of Y per lane (2M + 1 <= 448) and its event staging (32 factor slots per pose)
         h->fused_ok = false; h->p.fused = 0;
-        if (h->fused_mode != 0 && h->p.LD <= 448 && h->p.KP <= 32) {
+        if (!h->seg_ok && h->fused_mode != 0 && h->p.LD <= 448 && h->p.KP <= 32) {
             std::vector<int32_t> M((size_t)h->B);
             HIP_TRY(hipMemcpyAsync(M.data(), h->p.M, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -382,8 +413,8 @@ int pgs_solve(pgs_handle* h) {
             h->fused_ok = nt * (nt + 1) / 2 <= 72;
         }
     }
-    HIP_TRY(hipMemsetAsync(h->p.work, 0, 2 * sizeof(double), h->stream));
-    h->path_ms[0] = h->path_ms[1] = 0.0;
+    HIP_TRY(hipMemsetAsync(h->p.work, 0, 3 * sizeof(double), h->stream));
+    h->path_ms[0] = h->path_ms[1] = h->path_ms[2] = 0.0;
     int G = h->groups > 0 ? h->groups : (h->B >= 512 ? 2 : 1);
     if (G > 16) G = 16;
     if (G > h->B) G = h->B;
@@ -426,7 +457,7 @@ int pgs_solve(pgs_handle* h) {
                     h->kernel_ms[k] += ms;
                     const int tf = t < (int)h->trial_fused.size() ? h->trial_fused[t] : 0;
                     if (k == 1 && tf) h->path_ms[1] += ms;      // chain + SYRK in one launch
-                    if (k == 2 && !tf) h->path_ms[0] += ms;     // the SYRK launch of the two-launch path
+                    if (k == 2 && !tf) h->path_ms[h->seg_ok ? 2 : 0] += ms;     // the SYRK launch(es) of the two-launch path / of the segmented path
                     if (h->trace) fprintf(stderr, "%s%.3f%s", k == 0 ? "pgs trial kernels (ms): " : " ", ms, k + 1 == slam::kPgsTrialKernels ? "\n" : "");
                 }
         }
@@ -560,35 +591,33 @@ int pgs_error_stats(pgs_handle* h, int which, double* out) {
 
 int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launched) {
     TRY(check(h));
-    // per trial and instance: lower-triangular 64x64 tiles of Y^T Y over k = 3N rows, trimmed by the first-detection pose
+    // per trial and instance: what pgs_lm_begin_kernel priced one Schur-complement SYRK of the instance at (inst_flop: every stored
+    // element of the lower triangle of S_ext over the rows of Y that can be non-zero in it - by the elimination order the solve ran,
+    // sequential or segmented; independent of the kernels' tiling)
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t B = h->B;
-    std::vector<int32_t> M(B), tr(B), first(B * h->L_max);
-    HIP_TRY(hipMemcpy(M.data(), h->p.M, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    std::vector<int32_t> tr(B);
+    std::vector<double> fl(B);
     HIP_TRY(hipMemcpy(tr.data(), h->p.trials, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(first.data(), h->p.lm_first, sizeof(int32_t) * B * h->L_max, hipMemcpyDeviceToHost));
-    const int K3 = 3 * (h->timestep + 1);
+    HIP_TRY(hipMemcpy(fl.data(), h->p.inst_flop, sizeof(double) * B, hipMemcpyDeviceToHost));
     double tot = 0.0;
-    for (size_t b = 0; b < B; ++b) {   // tiling-independent: every stored element of the lower triangle of S_ext, each
-        const int m2 = 2 * M[b];        // over the k range where its row of Y^T can be non-zero
-        double per_trial = 0.0;
-        for (int r = 0; r < m2; ++r) per_trial += 2.0 * (r + 1) * (double)(K3 - 3 * first[b * h->L_max + (r >> 1)]);
-        per_trial += 2.0 * m2 * (double)K3;   // right-hand-side row gl - Y^T z
-        tot += per_trial * tr[b];
-    }
+    for (size_t b = 0; b < B; ++b) tot += fl[b] * tr[b];
     if (syrk_flop) *syrk_flop = tot;
     if (trials_launched) *trials_launched = h->last_trials;
     return SLAM_OK;
 }
 
 // The last PROFILED solve by path: out = {algorithmic SYRK FLOP of the trials that ran pgs_syrk_*_kernel, of the trials that ran
-// pgs_chain_syrk_kernel, ms in those SYRK launches, ms in those fused launches}
-int pgs_last_solve_paths(pgs_handle* h, double out[4]) {
+// pgs_chain_syrk_kernel, ms in those SYRK launches, ms in those fused launches, FLOP of the trials of the segmented elimination, ms in
+// its SYRK launches (tile kernel on the separator rows + pgs_seg_syrk_kernel), 1 if the solve ran the segmented elimination, segment length}
+int pgs_last_solve_paths(pgs_handle* h, double out[8]) {
     TRY(check(h));
     if (!out) return fail(SLAM_ERR_ARG, "NULL output");
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(out, h->p.work, 2 * sizeof(double), hipMemcpyDeviceToHost));
-    out[2] = h->path_ms[0]; out[3] = h->path_ms[1];
+    double w[3];
+    HIP_TRY(hipMemcpy(w, h->p.work, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    out[0] = w[0]; out[1] = w[1]; out[2] = h->path_ms[0]; out[3] = h->path_ms[1];
+    out[4] = w[2]; out[5] = h->path_ms[2]; out[6] = h->seg_ok ? 1.0 : 0.0; out[7] = (double)h->seg_len;
     return SLAM_OK;
 }
 int pgs_set_profiling(pgs_handle* h, int on) { TRY(check(h)); h->profiling = on != 0; return SLAM_OK; }

@@ -82,11 +82,35 @@ struct PgsParams {
     double* inst_flop;                 // [B] algorithmic FLOP of ONE Schur-complement SYRK of instance b (pgs_lm_begin_kernel)
     double* work;                      // [2] algorithmic SYRK FLOP of the trials GTSAM's loop consumed so far in this solve, by path:
                                        //     [0] pgs_syrk_*_kernel launches, [1] pgs_chain_syrk_kernel (pgs_decide_kernel adds)
+    // ---- segmented elimination of the pose chain (round 5, pgs_seg_impl.h) ----
+    // seg_len = SL > 0: the poses k SL (k = 1 .. NS, NS = (N - 2) / SL) are SEPARATORS; segment p = 0 .. NS holds the poses strictly
+    // between separators p and p + 1.  The interiors of all segments are eliminated first, independently (one workgroup each), then the
+    // NS separators as a short chain, then the landmarks: depth SL + NS instead of N, and a row of Y only has the columns of the
+    // landmarks its own segment sees.  seg_on: this solve runs that order (the host's choice, from the plan below).
+    int32_t seg_len, seg_on, nseg_max; // nseg_max: segments the arrays are sized for
+    int32_t* seg_ncol;                 // [S][nseg_max]          landmarks seen from the segment's interior poses (its columns: 2 ncol + 1)
+    int32_t* seg_lm;                   // [S][nseg_max * L_max]  local landmark -> landmark, ascending
+    int32_t* seg_inv;                  // [S][nseg_max * L_max]  landmark -> local landmark of the segment, -1: not seen there
+    int32_t* seg_evt;                  // [S][nseg_max * L_max]  local landmark -> its first event (evt_* order) at or after the segment's first pose
+    int32_t* sep_first;                // [S][L_max]             first separator (0-based) whose row of Y can be non-zero in the landmark's columns
+    int32_t* seg_umax;                 // [B]                    largest seg_ncol of the instance (the host picks the path from it)
+    double* Gs;                        // [S][N_max * 9]         spike blocks: coupling of interior pose i to its segment's LEFT separator
+    double* segout;                    // [S][nseg_max * 32]     per segment: sum Gs Gs^T (6) | Gright Gright^T (6) | Gright (9) | Gright Gs_e^T (9)
+    double* sepfac;                    // [S][nseg_max * 16]     per separator: Linv (6) | G (9) of the separator chain
+    int64_t yr_rc, yr_sep;             // rows of Y (leading dimension LD) where the segments' contributions to their separators' right-hand
+                                       // sides ([nseg][6]: left 3, right 3, local columns) and the separators' rows of Y ([NS][3], global columns) live
+    // the tile SYRK over an arbitrary block of Y rows: row offset, rows (-1: 3 N), per-landmark first non-zero row / 3 (NULL: lm_first)
+    int64_t syrk_row0; int32_t syrk_rows; const int32_t* syrk_first;
     unsigned long long* prof;          // optional [B][8] phase timers of the chol kernel (100 MHz wall clock), debug only
     // ---- factor constants ----
     double prior[3];
     double w_prior[3], w_btw[3], w_meas[2];   // 1 / sigma
 };
+
+// geometry of the segmented elimination: separators at the poses k SL, k = 1 .. seg_ns; segment ps holds the poses [seg_lo, seg_hi)
+__host__ __device__ inline int seg_ns(int N, int SL) { return N >= 2 ? (N - 2) / SL : 0; }
+__host__ __device__ inline int seg_lo(int ps, int SL) { return ps == 0 ? 0 : ps * SL + 1; }
+__host__ __device__ inline int seg_hi(int ps, int SL, int NS, int N) { return ps < NS ? (ps + 1) * SL : N; }
 
 hipError_t pgs_launch_init(const PgsParams& p, float x0, float y0, float yaw0, hipStream_t s);
 // append one timestep: BetweenFactor is implied by cmds[t]; meas [B][k_stride][3], count [B] (device); sec_pose [B][3]
@@ -95,6 +119,11 @@ hipError_t pgs_launch_append(const PgsParams& p, const float* d_meas, const int3
 // T timesteps of simulator + NaiveFilter secondary + append, on the device (cmds already in p.cmds)
 hipError_t pgs_launch_run_sim(const PgsParams& p, int T, uint32_t step0, hipStream_t s);
 hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s);
+// the segments' column sets of every instance (from the graph alone; before pgs_launch_lm_begin of a solve)
+hipError_t pgs_launch_seg_plan(const PgsParams& p, hipStream_t s);
+static constexpr int kPgsSegMaxLen = 32;      // poses a segment holds at most (seg_len <= this)
+static constexpr int kPgsSegMaxLm = 63;       // landmarks a segment's column set may hold for the segmented path (2 * 63 + 1 = 127 columns)
+static constexpr int kPgsSegMaxSep = 128;     // separators the separator kernel stages in LDS
 // one tryLambda for every active instance = kernels 0..5 in order: linearize, chain, syrk, chol, backsolve, evaluate
 static constexpr int kPgsTrialKernels = 6;
 hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s);

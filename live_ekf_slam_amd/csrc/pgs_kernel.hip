@@ -20,6 +20,7 @@
 //   evaluate    linearised and true cost of the candidate, retraction, GTSAM's accept / lambda / convergence logic
 // All per-instance decisions live on the device; the host only polls the number of active instances.
 #include "pgs_kernel.h"
+#include "lds_attr.h"
 
 #include <mutex>
 
@@ -304,14 +305,49 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
         }
     }
     __syncthreads();
-    {   // algorithmic FLOP of one SYRK of this instance: 2 per stored lower-triangle element of S_ext and per k where its row of
-        // Y^T can be non-zero (from the first detection of the row's landmark; the right-hand-side row is dense in k)
-        const int32_t* first = p.lm_first + (size_t)b * p.L_max;
-        const int m2 = 2 * M, K3 = 3 * N;
-        double f = 0.0;
-        for (int r = tid; r < m2; r += TPB) f += 2.0 * (r + 1) * (double)(K3 - 3 * first[r >> 1]);
+    if (p.seg_on) {   // segmented elimination: where each column of a segment starts in its landmark's event list
+        const int SL = p.seg_len, NS = seg_ns(N, SL), nseg = NS + 1;
+        const int32_t* evt_start = p.evt_start + (size_t)b * (p.L_max + 1);
+        const int32_t* evt_pose = p.evt_pose + (size_t)b * p.N_max * p.KP;
+        const int32_t* ncol = p.seg_ncol + (size_t)b * p.nseg_max;
+        const int32_t* slm = p.seg_lm + (size_t)b * p.nseg_max * p.L_max;
+        int32_t* sevt = p.seg_evt + (size_t)b * p.nseg_max * p.L_max;
+        for (int idx = tid; idx < nseg * p.L_max; idx += TPB) {
+            const int ps = idx / p.L_max, lc = idx - ps * p.L_max;
+            if (lc >= ncol[ps]) continue;
+            const int j = slm[idx], lo = seg_lo(ps, SL);
+            int e0 = evt_start[j], e1 = evt_start[j + 1];   // first event with pose >= lo (the list is chronological)
+            while (e0 < e1) {
+                const int mid = (e0 + e1) >> 1;
+                if (evt_pose[mid] < lo) e0 = mid + 1; else e1 = mid;
+            }
+            sevt[idx] = e0;
+        }
+    }
+    {   // algorithmic FLOP of one Schur-complement SYRK of this instance: 2 per stored lower-triangle element of S_ext and per row of Y
+        // that can be non-zero in it.  Sequential elimination: a column is dense from its landmark's first detection on (the
+        // right-hand-side row is dense in k).  Segmented: the 3 NS separator rows from the landmark's first separator on, plus per
+        // segment the Gram matrix of its own columns.
+        double f = 0.0, extra = 0.0;
+        const int m2 = 2 * M;
+        if (p.seg_on) {
+            const int SL = p.seg_len, NS = seg_ns(N, SL), nseg = NS + 1;
+            const int32_t* first = p.sep_first + (size_t)b * p.L_max;
+            const int32_t* ncol = p.seg_ncol + (size_t)b * p.nseg_max;
+            for (int r = tid; r < m2; r += TPB) f += 2.0 * (r + 1) * (double)(3 * NS - 3 * first[r >> 1]);
+            for (int ps = tid; ps < nseg; ps += TPB) {
+                const double nc = 2.0 * ncol[ps] + 1.0;
+                f += 3.0 * (seg_hi(ps, SL, NS, N) - seg_lo(ps, SL)) * nc * (nc + 1.0);
+            }
+            extra = 2.0 * m2 * (double)(3 * NS);
+        } else {
+            const int32_t* first = p.lm_first + (size_t)b * p.L_max;
+            const int K3 = 3 * N;
+            for (int r = tid; r < m2; r += TPB) f += 2.0 * (r + 1) * (double)(K3 - 3 * first[r >> 1]);
+            extra = 2.0 * m2 * (double)K3;
+        }
         f = block_sum<TPB>(f, s_buf);
-        if (tid == 0) p.inst_flop[b] = f + 2.0 * m2 * (double)K3;
+        if (tid == 0) p.inst_flop[b] = f + extra;
     }
     const double err = block_cost<TPB>(p, b, pw, lw, s_buf);
     if (tid == 0) {
@@ -341,6 +377,7 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, KP = p.KP, M = p.M[b];
+    if (p.seg_on && tid == 0) p.solve_ok[b] = 1;   // segmented elimination: a failing segment / separator clears it (the sequential chain kernel sets it itself)
     const Inst g = inst_view(p, b);
     const double* pose = p.pw + (size_t)b * p.N_max * 3;
     const double* lm = p.lw + (size_t)b * p.L_max * 2;
@@ -635,12 +672,15 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
     if (ti == tj && wr == 0 && wc == 1) return;     // strictly upper part of a diagonal tile
     const int rowbase = ti * SY_T + wr * WT, colbase = tj * SY_T + wc * WT;
     if (rowbase > m2 || colbase > m2) return;
-    const int K3 = 3 * p.N;
+    // (segmented elimination: the block of Y rows is the separators' - syrk_row0 / syrk_rows / syrk_first, pgs_kernel.h)
+    const int K3 = p.syrk_rows >= 0 ? p.syrk_rows : 3 * p.N;
     int k0 = 0;
     // Y[k][c] == 0 before the first detection of column c's landmark, and landmarks are numbered in order of first
     // detection: this wavefront's 64 rows are all zero before pose lm_first[rowbase / 2] (unless it holds the z row)
-    if (rowbase + WT - 1 < m2 && !p.syrk_notrim) k0 = (3 * p.lm_first[(size_t)b * p.L_max + (rowbase >> 1)]) & ~3;
-    const double* Yb = p.Y + (size_t)b * p.y_stride;
+    const int32_t* firstrow = p.syrk_first ? p.syrk_first : p.lm_first;
+    if (rowbase + WT - 1 < m2 && !p.syrk_notrim) k0 = (3 * firstrow[(size_t)b * p.L_max + (rowbase >> 1)]) & ~3;
+    if (k0 > K3) k0 = K3 & ~3;
+    const double* Yb = p.Y + (size_t)b * p.y_stride + (size_t)p.syrk_row0 * p.LD;
     dbl4_t acc[NI][NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -1935,7 +1975,7 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
             else if (error <= 0.0 || relDec <= relTol || absDec <= absTol) done = 1;
             else p.cur_error[b] = error;
         }
-        atomicAdd(p.work + (p.fused ? 1 : 0), (double)(trials - p.trials[b]) * p.inst_flop[b]);   // reporting only
+        atomicAdd(p.work + (p.seg_on ? 2 : (p.fused ? 1 : 0)), (double)(trials - p.trials[b]) * p.inst_flop[b]);   // reporting only
         p.lambda[b] = lambda; p.error[b] = error; p.iters[b] = iters; p.trials[b] = trials;
         // the next trial runs the next `lanes_next` lambdas of the sequence GTSAM would walk if every one of them failed:
         // lambda, 10 lambda, ... (lambda_j < lambdaUpper for j >= 1: reaching the bound ends the inner loop before that trial)
@@ -2021,6 +2061,8 @@ __global__ __launch_bounds__(TPB) void pgs_avg_error_kernel(const PgsParams p, i
     if (tid == 0) out[b] = ts > 0 ? tot / ts : 0.0;
 }
 
+#include "pgs_seg_impl.h"
+
 }  // namespace
 
 hipError_t pgs_launch_init(const PgsParams& p, float x0, float y0, float yaw0, hipStream_t s) {
@@ -2038,6 +2080,11 @@ hipError_t pgs_launch_run_sim(const PgsParams& p, int T, uint32_t step0, hipStre
     return hipGetLastError();
 }
 
+hipError_t pgs_launch_seg_plan(const PgsParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_seg_plan_kernel, dim3(p.B), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s) {
     hipLaunchKernelGGL(pgs_lm_begin_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
     return hipGetLastError();
@@ -2049,13 +2096,16 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     switch (which) {
     case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(nslot), dim3(TPB), 0, s, p); break;
     case 1: {
+        if (p.seg_on) {   // segmented elimination: the interiors of all segments side by side, then the separator chain
+            const int nseg = seg_ns(p.N, p.seg_len) + 1;
+            hipLaunchKernelGGL(pgs_seg_kernel, dim3(nslot * nseg), dim3(SG_TPB), 0, s, p);
+            if (nseg > 1) hipLaunchKernelGGL(pgs_sep_kernel, dim3(nslot), dim3(64 + p.LD), 0, s, p);
+            break;
+        }
         if (p.fused) {   // chain + SYRK in one launch, Y stays in LDS
-            static std::once_flag attr_once3;
-            std::call_once(attr_once3, []() {   // 22 KB static + the Y buffers (89 KB at LD = 448) of the 160 KB
-                (void)hipFuncSetAttribute((const void*)pgs_chain_syrk_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)hipFuncSetAttribute((const void*)pgs_chain_syrk_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)hipFuncSetAttribute((const void*)pgs_chain_syrk_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            });
+            // 22 KB static + the Y buffers (89 KB at LD = 448) of the 160 KB: per device, checked (lds_attr.h)
+            const void* fk = p.fused == 4 ? (const void*)pgs_chain_syrk_kernel<3, 4> : p.fused == 3 ? (const void*)pgs_chain_syrk_kernel<4, 3> : (const void*)pgs_chain_syrk_kernel<6, 2>;
+            if (const hipError_t e = slam_allow_full_lds(fk); e != hipSuccess) return e;
             const size_t lds = sizeof(double) * 2 * FC_ROWS * (size_t)(p.LD + 16);
             // p.fused = workgroups per instance: the more, the fewer tiles (and MFMA time) per workgroup next to the recursion
             if (p.fused == 4) hipLaunchKernelGGL((pgs_chain_syrk_kernel<3, 4>), dim3(4 * nslot), dim3(FC_TPB), lds, s, p);
@@ -2067,12 +2117,18 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
         break;
     }
     case 2: {
+        if (p.seg_on) {   // [D + lambda I; g_l^T] - Ysep^T Ysep by the tile kernel on the separators' rows, then the segments' Gram matrices in order
+            PgsParams q = p;
+            q.syrk_row0 = p.yr_sep; q.syrk_rows = 3 * seg_ns(p.N, p.seg_len); q.syrk_first = p.sep_first;
+            const int nt = (p.LD + 63) / 64;
+            hipLaunchKernelGGL(pgs_syrk_kernel<32>, dim3(8 * (nt * (nt + 1) / 2) * ((nslot + 7) / 8)), dim3(256), 0, s, q);
+            if (const hipError_t e = slam_allow_full_lds((const void*)pgs_seg_syrk_kernel); e != hipSuccess) return e;
+            hipLaunchKernelGGL(pgs_seg_syrk_kernel, dim3(nslot), dim3(SS_TPB), sizeof(double) * SS_ROWS * SS_LDL, s, p);
+            break;
+        }
         if (p.fused) break;   // done by the chain launch
         if (p.syrk_wave_tile == 1) {   // instance-resident accumulators
-            static std::once_flag attr_once2;
-            std::call_once(attr_once2, []() {
-                (void)hipFuncSetAttribute((const void*)pgs_syrk_inst_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            });
+            if (const hipError_t e = slam_allow_full_lds((const void*)pgs_syrk_inst_kernel); e != hipSuccess) return e;
             const size_t lds = sizeof(double) * 2 * SI_ROWS * (size_t)(p.LD + 16);
             hipLaunchKernelGGL(pgs_syrk_inst_kernel, dim3(8 * SI_NB * ((nslot + 7) / 8)), dim3(SI_TPB), lds, s, p);
             break;
@@ -2088,23 +2144,23 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     }
     case 3: {
         const size_t lds = sizeof(double) * (size_t)(p.LD + 16) * 17;   // panel rows x (NB + 1)
-        static std::once_flag attr_once;   // solve groups launch from several host threads
-        std::call_once(attr_once, []() {   // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB)
-            (void)hipFuncSetAttribute((const void*)pgs_chol_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            (void)hipFuncSetAttribute((const void*)pgs_chol_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        });
+        // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB); solve groups launch from several
+        // host threads and a single-process host may hold several devices: per (kernel, device), checked (lds_attr.h)
+        const void* ck = p.chol_threads == 256 ? (const void*)pgs_chol_kernel<256> : (p.chol_ll && p.LD <= 448) ? (const void*)pgs_chol_ll_kernel : (const void*)pgs_chol_kernel<1024>;
+        if (const hipError_t e = slam_allow_full_lds(ck); e != hipSuccess) return e;
         if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(nslot), dim3(256), lds, s, p); break; }
         if (p.chol_ll && p.LD <= 448) {   // left-looking: the panel [LD + 16][17] and the staged block rows [16][<= LD + 8] (its staging registers are sized for LD <= 448)
             const size_t lds_ll = lds + sizeof(double) * 16 * (size_t)(p.LD + 8);
-            static std::once_flag attr_ll;
-            std::call_once(attr_ll, []() { (void)hipFuncSetAttribute((const void*)pgs_chol_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
             hipLaunchKernelGGL(pgs_chol_ll_kernel, dim3(nslot), dim3(1024), lds_ll, s, p);
             break;
         }
         hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(nslot), dim3(1024), lds, s, p);
         break;
     }
-    case 4: hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(nslot), dim3(BTPB), 0, s, p); break;
+    case 4:
+        if (p.seg_on) hipLaunchKernelGGL(pgs_seg_backsolve_kernel, dim3(nslot), dim3(SB_TPB), 0, s, p);
+        else hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(nslot), dim3(BTPB), 0, s, p);
+        break;
     default:   // the candidates of every slot, then GTSAM's accept / lambda / convergence logic per instance
         hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(nslot), dim3(TPB), 0, s, p);
         hipLaunchKernelGGL(pgs_decide_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);

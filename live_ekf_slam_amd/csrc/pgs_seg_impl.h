@@ -1,0 +1,616 @@
+// pgs_seg_impl.h — the pose chain eliminated SEGMENT BY SEGMENT (round 5).  Included by pgs_kernel.hip inside namespace slam { namespace {.
+//
+// Reference: the linear solve inside gtsam::LevenbergMarquardtOptimizer::tryLambda, called from PoseGraph::solvePoseGraph
+// (ekf_ws/src/localization_pkg/src/pose_graph.cpp:273-300).  GTSAM eliminates in a COLAMD order; any exact elimination order gives the
+// same step up to rounding (oracle/slam_oracle_pgs.cpp: LIN_SCHUR == LIN_DENSE == LIN_SEG).  Rounds 1-4 eliminated the poses in
+// trajectory order 0, 1, 2, ...: a block-bidiagonal factor, ONE dependent 3x3 recursion of N = 1000 links per trial (0.56 ms whatever
+// the batch: 46 of the 90 ms of a batch-256 solve), and a Y = L^-1 [H_pl | g_p] whose rows are dense from a landmark's first detection
+// on (3N x (2M+1): 175 MFLOP of Schur-complement SYRK per instance-trial at 1000 x 170).
+//
+// Here the chain is cut at the SEPARATOR poses SL, 2 SL, ... (nested dissection with one level; the separators of a chain are single
+// poses).  Order: the interiors of all segments (independent of each other: one workgroup per (slot, segment), pgs_seg_kernel), then the
+// NS = (N - 2) / SL separators as a short chain (pgs_sep_kernel), then the landmarks (the dense Cholesky, unchanged).
+//   * depth: SL + NS (63 at N = 1000, SL = 32) dependent 3x3 steps instead of N;
+//   * fill: an interior row of Y only has the columns of the landmarks its own segment sees (<= 49 of 170 at SL = 32 on BASELINE
+//     configs[4]), only the 3 NS separator rows are dense: 8 MFLOP of SYRK per instance-trial instead of 175, a seventh of the
+//     column-recurrence work; the price is the SPIKE - every interior pose also couples to its segment's left separator (one more 3x3
+//     block per pose and column step).
+// Block algebra (oracle: Pgs::solve_seg, statement for statement).  Segment p, left separator a = p SL (p >= 1), right separator
+// b = (p + 1) SL (p < NS), interior poses i = lo .. hi - 1:
+//   Ginn_i = H[i][i-1] L_{i-1}^-T (zero at i = lo),  L_i = chol(A_i + lambda I - Ginn_i Ginn_i^T),
+//   spike:  B_lo = H[a][lo] = C_a^T,  B_i = -(Gs_{i-1} Ginn_i^T),  Gs_i = B_i L_i^-T,   separator a:  A_a -= sum_i Gs_i Gs_i^T,
+//   right end: Gr = C_{hi-1} L_{hi-1}^-T,  A_b -= Gr Gr^T,  H[b][a] = -(Gr Gs_{hi-1}^T);
+//   Y_i = L_i^-1 ([E_i | g_i] - Ginn_i Y_{i-1}) on the segment's columns,  R_a -= sum_i Gs_i Y_i,  R_b -= Gr Y_{hi-1};
+//   separators k = 1 .. NS: the same chain recurrence on (A_s - ..., H[s_k][s_{k-1}], R_s) with ALL columns;
+//   S_ext = [D + lambda I; g_l^T] - Ysep^T Ysep - sum_p Y_p^T Y_p  (tile kernel on the 3 NS dense rows, then the segments in order).
+// Everything an instance's result depends on is accumulated in a fixed order (no atomics on data): run-to-run and shard-invariant.
+#pragma once
+
+// (seg_ns / seg_lo / seg_hi: the geometry of the segments, pgs_kernel.h)
+
+// inverse of the Cholesky factor of the symmetric 3x3 (T0; T3 T4; T6 T7 T8): I = i00 i10 i11 i20 i21 i22.  Pivots through v_rsq_f64 +
+// two Newton steps like the sequential chain (rsqrt_nr); false if a pivot is not positive.
+__device__ __forceinline__ bool chol_inv3(double T0, double T3, double T4, double T6, double T7, double T8, double I[6]) {
+    if (!(T0 > 0.0)) return false;
+    I[0] = rsqrt_nr(T0);
+    const double l10 = T3 * I[0], l20 = T6 * I[0];
+    const double t11 = T4 - l10 * l10;
+    if (!(t11 > 0.0)) return false;
+    I[2] = rsqrt_nr(t11);
+    const double l21 = (T7 - l20 * l10) * I[2];
+    const double t22 = (T8 - l20 * l20) - l21 * l21;
+    if (!(t22 > 0.0)) return false;
+    I[5] = rsqrt_nr(t22);
+    I[1] = -(l10 * I[0]) * I[2];
+    I[4] = -(l21 * I[2]) * I[5];
+    I[3] = -(l20 * I[0] + l21 * I[1]) * I[5];
+    return true;
+}
+__device__ __forceinline__ void mul_linvT(const double* X, const double* I, double* G) {   // G = X Linv^T
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        G[3 * r + 0] = X[3 * r] * I[0];
+        G[3 * r + 1] = X[3 * r] * I[1] + X[3 * r + 1] * I[2];
+        G[3 * r + 2] = (X[3 * r] * I[3] + X[3 * r + 1] * I[4]) + X[3 * r + 2] * I[5];
+    }
+}
+__device__ __forceinline__ void mul_abT(const double* X, const double* Z, double* P) {   // P = X Z^T
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[3 * a + c] = (X[3 * a] * Z[3 * c] + X[3 * a + 1] * Z[3 * c + 1]) + X[3 * a + 2] * Z[3 * c + 2];
+}
+__device__ __forceinline__ void sym_ggT(const double* G, double* o) {   // lower triangle 00 10 11 20 21 22 of G G^T
+    o[0] = (G[0] * G[0] + G[1] * G[1]) + G[2] * G[2];
+    o[1] = (G[3] * G[0] + G[4] * G[1]) + G[5] * G[2];
+    o[2] = (G[3] * G[3] + G[4] * G[4]) + G[5] * G[5];
+    o[3] = (G[6] * G[0] + G[7] * G[1]) + G[8] * G[2];
+    o[4] = (G[6] * G[3] + G[7] * G[4]) + G[8] * G[5];
+    o[5] = (G[6] * G[6] + G[7] * G[7]) + G[8] * G[8];
+}
+#define SEG_SUB_GV(G, v0, v1, v2, u0, u1, u2)                          \
+    do {                                                               \
+        u0 -= ((G)[0] * (v0) + (G)[1] * (v1)) + (G)[2] * (v2);         \
+        u1 -= ((G)[3] * (v0) + (G)[4] * (v1)) + (G)[5] * (v2);         \
+        u2 -= ((G)[6] * (v0) + (G)[7] * (v1)) + (G)[8] * (v2);         \
+    } while (0)
+#define SEG_SUB_GTV(G, v0, v1, v2, u0, u1, u2)                         \
+    do {                                                               \
+        u0 -= ((G)[0] * (v0) + (G)[3] * (v1)) + (G)[6] * (v2);         \
+        u1 -= ((G)[1] * (v0) + (G)[4] * (v1)) + (G)[7] * (v2);         \
+        u2 -= ((G)[2] * (v0) + (G)[5] * (v1)) + (G)[8] * (v2);         \
+    } while (0)
+
+// ---- the plan: which landmarks each segment's interior poses see.  From the graph alone (cnt, mlm), once per solve and instance; the
+//      lambda lanes get copies (clone_instances).  Also the first separator row that can be non-zero per landmark (k range of the dense
+//      tile SYRK) and the largest column set (the host takes the sequential path if a segment sees more than kPgsSegMaxLm landmarks). ----
+__global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
+    __shared__ int s_has[256], s_first[256];   // L_max <= 255
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int N = p.N, SL = p.seg_len, NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP, M = p.M[b], L_max = p.L_max;
+    const int32_t* cnt = p.cnt + (size_t)b * p.N_max;
+    const int32_t* mlm = p.mlm + (size_t)b * p.N_max * KP;
+    int32_t* ncol = p.seg_ncol + (size_t)b * p.nseg_max;
+    int32_t* slm = p.seg_lm + (size_t)b * p.nseg_max * L_max;
+    int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * L_max;
+    if (tid < L_max) s_first[tid] = NS;
+    int umax = 0;
+    for (int ps = 0; ps < nseg; ++ps) {
+        if (tid < L_max) s_has[tid] = 0;
+        __syncthreads();
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
+        for (int idx = tid; idx < (hi - lo) * KP; idx += 256) {
+            const int i = lo + idx / KP, s = idx - (idx / KP) * KP;
+            if (s < cnt[i]) s_has[mlm[(size_t)i * KP + s] & (kPgsFirstBit - 1)] = 1;   // (every writer stores the same value)
+        }
+        __syncthreads();
+        if (tid < 64) {   // compaction in landmark order, 64 landmarks per ballot
+            int base = 0;
+            for (int j0 = 0; j0 < L_max; j0 += 64) {
+                const int j = j0 + lane;
+                const bool has = j < M && s_has[j < L_max ? j : 0] != 0;
+                const unsigned long long m = __ballot(has);
+                const int lc = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (j < L_max) sinv[(size_t)ps * L_max + j] = has ? lc : -1;
+                if (has) {
+                    slm[(size_t)ps * L_max + lc] = j;
+                    // segment ps feeds separator ps (its left one, 0-based row ps - 1) and separator ps + 1 (0-based row ps)
+                    const int fs = ps >= 1 ? ps - 1 : 0;
+                    if (fs < s_first[j]) s_first[j] = fs;
+                }
+                base += __popcll(m);
+            }
+            if (lane == 0) ncol[ps] = base;
+            umax = base > umax ? base : umax;
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < NS * KP; idx += 256) {   // detections AT the separator poses
+        const int k = idx / KP, s = idx - k * KP, i = (k + 1) * SL;
+        if (s < cnt[i]) atomicMin(&s_first[mlm[(size_t)i * KP + s] & (kPgsFirstBit - 1)], k);
+    }
+    __syncthreads();
+    if (tid < L_max) p.sep_first[(size_t)b * L_max + tid] = s_first[tid];
+    if (tid == 0) p.seg_umax[b] = umax;
+}
+
+// ---- interiors of one segment: the 3x3 chain with its spike (one lane), then the column recurrence on the segment's columns ----
+constexpr int SG_TPB = 192;   // >= 2 * kPgsSegMaxLm + 1 columns, one per thread
+__global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
+    __shared__ double s_in[kPgsSegMaxLen][18];    // A (00 10 11 20 21 22), C = H[i][i-1] (the segment's first pose: C_a = H[a+1][a]), g_p
+    __shared__ double s_fac[kPgsSegMaxLen][24];   // Linv (6), Ginn (9), Gs (9)
+    __shared__ double s_ce[9], s_gr[9];
+    __shared__ int s_fail;
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
+    const int bl = blockIdx.x / nseg, ps = blockIdx.x - bl * nseg;
+    const int b = pgs_slot(p, bl), tid = threadIdx.x;
+    if (p.state[b]) return;
+    const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N), len = hi - lo, LD = p.LD;
+    const double lambda = p.lambda[b];
+    const double* Ab = p.A + (size_t)b * p.N_max * 9;
+    const double* Cb = p.C + (size_t)b * p.N_max * 9;
+    const double* gpb = p.gp + (size_t)b * p.N_max * 3;
+    if (tid < len) {
+        const int i = lo + tid;
+        const double* A = Ab + 9 * i;
+        s_in[tid][0] = A[0]; s_in[tid][1] = A[3]; s_in[tid][2] = A[4]; s_in[tid][3] = A[6]; s_in[tid][4] = A[7]; s_in[tid][5] = A[8];
+        if (i > 0) {   // H[i][i-1]; for i = lo and ps >= 1 that is C_a, the coupling to the left separator
+            const double* C = Cb + 9 * (i - 1);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s_in[tid][6 + k] = C[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s_in[tid][6 + k] = 0.0;
+        }
+        s_in[tid][15] = gpb[3 * i]; s_in[tid][16] = gpb[3 * i + 1]; s_in[tid][17] = gpb[3 * i + 2];
+    }
+    if (tid >= 64 && tid < 73) s_ce[tid - 64] = ps < NS ? Cb[9 * (size_t)(hi - 1) + (tid - 64)] : 0.0;   // H[b][hi-1]
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid == 0) {
+        double I[6] = {0, 0, 0, 0, 0, 0}, Gsp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Bc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aL[6] = {0, 0, 0, 0, 0, 0};
+        if (ps >= 1) {   // H[a][lo] = C_a^T
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Bc[3 * r + c] = s_in[0][6 + 3 * c + r];
+        }
+        bool ok = true;
+#pragma unroll 1
+        for (int l = 0; l < len; ++l) {
+            const double* in = s_in[l];
+            double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (l > 0) mul_linvT(in + 6, I, G);
+            const double T0 = (in[0] + lambda) - ((G[0] * G[0] + G[1] * G[1]) + G[2] * G[2]);
+            const double T3 = in[1] - ((G[3] * G[0] + G[4] * G[1]) + G[5] * G[2]);
+            const double T4 = (in[2] + lambda) - ((G[3] * G[3] + G[4] * G[4]) + G[5] * G[5]);
+            const double T6 = in[3] - ((G[6] * G[0] + G[7] * G[1]) + G[8] * G[2]);
+            const double T7 = in[4] - ((G[6] * G[3] + G[7] * G[4]) + G[8] * G[5]);
+            const double T8 = (in[5] + lambda) - ((G[6] * G[6] + G[7] * G[7]) + G[8] * G[8]);
+            if (ps >= 1 && l > 0) {   // fill of eliminating the previous pose
+                double P[9];
+                mul_abT(Gsp, G, P);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Bc[k] = -P[k];
+            }
+            if (!chol_inv3(T0, T3, T4, T6, T7, T8, I)) { ok = false; break; }
+            double* o = s_fac[l];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = I[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[6 + k] = G[k];
+            if (ps >= 1) {
+                mul_linvT(Bc, I, Gsp);
+                double q[6];
+                sym_ggT(Gsp, q);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) aL[k] += q[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[15 + k] = Gsp[k];
+        }
+        double* so = p.segout + ((size_t)b * p.nseg_max + ps) * 32;
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) so[k] = aL[k];
+            double Gr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aR[6] = {0, 0, 0, 0, 0, 0}, Hba[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (ps < NS) {
+                mul_linvT(s_ce, I, Gr);
+                sym_ggT(Gr, aR);
+                if (ps >= 1) mul_abT(Gr, Gsp, Hba);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) so[6 + k] = aR[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { so[12 + k] = Gr[k]; so[21 + k] = Hba[k]; s_gr[k] = Gr[k]; }
+        } else {
+            s_fail = 1;
+        }
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) p.solve_ok[b] = 0;   // (every failing segment stores the same value)
+        return;
+    }
+    if (tid < len) {   // the factor for the pose back-substitution
+        const int i = lo + tid;
+        const double* o = s_fac[tid];
+        double* L = p.Linv + (size_t)b * p.N_max * 6 + 6 * i;
+        double* Go = p.G + (size_t)b * p.N_max * 9 + 9 * i;
+        double* Gso = p.Gs + (size_t)b * p.N_max * 9 + 9 * i;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) L[k] = o[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Go[k] = o[6 + k]; Gso[k] = o[15 + k]; }
+    }
+    // ---- columns: local column lc = tid; 2 ncol landmark columns, then the gradient column ----
+    const int ncol = p.seg_ncol[(size_t)b * p.nseg_max + ps], nc = 2 * ncol + 1;
+    if (tid >= nc) return;
+    const bool grad = tid == nc - 1;
+    const int myd = tid & 1;
+    int cur = 0, end = 0, next_i = 0x7fffffff;
+    const double* Elmb = p.Elm + (size_t)b * p.N_max * p.KP * 6;
+    const int32_t* evt_pose = p.evt_pose + (size_t)b * p.N_max * p.KP;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+    if (!grad) {
+        const size_t li = ((size_t)b * p.nseg_max + ps) * p.L_max + (tid >> 1);
+        const int j = p.seg_lm[li];
+        cur = p.seg_evt[li];
+        end = p.evt_start[(size_t)b * (p.L_max + 1) + j + 1];
+        if (cur < end) {
+            next_i = evt_pose[cur];
+            e0 = Elmb[6 * (size_t)cur + myd]; e1 = Elmb[6 * (size_t)cur + 2 + myd]; e2 = Elmb[6 * (size_t)cur + 4 + myd];
+        }
+    }
+    double* Yb = p.Y + (size_t)b * p.y_stride;
+    double* Yi = Yb + (size_t)3 * lo * LD + tid;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0;
+#pragma unroll 2
+    for (int l = 0; l < len; ++l) {
+        const int i = lo + l;
+        const double* o = s_fac[l];
+        double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+        if (grad) { u0 = s_in[l][15]; u1 = s_in[l][16]; u2 = s_in[l][17]; }
+        SEG_SUB_GV(o + 6, y0, y1, y2, u0, u1, u2);   // Ginn is zero at the segment's first pose
+        while (i == next_i) {   // (a message may hold the same landmark twice: two factors at one pose)
+            u0 += e0; u1 += e1; u2 += e2;
+            cur += 1;
+            if (cur < end) {
+                next_i = evt_pose[cur];
+                e0 = Elmb[6 * (size_t)cur + myd]; e1 = Elmb[6 * (size_t)cur + 2 + myd]; e2 = Elmb[6 * (size_t)cur + 4 + myd];
+            } else {
+                next_i = 0x7fffffff;
+            }
+        }
+        y0 = o[0] * u0;
+        y1 = o[1] * u0 + o[2] * u1;
+        y2 = (o[3] * u0 + o[4] * u1) + o[5] * u2;
+        Yi[0] = y0; Yi[LD] = y1; Yi[2 * (size_t)LD] = y2;
+        Yi += 3 * (size_t)LD;
+        // R_a -= Gs_i Y_i, kept with a plus sign (Gs is zero in segment 0)
+        r0 += (o[15] * y0 + o[16] * y1) + o[17] * y2;
+        r1 += (o[18] * y0 + o[19] * y1) + o[20] * y2;
+        r2 += (o[21] * y0 + o[22] * y1) + o[23] * y2;
+    }
+    double* Rc = Yb + (size_t)(p.yr_rc + 6 * ps) * LD + tid;
+    Rc[0] = r0; Rc[LD] = r1; Rc[2 * (size_t)LD] = r2;
+    Rc[3 * (size_t)LD] = (s_gr[0] * y0 + s_gr[1] * y1) + s_gr[2] * y2;   // Gr is zero in the last segment
+    Rc[4 * (size_t)LD] = (s_gr[3] * y0 + s_gr[4] * y1) + s_gr[5] * y2;
+    Rc[5 * (size_t)LD] = (s_gr[6] * y0 + s_gr[7] * y1) + s_gr[8] * y2;
+}
+
+// ---- the separators: a chain of NS poses over ALL columns (threads 64 .. 64 + LD - 1 own one global column each) ----
+__global__ __launch_bounds__(1024) void pgs_sep_kernel(const PgsParams p) {
+    __shared__ double s_sin[kPgsSegMaxSep][30];   // A (6), Gr Gr^T of the segment before (6), sum Gs Gs^T of the segment after (6), Gr Gs_e^T (9), g_p (3)
+    __shared__ double s_sf[kPgsSegMaxSep][16];    // Linv (6), G (9)
+    __shared__ int s_fail;
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), LD = p.LD, KP = p.KP, m2 = 2 * p.M[b];
+    if (NS == 0) return;
+    const double lambda = p.lambda[b];
+    const double* Ab = p.A + (size_t)b * p.N_max * 9;
+    const double* gpb = p.gp + (size_t)b * p.N_max * 3;
+    const double* sob = p.segout + (size_t)b * p.nseg_max * 32;
+    for (int k = tid; k < NS; k += blockDim.x) {   // separator k + 1 (0-based k), pose s
+        const int s = (k + 1) * SL;
+        const double* A = Ab + 9 * (size_t)s;
+        double* o = s_sin[k];
+        o[0] = A[0]; o[1] = A[3]; o[2] = A[4]; o[3] = A[6]; o[4] = A[7]; o[5] = A[8];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { o[6 + q] = sob[(size_t)k * 32 + 6 + q]; o[12 + q] = sob[(size_t)(k + 1) * 32 + q]; }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[18 + q] = sob[(size_t)k * 32 + 21 + q];
+        o[27] = gpb[3 * s]; o[28] = gpb[3 * s + 1]; o[29] = gpb[3 * s + 2];
+    }
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid == 0) {
+        double I[6] = {0, 0, 0, 0, 0, 0};
+        bool ok = true;
+#pragma unroll 1
+        for (int k = 0; k < NS && ok; ++k) {
+            const double* in = s_sin[k];
+            double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (k >= 1) {   // H[s_k][s_{k-1}] = -(Gr Gs_e^T) of the segment between them
+                double Hk[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Hk[q] = -in[18 + q];
+                mul_linvT(Hk, I, G);
+            }
+            const double T0 = (((in[0] + lambda) - in[6]) - in[12]) - ((G[0] * G[0] + G[1] * G[1]) + G[2] * G[2]);
+            const double T3 = ((in[1] - in[7]) - in[13]) - ((G[3] * G[0] + G[4] * G[1]) + G[5] * G[2]);
+            const double T4 = (((in[2] + lambda) - in[8]) - in[14]) - ((G[3] * G[3] + G[4] * G[4]) + G[5] * G[5]);
+            const double T6 = ((in[3] - in[9]) - in[15]) - ((G[6] * G[0] + G[7] * G[1]) + G[8] * G[2]);
+            const double T7 = ((in[4] - in[10]) - in[16]) - ((G[6] * G[3] + G[7] * G[4]) + G[8] * G[5]);
+            const double T8 = (((in[5] + lambda) - in[11]) - in[17]) - ((G[6] * G[6] + G[7] * G[7]) + G[8] * G[8]);
+            if (!chol_inv3(T0, T3, T4, T6, T7, T8, I)) { ok = false; break; }
+            double* o = s_sf[k];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o[q] = I[q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) o[6 + q] = G[q];
+        }
+        if (!ok) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) p.solve_ok[b] = 0;
+        return;
+    }
+    for (int k = tid; k < NS; k += blockDim.x) {
+        double* o = p.sepfac + ((size_t)b * p.nseg_max + k) * 16;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) o[q] = s_sf[k][q];
+    }
+    const int c = tid - 64;
+    if (c < 0 || c >= LD) return;
+    double* Yb = p.Y + (size_t)b * p.y_stride;
+    double* Ys = Yb + (size_t)p.yr_sep * LD + c;
+    if (c > m2) {   // columns the tile kernel's operand loads touch but never store
+        for (int k = 0; k < 3 * NS; ++k) Ys[(size_t)k * LD] = 0.0;
+        return;
+    }
+    const bool grad = c == m2;
+    const int j = c >> 1, d = c & 1;
+    const int32_t* ncolb = p.seg_ncol + (size_t)b * p.nseg_max;
+    const int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * p.L_max;
+    const int32_t* cnt = p.cnt + (size_t)b * p.N_max;
+    const int32_t* mlm = p.mlm + (size_t)b * p.N_max * KP;
+    const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
+    const double* Rc = Yb + (size_t)p.yr_rc * LD;
+    // pass 1 (no dependence between the separators: the loads of several of them are in flight at once): the right-hand side
+    // before the chain term, (g - right contribution of segment k) - left contribution of segment k + 1, + E at the separator's pose
+#pragma unroll 2
+    for (int k = 0; k < NS; ++k) {
+        const int s = (k + 1) * SL;
+        double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+        if (grad) { u0 = s_sin[k][27]; u1 = s_sin[k][28]; u2 = s_sin[k][29]; }
+        int lr, ll;
+        if (grad) { lr = 2 * ncolb[k]; ll = 2 * ncolb[k + 1]; }
+        else {
+            const int ir = sinv[(size_t)k * p.L_max + j], il = sinv[(size_t)(k + 1) * p.L_max + j];
+            lr = ir >= 0 ? 2 * ir + d : -1; ll = il >= 0 ? 2 * il + d : -1;
+        }
+        double rr0 = 0.0, rr1 = 0.0, rr2 = 0.0, rl0 = 0.0, rl1 = 0.0, rl2 = 0.0;
+        if (lr >= 0) { const double* q = Rc + (size_t)(6 * k + 3) * LD + lr; rr0 = q[0]; rr1 = q[LD]; rr2 = q[2 * (size_t)LD]; }
+        if (ll >= 0) { const double* q = Rc + (size_t)(6 * (k + 1)) * LD + ll; rl0 = q[0]; rl1 = q[LD]; rl2 = q[2 * (size_t)LD]; }
+        u0 = (u0 - rr0) - rl0; u1 = (u1 - rr1) - rl1; u2 = (u2 - rr2) - rl2;
+        if (!grad) {
+            const int kc = cnt[s];
+            for (int s2 = 0; s2 < kc; ++s2) {
+                const size_t f = (size_t)s * KP + s2;
+                if ((mlm[f] & (kPgsFirstBit - 1)) == j) { u0 += Eb[6 * f + d]; u1 += Eb[6 * f + 2 + d]; u2 += Eb[6 * f + 4 + d]; }
+            }
+        }
+        Ys[(size_t)(3 * k) * LD] = u0; Ys[(size_t)(3 * k + 1) * LD] = u1; Ys[(size_t)(3 * k + 2) * LD] = u2;
+    }
+    // pass 2: the chain recurrence (each thread re-reads what it wrote itself)
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < NS; ++k) {
+        const double* o = s_sf[k];
+        double u0 = Ys[(size_t)(3 * k) * LD], u1 = Ys[(size_t)(3 * k + 1) * LD], u2 = Ys[(size_t)(3 * k + 2) * LD];
+        SEG_SUB_GV(o + 6, y0, y1, y2, u0, u1, u2);   // G is zero at the first separator
+        y0 = o[0] * u0;
+        y1 = o[1] * u0 + o[2] * u1;
+        y2 = (o[3] * u0 + o[4] * u1) + o[5] * u2;
+        Ys[(size_t)(3 * k) * LD] = y0; Ys[(size_t)(3 * k + 1) * LD] = y1; Ys[(size_t)(3 * k + 2) * LD] = y2;
+    }
+}
+
+// ---- S_ext -= sum_p Y_p^T Y_p: one workgroup per slot walks the segments IN ORDER (the tile kernel has written
+//      [D + lambda I; g_l^T] - Ysep^T Ysep before).  Y_p ([3 len][2 ncol + 1], just written by pgs_seg_kernel: L2) is staged in LDS, its
+//      Gram matrix formed on v_mfma_f64_16x16x4_f64 (16x16 tiles of the lower triangle dealt to the 16 wavefronts) and subtracted from
+//      the rows / columns of S_ext its local columns map to (ascending, so lower stays lower).  A fixed order per element of S. ----
+constexpr int SS_TPB = 1024, SS_ROWS = 3 * kPgsSegMaxLen, SS_LDL = 128 + 16;
+__global__ __launch_bounds__(SS_TPB) void pgs_seg_syrk_kernel(const PgsParams p) {
+    extern __shared__ double s_y[];   // [SS_ROWS][SS_LDL]
+    __shared__ int s_g[128];
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1, LD = p.LD, m2 = 2 * p.M[b];
+    const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
+    const double* Yb = p.Y + (size_t)b * p.y_stride;
+    double* Sb = p.S + (size_t)b * LD * LD;
+    const int32_t* ncolb = p.seg_ncol + (size_t)b * p.nseg_max;
+    const int32_t* slm = p.seg_lm + (size_t)b * p.nseg_max * p.L_max;
+#pragma unroll 1
+    for (int ps = 0; ps < nseg; ++ps) {
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
+        const int nc = 2 * ncolb[ps] + 1, nr = 3 * (hi - lo), nrp = (nr + 3) & ~3, ncp = (nc + 15) & ~15;
+        const double* Yp = Yb + (size_t)3 * lo * LD;
+        for (int idx = tid; idx < nrp * ncp; idx += SS_TPB) {
+            const int r = idx / ncp, c = idx - r * ncp;
+            s_y[r * SS_LDL + c] = (r < nr && c < nc) ? Yp[(size_t)r * LD + c] : 0.0;
+        }
+        if (tid < nc) s_g[tid] = tid == nc - 1 ? m2 : 2 * slm[(size_t)ps * p.L_max + (tid >> 1)] + (tid & 1);
+        __syncthreads();
+        const int nt = ncp >> 4, ntile = nt * (nt + 1) / 2;
+        for (int t = w; t < ntile; t += SS_TPB / 64) {
+            int ti = 0, tt = t;
+            while (tt >= ti + 1) { tt -= ti + 1; ti += 1; }
+            const int tj = tt;
+            dbl4_t acc = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+            const double* ra = s_y + kq * SS_LDL + 16 * ti + cl;
+            const double* rb = s_y + kq * SS_LDL + 16 * tj + cl;
+#pragma unroll 4
+            for (int k = 0; k < nrp; k += 4) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[0], rb[0], acc, 0, 0, 0);
+                ra += 4 * SS_LDL; rb += 4 * SS_LDL;
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int lr = 16 * ti + kq + 4 * r4, lcn = 16 * tj + cl;   // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 reg
+                if (lr < nc && lcn <= lr) {
+                    double* q = Sb + (size_t)s_g[lr] * LD + s_g[lcn];
+                    *q = *q - acc[r4];
+                }
+            }
+        }
+        __syncthreads();   // LDS is reused; the updates of S are visible to the threads that touch the same elements next
+    }
+}
+
+// ---- pose step H_pp dp = g_p - H_pl dl through the segmented factor: forward over the interiors (one lane per segment), the
+//      separators (one lane), backward over the separators, backward over the interiors ----
+constexpr int SB_TPB = 256;
+__global__ __launch_bounds__(SB_TPB) void pgs_seg_backsolve_kernel(const PgsParams p) {
+    __shared__ double s_sf[kPgsSegMaxSep][16];
+    __shared__ double s_r[kPgsSegMaxSep + 1][6];
+    __shared__ double s_ds[kPgsSegMaxSep + 2][3];
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP;
+    const Inst g = inst_view(p, b);
+    const double* gpb = p.gp + (size_t)b * p.N_max * 3;
+    const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
+    const double* Lb = p.Linv + (size_t)b * p.N_max * 6;
+    const double* Gb = p.G + (size_t)b * p.N_max * 9;
+    const double* Gsb = p.Gs + (size_t)b * p.N_max * 9;
+    const double* sob = p.segout + (size_t)b * p.nseg_max * 32;
+    const double* dlb = p.dl + (size_t)b * p.L_max * 2;
+    double* dpb = p.dp + (size_t)b * p.N_max * 3;
+    for (int i = tid; i < N; i += SB_TPB) {   // u_i = g_i - E_i dl (into dp, overwritten in place by z and then by the step)
+        double u0 = gpb[3 * i], u1 = gpb[3 * i + 1], u2 = gpb[3 * i + 2];
+        const int kc = g.cnt[i];
+        for (int s = 0; s < kc; ++s) {
+            const size_t k = (size_t)i * KP + s;
+            const int j = g.mlm[k] & (kPgsFirstBit - 1);
+            const double* E = Eb + 6 * k;
+            const double d0 = dlb[2 * j], d1 = dlb[2 * j + 1];
+            u0 -= E[0] * d0 + E[1] * d1; u1 -= E[2] * d0 + E[3] * d1; u2 -= E[4] * d0 + E[5] * d1;
+        }
+        dpb[3 * i] = u0; dpb[3 * i + 1] = u1; dpb[3 * i + 2] = u2;
+    }
+    for (int k = tid; k < NS; k += SB_TPB) {
+        const double* o = p.sepfac + ((size_t)b * p.nseg_max + k) * 16;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) s_sf[k][q] = o[q];
+    }
+    __syncthreads();
+    for (int ps = tid; ps < nseg; ps += SB_TPB) {   // forward over the interior poses of segment ps
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        double f[24], fn[24];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fn[q] = Lb[6 * (size_t)lo + q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { fn[6 + q] = Gb[9 * (size_t)lo + q]; fn[15 + q] = Gsb[9 * (size_t)lo + q]; }
+        double un0 = dpb[3 * lo], un1 = dpb[3 * lo + 1], un2 = dpb[3 * lo + 2];
+#pragma unroll 1
+        for (int i = lo; i < hi; ++i) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) f[q] = fn[q];
+            double u0 = un0, u1 = un1, u2 = un2;
+            const int in = i + 1 < hi ? i + 1 : i;   // the next pose's factor is fetched under this pose's arithmetic
+#pragma unroll
+            for (int q = 0; q < 6; ++q) fn[q] = Lb[6 * (size_t)in + q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { fn[6 + q] = Gb[9 * (size_t)in + q]; fn[15 + q] = Gsb[9 * (size_t)in + q]; }
+            un0 = dpb[3 * in]; un1 = dpb[3 * in + 1]; un2 = dpb[3 * in + 2];
+            SEG_SUB_GV(f + 6, z0, z1, z2, u0, u1, u2);   // Ginn is zero at the segment's first pose
+            z0 = f[0] * u0;
+            z1 = f[1] * u0 + f[2] * u1;
+            z2 = (f[3] * u0 + f[4] * u1) + f[5] * u2;
+            dpb[3 * i] = z0; dpb[3 * i + 1] = z1; dpb[3 * i + 2] = z2;
+            r0 += (f[15] * z0 + f[16] * z1) + f[17] * z2;
+            r1 += (f[18] * z0 + f[19] * z1) + f[20] * z2;
+            r2 += (f[21] * z0 + f[22] * z1) + f[23] * z2;
+        }
+        const double* Gr = sob + (size_t)ps * 32 + 12;   // zero in the last segment
+        s_r[ps][0] = r0; s_r[ps][1] = r1; s_r[ps][2] = r2;
+        s_r[ps][3] = (Gr[0] * z0 + Gr[1] * z1) + Gr[2] * z2;
+        s_r[ps][4] = (Gr[3] * z0 + Gr[4] * z1) + Gr[5] * z2;
+        s_r[ps][5] = (Gr[6] * z0 + Gr[7] * z1) + Gr[8] * z2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < NS; ++k) {   // forward over the separators
+            const int s = (k + 1) * SL;
+            const double* o = s_sf[k];
+            double u0 = (dpb[3 * s] - s_r[k][3]) - s_r[k + 1][0];
+            double u1 = (dpb[3 * s + 1] - s_r[k][4]) - s_r[k + 1][1];
+            double u2 = (dpb[3 * s + 2] - s_r[k][5]) - s_r[k + 1][2];
+            SEG_SUB_GV(o + 6, z0, z1, z2, u0, u1, u2);
+            z0 = o[0] * u0;
+            z1 = o[1] * u0 + o[2] * u1;
+            z2 = (o[3] * u0 + o[4] * u1) + o[5] * u2;
+            s_ds[k + 1][0] = z0; s_ds[k + 1][1] = z1; s_ds[k + 1][2] = z2;
+        }
+        s_ds[NS + 1][0] = 0.0; s_ds[NS + 1][1] = 0.0; s_ds[NS + 1][2] = 0.0;
+        s_ds[0][0] = 0.0; s_ds[0][1] = 0.0; s_ds[0][2] = 0.0;
+#pragma unroll 1
+        for (int k = NS - 1; k >= 0; --k) {   // backward: s_ds[k + 1] = step of separator k (0-based)
+            double v0 = s_ds[k + 1][0], v1 = s_ds[k + 1][1], v2 = s_ds[k + 1][2];
+            if (k + 1 < NS) { const double* Gn = s_sf[k + 1] + 6; SEG_SUB_GTV(Gn, s_ds[k + 2][0], s_ds[k + 2][1], s_ds[k + 2][2], v0, v1, v2); }
+            const double* I = s_sf[k];
+            const double d2 = I[5] * v2;
+            const double d1 = I[2] * v1 + I[4] * v2;
+            const double d0 = (I[0] * v0 + I[1] * v1) + I[3] * v2;
+            s_ds[k + 1][0] = d0; s_ds[k + 1][1] = d1; s_ds[k + 1][2] = d2;
+            const int s = (k + 1) * SL;
+            dpb[3 * s] = d0; dpb[3 * s + 1] = d1; dpb[3 * s + 2] = d2;
+        }
+    }
+    __syncthreads();
+    for (int ps = tid; ps < nseg; ps += SB_TPB) {   // backward over the interior poses of segment ps
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
+        const double a0 = s_ds[ps][0], a1 = s_ds[ps][1], a2 = s_ds[ps][2];               // step of the left separator (zero for segment 0)
+        double n0 = s_ds[ps + 1][0], n1 = s_ds[ps + 1][1], n2 = s_ds[ps + 1][2];          // step of the pose after i: first the right separator
+        double Gn[9];   // coupling of pose i to the pose after it: Gright for the last interior pose, Ginn_{i+1} else
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Gn[q] = sob[(size_t)ps * 32 + 12 + q];
+        double fI[6], fS[9], fG[9], nI[6], nS[9], nG[9];
+        const int e = hi - 1;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) nI[q] = Lb[6 * (size_t)e + q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { nS[q] = Gsb[9 * (size_t)e + q]; nG[q] = Gb[9 * (size_t)e + q]; }
+        double zn0 = dpb[3 * e], zn1 = dpb[3 * e + 1], zn2 = dpb[3 * e + 2];
+#pragma unroll 1
+        for (int i = e; i >= lo; --i) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) fI[q] = nI[q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { fS[q] = nS[q]; fG[q] = nG[q]; }
+            double v0 = zn0, v1 = zn1, v2 = zn2;
+            const int ip = i - 1 >= lo ? i - 1 : i;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) nI[q] = Lb[6 * (size_t)ip + q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { nS[q] = Gsb[9 * (size_t)ip + q]; nG[q] = Gb[9 * (size_t)ip + q]; }
+            zn0 = dpb[3 * ip]; zn1 = dpb[3 * ip + 1]; zn2 = dpb[3 * ip + 2];
+            SEG_SUB_GTV(Gn, n0, n1, n2, v0, v1, v2);
+            SEG_SUB_GTV(fS, a0, a1, a2, v0, v1, v2);   // Gs is zero in segment 0
+            n2 = fI[5] * v2;
+            n1 = fI[2] * v1 + fI[4] * v2;
+            n0 = (fI[0] * v0 + fI[1] * v1) + fI[3] * v2;
+            dpb[3 * i] = n0; dpb[3 * i + 1] = n1; dpb[3 * i + 2] = n2;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Gn[q] = fG[q];   // Ginn_i couples pose i - 1 to pose i
+        }
+    }
+}

@@ -1018,6 +1018,16 @@ int slam_error_stats(slam_handle* h, double* avg) {
     return SLAM_OK;
 }
 
+extern "C" int slam_internal_error_stats_dev(slam_handle* h, double* d_out, long long pad) {
+    if (!h || !d_out || pad < h->B) return fail(SLAM_ERR_ARG, "bad argument");
+    if (!h->inited) return fail(SLAM_ERR_STATE, "slam_init has not been called");
+    FLUSH(h);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(slam::launch_avg_error(h->derr, h->dts, h->B, (int)pad, d_out, h->stream));
+    HIP_TRY(h->kind == SLAM_EKF_SLAM ? hipStreamSynchronize(h->stream) : hipDeviceSynchronize());
+    return SLAM_OK;
+}
+
 // ---- checkpoint / resume (the reference keeps the filter only in memory) ------------------------------
 namespace {
 struct CkptHeader {
@@ -1102,7 +1112,9 @@ int slam_load_state(slam_handle* h, const char* path) {
         int rc = column(2, "the landmark count", 0, h->L_max);
         if (!rc) rc = column(5, "the timestep", 0, INT32_MAX);
         if (!rc && h->kind != SLAM_EKF_SLAM) rc = column(9, "the size of the stored square root", 0, h->n_max);
-        if (!rc && h->kind != SLAM_EKF_SLAM) rc = column(12, "the age of the warm-start eigenvectors", 0, INT32_MAX);
+        // -1 is the cold-start marker (ukf_init_kernel, and both sqrt kernels after SLAM_INST_SQRT_FAILED); the kernels count the
+        // age up to kWarmMaxAge = 100 and start cold from there, so nothing a run can produce lies outside [-1, 100].
+        if (!rc && h->kind != SLAM_EKF_SLAM) rc = column(12, "the age of the warm-start eigenvectors", -1, 100);
         if (rc) { fclose(f); return rc; }
         if (fseek(f, (long)sizeof(hd), SEEK_SET) != 0) { fclose(f); return fail(SLAM_ERR_IO, "cannot rewind %s", path); }
     }

@@ -12,6 +12,7 @@
 
 #include "../../include/slam_batch.h"
 #include "jacobi_schedule.h"
+#include "lds_attr.h"
 #include "sim_device.h"
 #include "slam_math.h"
 #include "slam_rng.h"
@@ -469,8 +470,8 @@ hipError_t launch_ukf_big_step(const UkfStepParams& p, hipStream_t stream) {
     if (p.big_ws == nullptr) return hipErrorInvalidValue;
     const size_t lds = big_step_lds(p.L_max, p.sim ? p.L : 1);
     if (lds > 159 * 1024) return hipErrorInvalidConfiguration;
-    if (lds > 64 * 1024) {   // (beyond the default limit only: static + dynamic must stay within the CU's 160 KB)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ukf_big_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {   // once per device, to the kernel's maximum (lds_attr.h)
+        const hipError_t e = slam_allow_full_lds(reinterpret_cast<const void*>(&ukf_big_step_kernel));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(ukf_big_step_kernel, dim3(p.b_cnt), dim3(kTpb), lds, stream, p);

@@ -236,8 +236,9 @@ class BatchedPoseGraph:
 
     def last_solve_paths(self):
         """The last profiled solve by path: algorithmic SYRK FLOP and ms of the separate SYRK launches / of the fused chain + SYRK launches."""
-        self._need(); o = np.zeros(4); _lib.check(_lib.lib().pgs_last_solve_paths(self.h, _d(o)))
-        return dict(flop_separate=o[0], flop_fused=o[1], ms_separate_syrk=o[2], ms_fused=o[3])
+        self._need(); o = np.zeros(8); _lib.check(_lib.lib().pgs_last_solve_paths(self.h, _d(o)))
+        return dict(flop_separate=o[0], flop_fused=o[1], ms_separate_syrk=o[2], ms_fused=o[3], flop_segmented=o[4], ms_segmented_syrk=o[5],
+                    segmented=bool(o[6]), segment_length=int(o[7]))
 
     def sync(self):
         self._need(); _lib.check(_lib.lib().pgs_sync(self.h))

@@ -268,7 +268,7 @@ def run_ukf_batch(map_xy, cmds, B, L_max, seed=2025, inst0=0, cfg=None, math=MAT
     return dict(x=x, P=P, M=M, ids=ids, avg_err=err, flags=flags, truth=truth, seconds=secs)
 
 
-LIN_SCHUR, LIN_DENSE = 0, 1
+LIN_SCHUR, LIN_DENSE, LIN_SEG = 0, 1, 2   # LIN_SEG | (SL << 8): poses eliminated segment by segment (SL = 0: 32), what the GPU path does
 
 
 class OraclePoseGraph:

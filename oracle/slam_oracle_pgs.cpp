@@ -40,7 +40,13 @@
 namespace {
 using namespace orc;
 
-enum { LIN_SCHUR = 0, LIN_DENSE = 1 };
+// LIN_SEG (round 5): the same Schur complement with the poses eliminated in a NESTED-DISSECTION order instead of 0, 1, 2, ...:
+// the chain is cut at the separator poses SL, 2 SL, ... into segments whose interiors are eliminated first (independently of each
+// other - on the GPU in parallel), then the separators, then the landmarks.  Any order gives the same delta up to rounding; this one
+// has depth SL + N / SL instead of N and far less fill (a row of Y only holds the landmarks its own segment sees).  The GPU path
+// (pgs_seg_kernel / pgs_sep_kernel / pgs_seg_syrk_kernel / pgs_seg_backsolve_kernel) follows exactly this statement.  lin_mode =
+// LIN_SEG | (SL << 8), SL = 0: 32.
+enum { LIN_SCHUR = 0, LIN_DENSE = 1, LIN_SEG = 2 };
 enum { PGS_FLAG_POSE_CAP = 1, PGS_FLAG_LM_CAP = 2, PGS_FLAG_MEAS_CAP = 4, PGS_FLAG_NOT_CONVERGED = 8, PGS_FLAG_NONFINITE = 16 };
 
 struct LmStats {
@@ -404,6 +410,292 @@ struct Pgs {
         return true;
     }
 
+    // ---- 3x3 helpers of the segmented elimination (the operation order the GPU kernels mirror) ----
+    // I = inverse of the Cholesky factor of T (lower; i00 i10 i11 i20 i21 i22); false if a pivot is not positive
+    static bool chol_inv3(const double T[9], double I[6]) {
+        if (!(T[0] > 0.0)) return false;
+        const double l00 = ::sqrt(T[0]), l10 = T[3] / l00, l20 = T[6] / l00;
+        const double t11 = T[4] - l10 * l10;
+        if (!(t11 > 0.0)) return false;
+        const double l11 = ::sqrt(t11), l21 = (T[7] - l20 * l10) / l11;
+        const double t22 = (T[8] - l20 * l20) - l21 * l21;
+        if (!(t22 > 0.0)) return false;
+        const double l22 = ::sqrt(t22);
+        I[0] = 1.0 / l00; I[2] = 1.0 / l11; I[5] = 1.0 / l22;
+        I[1] = -(l10 * I[0]) * I[2];
+        I[4] = -(l21 * I[2]) * I[5];
+        I[3] = -(l20 * I[0] + l21 * I[1]) * I[5];
+        return true;
+    }
+    // G = X Linv^T for a 3x3 X (row r of G from row r of X), Linv lower triangular
+    static void mul_linvT(const double* X, const double* I, double* G) {
+        for (int r = 0; r < 3; ++r) {
+            G[3 * r + 0] = X[3 * r] * I[0];
+            G[3 * r + 1] = X[3 * r] * I[1] + X[3 * r + 1] * I[2];
+            G[3 * r + 2] = (X[3 * r] * I[3] + X[3 * r + 1] * I[4]) + X[3 * r + 2] * I[5];
+        }
+    }
+    // P = X Z^T (3x3)
+    static void mul_abT(const double* X, const double* Z, double* P) {
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) P[3 * a + b] = (X[3 * a] * Z[3 * b] + X[3 * a + 1] * Z[3 * b + 1]) + X[3 * a + 2] * Z[3 * b + 2];
+    }
+    static void linv_apply(const double* I, const double u[3], double y[3]) {   // y = Linv u
+        y[0] = I[0] * u[0];
+        y[1] = I[1] * u[0] + I[2] * u[1];
+        y[2] = (I[3] * u[0] + I[4] * u[1]) + I[5] * u[2];
+    }
+    static void linvT_apply(const double* I, const double u[3], double y[3]) {   // y = Linv^T u
+        y[2] = I[5] * u[2];
+        y[1] = I[2] * u[1] + I[4] * u[2];
+        y[0] = (I[0] * u[0] + I[1] * u[1]) + I[3] * u[2];
+    }
+    static void sub_Gv(const double* G, const double v[3], double u[3]) {        // u -= G v
+        for (int r = 0; r < 3; ++r) u[r] -= (G[3 * r] * v[0] + G[3 * r + 1] * v[1]) + G[3 * r + 2] * v[2];
+    }
+    static void sub_GTv(const double* G, const double v[3], double u[3]) {       // u -= G^T v
+        for (int r = 0; r < 3; ++r) u[r] -= (G[r] * v[0] + G[3 + r] * v[1]) + G[6 + r] * v[2];
+    }
+
+    // (J^T J + lambda I) delta = g with the poses eliminated segment by segment (LIN_SEG, see the top of the file).
+    // Separators: poses k SL (k = 1 .. NS, NS = (N - 2) / SL); segment p = 0 .. NS holds the poses strictly between separators p and
+    // p + 1 (segment 0 starts at pose 0, the last one ends at pose N - 1).
+    bool solve_seg(const Lin& L, double lambda, int SL, std::vector<double>& dp, std::vector<double>& dl) const {
+        const int n = N(), m2 = 2 * M, W = m2 + 1;
+        const int NS = n >= 2 ? (n - 2) / SL : 0, nseg = NS + 1;
+        auto seg_lo = [&](int p) { return p == 0 ? 0 : p * SL + 1; };
+        auto seg_hi = [&](int p) { return p < NS ? (p + 1) * SL : n; };
+        std::vector<double> Linv((size_t)6 * n), Ginn((size_t)9 * n, 0.0), Gsep((size_t)9 * n, 0.0);
+        std::vector<double> accL((size_t)6 * nseg, 0.0), Aright((size_t)6 * nseg, 0.0), Gright((size_t)9 * nseg, 0.0), Hba((size_t)9 * nseg, 0.0);
+        // ---- interiors: chain factor inside the segment + the spike towards the left separator ----
+        for (int p = 0; p < nseg; ++p) {
+            const int lo = seg_lo(p), hi = seg_hi(p), a = p * SL;
+            double Bcur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (p >= 1) {   // H[a][a+1] = C_a^T
+                const double* C = &L.C[9 * a];
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Bcur[3 * r + c] = C[3 * c + r];
+            }
+            for (int i = lo; i < hi; ++i) {
+                double T[9];
+                for (int k = 0; k < 9; ++k) T[k] = L.A[9 * i + k];
+                T[0] += lambda; T[4] += lambda; T[8] += lambda;
+                double* Gi = &Ginn[9 * i];
+                if (i > lo) {
+                    mul_linvT(&L.C[9 * (i - 1)], &Linv[6 * (i - 1)], Gi);
+                    for (int a2 = 0; a2 < 3; ++a2)
+                        for (int b2 = 0; b2 < 3; ++b2)
+                            T[3 * a2 + b2] -= (Gi[3 * a2] * Gi[3 * b2] + Gi[3 * a2 + 1] * Gi[3 * b2 + 1]) + Gi[3 * a2 + 2] * Gi[3 * b2 + 2];
+                    if (p >= 1) {   // fill of eliminating pose i-1: H[a][i] = -(Gsep_{i-1} Ginn_i^T)
+                        double P[9];
+                        mul_abT(&Gsep[9 * (i - 1)], Gi, P);
+                        for (int k = 0; k < 9; ++k) Bcur[k] = -P[k];
+                    }
+                }
+                if (!chol_inv3(T, &Linv[6 * i])) return false;
+                if (p >= 1) {
+                    double* Gs = &Gsep[9 * i];
+                    mul_linvT(Bcur, &Linv[6 * i], Gs);
+                    double* aL = &accL[6 * p];   // lower triangle 00 10 11 20 21 22 of sum Gsep Gsep^T
+                    aL[0] += (Gs[0] * Gs[0] + Gs[1] * Gs[1]) + Gs[2] * Gs[2];
+                    aL[1] += (Gs[3] * Gs[0] + Gs[4] * Gs[1]) + Gs[5] * Gs[2];
+                    aL[2] += (Gs[3] * Gs[3] + Gs[4] * Gs[4]) + Gs[5] * Gs[5];
+                    aL[3] += (Gs[6] * Gs[0] + Gs[7] * Gs[1]) + Gs[8] * Gs[2];
+                    aL[4] += (Gs[6] * Gs[3] + Gs[7] * Gs[4]) + Gs[8] * Gs[5];
+                    aL[5] += (Gs[6] * Gs[6] + Gs[7] * Gs[7]) + Gs[8] * Gs[8];
+                }
+            }
+            if (p < NS) {   // the right separator b = hi couples to the last interior pose e = hi - 1 through C_e
+                const int e = hi - 1;
+                double* Gr = &Gright[9 * p];
+                mul_linvT(&L.C[9 * e], &Linv[6 * e], Gr);
+                double* aR = &Aright[6 * p];
+                aR[0] = (Gr[0] * Gr[0] + Gr[1] * Gr[1]) + Gr[2] * Gr[2];
+                aR[1] = (Gr[3] * Gr[0] + Gr[4] * Gr[1]) + Gr[5] * Gr[2];
+                aR[2] = (Gr[3] * Gr[3] + Gr[4] * Gr[4]) + Gr[5] * Gr[5];
+                aR[3] = (Gr[6] * Gr[0] + Gr[7] * Gr[1]) + Gr[8] * Gr[2];
+                aR[4] = (Gr[6] * Gr[3] + Gr[7] * Gr[4]) + Gr[8] * Gr[5];
+                aR[5] = (Gr[6] * Gr[6] + Gr[7] * Gr[7]) + Gr[8] * Gr[8];
+                if (p >= 1) mul_abT(Gr, &Gsep[9 * e], &Hba[9 * p]);   // H[b][a] = -(this)
+            }
+        }
+        // ---- separators: a chain of NS poses ----
+        std::vector<double> LinvS((size_t)6 * std::max(NS, 1)), GS((size_t)9 * std::max(NS, 1), 0.0);
+        for (int k = 1; k <= NS; ++k) {
+            const int s = k * SL;
+            double T[9];
+            for (int q = 0; q < 9; ++q) T[q] = L.A[9 * s + q];
+            T[0] += lambda; T[4] += lambda; T[8] += lambda;
+            const double* aR = &Aright[6 * (k - 1)];
+            const double* aL = &accL[6 * k];
+            T[0] = (T[0] - aR[0]) - aL[0];
+            T[3] = (T[3] - aR[1]) - aL[1]; T[4] = (T[4] - aR[2]) - aL[2];
+            T[6] = (T[6] - aR[3]) - aL[3]; T[7] = (T[7] - aR[4]) - aL[4]; T[8] = (T[8] - aR[5]) - aL[5];
+            T[1] = T[3]; T[2] = T[6]; T[5] = T[7];
+            double* Gk = &GS[9 * (k - 1)];
+            if (k >= 2) {
+                double Hk[9];
+                for (int q = 0; q < 9; ++q) Hk[q] = -Hba[9 * (k - 1) + q];
+                mul_linvT(Hk, &LinvS[6 * (k - 2)], Gk);
+                for (int a2 = 0; a2 < 3; ++a2)
+                    for (int b2 = 0; b2 < 3; ++b2)
+                        T[3 * a2 + b2] -= (Gk[3 * a2] * Gk[3 * b2] + Gk[3 * a2 + 1] * Gk[3 * b2 + 1]) + Gk[3 * a2 + 2] * Gk[3 * b2 + 2];
+            }
+            if (!chol_inv3(T, &LinvS[6 * (k - 1)])) return false;
+        }
+        // ---- Y = L^-1 [H_pl | g_p] in the same order: interior rows, then separator rows; S = D + lambda I - Y^T Y ----
+        // per-pose E blocks by landmark column (dense row of 3 x W per pose would be N x W: walk the factor slots instead)
+        auto add_E = [&](int i, std::vector<double>& u /* [3][W] */) {
+            for (int s2 = 0; s2 < cnt[i]; ++s2) {
+                const size_t k = (size_t)i * KP + s2;
+                const int j = mlm[k];
+                for (int r = 0; r < 3; ++r) { u[(size_t)r * W + 2 * j] += L.E[6 * k + 2 * r]; u[(size_t)r * W + 2 * j + 1] += L.E[6 * k + 2 * r + 1]; }
+            }
+        };
+        std::vector<double> S((size_t)m2 * m2, 0.0), rhs(m2, 0.0);
+        for (int j = 0; j < M; ++j) {
+            S[(size_t)(2 * j) * m2 + 2 * j] = L.D[3 * j] + lambda;
+            S[(size_t)(2 * j + 1) * m2 + 2 * j] = L.D[3 * j + 1];
+            S[(size_t)(2 * j) * m2 + 2 * j + 1] = L.D[3 * j + 1];
+            S[(size_t)(2 * j + 1) * m2 + 2 * j + 1] = L.D[3 * j + 2] + lambda;
+            rhs[2 * j] = L.gl[2 * j]; rhs[2 * j + 1] = L.gl[2 * j + 1];
+        }
+        auto syrk_rows = [&](const double* y /* [W] */) {
+            for (int a2 = 0; a2 < m2; ++a2) {
+                const double ya = y[a2];
+                if (ya == 0.0) continue;
+                double* Sa = &S[(size_t)a2 * m2];
+                for (int b2 = 0; b2 <= a2; ++b2) Sa[b2] -= ya * y[b2];
+                rhs[a2] -= ya * y[m2];
+            }
+        };
+        std::vector<double> RcL((size_t)3 * W * nseg, 0.0), RcR((size_t)3 * W * nseg, 0.0), u((size_t)3 * W), yprev((size_t)3 * W), ysep;
+        // the separator rows are subtracted from S FIRST (the GPU forms base - Ysep^T Ysep with one tile kernel and then subtracts the
+        // segments' products in segment order), so they are computed before the interior rows are accumulated: two passes
+        std::vector<double> Yint((size_t)3 * n * W, 0.0);
+        for (int p = 0; p < nseg; ++p) {
+            const int lo = seg_lo(p), hi = seg_hi(p);
+            std::fill(yprev.begin(), yprev.end(), 0.0);
+            for (int i = lo; i < hi; ++i) {
+                std::fill(u.begin(), u.end(), 0.0);
+                u[m2] = L.gp[3 * i]; u[(size_t)W + m2] = L.gp[3 * i + 1]; u[(size_t)2 * W + m2] = L.gp[3 * i + 2];
+                const double* Gi = &Ginn[9 * i];
+                if (i > lo)
+                    for (int c = 0; c < W; ++c) {
+                        double v[3] = {yprev[c], yprev[W + c], yprev[2 * (size_t)W + c]}, uu[3] = {u[c], u[W + c], u[2 * (size_t)W + c]};
+                        sub_Gv(Gi, v, uu);
+                        u[c] = uu[0]; u[W + c] = uu[1]; u[2 * (size_t)W + c] = uu[2];
+                    }
+                add_E(i, u);
+                double* Yi = &Yint[(size_t)3 * i * W];
+                for (int c = 0; c < W; ++c) {
+                    const double uu[3] = {u[c], u[W + c], u[2 * (size_t)W + c]};
+                    double y[3];
+                    linv_apply(&Linv[6 * i], uu, y);
+                    Yi[c] = y[0]; Yi[W + c] = y[1]; Yi[2 * (size_t)W + c] = y[2];
+                    yprev[c] = y[0]; yprev[W + c] = y[1]; yprev[2 * (size_t)W + c] = y[2];
+                    if (p >= 1) {   // R_a -= Gsep_i Y_i, accumulated with a plus sign
+                        const double* Gs = &Gsep[9 * i];
+                        double* rc = &RcL[(size_t)3 * W * p];
+                        for (int r = 0; r < 3; ++r) rc[(size_t)r * W + c] += (Gs[3 * r] * y[0] + Gs[3 * r + 1] * y[1]) + Gs[3 * r + 2] * y[2];
+                    }
+                }
+            }
+            if (p < NS) {
+                const double* Gr = &Gright[9 * p];
+                double* rc = &RcR[(size_t)3 * W * p];
+                for (int c = 0; c < W; ++c)
+                    for (int r = 0; r < 3; ++r) rc[(size_t)r * W + c] = (Gr[3 * r] * yprev[c] + Gr[3 * r + 1] * yprev[W + c]) + Gr[3 * r + 2] * yprev[2 * (size_t)W + c];
+            }
+        }
+        std::vector<double> Ysep((size_t)3 * std::max(NS, 1) * W, 0.0);
+        for (int k = 1; k <= NS; ++k) {
+            const int s = k * SL;
+            std::fill(u.begin(), u.end(), 0.0);
+            u[m2] = L.gp[3 * s]; u[(size_t)W + m2] = L.gp[3 * s + 1]; u[(size_t)2 * W + m2] = L.gp[3 * s + 2];
+            const double* rr = &RcR[(size_t)3 * W * (k - 1)];
+            const double* rl = &RcL[(size_t)3 * W * k];
+            for (size_t q = 0; q < (size_t)3 * W; ++q) u[q] = (u[q] - rr[q]) - rl[q];
+            if (k >= 2) {
+                const double* Gk = &GS[9 * (k - 1)];
+                const double* Yp = &Ysep[(size_t)3 * (k - 2) * W];
+                for (int c = 0; c < W; ++c) {
+                    double v[3] = {Yp[c], Yp[W + c], Yp[2 * (size_t)W + c]}, uu[3] = {u[c], u[W + c], u[2 * (size_t)W + c]};
+                    sub_Gv(Gk, v, uu);
+                    u[c] = uu[0]; u[W + c] = uu[1]; u[2 * (size_t)W + c] = uu[2];
+                }
+            }
+            add_E(s, u);
+            double* Yk = &Ysep[(size_t)3 * (k - 1) * W];
+            for (int c = 0; c < W; ++c) {
+                const double uu[3] = {u[c], u[W + c], u[2 * (size_t)W + c]};
+                double y[3];
+                linv_apply(&LinvS[6 * (k - 1)], uu, y);
+                Yk[c] = y[0]; Yk[W + c] = y[1]; Yk[2 * (size_t)W + c] = y[2];
+            }
+        }
+        for (int k = 0; k < 3 * NS; ++k) syrk_rows(&Ysep[(size_t)k * W]);
+        for (int p = 0; p < nseg; ++p)
+            for (int k = 3 * seg_lo(p); k < 3 * seg_hi(p); ++k) syrk_rows(&Yint[(size_t)k * W]);
+        dl.assign(std::max(m2, 1), 0.0);
+        if (m2 > 0) {
+            if (!chol_solve(S, m2, rhs)) return false;
+            for (int a2 = 0; a2 < m2; ++a2) dl[a2] = rhs[a2];
+        }
+        // ---- poses: forward over interiors, then separators; backward over separators, then interiors ----
+        dp.assign((size_t)3 * n, 0.0);
+        std::vector<double> zz((size_t)3 * n), racc((size_t)3 * nseg, 0.0), rright((size_t)3 * nseg, 0.0), zs((size_t)3 * std::max(NS, 1)), ds((size_t)3 * (NS + 2), 0.0);
+        auto rhs_pose = [&](int i, double uu[3]) {
+            uu[0] = L.gp[3 * i]; uu[1] = L.gp[3 * i + 1]; uu[2] = L.gp[3 * i + 2];
+            for (int s2 = 0; s2 < cnt[i]; ++s2) {
+                const size_t k = (size_t)i * KP + s2;
+                const int j = mlm[k];
+                for (int r = 0; r < 3; ++r) uu[r] -= L.E[6 * k + 2 * r] * dl[2 * j] + L.E[6 * k + 2 * r + 1] * dl[2 * j + 1];
+            }
+        };
+        for (int p = 0; p < nseg; ++p) {
+            const int lo = seg_lo(p), hi = seg_hi(p);
+            for (int i = lo; i < hi; ++i) {
+                double uu[3];
+                rhs_pose(i, uu);
+                if (i > lo) sub_Gv(&Ginn[9 * i], &zz[3 * (i - 1)], uu);
+                linv_apply(&Linv[6 * i], uu, &zz[3 * i]);
+                if (p >= 1) {
+                    const double* Gs = &Gsep[9 * i];
+                    for (int r = 0; r < 3; ++r) racc[3 * p + r] += (Gs[3 * r] * zz[3 * i] + Gs[3 * r + 1] * zz[3 * i + 1]) + Gs[3 * r + 2] * zz[3 * i + 2];
+                }
+            }
+            if (p < NS) {
+                const double* Gr = &Gright[9 * p];
+                const double* ze = &zz[3 * (hi - 1)];
+                for (int r = 0; r < 3; ++r) rright[3 * p + r] = (Gr[3 * r] * ze[0] + Gr[3 * r + 1] * ze[1]) + Gr[3 * r + 2] * ze[2];
+            }
+        }
+        for (int k = 1; k <= NS; ++k) {
+            double uu[3];
+            rhs_pose(k * SL, uu);
+            for (int r = 0; r < 3; ++r) uu[r] = (uu[r] - rright[3 * (k - 1) + r]) - racc[3 * k + r];
+            if (k >= 2) sub_Gv(&GS[9 * (k - 1)], &zs[3 * (k - 2)], uu);
+            linv_apply(&LinvS[6 * (k - 1)], uu, &zs[3 * (k - 1)]);
+        }
+        for (int k = NS; k >= 1; --k) {   // ds[k] = step of separator k (ds[NS + 1] = 0)
+            double v[3] = {zs[3 * (k - 1)], zs[3 * (k - 1) + 1], zs[3 * (k - 1) + 2]};
+            if (k < NS) sub_GTv(&GS[9 * k], &ds[3 * (k + 1)], v);
+            linvT_apply(&LinvS[6 * (k - 1)], v, &ds[3 * k]);
+            for (int r = 0; r < 3; ++r) dp[3 * (k * SL) + r] = ds[3 * k + r];
+        }
+        for (int p = 0; p < nseg; ++p) {
+            const int lo = seg_lo(p), hi = seg_hi(p);
+            for (int i = hi - 1; i >= lo; --i) {
+                double v[3] = {zz[3 * i], zz[3 * i + 1], zz[3 * i + 2]};
+                if (i + 1 < hi) sub_GTv(&Ginn[9 * (i + 1)], &dp[3 * (i + 1)], v);
+                else if (p < NS) sub_GTv(&Gright[9 * p], &ds[3 * (p + 1)], v);
+                if (p >= 1) sub_GTv(&Gsep[9 * i], &ds[3 * p], v);
+                linvT_apply(&Linv[6 * i], v, &dp[3 * i]);
+            }
+        }
+        return true;
+    }
+
     // the same system as ONE dense matrix (validation of the elimination above; small graphs only)
     bool solve_dense(const Lin& L, double lambda, std::vector<double>& dp, std::vector<double>& dl) const {
         const int n = N(), np = 3 * n, nt = np + 2 * M;
@@ -501,7 +793,9 @@ struct Pgs {
             for (;;) {   // iterate(): while (!tryLambda()) {}
                 st.trials += 1;
                 bool success = false, stop = false;
-                const bool ok = lin_mode == LIN_DENSE ? solve_dense(L, lambda, dp, dl) : solve_schur(L, lambda, dp, dl);
+                const int lmode = lin_mode & 0xff, seg_len = (lin_mode >> 8) > 0 ? (lin_mode >> 8) : 32;
+                const bool ok = lmode == LIN_DENSE ? solve_dense(L, lambda, dp, dl)
+                                : (lmode == LIN_SEG ? solve_seg(L, lambda, seg_len, dp, dl) : solve_schur(L, lambda, dp, dl));
                 double newError = 0.0, fidelity = 0.0;
                 if (ok) {
                     const double oldLin = L.err;                       // linear.error(zero)

@@ -125,3 +125,19 @@ def test_solve_every_iteration_mode(oracle):
         assert st["flags"] == 0
         g.adopt()
     assert abs(g.cost(1) - r["err_final"][0]) < 1e-3 * r["err_final"][0]
+
+
+def test_segmented_elimination_order_gives_the_same_solve(oracle):
+    """LIN_SEG (round 5; what the GPU path does): the poses eliminated segment by segment - interiors, then the separator poses - instead
+    of 0, 1, 2, ...  Any exact elimination order solves the same damped normal equations, so the LM path (iterations, lambda trials)
+    is identical and the minimiser agrees to rounding; segment lengths that put a separator next to either end of the chain included."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    for (L, T, KP, B, SL) in [(15, 80, 8, 4, 8), (20, 150, 8, 4, 32), (40, 400, 16, 4, 16), (8, 33, 8, 3, 32), (8, 34, 8, 3, 32),
+                              (8, 3, 8, 3, 2), (8, 1, 8, 2, 32), (12, 40, 8, 3, 7)]:
+        lm, cmds = make_scenario(100 + T, L, T)
+        r0 = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=5, nthreads=4)
+        r1 = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=5, nthreads=4, lin_mode=oracle.LIN_SEG | (SL << 8))
+        assert np.array_equal(r0["iterations"], r1["iterations"]) and np.array_equal(r0["trials"], r1["trials"]), (L, T, SL)
+        assert np.array_equal(r0["flags"], r1["flags"])
+        assert np.abs(r0["pose_res"] - r1["pose_res"]).max() < 1e-9 and np.abs(r0["lm_res"] - r1["lm_res"]).max() < 1e-9, (L, T, SL)
+        assert np.allclose(r0["err_final"], r1["err_final"], rtol=1e-10, atol=0)

@@ -38,8 +38,9 @@ def _wpf(monkeypatch, w, L_max=50, dtype=0):
     defaults of every size class / storage type; the others exist in SLAM_SWEEP=1 builds only."""
     if w:
         from live_ekf_slam_amd import _lib
-        if not _lib.lib().slam_variant_available(L_max, dtype, w):
-            pytest.skip(f"kernel variant {w} is only part of SLAM_SWEEP=1 builds")
+        # every variant a test names is part of the release build (build.py EKF_DEFAULT_VARIANTS); the sweep-only ones are
+        # exercised by tools/gpu_variants.py in SLAM_SWEEP=1 builds, not by parametrisations that would skip here (VERDICT r04)
+        assert _lib.lib().slam_variant_available(L_max, dtype, w), f"kernel variant {w} is missing from the build"
         monkeypatch.setenv("SLAM_WAVES_PER_FILTER", str(w))
     else:
         monkeypatch.delenv("SLAM_WAVES_PER_FILTER", raising=False)
@@ -68,10 +69,8 @@ def test_device_math_bit_exact(S, oracle):
 
 
 @pytest.mark.parametrize("fixture,L_max,wpf", [("sim_seed0_L20_T1000.npz", 20, 0), ("sim_seed1_L20_T400.npz", 20, 1124),
-                                               ("sim_seed1_L20_T400.npz", 20, 1148),
-                                               ("sim_seed2_L50_T1000.npz", 50, 1248), ("sim_seed2_L50_T1000.npz", 50, 1444), ("sim_seed2_L50_T1000.npz", 50, 1454), ("sim_seed2_L50_T1000.npz", 50, 1464),
+                                               ("sim_seed2_L50_T1000.npz", 50, 1444), ("sim_seed2_L50_T1000.npz", 50, 1454), ("sim_seed2_L50_T1000.npz", 50, 1464),
                                                ("sim_seed1_L20_T400.npz", 20, 1244),
-                                               ("sim_seed1234_L50_T400.npz", 50, 1424), ("sim_seed0_L20_T1000.npz", 50, 444),
                                                ("sim_seed0_L20_T1000.npz", 90, 0),
                                                ("sim_igvc1_seed5_T200.npz", 37, 0), ("sim_grid_seed5_T200.npz", 25, 0),
                                                ("sim_demo_seed5_T200.npz", 20, 0)])
@@ -100,8 +99,7 @@ def test_update_on_reference_measurement_stream(S, oracle, monkeypatch, fixture,
     f.close()
 
 
-@pytest.mark.parametrize("L,T,B,wpf", [(20, 400, 192, 0), (50, 400, 96, 1842), (50, 400, 96, 0), (50, 400, 96, 1444), (50, 400, 96, 1454), (20, 400, 96, 1124), (20, 300, 64, 1224), (20, 300, 64, 1244),
-                                       (50, 300, 64, 1448)])
+@pytest.mark.parametrize("L,T,B,wpf", [(20, 400, 192, 0), (50, 400, 96, 0), (50, 400, 96, 1444), (50, 400, 96, 1454), (20, 400, 96, 1124), (20, 300, 64, 1244)])
 def test_sim_step_parity(S, oracle, monkeypatch, L, T, B, wpf):
     """Device-side generator + filter in one kernel vs oracle generator + oracle filter, per-instance noise
     streams keyed by global instance id; also the measurements themselves and the error statistic."""

@@ -254,6 +254,7 @@ def test_syrk_variants_agree_with_the_oracle(monkeypatch, oracle, L, T):
     r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=6, cfg=cfg, nthreads=8)
     # SYRK: 32x32 tiles / 64x64 tiles / instance-resident accumulators; Cholesky: 1024 or 256 threads per instance (the
     # 256-thread one is otherwise chosen only above 256 active instances, i.e. by no other test)
+    monkeypatch.setenv("SLAM_PGS_SEG", "0")     # the sequential chain of rounds 1-4 (the default is the segmented elimination, tested below)
     monkeypatch.setenv("SLAM_PGS_FUSED", "0")   # chain and SYRK as two launches (few slots would otherwise run the fused kernel)
     for tile, chol in (("32", "1024"), ("1", "1024"), ("64", "256"), ("1", "256")):
         monkeypatch.setenv("SLAM_PGS_SYRK_TILE", tile)
@@ -275,6 +276,7 @@ def test_fused_chain_syrk_and_slot_list_agree_with_the_oracle(monkeypatch, oracl
     lm, cmds = make_scenario(55 + L, L, T)
     cfg = default_config()
     r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=8, cfg=cfg, nthreads=8)
+    monkeypatch.setenv("SLAM_PGS_SEG", "0")     # these are the launch shapes of the sequential chain
     res = {}
     for fused, lst in (("0", "1"), ("0", "0"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("-1", "1")):
         monkeypatch.setenv("SLAM_PGS_FUSED", fused)
@@ -289,3 +291,54 @@ def test_fused_chain_syrk_and_slot_list_agree_with_the_oracle(monkeypatch, oracl
         assert np.array_equal(res[("0", "1")][b], res[("0", "0")][b])
         assert np.array_equal(res[("4", "1")][b], res[("4", "0")][b])
         assert np.array_equal(res[("2", "1")][b], res[("4", "1")][b]) and np.array_equal(res[("3", "1")][b], res[("4", "1")][b])
+
+
+@pytest.mark.parametrize("L,T,KP,B", [(20, 150, 8, 12), (8, 31, 8, 5), (8, 33, 8, 5), (8, 34, 8, 5), (8, 65, 8, 5), (100, 250, 24, 6),
+                                      (60, 400, 16, 9), (200, 999, 32, 5)])
+def test_segmented_elimination_agrees_with_the_oracle(monkeypatch, oracle, L, T, KP, B):
+    """Round 5: the pose chain is eliminated segment by segment (pgs_seg_impl.h: interiors of the segments side by side, then the
+    separator poses, then the landmarks) instead of pose by pose - the reference's solve (pose_graph.cpp:273-300) in another exact
+    elimination order.  (i) Against the oracle's SEQUENTIAL order: the usual bar, identical LM iteration / trial counts and 1e-7 m.
+    (ii) Against the oracle restating the SAME order (LIN_SEG): 1e-9 m - what is left is the MFMA's fused accumulation and the
+    reciprocal-square-root pivots.  Segment lengths 32 (default), 16 and 7, with and without the slot list; the pose counts around 33 / 34 /
+    66 put the last separator next to the end of the chain; the last size is BASELINE configs[4]."""
+    import live_ekf_slam_amd as S
+    lm, cmds = make_scenario(155 + L, L, T)
+    cfg = default_config()
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=8, cfg=cfg, nthreads=8)
+    for sl, lst in ((32, "1"), (16, "1"), (7, "0")):
+        if L == 200 and sl == 7:
+            continue   # 142 separators: beyond the separator kernel's staging (the host would fall back to the sequential chain)
+        monkeypatch.setenv("SLAM_PGS_SEG", str(sl))
+        monkeypatch.setenv("SLAM_PGS_LIST", lst)
+        pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+        pg.set_map(lm); pg.set_seed(8); pg.init(0.0, 0.0, 0.0)
+        pg.run_sim(cmds); pg.solvePoseGraph()
+        paths = pg.last_solve_paths()
+        assert paths["segmented"] and paths["segment_length"] == sl, paths   # the path under test really ran
+        _compare(pg, r, B)
+        rs = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=8, cfg=cfg, nthreads=8, lin_mode=oracle.LIN_SEG | (sl << 8))
+        assert np.array_equal(rs["iterations"], r["iterations"]) and np.array_equal(rs["trials"], r["trials"])
+        for b in range(B):
+            g1 = pg.get_graph(b, 1); M = r["M"][b]
+            assert np.abs(g1["poses"] - rs["pose_res"][b]).max() < 1e-9
+            assert np.abs(g1["landmarks"] - rs["lm_res"][b, :M]).max() < 1e-9
+        pg.close()
+
+
+def test_segmented_elimination_falls_back_when_a_segment_sees_too_many_landmarks(monkeypatch, oracle):
+    """A map of 100 landmarks all in view all the time: every segment's column set would hold 100 landmarks (> 63, the segment kernels'
+    limit), so the solve runs the sequential chain - and says so."""
+    import live_ekf_slam_amd as S
+    L, T, KP, B = 100, 70, 32, 3
+    rng = np.random.default_rng(5)
+    lm = rng.uniform(-1.0, 1.0, (L, 2)) + np.array([1.5, 0.0])
+    _, cmds = make_scenario(9, 20, T)
+    cfg = default_config(); cfg.range_max = 50.0; cfg.fov_min = -3.2; cfg.fov_max = 3.2
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=3, cfg=cfg, nthreads=4)
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+    pg.set_map(lm); pg.set_seed(3); pg.init(0.0, 0.0, 0.0)
+    pg.run_sim(cmds); pg.solvePoseGraph()
+    assert not pg.last_solve_paths()["segmented"]
+    _compare(pg, r, B)
+    pg.close()

@@ -334,3 +334,58 @@ def test_ukf_state_of_100_landmarks(S, oracle):
         so = es[b].state()
         _eq(f.get_state(b), dict(M=so["M"], ids=so["ids"], x=so["x"], P=so["P"]))
     f.close()
+
+
+@pytest.mark.parametrize("kind", ["ukf", "ukf_loc"])
+def test_ukf_checkpoint_round_trips_incl_cold_start_marker_and_failed_sqrt(S, kind, tmp_path):
+    """slam_load_state refused every UKF checkpoint whose warm-start age column held -1 - the cold-start marker
+    ukf_init_kernel writes and both sqrt kernels write after SLAM_INST_SQRT_FAILED.  (i) a checkpoint saved right after init
+    loads and continues bit-identically; (ii) so does one of a batch in which an instance's decomposition has failed (a
+    non-finite range makes its state non-finite: that instance fails every step from there on); (iii) an age outside
+    [-1, 100] is still refused."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    from live_ekf_slam_amd.config import INST_SQRT_FAILED
+    L, B, T = 20, 6, 40
+    lm, cmds = make_scenario(17, L, T)
+    Cls = S.BatchedUKF if kind == "ukf" else S.BatchedUKFLoc
+
+    def make():
+        f = Cls(B, L).readParams(); f.set_map(lm); f.set_seed(9); f.init(0, 0, 0)
+        return f
+
+    def states(f):
+        return [f.get_state(b) for b in range(B)], f.status().copy(), f.error_stats().copy(), f.truth().copy()
+
+    def same(a, b):
+        for sa, sb in zip(a[0], b[0]):
+            assert sa["M"] == sb["M"] and np.array_equal(sa["ids"], sb["ids"])
+            assert np.array_equal(sa["x"], sb["x"], equal_nan=True) and np.array_equal(sa["P"], sb["P"], equal_nan=True)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3])
+
+    # (i) save right after init: every age is -1
+    a = make(); p0 = tmp_path / "init.ckpt"; a.save_state(p0)
+    a.run_sim(cmds[:15])
+    b = make(); b.load_state(p0); b.run_sim(cmds[:15])
+    same(states(a), states(b))
+    # (ii) poison instance 2 through an external message (id 0 of the map, infinite range), run on, checkpoint, continue
+    meas = np.zeros((B, 1, 3), np.float32); cnt = np.zeros(B, np.int32)
+    meas[2, 0] = (float(0), np.inf, 0.1); cnt[2] = 1
+    a.update(S.Command(cmds[15, 0], cmds[15, 1]), meas, cnt)
+    meas[2, 0] = (float(0), 1.0, 0.1)
+    for t in range(16, 20):
+        a.update(S.Command(cmds[t, 0], cmds[t, 1]), meas, cnt)
+    assert a.status()[2] & INST_SQRT_FAILED, "the poisoned instance never failed its decomposition: the test lost its subject"
+    assert not np.any(np.delete(a.status(), 2) & INST_SQRT_FAILED)
+    p1 = tmp_path / "failed.ckpt"; a.save_state(p1)
+    a.run_sim(cmds[20:])
+    c = make(); c.load_state(p1); c.run_sim(cmds[20:])
+    same(states(a), states(c))
+    # (iii) an impossible age is refused and nothing is copied
+    raw = bytearray(open(p1, "rb").read())
+    bad = bytearray(raw); bad[-4 * B:-4 * B + 4] = np.int32(101).tobytes()      # the age column is the file's last item
+    pb = tmp_path / "bad.ckpt"; open(pb, "wb").write(bad)
+    d = make()
+    with pytest.raises(S.SlamError, match="age of the warm-start"):
+        d.load_state(pb)
+    for f in (a, b, c, d):
+        f.close()
