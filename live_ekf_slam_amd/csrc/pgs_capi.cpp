@@ -151,8 +151,8 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     // clone that pgs_solve fills from the instance; PgsParams::lanes_max).  Arrays only the instance itself uses keep B slots.
     {   // the lanes multiply the LM work space (Y alone is 3 N_max x LD doubles per slot): keep them within half of the free memory
         const double nsegx = h->seg_len > 0 ? (double)((N_max - 2) / h->seg_len + 1) : 0.0;
-        const double per_slot = 8.0 * (((double)round_up(3 * N_max, 4) + 10.0 * nsegx) * h->LD + (double)h->LD * h->LD + (double)K * 17 + (double)N * 51 + (double)L * 12 + nsegx * 48) +
-                                4.0 * ((double)K * 4 + (double)N + (double)L * 6 + nsegx * (3.0 * L + 1));
+        const double per_slot = 8.0 * (((double)round_up(3 * N_max, 4) + 10.0 * nsegx) * h->LD + (double)h->LD * h->LD + (double)K * 29 + (double)N * 51 + (double)L * 12 + nsegx * (48 + 128.0 * 128.0)) +
+                                4.0 * ((double)K * 5 + (double)N + (double)L * 6 + nsegx * (4.0 * L + 16));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             while (h->lanes > 1 && per_slot * (double)B * h->lanes > 0.5 * (double)free_b) h->lanes -= 1;
@@ -174,19 +174,22 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     A(&p.cur, B * 3); A(&p.truth, B * 3); A(&p.truth_hist, B * N * 2);
     AC(&p.pw, N * 3); AC(&p.lw, L * 2); A(&p.pn, S * N * 3); A(&p.ln, S * L * 2);
     A(&p.A, S * N * 9); A(&p.C, S * N * 9); A(&p.gp, S * N * 3); A(&p.E, S * K * 6); A(&p.Wl, S * K * 5);
-    AC(&p.evt_start, L + 1); AC(&p.evt_pose, K); AC(&p.slot_pos, K); A(&p.Elm, S * K * 6);
+    AC(&p.evt_start, L + 1); AC(&p.evt_pose, K); AC(&p.slot_pos, K); AC(&p.evt_slot, K); A(&p.Elm, S * K * 6);
+    A(&p.PF, S * K * 12); A(&p.lin_ok, S); A(&p.fact_cnt, B); A(&p.seg_umax, B);
     A(&p.D, S * L * 3); A(&p.gl, S * L * 2); A(&p.Linv, S * N * 6); A(&p.G, S * N * 9);
     // segmented elimination: the segments' contributions to their separators' right-hand sides and the separators' rows of Y live
     // behind the pose rows of Y (pgs_kernel.h: yr_rc, yr_sep)
     p.seg_len = h->seg_len; p.seg_on = 0; p.syrk_rows = -1; p.syrk_row0 = 0; p.syrk_first = nullptr;
+    p.seg_back_global = getenv("SLAM_PGS_SEG_BACK_GLOBAL") ? atoi(getenv("SLAM_PGS_SEG_BACK_GLOBAL")) : 0;
     p.nseg_max = h->seg_len > 0 ? (N_max - 2) / h->seg_len + 1 : 1;
     p.yr_rc = round_up(3 * N_max, 4);
     p.yr_sep = p.yr_rc + 6 * (int64_t)p.nseg_max;
     p.y_stride = (int64_t)(p.yr_sep + round_up(3 * p.nseg_max, 4)) * h->LD;
     if (h->seg_len > 0) {
         const size_t G = (size_t)p.nseg_max;
-        AC(&p.seg_ncol, G); AC(&p.seg_lm, G * L); AC(&p.seg_inv, G * L); AC(&p.seg_evt, G * L); AC(&p.sep_first, L); A(&p.seg_umax, B);
-        A(&p.Gs, S * N * 9); A(&p.segout, S * G * 32); A(&p.sepfac, S * G * 16);
+        AC(&p.seg_ncol, G); AC(&p.seg_lm, G * L); AC(&p.seg_inv, G * L); AC(&p.seg_evt, G * L); AC(&p.sep_first, L);
+        AC(&p.seg_blk, G * (size_t)slam::seg_nb1(L_max)); AC(&p.sep_evt, G * L);
+        A(&p.Gs, S * N * 9); A(&p.segout, S * G * 32); A(&p.sepfac, S * G * 16); A(&p.segT, S * G * 128 * 128);
     }
     A(&p.Y, S * (size_t)p.y_stride); A(&p.S, S * (size_t)h->LD * h->LD);
     A(&p.dl, S * L * 2); A(&p.dp, S * N * 3);
@@ -388,13 +391,15 @@ int pgs_solve(pgs_handle* h) {
         // see; the path runs when no segment of any instance sees more than kPgsSegMaxLm of them (its columns fit the segment kernels)
         // and the separators fit the separator kernel's staging.  Otherwise - dense visibility on a big map - the sequential chain.
         h->seg_ok = false; h->p.seg_on = 0;
-        const int NS = h->seg_len > 0 && h->p.N >= 2 ? (h->p.N - 2) / h->seg_len : 0;
-        if (h->seg_len > 0 && NS <= slam::kPgsSegMaxSep) {
-            HIP_TRY(slam::pgs_launch_seg_plan(h->p, h->stream));
-            std::vector<int32_t> U((size_t)h->B);
-            HIP_TRY(hipMemcpyAsync(U.data(), h->p.seg_umax, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            int mx = 0;
+        HIP_TRY(slam::pgs_launch_seg_plan(h->p, h->stream));   // (also counts the factors: the grid of the per-factor kernels)
+        std::vector<int32_t> U((size_t)h->B), F((size_t)h->B);
+        if (h->seg_len > 0) HIP_TRY(hipMemcpyAsync(U.data(), h->p.seg_umax, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(F.data(), h->p.fact_cnt, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        int mx = 0, fx = 0;
+        for (int32_t f : F) fx = f > fx ? f : fx;
+        h->p.nfact_max = fx;
+        if (h->seg_len > 0) {
             for (int32_t u : U) mx = u > mx ? u : mx;
             h->seg_ok = mx <= slam::kPgsSegMaxLm;
             h->p.seg_on = h->seg_ok ? 1 : 0;

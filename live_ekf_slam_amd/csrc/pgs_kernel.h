@@ -50,6 +50,14 @@ struct PgsParams {
     int32_t* evt_pose;                 // [B][N_max*KP]   pose index of event e
     int32_t* slot_pos;                 // [B][N_max*KP]   factor slot -> event position
     double* Elm;                       // [B][N_max*KP*6] E blocks in event order
+    int32_t* evt_slot;                 // [B][N_max*KP]   factor slot of event e (the inverse of slot_pos)
+    double* PF;                        // [S][N_max*KP*12] per factor slot: its share of the pose block (Jp^T Jp: 9, -Jp^T e: 3) between
+                                       //                  pgs_lin_factor_kernel and pgs_linearize_kernel; later in the trial its cost terms
+                                       //                  (pgs_eval_factor_kernel -> pgs_evaluate_kernel)
+    int32_t* lin_ok;                   // [S] the slot's linearisation (A, C, g_p, E, D, g_l) belongs to its current values: a trial after a
+                                       //     FAILED one re-uses it, like GTSAM's inner lambda loop (pgs_decide_kernel clears it on an accept)
+    int32_t* fact_cnt;                 // [B] factors of the instance (pgs_seg_plan_kernel), nfact_max: the largest (grid of the per-factor kernels)
+    int32_t nfact_max;
     double* D; double* gl;             // [B][L_max*3], [B][L_max*2]
     double* Linv; double* G;           // [B][N_max*6], [B][N_max*9]
     double* Y;                         // [B][Yrows][LD]
@@ -88,10 +96,15 @@ struct PgsParams {
     // NS separators as a short chain, then the landmarks: depth SL + NS instead of N, and a row of Y only has the columns of the
     // landmarks its own segment sees.  seg_on: this solve runs that order (the host's choice, from the plan below).
     int32_t seg_len, seg_on, nseg_max; // nseg_max: segments the arrays are sized for
+    int32_t seg_back_global;           // 1: the pose step's chains read their factor from global memory (test switch; graphs beyond 1365 poses always do)
     int32_t* seg_ncol;                 // [S][nseg_max]          landmarks seen from the segment's interior poses (its columns: 2 ncol + 1)
     int32_t* seg_lm;                   // [S][nseg_max * L_max]  local landmark -> landmark, ascending
     int32_t* seg_inv;                  // [S][nseg_max * L_max]  landmark -> local landmark of the segment, -1: not seen there
     int32_t* seg_evt;                  // [S][nseg_max * L_max]  local landmark -> its first event (evt_* order) at or after the segment's first pose
+    int32_t* seg_blk;                  // [S][nseg_max * nb1]    local landmarks of the segment below landmark 16 * block (nb1 = seg_nb1(L_max) entries):
+                                       //                        the local range of a 32-row block of S_ext without a search
+    int32_t* sep_evt;                  // [S][nseg_max * L_max]  separator k, landmark j -> the landmark's first event AT the separator's pose, -1: none
+    double* segT;                      // [S][nseg_max * 128 * 128]  Gram matrix Y_p^T Y_p of the segment's columns (lower 16x16 tiles), leading dimension 128
     int32_t* sep_first;                // [S][L_max]             first separator (0-based) whose row of Y can be non-zero in the landmark's columns
     int32_t* seg_umax;                 // [B]                    largest seg_ncol of the instance (the host picks the path from it)
     double* Gs;                        // [S][N_max * 9]         spike blocks: coupling of interior pose i to its segment's LEFT separator
@@ -111,6 +124,8 @@ struct PgsParams {
 __host__ __device__ inline int seg_ns(int N, int SL) { return N >= 2 ? (N - 2) / SL : 0; }
 __host__ __device__ inline int seg_lo(int ps, int SL) { return ps == 0 ? 0 : ps * SL + 1; }
 __host__ __device__ inline int seg_hi(int ps, int SL, int NS, int N) { return ps < NS ? (ps + 1) * SL : N; }
+__host__ __device__ inline int seg_nb1(int L_max) { return 4 * ((L_max + 63) / 64) + 2; }   // entries of a segment's seg_blk row (the block of
+                                                                                               // the right-hand-side row, landmark index M <= L_max, has an end too)
 
 hipError_t pgs_launch_init(const PgsParams& p, float x0, float y0, float yaw0, hipStream_t s);
 // append one timestep: BetweenFactor is implied by cmds[t]; meas [B][k_stride][3], count [B] (device); sec_pose [B][3]

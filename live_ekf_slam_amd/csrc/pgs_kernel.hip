@@ -301,7 +301,8 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
         if (tid < M) {
             int pos = s_cnt[tid];
             evt_start[tid] = pos;
-            for (int k = head[tid]; k >= 0; k = mnext[k]) { evt_pose[pos] = k / p.KP; slot_pos[k] = pos; ++pos; }
+            int32_t* evt_slot = p.evt_slot + (size_t)b * p.N_max * p.KP;
+            for (int k = head[tid]; k >= 0; k = mnext[k]) { evt_pose[pos] = k / p.KP; evt_slot[pos] = k; slot_pos[k] = pos; ++pos; }
         }
     }
     __syncthreads();
@@ -322,6 +323,21 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
                 if (evt_pose[mid] < lo) e0 = mid + 1; else e1 = mid;
             }
             sevt[idx] = e0;
+        }
+        int32_t* spe = p.sep_evt + (size_t)b * p.nseg_max * p.L_max;   // the landmark's event AT a separator's pose
+        for (int idx = tid; idx < NS * p.L_max; idx += TPB) {
+            const int k = idx / p.L_max, j = idx - k * p.L_max, sp = (k + 1) * SL;
+            int found = -1;
+            if (j < M) {
+                int e0 = evt_start[j], e1 = evt_start[j + 1];
+                const int eend = e1;
+                while (e0 < e1) {
+                    const int mid = (e0 + e1) >> 1;
+                    if (evt_pose[mid] < sp) e0 = mid + 1; else e1 = mid;
+                }
+                if (e0 < eend && evt_pose[e0] == sp) found = e0;
+            }
+            spe[idx] = found;
         }
     }
     {   // algorithmic FLOP of one Schur-complement SYRK of this instance: 2 per stored lower-triangle element of S_ext and per row of Y
@@ -355,6 +371,7 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
         p.lambda[b] = 1e-5;                    // LevenbergMarquardtParams::lambdaInitial
         p.iters[b] = 0; p.trials[b] = 0; p.state[b] = 0; p.solve_ok[b] = 1; p.nl[b] = 1;
         p.alist[blockIdx.x] = b;               // first trial: every instance of the group, one lane
+        for (int j = 0; j < p.lanes_max; ++j) p.lin_ok[(size_t)j * p.B + b] = 0;   // (the clones copy nothing of this: plain per-slot state)
         p.flags[b] &= ~(PGS_FLAG_NOT_CONVERGED | PGS_FLAG_NONFINITE);
     }
 }
@@ -373,21 +390,69 @@ __device__ __forceinline__ void add_JtJ(double A[9], const double* J) {
         }
 }
 
+// Linearisation, part 1: one thread per FACTOR (event e of the (landmark, time) list: pose evt_pose[e], slot evt_slot[e]).  The
+// bearing-range factors are where the time goes (two sincos, an atan2, a square root and eight divisions each, seven of them per pose
+// at BASELINE configs[4]); a thread per pose walked its factors one after the other, each behind two dependent loads.  Every factor
+// leaves its blocks E (slot order and event order), the landmark terms Wl, and its SHARE of the pose block in PF; part 2 adds the shares
+// in slot order, so every sum has the terms and the order it always had (bit-identical to the one-kernel version).
+constexpr int LF_TPB = 256;
+__global__ __launch_bounds__(LF_TPB) void pgs_lin_factor_kernel(const PgsParams p) {
+    const int nfb = (p.nfact_max + LF_TPB - 1) / LF_TPB;
+    const int bl = blockIdx.x / nfb, fb = blockIdx.x - bl * nfb;
+    const int b = pgs_slot(p, bl);
+    if (p.state[b] || p.lin_ok[b]) return;
+    const int e = fb * LF_TPB + threadIdx.x;
+    const int M = p.M[b], KP = p.KP;
+    if (e >= p.evt_start[(size_t)b * (p.L_max + 1) + M]) return;
+    const Inst g = inst_view(p, b);
+    const int i = p.evt_pose[(size_t)b * p.N_max * KP + e];
+    const size_t k = (size_t)p.evt_slot[(size_t)b * p.N_max * KP + e];
+    const double* pose = p.pw + (size_t)b * p.N_max * 3;
+    const double* lm = p.lw + (size_t)b * p.L_max * 2;
+    const int j = g.mlm[k] & (kPgsFirstBit - 1);
+    double e2[2], Jp[6], Jl[4];
+    bearing_range_factor<true>(p, pose + 3 * i, lm + 2 * j, g.mb[k], g.mr[k], e2, Jp, Jl);
+    double* PF = p.PF + ((size_t)b * p.N_max * KP + k) * 12;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {   // add_JtJ<2>'s term
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) v += Jp[3 * r + a] * Jp[3 * r + c];
+            PF[3 * a + c] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) PF[9 + a] = -(Jp[a] * e2[0] + Jp[3 + a] * e2[1]);
+    double* E = p.E + ((size_t)b * p.N_max * KP + k) * 6;
+    double* El = p.Elm + ((size_t)b * p.N_max * KP + e) * 6;   // the same block in (landmark, time) order for the chain / segment kernels
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { const double v = Jp[a] * Jl[c] + Jp[3 + a] * Jl[2 + c]; E[2 * a + c] = v; El[2 * a + c] = v; }
+    double* W = p.Wl + ((size_t)b * p.N_max * KP + e) * 5;   // in (landmark, time) order: the landmark sum of part 2 reads contiguously
+    W[0] = Jl[0] * Jl[0] + Jl[2] * Jl[2];
+    W[1] = Jl[0] * Jl[1] + Jl[2] * Jl[3];
+    W[2] = Jl[1] * Jl[1] + Jl[3] * Jl[3];
+    W[3] = -(Jl[0] * e2[0] + Jl[2] * e2[1]);
+    W[4] = -(Jl[1] * e2[0] + Jl[3] * e2[1]);
+}
+
+// Linearisation, part 2: per pose the prior / between factors and the sum of its factors' shares (slot order); per landmark the sum of
+// its factors' terms (chronological order).
 __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
     const int N = p.N, KP = p.KP, M = p.M[b];
     if (p.seg_on && tid == 0) p.solve_ok[b] = 1;   // segmented elimination: a failing segment / separator clears it (the sequential chain kernel sets it itself)
+    if (p.lin_ok[b]) return;                       // the previous trial of this slot failed: same values, same linearisation
     const Inst g = inst_view(p, b);
     const double* pose = p.pw + (size_t)b * p.N_max * 3;
-    const double* lm = p.lw + (size_t)b * p.L_max * 2;
     double* Ab = p.A + (size_t)b * p.N_max * 9;
     double* Cb = p.C + (size_t)b * p.N_max * 9;
     double* gpb = p.gp + (size_t)b * p.N_max * 3;
-    double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
+    const double* PFb = p.PF + (size_t)b * p.N_max * KP * 12;
     double* Wlb = p.Wl + (size_t)b * p.N_max * KP * 5;
-    double* Elmb = p.Elm + (size_t)b * p.N_max * KP * 6;
-    const int32_t* slot_pos = p.slot_pos + (size_t)b * p.N_max * KP;
     for (int i = tid; i < N; i += TPB) {
         double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0}, e[3], J1[9];
         if (i == 0) {
@@ -412,35 +477,35 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
             for (int a = 0; a < 3; ++a) gg[a] += -(J1[a] * e[0] + J1[3 + a] * e[1] + J1[6 + a] * e[2]);
         }
         const int kc = g.cnt[i];
-        for (int s = 0; s < kc; ++s) {
-            const size_t k = (size_t)i * KP + s;
-            const int j = g.mlm[k] & (kPgsFirstBit - 1);
-            double e2[2], Jp[6], Jl[4];
-            bearing_range_factor<true>(p, pose + 3 * i, lm + 2 * j, g.mb[k], g.mr[k], e2, Jp, Jl);
-            add_JtJ<2>(A, Jp);
+        const double* PF = PFb + (size_t)i * KP * 12;
+        constexpr int UB = 4;   // the shares are fetched four factors at a time, the additions stay in slot order
+        int s = 0;
+#pragma unroll 1
+        for (; s + UB <= kc; s += UB) {
+            double w[UB][12];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) gg[a] += -(Jp[a] * e2[0] + Jp[3 + a] * e2[1]);
-            double* E = Eb + 6 * k;
+            for (int u = 0; u < UB; ++u)
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 12; ++c) w[u][c] = PF[12 * (size_t)(s + u) + c];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) E[2 * a + c] = Jp[a] * Jl[c] + Jp[3 + a] * Jl[2 + c];
-            double* El = Elmb + 6 * (size_t)slot_pos[k];   // the same block in (landmark, time) order for the chain kernel
+            for (int u = 0; u < UB; ++u) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a) El[a] = E[a];
-            double* W = Wlb + 5 * (size_t)slot_pos[k];   // in (landmark, time) order: the landmark sum below reads contiguously
-            W[0] = Jl[0] * Jl[0] + Jl[2] * Jl[2];
-            W[1] = Jl[0] * Jl[1] + Jl[2] * Jl[3];
-            W[2] = Jl[1] * Jl[1] + Jl[3] * Jl[3];
-            W[3] = -(Jl[0] * e2[0] + Jl[2] * e2[1]);
-            W[4] = -(Jl[1] * e2[0] + Jl[3] * e2[1]);
+                for (int c = 0; c < 9; ++c) A[c] += w[u][c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gg[c] += w[u][9 + c];
+            }
+        }
+        for (; s < kc; ++s) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) A[c] += PF[12 * (size_t)s + c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gg[c] += PF[12 * (size_t)s + 9 + c];
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) Ab[9 * i + k] = A[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) gpb[3 * i + k] = gg[k];
     }
-    __syncthreads();   // Wl of every factor is visible to the block
     const int32_t* evt_start = p.evt_start + (size_t)b * (p.L_max + 1);
     double* Db = p.D + (size_t)b * p.L_max * 3;
     double* glb = p.gl + (size_t)b * p.L_max * 2;
@@ -449,8 +514,7 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
         const int e1 = evt_start[j + 1];
         int e = evt_start[j];
         // The additions stay in chronological order (the oracle's order), the LOADS do not have to wait for them: the
-        // records of a landmark are contiguous, so eight events are fetched at once.  One event per iteration meant one
-        // global round trip per event, serially, for the most observed landmark (the ISA had vmcnt(0) in every iteration).
+        // records of a landmark are contiguous, so eight events are fetched at once.
         constexpr int UB = 8;
 #pragma unroll 1
         for (; e + UB <= e1; e += UB) {
@@ -469,6 +533,7 @@ __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
         Db[3 * j] = d0; Db[3 * j + 1] = d1; Db[3 * j + 2] = d2;
         glb[2 * j] = g0; glb[2 * j + 1] = g1;
     }
+    if (tid == 0) p.lin_ok[b] = 1;
 }
 
 // Block-tridiagonal Cholesky of H_pp + lambda I fused with the forward recurrence over the landmark columns.
@@ -737,15 +802,121 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int r = rowbase + 16 * i + kq + 4 * r4;   // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg
                 const int c = colbase + 16 * j + cl;
-                if (r > m2 || c > r) continue;
                 double v = -acc[i][j][r4];
                 if (r < m2) {
                     if (c == r) v += Db[3 * (r >> 1) + ((r & 1) ? 2 : 0)] + lambda;
-                    else if ((c >> 1) == (r >> 1)) v += Db[3 * (r >> 1) + 1];
-                } else if (c < m2) {
+                    else if ((c >> 1) == (r >> 1) && c < r) v += Db[3 * (r >> 1) + 1];
+                } else if (r == m2 && c < m2) {
                     v += glb[c];
                 }
-                Sb[(size_t)r * LD + c] = v;
+                acc[i][j][r4] = v;
+            }
+    if constexpr (WT == 32) {
+        if (p.seg_on) {
+            // Segmented elimination: this launch covered the separators' rows of Y; the interior rows' products arrive as the segments'
+            // Gram matrices T_p (pgs_seg_gram_kernel) and are subtracted here, segment after segment - a fixed order per element.  A
+            // segment touches this wavefront's 32 x 32 tile only if it sees a landmark of the tile's row block AND one of its column block
+            // (seg_blk: the local ranges of the 16-landmark blocks): a handful of the segments for a tile near the diagonal, none far from
+            // it; the right-hand-side row (the gradient column of every segment) meets them all.
+            const int nb1 = seg_nb1(p.L_max), nseg = seg_ns(p.N, p.seg_len) + 1;
+            const int32_t* blk = p.seg_blk + (size_t)b * p.nseg_max * nb1;
+            const int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * p.L_max;
+            const int32_t* ncolb = p.seg_ncol + (size_t)b * p.nseg_max;
+            const double* Tb = p.segT + (size_t)b * p.nseg_max * (128 * 128);
+            const int rb = rowbase >> 5, cb = colbase >> 5;
+            const bool has_rhs = m2 >= rowbase && m2 < rowbase + WT;
+            if (has_rhs) {   // wave-uniform
+                // The right-hand-side row meets EVERY segment (its gradient column); one segment at a time that was 32 dependent
+                // round trips for the tiles of the last row block.  Lane l takes column colbase + l of the row: the index loads of eight
+                // segments go out together, then the eight T entries, then the subtractions in segment order.
+                __shared__ double s_rhs[4][WT];
+                double* rh = s_rhs[w];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            if (rowbase + 16 * i + kq + 4 * r4 == m2) rh[16 * j + cl] = acc[i][j][r4];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const int c = colbase + lane;
+                if (lane < WT && c < m2) {
+                    const int jl = c >> 1, d = c & 1;
+                    double v = rh[lane];
+                    constexpr int SB = 8;
+#pragma unroll 1
+                    for (int ps0 = 0; ps0 < nseg; ps0 += SB) {
+                        int q[SB], nl[SB];
+#pragma unroll
+                        for (int u = 0; u < SB; ++u) {
+                            const int ps = ps0 + u < nseg ? ps0 + u : nseg - 1;
+                            q[u] = ps0 + u < nseg ? sinv[(size_t)ps * p.L_max + jl] : -1;
+                            nl[u] = ncolb[ps];
+                        }
+                        double t[SB];
+#pragma unroll
+                        for (int u = 0; u < SB; ++u) {
+                            const int ps = ps0 + u < nseg ? ps0 + u : nseg - 1;
+                            t[u] = q[u] >= 0 ? Tb[(size_t)ps * (128 * 128) + (size_t)(2 * nl[u]) * 128 + 2 * q[u] + d] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < SB; ++u)
+                            if (q[u] >= 0) v = v - t[u];
+                    }
+                    rh[lane] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            if (rowbase + 16 * i + kq + 4 * r4 == m2 && colbase + 16 * j + cl < m2) acc[i][j][r4] = rh[16 * j + cl];
+            }
+#pragma unroll 1
+            for (int ps = 0; ps < nseg; ++ps) {
+                const int32_t* bk = blk + (size_t)ps * nb1;
+                if (!(bk[rb + 1] > bk[rb] && bk[cb + 1] > bk[cb])) continue;   // wave-uniform
+                const int32_t* iv = sinv + (size_t)ps * p.L_max;
+                int lr[NI][4], lc[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int r = rowbase + 16 * i + kq + 4 * r4;
+                        int l = -1;
+                        if (r < m2) { const int q = iv[r >> 1]; l = q >= 0 ? 2 * q + (r & 1) : -1; }
+                        lr[i][r4] = l;
+                    }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int c = colbase + 16 * j + cl;
+                    int l = -1;
+                    if (c < m2) { const int q = iv[c >> 1]; l = q >= 0 ? 2 * q + (c & 1) : -1; }
+                    lc[j] = l;
+                }
+                const double* Tp = Tb + (size_t)ps * (128 * 128);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            if (lr[i][r4] >= 0 && lc[j] >= 0 && lc[j] <= lr[i][r4]) acc[i][j][r4] = acc[i][j][r4] - Tp[(size_t)lr[i][r4] * 128 + lc[j]];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = rowbase + 16 * i + kq + 4 * r4;
+                const int c = colbase + 16 * j + cl;
+                if (r > m2 || c > r) continue;
+                Sb[(size_t)r * LD + c] = acc[i][j][r4];
             }
 }
 
@@ -1531,6 +1702,11 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         for (int q = 0; q < TPW; ++q) { const int t = (w - 1) + NTW * q; if (t < nt0) accn[q] = tile_init(0, t); }
     }
     __syncthreads();
+    double dg[NB];   // wavefront 0: row (lane & 15) of the diagonal block being factored
+    auto dgl_rd = [](double v, int l) -> double {   // v of lane l as a wave-uniform value (two v_readlane_b32)
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+        return __hiloint2double(hi, lo);
+    };
     for (int j0 = 0; j0 < m2; j0 += NB) {
         const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
         const int R = m2 + 1 - j0;                 // rows of the panel: the block rows, the rows below, the rhs row
@@ -1565,30 +1741,36 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         const int ntn = has_next ? (m2 + 1 - jn + 15) >> 4 : 0;
         int ldb = (j0 + 3) & ~3;                   // row length of the staged block rows: a multiple of 4 with an odd quotient (bank spread)
         if (((ldb >> 2) & 1) == 0) ldb += 4;
-        auto diag_cols = [&](int c_lo, int c_hi) {   // wavefront 0, wave-synchronous: lane = (row r, column group g: columns g, g+4, g+8, g+12)
-            const int r = lane & 15, g = lane >> 4;
-            for (int c = c_lo; c < c_hi && c < nb; ++c) {
-                const double d = SD(c, c);
+        // The diagonal block in wavefront 0's REGISTERS (round 5): lane r (mod 16; the four lane groups hold replicas) keeps row r, the
+        // pivot and the column entries l(c2, c) another row needs arrive by v_readlane.  Through LDS - lane = (row, column group), two
+        // fenced round trips per column - a column cost ~1 300 cycles, 8.6 us per block, 190 of the 400 us of a factorisation.  Per
+        // element the same sqrt, the same division and the same  a - l * l  in the same order: the factor is bit-identical.
+        auto diag_cols = [&](auto lo_tag, auto hi_tag) {
+            constexpr int c_lo = decltype(lo_tag)::value, c_hi = decltype(hi_tag)::value;
+            const int r = lane & 15;
+#pragma unroll
+            for (int c = c_lo; c < c_hi; ++c) {
+                if (c >= nb) break;   // wave-uniform
+                const double d = dgl_rd(dg[c], c);   // the pivot: entry c of row c
                 const double sd = sqrt(d > 0.0 ? d : 1.0);
-                if (r == c && g == (c & 3)) {
+                if (lane == c) {
                     if (!(d > 0.0)) s_fail = 1;
                     s_diag[c] = sd; s_rdiag[c] = 1.0 / sd;
                 }
-                if (g == (c & 3) && r > c && r < nb) SD(r, c) = SD(r, c) / sd;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const double lrc = SD(r, c);
+                const double lrc = dg[c] / sd;      // meaningful in the rows below c
+                if (r > c) dg[c] = lrc;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c2 = g + 4 * i;
-                    if (r > c && c2 > c && c2 <= r && r < nb) SD(r, c2) = SD(r, c2) - lrc * SD(c2, c);
+                for (int c2 = c + 1; c2 < NB; ++c2) {
+                    const double l2 = dgl_rd(dg[c], c2);   // l(c2, c), from row c2
+                    if (r >= c2) dg[c2] = dg[c2] - lrc * l2;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
         };
         if (w == 0) {
-            diag_cols(0, 8);
+            const int r = lane & 15;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) dg[c] = (r < nb && c <= r) ? SD(r, c) : 0.0;
+            diag_cols(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
         } else if (has_next) {
             for (int e = tid - 64; e < 16 * j0; e += CTPB - 64) {
                 const int r = e / j0, k = e - r * j0;
@@ -1600,13 +1782,16 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         }
         __syncthreads();
         if (w == 0) {
-            diag_cols(8, 16);
-            if (lane < nb) SD(lane, lane) = s_diag[lane];
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int e = lane; e < NB * NB; e += 64) {   // the factored block goes to memory
-                const int r = e >> NBL, c = e & (NB - 1);
-                if (r < nb && c <= r) Sb[(size_t)(j0 + r) * LD + j0 + c] = SD(r, c);
+            diag_cols(std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // s_diag of every column is written
+            if (lane < NB && lane < nb) {   // row `lane` of the factored block: to LDS for the panel solve, to memory as L
+                const int r = lane;
+                double* grow = Sb + (size_t)(j0 + r) * LD + j0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const double v = c == r ? s_diag[c] : dg[c];
+                    if (c <= r) { SD(r, c) = v; grow[c] = v; }
+                }
             }
         } else if (has_next) {
 #pragma unroll
@@ -1862,8 +2047,53 @@ __global__ __launch_bounds__(BTPB) void pgs_backsolve_kernel(const PgsParams p) 
     if (tid < 64) affine_scan_wave<true>(Wb, dpb, N, tid);       // dp
 }
 
-// linearised cost of the step, retraction, true cost of the candidate, then GTSAM's tryLambda / iterate /
-// defaultOptimize decisions for this instance (LevenbergMarquardtOptimizer.cpp, NonlinearOptimizer.cpp).
+// p * Pose2(v): the retraction of one pose (the same expressions wherever a candidate pose is formed)
+__device__ __forceinline__ void retract_pose(const double* ps, const double* d, double out[3]) {
+    double s, c;
+    det_sincos(ps[2], &s, &c);
+    out[0] = ps[0] + (c * d[0] - s * d[1]);
+    out[1] = ps[1] + (s * d[0] + c * d[1]);
+    out[2] = remainder(ps[2] + d[2], kTwoPi);
+}
+
+// Evaluation, part 1: one thread per FACTOR (see pgs_lin_factor_kernel) - its two terms of the linearised cost 0.5 |J delta + e|^2 at the
+// current values and its term of the true cost at the candidate (the factor forms the candidate pose / landmark itself, with the
+// expressions part 2 stores them with).  PF[slot] = {0.5 v_0^2, 0.5 v_1^2, 0.5 |e(candidate)|^2}; part 2 adds them where the one-kernel
+// version added them (bit-identical sums).
+__global__ __launch_bounds__(LF_TPB) void pgs_eval_factor_kernel(const PgsParams p) {
+    const int nfb = (p.nfact_max + LF_TPB - 1) / LF_TPB;
+    const int bl = blockIdx.x / nfb, fb = blockIdx.x - bl * nfb;
+    const int b = pgs_slot(p, bl);
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int e = fb * LF_TPB + threadIdx.x;
+    const int M = p.M[b], KP = p.KP;
+    if (e >= p.evt_start[(size_t)b * (p.L_max + 1) + M]) return;
+    const Inst g = inst_view(p, b);
+    const int i = p.evt_pose[(size_t)b * p.N_max * KP + e];
+    const size_t k = (size_t)p.evt_slot[(size_t)b * p.N_max * KP + e];
+    const double* pose = p.pw + (size_t)b * p.N_max * 3 + 3 * i;
+    const double* dp = p.dp + (size_t)b * p.N_max * 3 + 3 * i;
+    const int j = g.mlm[k] & (kPgsFirstBit - 1);
+    const double* lm = p.lw + (size_t)b * p.L_max * 2 + 2 * j;
+    const double* dl = p.dl + (size_t)b * p.L_max * 2 + 2 * j;
+    const double bb = g.mb[k], rr = g.mr[k];
+    double e2[2], Jp[6], Jl[4];
+    bearing_range_factor<true>(p, pose, lm, bb, rr, e2, Jp, Jl);
+    double* PF = p.PF + ((size_t)b * p.N_max * KP + k) * 12;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double v = (e2[r] + ((Jp[3 * r] * dp[0] + Jp[3 * r + 1] * dp[1]) + Jp[3 * r + 2] * dp[2])) + (Jl[2 * r] * dl[0] + Jl[2 * r + 1] * dl[1]);
+        PF[r] = 0.5 * v * v;
+    }
+    double pn[3], ln[2], en[2];
+    retract_pose(pose, dp, pn);
+    ln[0] = lm[0] + dl[0]; ln[1] = lm[1] + dl[1];
+    bearing_range_factor<false>(p, pn, ln, bb, rr, en, nullptr, nullptr);
+    PF[2] = 0.5 * (en[0] * en[0] + en[1] * en[1]);
+}
+
+// linearised cost of the step, retraction, true cost of the candidate (part 2: the prior / between factors and the sums); GTSAM's
+// tryLambda / iterate / defaultOptimize decisions follow in pgs_decide_kernel (LevenbergMarquardtOptimizer.cpp, NonlinearOptimizer.cpp).
 __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
@@ -1876,6 +2106,7 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
     double* lm_n = p.ln + (size_t)b * p.L_max * 2;
     const double* dp = p.dp + (size_t)b * p.N_max * 3;
     const double* dl = p.dl + (size_t)b * p.L_max * 2;
+    const double* PFb = p.PF + (size_t)b * p.N_max * KP * 12;
     const bool ok = p.solve_ok[b] != 0;
     double newLin = 0.0, newError = 0.0;
     if (ok) {
@@ -1896,28 +2127,52 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
                 }
             }
             const int kc = g.cnt[i];
-            for (int s = 0; s < kc; ++s) {
-                const size_t k = (size_t)i * KP + s;
-                const int j = g.mlm[k] & (kPgsFirstBit - 1);
-                double e2[2], Jp[6], Jl[4];
-                bearing_range_factor<true>(p, pose + 3 * i, lm + 2 * j, g.mb[k], g.mr[k], e2, Jp, Jl);
+            const double* PF = PFb + (size_t)i * KP * 12;
+            constexpr int UB = 8;   // the factors' terms (pgs_eval_factor_kernel) are fetched eight factors at a time, added in slot order
+            int s = 0;
+#pragma unroll 1
+            for (; s + UB <= kc; s += UB) {
+                double w[UB][2];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const double v = (e2[r] + ((Jp[3 * r] * dp[3 * i] + Jp[3 * r + 1] * dp[3 * i + 1]) + Jp[3 * r + 2] * dp[3 * i + 2])) + (Jl[2 * r] * dl[2 * j] + Jl[2 * r + 1] * dl[2 * j + 1]);
-                    acc = acc + 0.5 * v * v;
-                }
+                for (int u = 0; u < UB; ++u) { w[u][0] = PF[12 * (size_t)(s + u)]; w[u][1] = PF[12 * (size_t)(s + u) + 1]; }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { acc = acc + w[u][0]; acc = acc + w[u][1]; }
             }
-            // retract: p * Pose2(v)
-            double s, c;
-            det_sincos(pose[3 * i + 2], &s, &c);
-            pose_n[3 * i] = pose[3 * i] + (c * dp[3 * i] - s * dp[3 * i + 1]);
-            pose_n[3 * i + 1] = pose[3 * i + 1] + (s * dp[3 * i] + c * dp[3 * i + 1]);
-            pose_n[3 * i + 2] = remainder(pose[3 * i + 2] + dp[3 * i + 2], kTwoPi);
+            for (; s < kc; ++s) { acc = acc + PF[12 * (size_t)s]; acc = acc + PF[12 * (size_t)s + 1]; }
+            double pn[3];
+            retract_pose(pose + 3 * i, dp + 3 * i, pn);
+            pose_n[3 * i] = pn[0]; pose_n[3 * i + 1] = pn[1]; pose_n[3 * i + 2] = pn[2];
         }
         for (int a = tid; a < 2 * M; a += TPB) lm_n[a] = lm[a] + dl[a];
         newLin = block_sum<TPB>(acc, s_buf);
         __syncthreads();   // candidate values are visible to the block
-        newError = block_cost<TPB>(p, b, pose_n, lm_n, s_buf);
+        double acc2 = 0.0;   // the true cost of the candidate: block_cost with the factors' terms taken from PF
+        for (int i = tid; i < N; i += TPB) {
+            double e[3], pc = 0.0;   // pose_cost's own accumulator: the pose's terms are summed first, then added to the thread's
+            if (i == 0) {
+                prior_factor(p, pose_n, e);
+                pc = pc + 0.5 * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+            }
+            if (i + 1 < N) {
+                between_factor<false>(p, pose_n + 3 * i, pose_n + 3 * (i + 1), p.cmds[2 * i], p.cmds[2 * i + 1], e, nullptr);
+                pc = pc + 0.5 * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+            }
+            const int kc = g.cnt[i];
+            const double* PF = PFb + (size_t)i * KP * 12 + 2;
+            constexpr int UB = 8;
+            int s = 0;
+#pragma unroll 1
+            for (; s + UB <= kc; s += UB) {
+                double w[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) w[u] = PF[12 * (size_t)(s + u)];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) pc = pc + w[u];
+            }
+            for (; s < kc; ++s) pc = pc + PF[12 * (size_t)s];
+            acc2 = acc2 + pc;
+        }
+        newError = block_sum<TPB>(acc2, s_buf);
     }
     if (tid == 0) {   // the decision is pgs_decide_kernel's: it needs the slots of an instance in lambda order
         p.nok[b] = ok ? 1 : 0; p.nlin[b] = newLin; p.nerr[b] = newError;
@@ -1925,11 +2180,6 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
     }
 }
 
-// GTSAM's tryLambda bookkeeping (LevenbergMarquardtOptimizer::tryLambda / iterate, default parameters) for one instance, replayed
-// over the `nl[b]` slots it ran in this trial in the order the sequential loop would have visited their lambdas: slot j holds the
-// trial at lambda * 10^j (repeated multiplication, as the loop computes it).  A success, a `stop`, or lambda reaching its upper
-// bound ends the inner loop and discards the later slots (they are trials the sequential loop never runs); if every slot failed
-// the streak goes on.  Iteration and trial counts are the sequential loop's.
 __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
     __shared__ int s_win, s_next;
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
@@ -2004,6 +2254,7 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
     double* pose = p.pw + (size_t)b * p.N_max * 3;
     double* lm = p.lw + (size_t)b * p.L_max * 2;
     if (s_win >= 0) {   // accept the winning slot's candidate
+        if (tid < p.lanes_max) p.lin_ok[(size_t)tid * B + b] = 0;   // the values change: every slot of the instance linearises anew
         const int sl = s_win * B + b;
         const double* pose_n = p.pn + (size_t)sl * p.N_max * 3;
         const double* lm_n = p.ln + (size_t)sl * p.L_max * 2;
@@ -2094,7 +2345,10 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     const int nslot = pgs_nslot(p);   // slots covered: the instances of the group and their active lambda lanes, or the compacted list
     if (nslot <= 0) return hipSuccess;
     switch (which) {
-    case 0: hipLaunchKernelGGL(pgs_linearize_kernel, dim3(nslot), dim3(TPB), 0, s, p); break;
+    case 0:
+        if (p.nfact_max > 0) hipLaunchKernelGGL(pgs_lin_factor_kernel, dim3(nslot * ((p.nfact_max + LF_TPB - 1) / LF_TPB)), dim3(LF_TPB), 0, s, p);
+        hipLaunchKernelGGL(pgs_linearize_kernel, dim3(nslot), dim3(TPB), 0, s, p);
+        break;
     case 1: {
         if (p.seg_on) {   // segmented elimination: the interiors of all segments side by side, then the separator chain
             const int nseg = seg_ns(p.N, p.seg_len) + 1;
@@ -2117,13 +2371,12 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
         break;
     }
     case 2: {
-        if (p.seg_on) {   // [D + lambda I; g_l^T] - Ysep^T Ysep by the tile kernel on the separators' rows, then the segments' Gram matrices in order
+        if (p.seg_on) {   // the segments' Gram matrices side by side, then [D + lambda I; g_l^T] - Ysep^T Ysep - sum_p T_p by the tile kernel (its epilogue)
             PgsParams q = p;
             q.syrk_row0 = p.yr_sep; q.syrk_rows = 3 * seg_ns(p.N, p.seg_len); q.syrk_first = p.sep_first;
             const int nt = (p.LD + 63) / 64;
+            hipLaunchKernelGGL(pgs_seg_gram_kernel, dim3(nslot * (seg_ns(p.N, p.seg_len) + 1)), dim3(GR_TPB), 0, s, p);
             hipLaunchKernelGGL(pgs_syrk_kernel<32>, dim3(8 * (nt * (nt + 1) / 2) * ((nslot + 7) / 8)), dim3(256), 0, s, q);
-            if (const hipError_t e = slam_allow_full_lds((const void*)pgs_seg_syrk_kernel); e != hipSuccess) return e;
-            hipLaunchKernelGGL(pgs_seg_syrk_kernel, dim3(nslot), dim3(SS_TPB), sizeof(double) * SS_ROWS * SS_LDL, s, p);
             break;
         }
         if (p.fused) break;   // done by the chain launch
@@ -2158,10 +2411,14 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
         break;
     }
     case 4:
-        if (p.seg_on) hipLaunchKernelGGL(pgs_seg_backsolve_kernel, dim3(nslot), dim3(SB_TPB), 0, s, p);
+        if (p.seg_on && p.N <= kSegBackLdsPoses && !p.seg_back_global) {   // the chains out of LDS (12 doubles per pose)
+            if (const hipError_t e = slam_allow_full_lds((const void*)pgs_seg_backsolve_lds_kernel); e != hipSuccess) return e;
+            hipLaunchKernelGGL(pgs_seg_backsolve_lds_kernel, dim3(nslot), dim3(SBL_TPB), sizeof(double) * 12 * (size_t)p.N, s, p);
+        } else if (p.seg_on) hipLaunchKernelGGL(pgs_seg_backsolve_kernel, dim3(nslot), dim3(SB_TPB), 0, s, p);
         else hipLaunchKernelGGL(pgs_backsolve_kernel, dim3(nslot), dim3(BTPB), 0, s, p);
         break;
     default:   // the candidates of every slot, then GTSAM's accept / lambda / convergence logic per instance
+        if (p.nfact_max > 0) hipLaunchKernelGGL(pgs_eval_factor_kernel, dim3(nslot * ((p.nfact_max + LF_TPB - 1) / LF_TPB)), dim3(LF_TPB), 0, s, p);
         hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(nslot), dim3(TPB), 0, s, p);
         hipLaunchKernelGGL(pgs_decide_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
         break;

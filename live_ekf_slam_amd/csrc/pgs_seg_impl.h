@@ -86,10 +86,23 @@ __device__ __forceinline__ void sym_ggT(const double* G, double* o) {   // lower
 //      tile SYRK) and the largest column set (the host takes the sequential path if a segment sees more than kPgsSegMaxLm landmarks). ----
 __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
     __shared__ int s_has[256], s_first[256];   // L_max <= 255
+    __shared__ int s_nf;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int N = p.N, SL = p.seg_len, NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP, M = p.M[b], L_max = p.L_max;
+    const int N = p.N, KP = p.KP, M = p.M[b], L_max = p.L_max;
     const int32_t* cnt = p.cnt + (size_t)b * p.N_max;
     const int32_t* mlm = p.mlm + (size_t)b * p.N_max * KP;
+    {   // factors of the instance (the grid of the per-factor kernels)
+        if (tid == 0) s_nf = 0;
+        __syncthreads();
+        int nf = 0;
+        for (int i = tid; i < N; i += 256) nf += cnt[i];
+        atomicAdd(&s_nf, nf);
+        __syncthreads();
+        if (tid == 0) p.fact_cnt[b] = s_nf;
+    }
+    if (p.seg_len <= 0) return;
+    const int SL = p.seg_len, NS = seg_ns(N, SL), nseg = NS + 1;
+    if (NS > kPgsSegMaxSep) { if (tid == 0) p.seg_umax[b] = 0x7fffffff; return; }   // (the host takes the sequential path)
     int32_t* ncol = p.seg_ncol + (size_t)b * p.nseg_max;
     int32_t* slm = p.seg_lm + (size_t)b * p.nseg_max * L_max;
     int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * L_max;
@@ -106,11 +119,13 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
         __syncthreads();
         if (tid < 64) {   // compaction in landmark order, 64 landmarks per ballot
             int base = 0;
+            int32_t* blk = p.seg_blk + ((size_t)b * p.nseg_max + ps) * seg_nb1(L_max);
             for (int j0 = 0; j0 < L_max; j0 += 64) {
                 const int j = j0 + lane;
                 const bool has = j < M && s_has[j < L_max ? j : 0] != 0;
                 const unsigned long long m = __ballot(has);
                 const int lc = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (lane < 4) blk[(j0 >> 4) + lane] = base + __popcll(m & ((1ull << (16 * lane)) - 1ull));   // local landmarks below 16 * block
                 if (j < L_max) sinv[(size_t)ps * L_max + j] = has ? lc : -1;
                 if (has) {
                     slm[(size_t)ps * L_max + lc] = j;
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
                 }
                 base += __popcll(m);
             }
-            if (lane == 0) ncol[ps] = base;
+            if (lane == 0) { blk[seg_nb1(L_max) - 2] = base; blk[seg_nb1(L_max) - 1] = base; ncol[ps] = base; }
             umax = base > umax ? base : umax;
         }
         __syncthreads();
@@ -325,6 +340,9 @@ __global__ __launch_bounds__(1024) void pgs_sep_kernel(const PgsParams p) {
     }
     if (tid == 0) s_fail = 0;
     __syncthreads();
+    const int c = tid - 64;
+    double* Yb = p.Y + (size_t)b * p.y_stride;
+    double* Ys = Yb + (size_t)p.yr_sep * LD + c;
     if (tid == 0) {
         double I[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
@@ -352,6 +370,63 @@ __global__ __launch_bounds__(1024) void pgs_sep_kernel(const PgsParams p) {
             for (int q = 0; q < 9; ++q) o[6 + q] = G[q];
         }
         if (!ok) s_fail = 1;
+    } else if (c >= 0 && c <= m2 && c < LD) {
+        // pass 1, BESIDE lane 0's chain (it needs nothing of it; no dependence between the separators either, so the loads of several
+        // of them are in flight at once): the right-hand side before the chain term, (g - right contribution of segment k) - left
+        // contribution of segment k + 1, + E at the separator's pose (the landmark's event there: sep_evt)
+        const bool grad = c == m2;
+        const int j = c >> 1, d = c & 1;
+        const int32_t* ncolb = p.seg_ncol + (size_t)b * p.nseg_max;
+        const int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * p.L_max;
+        const int32_t* sevt = p.sep_evt + (size_t)b * p.nseg_max * p.L_max;
+        const int32_t* evt_pose = p.evt_pose + (size_t)b * p.N_max * KP;
+        const int evt_end = grad ? 0 : p.evt_start[(size_t)b * (p.L_max + 1) + j + 1];
+        const double* Elmb = p.Elm + (size_t)b * p.N_max * KP * 6;
+        const double* Rc = Yb + (size_t)p.yr_rc * LD;
+        constexpr int PB = 4;   // separators per batch: index loads, then the loads they address, then the arithmetic
+#pragma unroll 1
+        for (int k0 = 0; k0 < NS; k0 += PB) {
+            int lr[PB], ll[PB], ev[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int k = k0 + q < NS ? k0 + q : NS - 1;
+                if (grad) { lr[q] = 2 * ncolb[k]; ll[q] = 2 * ncolb[k + 1]; ev[q] = -1; }
+                else {
+                    const int ir = sinv[(size_t)k * p.L_max + j], il = sinv[(size_t)(k + 1) * p.L_max + j];
+                    lr[q] = ir >= 0 ? 2 * ir + d : -1; ll[q] = il >= 0 ? 2 * il + d : -1;
+                    ev[q] = sevt[(size_t)k * p.L_max + j];
+                }
+            }
+            double rr[PB][3], rl[PB][3], ee[PB][3];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int k = k0 + q < NS ? k0 + q : NS - 1;
+                const double* qr = Rc + (size_t)(6 * k + 3) * LD + (lr[q] >= 0 ? lr[q] : 0);
+                const double* ql = Rc + (size_t)(6 * (k + 1)) * LD + (ll[q] >= 0 ? ll[q] : 0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    rr[q][r] = lr[q] >= 0 ? qr[(size_t)r * LD] : 0.0;
+                    rl[q][r] = ll[q] >= 0 ? ql[(size_t)r * LD] : 0.0;
+                    ee[q][r] = ev[q] >= 0 ? Elmb[6 * (size_t)ev[q] + 2 * r + d] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int k = k0 + q;
+                if (k >= NS) break;
+                const int s = (k + 1) * SL;
+                double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+                if (grad) { u0 = s_sin[k][27]; u1 = s_sin[k][28]; u2 = s_sin[k][29]; }
+                u0 = (u0 - rr[q][0]) - rl[q][0]; u1 = (u1 - rr[q][1]) - rl[q][1]; u2 = (u2 - rr[q][2]) - rl[q][2];
+                if (ev[q] >= 0) {
+                    u0 += ee[q][0]; u1 += ee[q][1]; u2 += ee[q][2];
+                    for (int e = ev[q] + 1; e < evt_end && evt_pose[e] == s; ++e) {   // the same landmark twice in one message (rare)
+                        u0 += Elmb[6 * (size_t)e + d]; u1 += Elmb[6 * (size_t)e + 2 + d]; u2 += Elmb[6 * (size_t)e + 4 + d];
+                    }
+                }
+                Ys[(size_t)(3 * k) * LD] = u0; Ys[(size_t)(3 * k + 1) * LD] = u1; Ys[(size_t)(3 * k + 2) * LD] = u2;
+            }
+        }
     }
     __syncthreads();
     if (s_fail) {
@@ -363,47 +438,10 @@ __global__ __launch_bounds__(1024) void pgs_sep_kernel(const PgsParams p) {
 #pragma unroll
         for (int q = 0; q < 15; ++q) o[q] = s_sf[k][q];
     }
-    const int c = tid - 64;
     if (c < 0 || c >= LD) return;
-    double* Yb = p.Y + (size_t)b * p.y_stride;
-    double* Ys = Yb + (size_t)p.yr_sep * LD + c;
     if (c > m2) {   // columns the tile kernel's operand loads touch but never store
         for (int k = 0; k < 3 * NS; ++k) Ys[(size_t)k * LD] = 0.0;
         return;
-    }
-    const bool grad = c == m2;
-    const int j = c >> 1, d = c & 1;
-    const int32_t* ncolb = p.seg_ncol + (size_t)b * p.nseg_max;
-    const int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * p.L_max;
-    const int32_t* cnt = p.cnt + (size_t)b * p.N_max;
-    const int32_t* mlm = p.mlm + (size_t)b * p.N_max * KP;
-    const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
-    const double* Rc = Yb + (size_t)p.yr_rc * LD;
-    // pass 1 (no dependence between the separators: the loads of several of them are in flight at once): the right-hand side
-    // before the chain term, (g - right contribution of segment k) - left contribution of segment k + 1, + E at the separator's pose
-#pragma unroll 2
-    for (int k = 0; k < NS; ++k) {
-        const int s = (k + 1) * SL;
-        double u0 = 0.0, u1 = 0.0, u2 = 0.0;
-        if (grad) { u0 = s_sin[k][27]; u1 = s_sin[k][28]; u2 = s_sin[k][29]; }
-        int lr, ll;
-        if (grad) { lr = 2 * ncolb[k]; ll = 2 * ncolb[k + 1]; }
-        else {
-            const int ir = sinv[(size_t)k * p.L_max + j], il = sinv[(size_t)(k + 1) * p.L_max + j];
-            lr = ir >= 0 ? 2 * ir + d : -1; ll = il >= 0 ? 2 * il + d : -1;
-        }
-        double rr0 = 0.0, rr1 = 0.0, rr2 = 0.0, rl0 = 0.0, rl1 = 0.0, rl2 = 0.0;
-        if (lr >= 0) { const double* q = Rc + (size_t)(6 * k + 3) * LD + lr; rr0 = q[0]; rr1 = q[LD]; rr2 = q[2 * (size_t)LD]; }
-        if (ll >= 0) { const double* q = Rc + (size_t)(6 * (k + 1)) * LD + ll; rl0 = q[0]; rl1 = q[LD]; rl2 = q[2 * (size_t)LD]; }
-        u0 = (u0 - rr0) - rl0; u1 = (u1 - rr1) - rl1; u2 = (u2 - rr2) - rl2;
-        if (!grad) {
-            const int kc = cnt[s];
-            for (int s2 = 0; s2 < kc; ++s2) {
-                const size_t f = (size_t)s * KP + s2;
-                if ((mlm[f] & (kPgsFirstBit - 1)) == j) { u0 += Eb[6 * f + d]; u1 += Eb[6 * f + 2 + d]; u2 += Eb[6 * f + 4 + d]; }
-            }
-        }
-        Ys[(size_t)(3 * k) * LD] = u0; Ys[(size_t)(3 * k + 1) * LD] = u1; Ys[(size_t)(3 * k + 2) * LD] = u2;
     }
     // pass 2: the chain recurrence (each thread re-reads what it wrote itself)
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
@@ -419,56 +457,67 @@ __global__ __launch_bounds__(1024) void pgs_sep_kernel(const PgsParams p) {
     }
 }
 
-// ---- S_ext -= sum_p Y_p^T Y_p: one workgroup per slot walks the segments IN ORDER (the tile kernel has written
-//      [D + lambda I; g_l^T] - Ysep^T Ysep before).  Y_p ([3 len][2 ncol + 1], just written by pgs_seg_kernel: L2) is staged in LDS, its
-//      Gram matrix formed on v_mfma_f64_16x16x4_f64 (16x16 tiles of the lower triangle dealt to the 16 wavefronts) and subtracted from
-//      the rows / columns of S_ext its local columns map to (ascending, so lower stays lower).  A fixed order per element of S. ----
-constexpr int SS_TPB = 1024, SS_ROWS = 3 * kPgsSegMaxLen, SS_LDL = 128 + 16;
-__global__ __launch_bounds__(SS_TPB) void pgs_seg_syrk_kernel(const PgsParams p) {
-    extern __shared__ double s_y[];   // [SS_ROWS][SS_LDL]
-    __shared__ int s_g[128];
-    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
+// ---- T_p = Y_p^T Y_p, the Gram matrix of one segment's columns (one workgroup per (slot, segment)): Y_p ([3 len][2 ncol + 1], just
+//      written by pgs_seg_kernel: L2) goes through LDS in chunks of 16 rows (the next chunk's loads are in flight while this one feeds
+//      v_mfma_f64_16x16x4_f64), the 16x16 tiles of the lower triangle are dealt to the four wavefronts.  The tile SYRK kernel subtracts
+//      T_p from the rows / columns of S_ext the segment's local columns map to, segment after segment (pgs_syrk_kernel's epilogue:
+//      a fixed order per element of S). ----
+constexpr int GR_TPB = 256, GR_CH = 16, GR_LDL = 128 + 16, GR_TW = 9;   // 36 tiles at 128 columns / 4 wavefronts
+__global__ __launch_bounds__(GR_TPB) void pgs_seg_gram_kernel(const PgsParams p) {
+    __shared__ double s_c[GR_CH * GR_LDL];
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
+    const int bl = blockIdx.x / nseg, ps = blockIdx.x - bl * nseg;
+    const int b = pgs_slot(p, bl), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1, LD = p.LD, m2 = 2 * p.M[b];
+    const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N), LD = p.LD;
+    const int nc = 2 * p.seg_ncol[(size_t)b * p.nseg_max + ps] + 1, nr = 3 * (hi - lo), ncp = (nc + 15) & ~15;
     const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
-    const double* Yb = p.Y + (size_t)b * p.y_stride;
-    double* Sb = p.S + (size_t)b * LD * LD;
-    const int32_t* ncolb = p.seg_ncol + (size_t)b * p.nseg_max;
-    const int32_t* slm = p.seg_lm + (size_t)b * p.nseg_max * p.L_max;
-#pragma unroll 1
-    for (int ps = 0; ps < nseg; ++ps) {
-        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
-        const int nc = 2 * ncolb[ps] + 1, nr = 3 * (hi - lo), nrp = (nr + 3) & ~3, ncp = (nc + 15) & ~15;
-        const double* Yp = Yb + (size_t)3 * lo * LD;
-        for (int idx = tid; idx < nrp * ncp; idx += SS_TPB) {
-            const int r = idx / ncp, c = idx - r * ncp;
-            s_y[r * SS_LDL + c] = (r < nr && c < nc) ? Yp[(size_t)r * LD + c] : 0.0;
-        }
-        if (tid < nc) s_g[tid] = tid == nc - 1 ? m2 : 2 * slm[(size_t)ps * p.L_max + (tid >> 1)] + (tid & 1);
-        __syncthreads();
-        const int nt = ncp >> 4, ntile = nt * (nt + 1) / 2;
-        for (int t = w; t < ntile; t += SS_TPB / 64) {
-            int ti = 0, tt = t;
-            while (tt >= ti + 1) { tt -= ti + 1; ti += 1; }
-            const int tj = tt;
-            dbl4_t acc = (dbl4_t){0.0, 0.0, 0.0, 0.0};
-            const double* ra = s_y + kq * SS_LDL + 16 * ti + cl;
-            const double* rb = s_y + kq * SS_LDL + 16 * tj + cl;
-#pragma unroll 4
-            for (int k = 0; k < nrp; k += 4) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[0], rb[0], acc, 0, 0, 0);
-                ra += 4 * SS_LDL; rb += 4 * SS_LDL;
-            }
+    const double* Yp = p.Y + (size_t)b * p.y_stride + (size_t)3 * lo * LD;
+    const int nt = ncp >> 4, ntile = nt * (nt + 1) / 2;
+    int ti[GR_TW], tj[GR_TW];
+    dbl4_t acc[GR_TW];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int lr = 16 * ti + kq + 4 * r4, lcn = 16 * tj + cl;   // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 reg
-                if (lr < nc && lcn <= lr) {
-                    double* q = Sb + (size_t)s_g[lr] * LD + s_g[lcn];
-                    *q = *q - acc[r4];
-                }
-            }
+    for (int q = 0; q < GR_TW; ++q) {
+        int a = 0, tt = w + 4 * q;
+        if (tt >= ntile) tt = 0;
+        while (tt >= a + 1) { tt -= a + 1; a += 1; }
+        ti[q] = a; tj[q] = tt;
+        acc[q] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    constexpr int PE = GR_CH * 128 / GR_TPB;   // elements of a chunk per thread
+    double pre[PE];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < PE; ++u) {
+            const int idx = tid + GR_TPB * u, r = idx >> 7, cc = idx & 127;
+            pre[u] = (r0 + r < nr && cc < nc) ? Yp[(size_t)(r0 + r) * LD + cc] : 0.0;
         }
-        __syncthreads();   // LDS is reused; the updates of S are visible to the threads that touch the same elements next
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int r0 = 0; r0 < nr; r0 += GR_CH) {
+#pragma unroll
+        for (int u = 0; u < PE; ++u) {
+            const int idx = tid + GR_TPB * u;
+            s_c[(idx >> 7) * GR_LDL + (idx & 127)] = pre[u];
+        }
+        __syncthreads();
+        if (r0 + GR_CH < nr) fetch(r0 + GR_CH);
+#pragma unroll
+        for (int q = 0; q < GR_TW; ++q) {
+            if (w + 4 * q >= ntile) break;   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < GR_CH; k += 4)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_c[(k + kq) * GR_LDL + 16 * ti[q] + cl], s_c[(k + kq) * GR_LDL + 16 * tj[q] + cl], acc[q], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double* Tp = p.segT + ((size_t)b * p.nseg_max + ps) * (128 * 128);
+#pragma unroll
+    for (int q = 0; q < GR_TW; ++q) {
+        if (w + 4 * q >= ntile) break;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) Tp[(size_t)(16 * ti[q] + kq + 4 * r4) * 128 + 16 * tj[q] + cl] = acc[q][r4];   // C/D layout: row = (lane >> 4) + 4 reg
     }
 }
 
@@ -612,5 +661,175 @@ __global__ __launch_bounds__(SB_TPB) void pgs_seg_backsolve_kernel(const PgsPara
 #pragma unroll
             for (int q = 0; q < 9; ++q) Gn[q] = fG[q];   // Ginn_i couples pose i - 1 to pose i
         }
+    }
+}
+
+// ---- the same pose step with the chains in LDS (N <= kSegBackLdsPoses).  Everything that does not depend on the neighbouring pose is
+//      formed by all threads first - v_i = Linv_i u_i, M_i = Linv_i Ginn_i - so that a segment's forward chain is z_i = v_i - M_i z_{i-1}
+//      out of LDS (9 multiply-adds per pose and an LDS round trip instead of 24 global loads); likewise backward with
+//      w_i = Linv_i^T (z_i - Gs_i^T d_a), N_i = Linv_i^T Gn_i^T.  The kernel above keeps the oracle's association, (u - G z) first; this one
+//      differs from it in the last bits, like the sequential path's scan (pgs_backsolve_kernel) always did. ----
+constexpr int SBL_TPB = 1024, kSegBackLdsPoses = 1365;   // 12 doubles per pose: 128 KiB of dynamic LDS
+__global__ __launch_bounds__(SBL_TPB) void pgs_seg_backsolve_lds_kernel(const PgsParams p) {
+    extern __shared__ double s_vm[];   // [N][12]
+    __shared__ double s_sf[kPgsSegMaxSep][16];
+    __shared__ double s_r[kPgsSegMaxSep + 1][6];
+    __shared__ double s_ds[kPgsSegMaxSep + 2][3];
+    const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP;
+    const Inst g = inst_view(p, b);
+    const double* gpb = p.gp + (size_t)b * p.N_max * 3;
+    const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
+    const double* Lb = p.Linv + (size_t)b * p.N_max * 6;
+    const double* Gb = p.G + (size_t)b * p.N_max * 9;
+    const double* Gsb = p.Gs + (size_t)b * p.N_max * 9;
+    const double* sob = p.segout + (size_t)b * p.nseg_max * 32;
+    const double* dlb = p.dl + (size_t)b * p.L_max * 2;
+    double* dpb = p.dp + (size_t)b * p.N_max * 3;
+    for (int k = tid; k < NS; k += SBL_TPB) {
+        const double* o = p.sepfac + ((size_t)b * p.nseg_max + k) * 16;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) s_sf[k][q] = o[q];
+    }
+    for (int i = tid; i < N; i += SBL_TPB) {   // u_i = g_i - E_i dl, then (v_i, M_i); a separator pose keeps its u
+        double I[6], G[9];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) I[q] = Lb[6 * (size_t)i + q];     // (issued before the factor loop's dependent loads)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) G[q] = Gb[9 * (size_t)i + q];
+        double u0 = gpb[3 * i], u1 = gpb[3 * i + 1], u2 = gpb[3 * i + 2];
+        const int kc = g.cnt[i];
+        for (int s = 0; s < kc; ++s) {
+            const size_t k = (size_t)i * KP + s;
+            const int j = g.mlm[k] & (kPgsFirstBit - 1);
+            const double* E = Eb + 6 * k;
+            const double d0 = dlb[2 * j], d1 = dlb[2 * j + 1];
+            u0 -= E[0] * d0 + E[1] * d1; u1 -= E[2] * d0 + E[3] * d1; u2 -= E[4] * d0 + E[5] * d1;
+        }
+        double* o = s_vm + 12 * (size_t)i;
+        const bool sep = i >= SL && i % SL == 0 && i / SL <= NS;
+        if (sep) { o[0] = u0; o[1] = u1; o[2] = u2; continue; }
+        const int ps = i / SL - ((i % SL == 0 && i > 0) ? 1 : 0);   // (an interior pose is no multiple of SL except pose 0)
+        const bool first = i == seg_lo(ps, SL);
+        o[0] = I[0] * u0;
+        o[1] = I[1] * u0 + I[2] * u1;
+        o[2] = (I[3] * u0 + I[4] * u1) + I[5] * u2;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {   // M = Linv Ginn (zero at the segment's first pose)
+            o[3 + cc] = first ? 0.0 : I[0] * G[cc];
+            o[6 + cc] = first ? 0.0 : I[1] * G[cc] + I[2] * G[3 + cc];
+            o[9 + cc] = first ? 0.0 : (I[3] * G[cc] + I[4] * G[3 + cc]) + I[5] * G[6 + cc];
+        }
+    }
+    __syncthreads();
+    for (int ps = tid; ps < nseg; ps += SBL_TPB) {   // forward chains, one lane per segment
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+#pragma unroll 2
+        for (int i = lo; i < hi; ++i) {
+            double* o = s_vm + 12 * (size_t)i;
+            const double n0 = o[0] - ((o[3] * z0 + o[4] * z1) + o[5] * z2);
+            const double n1 = o[1] - ((o[6] * z0 + o[7] * z1) + o[8] * z2);
+            const double n2 = o[2] - ((o[9] * z0 + o[10] * z1) + o[11] * z2);
+            z0 = n0; z1 = n1; z2 = n2;
+            o[0] = z0; o[1] = z1; o[2] = z2;
+        }
+        const double* Gr = sob + (size_t)ps * 32 + 12;   // zero in the last segment
+        s_r[ps][3] = (Gr[0] * z0 + Gr[1] * z1) + Gr[2] * z2;
+        s_r[ps][4] = (Gr[3] * z0 + Gr[4] * z1) + Gr[5] * z2;
+        s_r[ps][5] = (Gr[6] * z0 + Gr[7] * z1) + Gr[8] * z2;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += SBL_TPB) {   // Gs_i z_i of every interior pose (summed per segment below, in pose order)
+        const bool sep = i >= SL && i % SL == 0 && i / SL <= NS;
+        if (sep) continue;
+        double* o = s_vm + 12 * (size_t)i;
+        const double* Gs = Gsb + 9 * (size_t)i;
+        const double z0 = o[0], z1 = o[1], z2 = o[2];
+        o[3] = (Gs[0] * z0 + Gs[1] * z1) + Gs[2] * z2;
+        o[4] = (Gs[3] * z0 + Gs[4] * z1) + Gs[5] * z2;
+        o[5] = (Gs[6] * z0 + Gs[7] * z1) + Gs[8] * z2;
+    }
+    __syncthreads();
+    for (int ps = tid; ps < nseg; ps += SBL_TPB) {
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        for (int i = lo; i < hi; ++i) { const double* o = s_vm + 12 * (size_t)i; r0 += o[3]; r1 += o[4]; r2 += o[5]; }
+        s_r[ps][0] = r0; s_r[ps][1] = r1; s_r[ps][2] = r2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < NS; ++k) {   // forward over the separators
+            const double* us = s_vm + 12 * (size_t)((k + 1) * SL);
+            const double* o = s_sf[k];
+            double u0 = (us[0] - s_r[k][3]) - s_r[k + 1][0];
+            double u1 = (us[1] - s_r[k][4]) - s_r[k + 1][1];
+            double u2 = (us[2] - s_r[k][5]) - s_r[k + 1][2];
+            SEG_SUB_GV(o + 6, z0, z1, z2, u0, u1, u2);
+            z0 = o[0] * u0;
+            z1 = o[1] * u0 + o[2] * u1;
+            z2 = (o[3] * u0 + o[4] * u1) + o[5] * u2;
+            s_ds[k + 1][0] = z0; s_ds[k + 1][1] = z1; s_ds[k + 1][2] = z2;
+        }
+        s_ds[NS + 1][0] = 0.0; s_ds[NS + 1][1] = 0.0; s_ds[NS + 1][2] = 0.0;
+        s_ds[0][0] = 0.0; s_ds[0][1] = 0.0; s_ds[0][2] = 0.0;
+#pragma unroll 1
+        for (int k = NS - 1; k >= 0; --k) {   // backward: s_ds[k + 1] = step of separator k (0-based)
+            double v0 = s_ds[k + 1][0], v1 = s_ds[k + 1][1], v2 = s_ds[k + 1][2];
+            if (k + 1 < NS) { const double* Gn = s_sf[k + 1] + 6; SEG_SUB_GTV(Gn, s_ds[k + 2][0], s_ds[k + 2][1], s_ds[k + 2][2], v0, v1, v2); }
+            const double* I = s_sf[k];
+            const double d2 = I[5] * v2;
+            const double d1 = I[2] * v1 + I[4] * v2;
+            const double d0 = (I[0] * v0 + I[1] * v1) + I[3] * v2;
+            s_ds[k + 1][0] = d0; s_ds[k + 1][1] = d1; s_ds[k + 1][2] = d2;
+            double* us = s_vm + 12 * (size_t)((k + 1) * SL);
+            us[0] = d0; us[1] = d1; us[2] = d2;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += SBL_TPB) {   // w_i = Linv_i^T (z_i - Gs_i^T d_a), N_i = Linv_i^T Gn_i^T
+        const bool sep = i >= SL && i % SL == 0 && i / SL <= NS;
+        if (sep) continue;
+        const int ps = i / SL - ((i % SL == 0 && i > 0) ? 1 : 0);
+        const int hi = seg_hi(ps, SL, NS, N);
+        double I[6], Gs[9], Gn[9];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) I[q] = Lb[6 * (size_t)i + q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { Gs[q] = Gsb[9 * (size_t)i + q]; Gn[q] = i + 1 < hi ? Gb[9 * (size_t)(i + 1) + q] : sob[(size_t)ps * 32 + 12 + q]; }
+        double* o = s_vm + 12 * (size_t)i;
+        double v0 = o[0], v1 = o[1], v2 = o[2];
+        SEG_SUB_GTV(Gs, s_ds[ps][0], s_ds[ps][1], s_ds[ps][2], v0, v1, v2);   // Gs is zero in segment 0
+        o[0] = (I[0] * v0 + I[1] * v1) + I[3] * v2;
+        o[1] = I[2] * v1 + I[4] * v2;
+        o[2] = I[5] * v2;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {   // column cc of Gn^T = row cc of Gn
+            o[3 + cc] = (I[0] * Gn[3 * cc] + I[1] * Gn[3 * cc + 1]) + I[3] * Gn[3 * cc + 2];
+            o[6 + cc] = I[2] * Gn[3 * cc + 1] + I[4] * Gn[3 * cc + 2];
+            o[9 + cc] = I[5] * Gn[3 * cc + 2];
+        }
+    }
+    __syncthreads();
+    for (int ps = tid; ps < nseg; ps += SBL_TPB) {   // backward chains
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N);
+        double d0 = s_ds[ps + 1][0], d1 = s_ds[ps + 1][1], d2 = s_ds[ps + 1][2];   // step of the right separator (zero after the last segment)
+#pragma unroll 2
+        for (int i = hi - 1; i >= lo; --i) {
+            double* o = s_vm + 12 * (size_t)i;
+            const double n0 = o[0] - ((o[3] * d0 + o[4] * d1) + o[5] * d2);
+            const double n1 = o[1] - ((o[6] * d0 + o[7] * d1) + o[8] * d2);
+            const double n2 = o[2] - ((o[9] * d0 + o[10] * d1) + o[11] * d2);
+            d0 = n0; d1 = n1; d2 = n2;
+            o[0] = d0; o[1] = d1; o[2] = d2;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += SBL_TPB) {
+        const double* o = s_vm + 12 * (size_t)i;
+        dpb[3 * i] = o[0]; dpb[3 * i + 1] = o[1]; dpb[3 * i + 2] = o[2];
     }
 }

@@ -2,8 +2,13 @@
 
 Graph building is integer / copy work plus one sincos per new landmark: compared BIT-EXACT.  The LM solve is an
 iterative fp64 computation whose Schur complement is accumulated by MFMA in a different order than the oracle's
-sequential loops: tolerance 1e-7 m on poses / landmarks, 1e-9 relative on the objective, identical iteration and
-lambda-trial counts."""
+sequential loops: identical iteration and lambda-trial counts, 1e-9 relative on the objective, and on poses / landmarks
+    max(1e-7 m, 10 x the instance's own ROUNDING SPREAD):
+the largest distance between the results the ORACLE reaches with its exact elimination orders (sequential Schur / segmented
+with 32, 16, 8 poses per segment; they differ in rounding only).  For all but a handful of instances in ten thousand that spread is
+below 1e-9 m and the bound is the fixed 1e-7 m; an instance whose LM path is long (15+ iterations, lambda walking up and down)
+amplifies one ulp in a linear solve to 1e-8 ... 1e-7 m, for ANY implementation - test_the_ill_conditioned_instance_of_the_round_4_soak
+pins one (found by tools/gpu_soak_pgs.py: GPU at 2.75e-7 m with equal counts and objective)."""
 import numpy as np
 import pytest
 
@@ -311,6 +316,7 @@ def test_segmented_elimination_agrees_with_the_oracle(monkeypatch, oracle, L, T,
             continue   # 142 separators: beyond the separator kernel's staging (the host would fall back to the sequential chain)
         monkeypatch.setenv("SLAM_PGS_SEG", str(sl))
         monkeypatch.setenv("SLAM_PGS_LIST", lst)
+        monkeypatch.setenv("SLAM_PGS_SEG_BACK_GLOBAL", "1" if sl == 16 else "0")   # the pose step's chains from global memory / out of LDS
         pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
         pg.set_map(lm); pg.set_seed(8); pg.init(0.0, 0.0, 0.0)
         pg.run_sim(cmds); pg.solvePoseGraph()
@@ -327,10 +333,10 @@ def test_segmented_elimination_agrees_with_the_oracle(monkeypatch, oracle, L, T,
 
 
 def test_segmented_elimination_falls_back_when_a_segment_sees_too_many_landmarks(monkeypatch, oracle):
-    """A map of 100 landmarks all in view all the time: every segment's column set would hold 100 landmarks (> 63, the segment kernels'
-    limit), so the solve runs the sequential chain - and says so."""
+    """A map of 64 landmarks all in view all the time (64 factor slots per pose, the device simulator's message limit): every segment's
+    column set would hold 64 landmarks (> 63, the segment kernels' limit), so the solve runs the sequential chain - and says so."""
     import live_ekf_slam_amd as S
-    L, T, KP, B = 100, 70, 32, 3
+    L, T, KP, B = 64, 70, 64, 3
     rng = np.random.default_rng(5)
     lm = rng.uniform(-1.0, 1.0, (L, 2)) + np.array([1.5, 0.0])
     _, cmds = make_scenario(9, 20, T)
@@ -341,4 +347,47 @@ def test_segmented_elimination_falls_back_when_a_segment_sees_too_many_landmarks
     pg.run_sim(cmds); pg.solvePoseGraph()
     assert not pg.last_solve_paths()["segmented"]
     _compare(pg, r, B)
+    pg.close()
+
+
+def _rounding_spread(oracle, lm, cmds, B, L, KP, seed, cfg, r):
+    """Per instance: the largest distance between the oracle's sequential-Schur result `r` and its results with the segmented
+    elimination at 32, 16 and 8 poses per segment - the same exact solve, rounded differently (module docstring)."""
+    sp = np.zeros(B)
+    for sl in (32, 16, 8):
+        v = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8, lin_mode=oracle.LIN_SEG | (sl << 8))
+        assert np.array_equal(v["trials"], r["trials"]) and np.array_equal(v["iterations"], r["iterations"])
+        for b in range(B):
+            sp[b] = max(sp[b], np.abs(v["pose_res"][b] - r["pose_res"][b]).max(), np.abs(v["lm_res"][b] - r["lm_res"][b]).max())
+    return sp
+
+
+@pytest.mark.parametrize("seg", ["32", "0"])
+def test_the_ill_conditioned_instance_of_the_round_4_soak(monkeypatch, oracle, seg):
+    """profiles/r04b/soak_final: L=40 T=846 KP=32 B=11 seed=1058182634 scenario=1043562854 fused=3 list=1 groups=3 lanes=4 - instance 9
+    (19 iterations, 36 lambda trials) came out 2.75e-7 m from the oracle with identical counts, flags and objective: beyond the fixed
+    1e-7 m.  Its LM path amplifies rounding: the oracle's OWN elimination orders end up to 7e-8 m apart on it (2.5e-9 m Schur vs dense,
+    7.2e-8 m Schur vs 8-pose segments) while the other ten instances agree to 1e-10 m.  The bar of this module - max(1e-7 m, 10 x that
+    spread) - is what the instance is held to, on the launch shape that reported it (seg = 0: the sequential chain, fused on three
+    workgroups) and on the default segmented path."""
+    import live_ekf_slam_amd as S
+    L, T, KP, B, seed, sc = 40, 846, 32, 11, 1058182634, 1043562854
+    lm, cmds = make_scenario(sc, L, T)
+    cfg = default_config()
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8)
+    spread = _rounding_spread(oracle, lm, cmds, B, L, KP, seed, cfg, r)
+    assert spread[9] > 1e-8 and np.all(np.delete(spread, 9) < 1e-8), spread     # the premise: ONE instance is that sensitive
+    monkeypatch.setenv("SLAM_PGS_SEG", seg)
+    monkeypatch.setenv("SLAM_PGS_FUSED", "3"); monkeypatch.setenv("SLAM_PGS_LIST", "1"); monkeypatch.setenv("SLAM_PGS_LANES", "4")
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+    pg.set_groups(3)
+    pg.set_map(lm); pg.set_seed(seed); pg.init(0.0, 0.0, 0.0)
+    pg.run_sim(cmds); pg.solvePoseGraph()
+    st = pg.stats()
+    assert np.array_equal(st["flags"], r["flags"]) and np.array_equal(st["iterations"], r["iterations"]) and np.array_equal(st["trials"], r["trials"])
+    assert np.allclose(st["err_final"], r["err_final"], rtol=OBJ_RTOL, atol=0)
+    for b in range(B):
+        g1 = pg.get_graph(b, 1); M = r["M"][b]
+        err = max(np.abs(g1["poses"] - r["pose_res"][b]).max(), np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max())
+        assert err < max(POSE_TOL, 10.0 * spread[b]), (b, err, spread[b])
     pg.close()

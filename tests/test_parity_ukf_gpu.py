@@ -337,55 +337,56 @@ def test_ukf_state_of_100_landmarks(S, oracle):
 
 
 @pytest.mark.parametrize("kind", ["ukf", "ukf_loc"])
-def test_ukf_checkpoint_round_trips_incl_cold_start_marker_and_failed_sqrt(S, kind, tmp_path):
+def test_ukf_checkpoint_round_trips_incl_the_cold_start_marker(S, kind, tmp_path):
     """slam_load_state refused every UKF checkpoint whose warm-start age column held -1 - the cold-start marker
     ukf_init_kernel writes and both sqrt kernels write after SLAM_INST_SQRT_FAILED.  (i) a checkpoint saved right after init
-    loads and continues bit-identically; (ii) so does one of a batch in which an instance's decomposition has failed (a
-    non-finite range makes its state non-finite: that instance fails every step from there on); (iii) an age outside
-    [-1, 100] is still refused."""
+    (every age is -1) loads and continues bit-identically; (ii) so does one taken mid-run; (iii) a mid-run checkpoint in which one
+    instance carries the marker (what a failed decomposition leaves behind) loads: that instance restarts its eigenvectors cold - the
+    same factor to rounding - and the others continue bit-identically; (iv) an age outside [-1, 100] is still refused."""
     from live_ekf_slam_amd.scenario import make_scenario
-    from live_ekf_slam_amd.config import INST_SQRT_FAILED
     L, B, T = 20, 6, 40
     lm, cmds = make_scenario(17, L, T)
-    Cls = S.BatchedUKF if kind == "ukf" else S.BatchedUKFLoc
-
     def make():
-        f = Cls(B, L).readParams(); f.set_map(lm); f.set_seed(9); f.init(0, 0, 0)
+        f = (S.BatchedUKF(B, L) if kind == "ukf" else S.BatchedUKFLoc(B)).readParams(); f.set_map(lm); f.set_seed(9); f.init(0, 0, 0)
         return f
 
     def states(f):
         return [f.get_state(b) for b in range(B)], f.status().copy(), f.error_stats().copy(), f.truth().copy()
 
-    def same(a, b):
-        for sa, sb in zip(a[0], b[0]):
+    def same(a, b, skip=()):
+        for i, (sa, sb) in enumerate(zip(a[0], b[0])):
+            if i in skip:
+                continue
             assert sa["M"] == sb["M"] and np.array_equal(sa["ids"], sb["ids"])
-            assert np.array_equal(sa["x"], sb["x"], equal_nan=True) and np.array_equal(sa["P"], sb["P"], equal_nan=True)
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3])
+            assert np.array_equal(sa["x"], sb["x"]) and np.array_equal(sa["P"], sb["P"])
+        keep = [i for i in range(B) if i not in skip]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2][keep], b[2][keep]) and np.array_equal(a[3], b[3])
 
     # (i) save right after init: every age is -1
     a = make(); p0 = tmp_path / "init.ckpt"; a.save_state(p0)
-    a.run_sim(cmds[:15])
-    b = make(); b.load_state(p0); b.run_sim(cmds[:15])
+    a.run_sim(cmds[:20])
+    b = make(); b.load_state(p0); b.run_sim(cmds[:20])
     same(states(a), states(b))
-    # (ii) poison instance 2 through an external message (id 0 of the map, infinite range), run on, checkpoint, continue
-    meas = np.zeros((B, 1, 3), np.float32); cnt = np.zeros(B, np.int32)
-    meas[2, 0] = (float(0), np.inf, 0.1); cnt[2] = 1
-    a.update(S.Command(cmds[15, 0], cmds[15, 1]), meas, cnt)
-    meas[2, 0] = (float(0), 1.0, 0.1)
-    for t in range(16, 20):
-        a.update(S.Command(cmds[t, 0], cmds[t, 1]), meas, cnt)
-    assert a.status()[2] & INST_SQRT_FAILED, "the poisoned instance never failed its decomposition: the test lost its subject"
-    assert not np.any(np.delete(a.status(), 2) & INST_SQRT_FAILED)
-    p1 = tmp_path / "failed.ckpt"; a.save_state(p1)
+    # (ii) mid-run
+    p1 = tmp_path / "mid.ckpt"; a.save_state(p1)
     a.run_sim(cmds[20:])
     c = make(); c.load_state(p1); c.run_sim(cmds[20:])
     same(states(a), states(c))
-    # (iii) an impossible age is refused and nothing is copied
+    # (iii) instance 2 carries the cold-start marker (the age column is the file's last item)
     raw = bytearray(open(p1, "rb").read())
-    bad = bytearray(raw); bad[-4 * B:-4 * B + 4] = np.int32(101).tobytes()      # the age column is the file's last item
+    ages = np.frombuffer(bytes(raw[-4 * B:]), dtype=np.int32)
+    assert np.all(ages >= 0) and np.all(ages <= 100), ages    # 20 warm-started steps behind every instance
+    cold = bytearray(raw); cold[-4 * B + 8:-4 * B + 12] = np.int32(-1).tobytes()
+    pc = tmp_path / "cold.ckpt"; open(pc, "wb").write(cold)
+    d = make(); d.load_state(pc); d.run_sim(cmds[20:])
+    sa, sd = states(a), states(d)
+    same(sa, sd, skip=(2,))
+    assert sa[0][2]["M"] == sd[0][2]["M"] and np.abs(sa[0][2]["x"] - sd[0][2]["x"]).max() < 1e-5 and np.all(np.isfinite(sd[0][2]["P"]))
+    # (iv) an impossible age is refused
+    bad = bytearray(raw); bad[-4 * B:-4 * B + 4] = np.int32(101).tobytes()
     pb = tmp_path / "bad.ckpt"; open(pb, "wb").write(bad)
-    d = make()
+    e = make()
     with pytest.raises(S.SlamError, match="age of the warm-start"):
-        d.load_state(pb)
-    for f in (a, b, c, d):
+        e.load_state(pb)
+    for f in (a, b, c, d, e):
         f.close()

@@ -27,7 +27,9 @@ while time.time() < t_end:
     seed, sc = int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1 << 30))
     fused = str(rng.choice(["-1", "0", "2", "3", "4"])); lst = str(rng.choice(["1", "1", "0"])); groups = int(rng.choice([0, 0, 2, 3]))
     lanes = str(rng.choice(["4", "4", "1", "2"]))
-    os.environ["SLAM_PGS_FUSED"] = fused; os.environ["SLAM_PGS_LIST"] = lst; os.environ["SLAM_PGS_LANES"] = lanes
+    seg = str(rng.choice(["32", "32", "16", "8", "5", "0"]))   # round 5: poses per segment of the segmented elimination (0: the sequential chain)
+    os.environ["SLAM_PGS_FUSED"] = fused; os.environ["SLAM_PGS_LIST"] = lst; os.environ["SLAM_PGS_LANES"] = lanes; os.environ["SLAM_PGS_SEG"] = seg
+    os.environ["SLAM_PGS_SEG_BACK_GLOBAL"] = str(rng.choice(["0", "0", "1"]))
     lm, cmds = make_scenario(sc, L, T)
     cfg = default_config()
     r = O.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8)
@@ -48,8 +50,12 @@ while time.time() < t_end:
         # A long LM path (15+ iterations, lambda walking) ends in a poorly conditioned system: the oracle's own two eliminations
         # (Schur complement, poses first / dense Cholesky of the whole system) then differ by more than 1e-7 m themselves.  The
         # yardstick for such an instance is that difference, not the fixed tolerance.
-        rd = O.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8, lin_mode=O.LIN_DENSE)
-        ed = max(float(np.abs(rd["pose_res"] - r["pose_res"]).max()), float(np.abs(rd["lm_res"] - r["lm_res"]).max()))
+        # (round 5: the oracle's segmented orders join the yardstick - for the instance round 4's soak reported, Schur vs dense is 2.5e-9 m
+        # and Schur vs 8-pose segments 7.2e-8 m: tests/test_parity_pgs_gpu.py::test_the_ill_conditioned_instance_of_the_round_4_soak)
+        ed = 0.0
+        for lmode in ([O.LIN_DENSE] if T * 3 + 2 * L <= 1400 else []) + [O.LIN_SEG | (32 << 8), O.LIN_SEG | (16 << 8), O.LIN_SEG | (8 << 8)]:
+            rd = O.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8, lin_mode=lmode)
+            ed = max(ed, float(np.abs(rd["pose_res"] - r["pose_res"]).max()), float(np.abs(rd["lm_res"] - r["lm_res"]).max()))
         if err < 10.0 * ed:
             soft += 1; note = f" (ill-conditioned: the oracle's two eliminations differ by {ed:.1e} m, the GPU by {err:.1e} m)"
             if os.environ.get("SOAK_VERBOSE"): print("NOTE", note, flush=True)
@@ -59,7 +65,7 @@ while time.time() < t_end:
     runs += 1
     if not ok:
         fails += 1
-        print(f"MISMATCH L={L} T={T} KP={KP} B={B} seed={seed} scenario={sc} fused={fused} list={lst} groups={groups} lanes={lanes}: max err {err:.3e}, "
+        print(f"MISMATCH L={L} T={T} KP={KP} B={B} seed={seed} scenario={sc} fused={fused} list={lst} groups={groups} lanes={lanes} seg={seg}: max err {err:.3e}, "
               f"iterations {st['iterations'].tolist()} vs {r['iterations'].tolist()}, trials {st['trials'].tolist()} vs {r['trials'].tolist()}, flags {st['flags'].tolist()} vs {r['flags'].tolist()}", flush=True)
 print(f"{runs} random pose-graph configurations in {budget:.0f} s, {fails} mismatches" + (f"; {soft} ill-conditioned instances beyond 1e-7 m but within 10 x the distance of the oracle's own two eliminations" if soft else ""))
 sys.exit(1 if fails else 0)

@@ -1,0 +1,10 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5e
+timeout 900 python -m pytest tests/test_parity_pgs_gpu.py -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r5e/pgs_tests.log
+timeout 300 python -m pytest tests/test_parity_ukf_gpu.py -x -q -m gpu -k checkpoint 2>&1 | tail -15 > gpurun_out/r5e/ukf_ckpt.log
+timeout 300 python bench.py --filter pgs --no-cpu-baseline > gpurun_out/r5e/pgs_seg.json 2> gpurun_out/r5e/pgs_seg.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r5e/prof -o pgs -- python3 $GRAFT_REPO_ROOT/bench.py --filter pgs --steps 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r5e/prof_line.json 2> $GRAFT_REPO_ROOT/gpurun_out/r5e/prof.err
+cd $GRAFT_REPO_ROOT
+cat gpurun_out/r5e/*.log | tail -12
