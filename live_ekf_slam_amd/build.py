@@ -21,7 +21,7 @@ HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", 
 # sessions: SLAM_SWEEP=1 python -m live_ekf_slam_amd.build --force
 EKF_DEFAULT_VARIANTS = [(43, 2, 5, 4, 0, 1), (43, 2, 4, 4, 0, 1), (103, 4, 6, 4, 0, 1), (103, 4, 5, 4, 0, 1), (103, 4, 4, 4, 0, 1),
                         (203, 4, 5, 4, 0, 1), (203, 4, 4, 4, 0, 1), (403, 4, 4, 4, 0, 1),
-                        (43, 2, 4, 4, 1, 1), (103, 4, 4, 2, 1, 1),
+                        (43, 2, 4, 4, 1, 1), (103, 4, 6, 2, 1, 1), (103, 4, 4, 2, 1, 1),
                         (43, 1, 2, 4, 0, 1)]   # one wavefront per filter: no decoupled loop, every step through the synchronised path
 EKF_SWEEP_VARIANTS = [(103, 3, 6, 4, 0, 1), (103, 3, 5, 4, 0, 1), (103, 3, 4, 4, 0, 1, 2), (103, 3, 5, 4, 0, 1, 2), (103, 2, 3, 4, 0, 1, 2), (103, 2, 4, 4, 0, 1, 2), (103, 3, 6, 4, 0, 1, 2),
                       (103, 4, 4, 4, 0, 1, 2), (103, 4, 5, 4, 0, 1, 2), (103, 3, 4, 4, 0, 1, 3), (103, 4, 6, 2, 0, 1), (43, 2, 6, 4, 0, 1),
@@ -55,6 +55,8 @@ def build_extension(force=False, verbose=False):
     # in AGPRs and copied all of them in and out around every k-block of the covariance contraction)
     per_file = {"ukf_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}   # (ukf_big_kernel.hip has no MFMA)
     variants = list(EKF_DEFAULT_VARIANTS) + (EKF_SWEEP_VARIANTS if os.environ.get("SLAM_SWEEP") else [])
+    # A/B builds: SLAM_EXTRA_VARIANTS="103,4,6,4,1,1;103,4,6,2,1,1" adds instantiations to the defaults (NMAX,W,KG,UNR,f32,PIPE[,KP])
+    variants += [tuple(int(x) for x in v.split(",")) for v in os.environ.get("SLAM_EXTRA_VARIANTS", "").split(";") if v.strip()]
     variants = list(dict.fromkeys(variants))
     for v in variants:
         nmax, w, kg, unr, f32, pipe = v[:6]

@@ -17,7 +17,10 @@ class SlamConfig(C.Structure):
         ("range_max", C.c_double), ("fov_min", C.c_double), ("fov_max", C.c_double),
         ("init_x", C.c_double), ("init_y", C.c_double), ("init_yaw", C.c_double),
         ("replicate_vw_quirk", C.c_int), ("ukf_float_trig", C.c_int),
-        ("reserved", C.c_int * 6),
+        ("reserved", C.c_int * 2),
+        # quirk switches of round 5 (include/slam_batch.h): 0 = the reference's behaviour as this build reads it
+        ("ekf_abs_is_int", C.c_int), ("ekf_landmark_from_x_pred", C.c_int),
+        ("ukf_accumulate_zest1", C.c_int), ("ukf_sensing_yaw_from_sigma", C.c_int),
     ]
 
     def copy(self):

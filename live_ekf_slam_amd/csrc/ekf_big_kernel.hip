@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kBigTpb) void ekf_big_step_kernel(const EkfStepPara
                 const float x_det = (float)(s_xp[0] + (double)r_m * c);
                 const float y_det = (float)(s_xp[1] + (double)r_m * s);
                 for (int j = tid; j < M; j += kBigTpb) {
-                    const float xd = (float)fabs((double)x_det - s_xp[3 + 2 * j]);
-                    const float yd = (float)fabs((double)y_det - s_xp[3 + 2 * j + 1]);
+                    const float xd = assoc_abs((double)x_det - s_xp[3 + 2 * j], p.abs_is_int);
+                    const float yd = assoc_abs((double)y_det - s_xp[3 + 2 * j + 1], p.abs_is_int);
                     if (xd < p.min_sep && yd < p.min_sep) { hit = j; break; }
                 }
             }
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(kBigTpb) void ekf_big_step_kernel(const EkfStepPara
                 break;
             }
             if (tid == 0) {   // the scalar chain: Jacobian entries with the reference's float truncations, innovation
-                const double dx = s_xt[ii] - s_xp[0], dy = s_xt[ii + 1] - s_xp[1];
+                const double* const xl = p.lm_from_pred ? s_xp : s_xt;   // quirk D-2
+                const double dx = xl[ii] - s_xp[0], dy = xl[ii + 1] - s_xp[1];
                 const float dist = (float)sqrt(dx * dx + dy * dy);
                 const double dd = (double)dist, d2 = (double)(dist * dist);
                 s_sc[0] = -dx / dd; s_sc[1] = -dy / dd; s_sc[2] = dx / dd; s_sc[3] = dy / dd;           // H0 at columns 0, 1, ii, ii+1

@@ -41,6 +41,7 @@ struct EkfStepParams {
     double V00, V11, W00, W11;
     int32_t id_known;
     float min_sep;
+    int32_t abs_is_int, lm_from_pred;   // quirk switches ekf_abs_is_int / ekf_landmark_from_x_pred (include/slam_batch.h), 0 = reference
     // ---- simulator config (raw YAML values, used as half-widths: sim_node.py:216-217,247-248) ----
     double sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max;
     uint64_t seed;

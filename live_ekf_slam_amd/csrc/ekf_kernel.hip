@@ -29,7 +29,9 @@
 #define SLAM_DEF_203 1454
 #endif
 #ifndef SLAM_DEF_103_F32
-#define SLAM_DEF_103_F32 1442   // fp32 storage: strips of two rows (0.88 vs 0.99 ms/step with four; fp64 prefers four: 0.92 vs 0.97)
+#define SLAM_DEF_103_F32 1462   // fp32 storage: strips of two rows (0.88 vs 0.99 ms/step with four; fp64 prefers four: 0.92 vs 0.97).  Round 5: SIX
+                                // ring slots with passes at four pending updates (1442 with passes at three until then; same-box table
+                                // profiles/r05a/f32_variants.txt: 0.871 vs 0.894 ms/step on the bench window, 1.03 vs 1.24 at 2.4 detections per step)
 #endif
 
 namespace slam {

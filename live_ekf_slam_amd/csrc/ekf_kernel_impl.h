@@ -108,9 +108,10 @@ __device__ __forceinline__ bool inv2x2_lu(const double S[4], double Si[4]) {
 #ifndef SLAM_SLEEP_PASS
 #define SLAM_SLEEP_PASS 1     // streamers waiting for the next pass
 #endif
-#ifndef SLAM_PASS_MIN_F32
-#define SLAM_PASS_MIN_F32 3   // fp32 storage: a pass moves half the bytes, so starting one slot earlier (the control wavefront keeps a free slot) wins: 1.07 -> 0.99 ms/step
-#endif
+// fp32 storage: a pass moves half the bytes, so starting passes earlier (the control wavefront keeps free slots) wins: with four ring
+// slots passes start at three pending updates (1.07 -> 0.99 ms/step, round 2); from five slots on two stay free (round 5, six slots: passes at
+// four - 0.871 ms/step against 0.894 for four slots / three, 0.899 for six slots with four-row strips, 0.875 with passes at five).
+// -DSLAM_PASS_MIN_F32=n forces a value for every fp32 variant (tuning builds).
 #ifndef SLAM_PASS_MIN
 #define SLAM_PASS_MIN 4   // decoupled loop: the streamers start a pass when this many updates are pending (or on request).  With the default
                           // ring of KG = 5 slots that leaves one free for the control wavefront during a pass (KG = 5 with passes at five pending:
@@ -392,6 +393,11 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : SLAM_W1_WAVES)) void ekf_step
                 ps[5] = cv * cs; ps[6] = cv * sn; ps[7] = sv * cs; ps[8] = sv * sn;
             }
         }
+#ifdef SLAM_EXP_ASSOC_REP   // timing experiment (round 5): the association SLAM_EXP_ASSOC_REP extra times - what it costs is what moving it to the
+        // generator wavefront could save (same results: it rewrites the same values)
+#pragma unroll 1
+        for (int rep_ = 0; rep_ <= SLAM_EXP_ASSOC_REP; ++rep_)
+#endif
         if (p.id_known) {
             const int kn = kraw < KCAP ? kraw : KCAP;
             // lanes scan lm_IDs in parallel for each detection (first match wins, ekf.cpp:102-107); lane l % 64 then keeps the
@@ -487,7 +493,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : SLAM_W1_WAVES)) void ekf_step
     //      H = {H00, H01, H0i, H0i+1, H10, H11, H1i, H1i+1} (H12 = -1), innovation (nu0, nu1), Si = S^-1.  Every lane of the
     //      wavefront returns the same values.  false: zero pivot in the PartialPivLU of S. ----
     auto leader_chain = [&](int ii, int si, float r_m, float b_m, double (&H)[8], double& nu0, double& nu1, double (&Si)[4]) -> bool {
-        const double dx = s_xt[ii] - s_xp[0], dy = s_xt[ii + 1] - s_xp[1];
+        const double* const xl = p.lm_from_pred ? s_xp : s_xt;   // quirk D-2 (ekf.cpp:115-116): the landmark is read from x_t
+        const double dx = xl[ii] - s_xp[0], dy = xl[ii + 1] - s_xp[1];
         const float dist = (float)sqrt(dx * dx + dy * dy);
         const double dd = (double)dist, d2 = (double)(dist * dist);
         // lane j < 8: H entry j = num_j / den_j
@@ -1332,7 +1339,12 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : SLAM_W1_WAVES)) void ekf_step
                 constexpr int kPassMinCfg = SLAM_PASS_MIN_FORCE;
 #else
                 // fp64: a pass starts at SLAM_PASS_MIN = 4 pending updates, and from five ring slots on at KG - 1 (one slot stays free)
-                constexpr int kPassMinCfg = kWide ? (KG > SLAM_PASS_MIN + 1 ? KG - 1 : SLAM_PASS_MIN) : SLAM_PASS_MIN_F32;
+#ifdef SLAM_PASS_MIN_F32
+                constexpr int kPassMinF32 = SLAM_PASS_MIN_F32;
+#else
+                constexpr int kPassMinF32 = KG > 4 ? KG - 2 : 3;
+#endif
+                constexpr int kPassMinCfg = kWide ? (KG > SLAM_PASS_MIN + 1 ? KG - 1 : SLAM_PASS_MIN) : kPassMinF32;
 #endif
                 constexpr int kPassMin = kPassMinCfg < KG ? kPassMinCfg : KG;
                 int seen = 0;   // passes this wavefront has taken part in
@@ -1533,8 +1545,8 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : SLAM_W1_WAVES)) void ekf_step
                     idx = -2;
 #pragma unroll 1
                     for (int j = 0; j < M_g; ++j) {
-                        const float xd = (float)fabs((double)x_det - s_xp[3 + 2 * j]);
-                        const float yd = (float)fabs((double)y_det - s_xp[3 + 2 * j + 1]);
+                        const float xd = assoc_abs((double)x_det - s_xp[3 + 2 * j], p.abs_is_int);       // ekf.cpp:91-92: which `abs`
+                        const float yd = assoc_abs((double)y_det - s_xp[3 + 2 * j + 1], p.abs_is_int);
                         if (xd < p.min_sep && yd < p.min_sep) { idx = j; break; }
                     }
                     if (idx == -2) idx = (M_g < p.L_max && M_g < LMAX && na_g + 2 <= nf) ? M_g : -1;

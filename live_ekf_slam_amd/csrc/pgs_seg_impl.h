@@ -145,6 +145,15 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
         if (s < cnt[i]) atomicMin(&s_first[mlm[(size_t)i * KP + s] & (kPgsFirstBit - 1)], k);
     }
     __syncthreads();
+    // The tile SYRK takes the k range of a 32-row wavefront tile from the tile's FIRST row, i.e. it needs first[] non-decreasing in the
+    // landmark index.  Landmarks are numbered by first detection, but a detection beyond the KP factor slots of its pose is dropped
+    // (PGS_FLAG_MEAS_CAP) while its landmark is created: such a landmark's first FACTOR can come long after those of the landmarks numbered
+    // after it.  So: the suffix minimum (found by tools/gpu_soak_pgs.py on KP = 4 graphs: steps wrong by metres).
+    if (tid == 0) {
+        int run = NS;
+        for (int j = L_max - 1; j >= 0; --j) { run = s_first[j] < run ? s_first[j] : run; s_first[j] = run; }
+    }
+    __syncthreads();
     if (tid < L_max) p.sep_first[(size_t)b * L_max + tid] = s_first[tid];
     if (tid == 0) p.seg_umax[b] = umax;
 }
@@ -152,8 +161,10 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
 // ---- interiors of one segment: the 3x3 chain with its spike (one lane), then the column recurrence on the segment's columns ----
 constexpr int SG_TPB = 192;   // >= 2 * kPgsSegMaxLm + 1 columns, one per thread
 __global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
-    __shared__ double s_in[kPgsSegMaxLen][18];    // A (00 10 11 20 21 22), C = H[i][i-1] (the segment's first pose: C_a = H[a+1][a]), g_p
-    __shared__ double s_fac[kPgsSegMaxLen][24];   // Linv (6), Ginn (9), Gs (9)
+    // (a segment holds at most SL poses - except the ONLY segment of a graph of exactly SL + 1 poses, which has no separator yet: SL + 1;
+    // found by tools/gpu_soak_pgs.py on 33-pose graphs)
+    __shared__ double s_in[kPgsSegMaxLen + 1][18];    // A (00 10 11 20 21 22), C = H[i][i-1] (the segment's first pose: C_a = H[a+1][a]), g_p
+    __shared__ double s_fac[kPgsSegMaxLen + 1][24];   // Linv (6), Ginn (9), Gs (9)
     __shared__ double s_ce[9], s_gr[9];
     __shared__ int s_fail;
     const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;

@@ -168,6 +168,7 @@ void fill_params(slam_handle* h, slam::EkfStepParams& p, const float cmd[2]) {
     }
     p.id_known = c.landmark_id_is_known;
     p.min_sep = c.min_landmark_separation;
+    p.abs_is_int = c.ekf_abs_is_int ? 1 : 0; p.lm_from_pred = c.ekf_landmark_from_x_pred ? 1 : 0;
     p.sV00 = c.V_00; p.sV11 = c.V_11; p.sW00 = c.W_00; p.sW11 = c.W_11;
     p.d_max = c.d_max; p.th_max = c.th_max;
     p.range_max = h->range_max; p.fov_min = h->fov_min; p.fov_max = h->fov_max;
@@ -189,6 +190,7 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     if (c.replicate_vw_quirk) { p.V00 = c.W_00; p.V11 = c.W_11; p.W00 = 1.0; p.W11 = 1.0; }
     else { p.V00 = c.V_00; p.V11 = c.V_11; p.W00 = c.W_00; p.W11 = c.W_11; }
     p.float_trig = c.ukf_float_trig;
+    p.acc_zest1 = c.ukf_accumulate_zest1 ? 1 : 0; p.yaw_sigma = c.ukf_sensing_yaw_from_sigma ? 1 : 0;
     p.sV00 = c.V_00; p.sV11 = c.V_11; p.sW00 = c.W_00; p.sW11 = c.W_11;
     p.d_max = c.d_max; p.th_max = c.th_max;
     p.range_max = h->range_max; p.fov_min = h->fov_min; p.fov_max = h->fov_max;

@@ -25,6 +25,17 @@
 #endif
 
 namespace slam {
+// |d| as the unknown-id association of ekf.cpp:91-92 sees it: the double overload of abs (as_int = 0), or - if the unqualified `abs`
+// resolves to ::abs(int) - the value truncated to an int first (out-of-range values saturate, here and in the oracle alike).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline float assoc_abs(double d, int as_int) {
+    if (!as_int) return (float)fabs(d);
+    const double t = d >= 2147483647.0 ? 2147483647.0 : (d <= -2147483647.0 ? -2147483647.0 : (d != d ? 0.0 : d));
+    const int i = (int)t;
+    return (float)(i < 0 ? -i : i);
+}
 
 // filter.h:42  `#define pi 3.14159265358979323846` ; every wrap in the reference is remainder(x, 2*pi).
 static constexpr double kPi = 3.14159265358979323846;

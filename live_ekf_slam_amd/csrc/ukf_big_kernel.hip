@@ -347,15 +347,19 @@ __global__ __launch_bounds__(kTpb) void ukf_big_step_kernel(const UkfStepParams 
         for (int i = tid; i < ns; i += kTpb) {   // sensing model of every sigma point (yaw from x_t)
             const double dx = xel(li, i) - xel(0, i), dy = xel(li + 1, i) - xel(1, i);
             s_Z0[i] = sqrt(dx * dx + dy * dy) + (double)p.w_r;
-            s_Z1[i] = remainder((det_atan2(dy, dx) - (double)yaw_t) + (double)p.w_b, kTwoPi);
+            const double yaw_i = p.yaw_sigma ? (double)yawf(xel(2, i), xel(3, i)) : (double)yaw_t;   // quirk D-9: from x_t
+            s_Z1[i] = remainder((det_atan2(dy, dx) - yaw_i) + (double)p.w_b, kTwoPi);
         }
         __syncthreads();
-        if (tid == 0) {   // z_est (the bearing component is never accumulated, ukf.cpp:310-314) and S
-            double z0 = 0.0;
+        if (tid == 0) {   // z_est (the bearing component is never accumulated, ukf.cpp:310-314 - quirk D-8 - unless switched) and S
+            double z0 = 0.0, zb = 0.0;
             for (int i = 0; i < ns; ++i) z0 = z0 + (i == 0 ? w0 : wi) * s_Z0[i];
+            if (p.acc_zest1)
+                for (int i = 0; i < ns; ++i) zb = zb + (i == 0 ? w0 : wi) * s_Z1[i];
+            s_sc[1] = zb;
             double S[4] = {0.0, 0.0, 0.0, 0.0};
             for (int i = 0; i < ns; ++i) {
-                const double d0 = s_Z0[i] - z0, d1 = remainder(s_Z1[i] - 0.0, kTwoPi);
+                const double d0 = s_Z0[i] - z0, d1 = remainder(s_Z1[i] - zb, kTwoPi);
                 const double ww = (i == 0 ? w0 : wi);
                 const double a0 = ww * d0, a1 = ww * d1;
                 S[0] = S[0] + a0 * d0; S[1] = S[1] + a0 * d1; S[2] = S[2] + a1 * d0; S[3] = S[3] + a1 * d1;
@@ -366,17 +370,17 @@ __global__ __launch_bounds__(kTpb) void ukf_big_step_kernel(const UkfStepParams 
             s_sc[0] = z0;
             for (int q = 0; q < 4; ++q) { s_sc[4 + q] = S[q]; s_sc[8 + q] = Si[q]; }
             s_sc[12] = (double)r_m - z0;
-            s_sc[13] = remainder((double)b_m - 0.0, kTwoPi);
+            s_sc[13] = remainder((double)b_m - zb, kTwoPi);
         }
         __syncthreads();
         {
-            const double z0 = s_sc[0];
+            const double z0 = s_sc[0], zb = s_sc[1];
             for (int r = tid; r < n; r += kTpb) {   // cross covariance C (uses the CURRENT x_pred, ukf.cpp:330), K = C S^-1
                 const double xr = s_xp[r];
                 double c0 = 0.0, c1 = 0.0;
                 for (int i = 0; i < ns; ++i) {
                     const double wd = (i == 0 ? w0 : wi) * (xel(r, i) - xr);
-                    const double d0 = s_Z0[i] - z0, d1 = remainder(s_Z1[i] - 0.0, kTwoPi);
+                    const double d0 = s_Z0[i] - z0, d1 = remainder(s_Z1[i] - zb, kTwoPi);
                     c0 = c0 + wd * d0; c1 = c1 + wd * d1;
                 }
                 const double k0 = c0 * s_sc[8] + c1 * s_sc[10], k1 = c0 * s_sc[9] + c1 * s_sc[11];

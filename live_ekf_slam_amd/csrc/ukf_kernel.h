@@ -36,6 +36,7 @@ struct UkfStepParams {
     float v_d, v_th, w_r, w_b;
     double V00, V11, W00, W11;
     int32_t float_trig;  // unqualified cos/sin(float): float overload (1) or double function (0)
+    int32_t acc_zest1, yaw_sigma;   // quirk switches ukf_accumulate_zest1 / ukf_sensing_yaw_from_sigma (include/slam_batch.h), 0 = reference
     // ---- simulator config ----
     double sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max;
     uint64_t seed;

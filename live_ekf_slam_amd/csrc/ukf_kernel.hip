@@ -1071,8 +1071,10 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 128 && !PROF) ? SLAM_UKF
             for (int i = tid; i < ns; i += TPB) {
                 const double dx = (p.loc ? mx : xpred_elem(li, i)) - xpred_elem(0, i), dy = (p.loc ? my : xpred_elem(li + 1, i)) - xpred_elem(1, i);
                 sZ0[i] = sqrt(dx * dx + dy * dy) + (double)p.w_r;
-                const double z1 = remainder((det_atan2(dy, dx) - yaw_s) + (double)p.w_b, kTwoPi);
-                sD1[i] = remainder(z1 - 0.0, kTwoPi);   // z_est(1) stays 0 (ukf.cpp:310-314)
+                // the sensing model's yaw comes from x_t (quirk D-9, ukf.cpp:139) unless switched to the sigma point's own rows 2, 3
+                const double yaw_i = p.yaw_sigma ? (double)yaw_of(xpred_elem(2, i), xpred_elem(3, i)) : yaw_s;
+                const double z1 = remainder((det_atan2(dy, dx) - yaw_i) + (double)p.w_b, kTwoPi);
+                sD1[i] = p.acc_zest1 ? z1 : remainder(z1 - 0.0, kTwoPi);   // z_est(1) stays 0 (quirk D-8, ukf.cpp:310-314); switched off: the leader subtracts it below
             }
             __syncthreads();
         UKF_STAMP(4);
@@ -1084,6 +1086,12 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 128 && !PROF) ? SLAM_UKF
                 z0 = z0 + w0 * sZ0[0];
 #pragma unroll 8
                 for (int i = 1; i < ns; ++i) z0 = z0 + wi * sZ0[i];
+                double zb = 0.0;
+                if (p.acc_zest1) {   // quirk D-8 switched off (not the reference): z_est(1) = the weighted mean of the bearings; the deviations follow
+                    zb = zb + w0 * sD1[0];
+                    for (int i = 1; i < ns; ++i) zb = zb + wi * sD1[i];
+                    for (int i = 0; i < ns; ++i) sD1[i] = remainder(sD1[i] - zb, kTwoPi);
+                }
                 double S[4] = {0.0, 0.0, 0.0, 0.0}, Si[4];
                 {   // i = 0 carries w0
                     const double d0 = sZ0[0] - z0, d1 = sD1[0];
@@ -1102,7 +1110,7 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 128 && !PROF) ? SLAM_UKF
                 s_sc[6] = S[0]; s_sc[7] = S[1]; s_sc[8] = S[2]; s_sc[9] = S[3];
                 s_sc[10] = Si[0]; s_sc[11] = Si[1]; s_sc[12] = Si[2]; s_sc[13] = Si[3];
                 s_sc[14] = (double)r_m - z0;
-                s_sc[15] = remainder((double)b_m - 0.0, kTwoPi);
+                s_sc[15] = remainder((double)b_m - zb, kTwoPi);
             }
             __syncthreads();
         UKF_STAMP(5);

@@ -297,8 +297,8 @@ int Ekf::update_t(float fwd, float ang, const float* meas, int k) {
             const float x_det = (float)(x_pred[0] + (double)r * c);
             const float y_det = (float)(x_pred[1] + (double)r * s);
             for (int j = 0; j < M; ++j) {
-                const float xd = (float)fabs((double)x_det - x_pred[3 + 2 * j]);
-                const float yd = (float)fabs((double)y_det - x_pred[3 + 2 * j + 1]);
+                const float xd = slam::assoc_abs((double)x_det - x_pred[3 + 2 * j], cfg.ekf_abs_is_int);       // ekf.cpp:91-92: which `abs`
+                const float yd = slam::assoc_abs((double)y_det - x_pred[3 + 2 * j + 1], cfg.ekf_abs_is_int);
                 if (xd < cfg.min_landmark_separation && yd < cfg.min_landmark_separation) { i = j; id = j; break; }
             }
         } else {                                     // ekf.cpp:99-108
@@ -314,7 +314,8 @@ int Ekf::update_t(float fwd, float ang, const float* meas, int k) {
                 M = M_before; ids = ids_before; timestep -= 1; x_pred = x_t; P_pred = P_t;
                 return flags;
             }
-            const double dx = x_t[ii] - x_pred[0], dy = x_t[ii + 1] - x_pred[1];
+            const double* xl = cfg.ekf_landmark_from_x_pred ? x_pred.data() : x_t.data();   // quirk D-2: the landmark comes from x_t
+            const double dx = xl[ii] - x_pred[0], dy = xl[ii + 1] - x_pred[1];
             const float dist = (float)::sqrt(MP::sq(dx) + MP::sq(dy));      // ekf.cpp:115 (float)
             const double dd = (double)dist, d2 = (double)(dist * dist);     // dist*dist is a float product
             const double H0[5] = {-dx / dd, -dy / dd, 0.0, dx / dd, dy / dd};

@@ -351,13 +351,20 @@ struct Ukf {
         for (int i = 0; i < ns; ++i) {
             const double dx = (loc ? mx : xpred_elem(li, i, nn)) - xpred_elem(0, i, nn), dy = (loc ? my : xpred_elem(li + 1, i, nn)) - xpred_elem(1, i, nn);
             Z0[i] = ::sqrt(MP::sq(dx) + MP::sq(dy)) + (double)cfg.w_r;
-            Z1[i] = remainder((MP::atan2(dy, dx) - (double)yaw) + (double)cfg.w_b, slam::kTwoPi);
+            double yaw_i = (double)yaw;
+            if (cfg.ukf_sensing_yaw_from_sigma) {   // quirk D-9 off: the yaw of the sigma point the model is evaluated at
+                const double v[4] = {0.0, 0.0, xpred_elem(2, i, nn), xpred_elem(3, i, nn)};
+                yaw_i = (double)yaw_of<MP>(v);
+            }
+            Z1[i] = remainder((MP::atan2(dy, dx) - yaw_i) + (double)cfg.w_b, slam::kTwoPi);
         }
-        double z0 = 0.0;
-        for (int i = 0; i < ns; ++i) z0 = z0 + wt(i, nn) * Z0[i];   // z_est(1) is never accumulated (ukf.cpp:310-314)
+        double z0 = 0.0, z1 = 0.0;
+        for (int i = 0; i < ns; ++i) z0 = z0 + wt(i, nn) * Z0[i];   // z_est(1) is never accumulated (ukf.cpp:310-314) ...
+        if (cfg.ukf_accumulate_zest1)                               // ... unless quirk D-8 is switched off
+            for (int i = 0; i < ns; ++i) z1 = z1 + wt(i, nn) * Z1[i];
         double S[4] = {0, 0, 0, 0};
         for (int i = 0; i < ns; ++i) {
-            const double d0 = Z0[i] - z0, d1 = remainder(Z1[i] - 0.0, slam::kTwoPi);
+            const double d0 = Z0[i] - z0, d1 = remainder(Z1[i] - z1, slam::kTwoPi);
             const double w0 = wt(i, nn) * d0, w1 = wt(i, nn) * d1;
             S[0] = S[0] + w0 * d0; S[1] = S[1] + w0 * d1; S[2] = S[2] + w1 * d0; S[3] = S[3] + w1 * d1;
         }
@@ -367,7 +374,7 @@ struct Ukf {
             double c0 = 0.0, c1 = 0.0;
             for (int i = 0; i < ns; ++i) {
                 const double wd = wt(i, nn) * (xpred_elem(r, i, nn) - x_pred[r]);
-                const double d0 = Z0[i] - z0, d1 = remainder(Z1[i] - 0.0, slam::kTwoPi);
+                const double d0 = Z0[i] - z0, d1 = remainder(Z1[i] - z1, slam::kTwoPi);
                 c0 = c0 + wd * d0; c1 = c1 + wd * d1;
             }
             C[(size_t)2 * r] = c0; C[(size_t)2 * r + 1] = c1;
@@ -375,7 +382,7 @@ struct Ukf {
         double Si[4];
         if (!inv2x2_lu(S, Si)) flags |= SLAM_INST_S_SINGULAR;
         std::vector<double> K((size_t)nn * 2), KS((size_t)nn * 2);
-        const double i0 = (double)r_m - z0, i1 = remainder((double)b_m - 0.0, slam::kTwoPi);
+        const double i0 = (double)r_m - z0, i1 = remainder((double)b_m - z1, slam::kTwoPi);
         for (int r = 0; r < nn; ++r) {
             K[(size_t)2 * r] = C[(size_t)2 * r] * Si[0] + C[(size_t)2 * r + 1] * Si[2];
             K[(size_t)2 * r + 1] = C[(size_t)2 * r] * Si[1] + C[(size_t)2 * r + 1] * Si[3];

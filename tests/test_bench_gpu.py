@@ -63,6 +63,23 @@ def test_two_ranks_strong_scaling_on_one_gpu():
     assert d["config"]["state_rmse_vs_oracle"] == 0.0 and d["config"]["instances_flagged"] == 0
 
 
+def test_two_ranks_short_window_reports_the_long_launch():
+    """N > 1 and a K-step window below 10 ms per GPU: `value` comes from the 1000-step steady-state launch of the same run (the host-clocked
+    barrier brackets would otherwise be a visible share of a 2.5 ms window at N = 8); the K-step figures stay in k_step_window / device_time."""
+    env = dict(os.environ, BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--batch", "4096", "--no-cpu-baseline", "--no-once-per-step"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 5
+    assert d["config"]["value_source"].startswith("steady_state_long_run") and "steady-state launch" in d["config"]["parallelism"]
+    assert d["k_step_window"]["steps"] == 5 and d["k_step_window"]["value"] > 0
+    assert abs(d["value"] - d["config"]["steady_state_long_run"]["value"]) <= 1e-6 * d["value"]
+    assert d["config"]["state_rmse_vs_oracle"] == 0.0
+
+
 def test_two_ranks_over_rccl_on_one_gpu_or_the_reason_why_not():
     """the RCCL branch of bench.py (init_process_group("nccl"), the barrier-bracketed timing, the end-of-run
     all-gather / all-reduce of the error statistics) has only ever run with one rank.  Two ranks on GPU 0 over the nccl backend

@@ -255,6 +255,31 @@ def test_config_switches(S, oracle, quirk, idknown):
     f.close()
 
 
+@pytest.mark.parametrize("switch,idknown,L_max,fixture,T", [("ekf_abs_is_int", 0, 50, "sim_seed2_L50_T1000.npz", 400), ("ekf_abs_is_int", 0, 230, "sim_seed2_L50_T1000.npz", 120),
+                                                            ("ekf_landmark_from_x_pred", 1, 20, "sim_seed1_L20_T400.npz", 160),
+                                                            ("ekf_landmark_from_x_pred", 1, 230, "sim_seed1_L20_T400.npz", 160)])
+def test_appendix_d_quirk_switches_ekf(S, oracle, switch, idknown, L_max, fixture, T):
+    """SURVEY Appendix D asks for every quirk behind a named switch: `ekf_abs_is_int` (the unqualified abs of
+    ekf.cpp:91-92 as ::abs(int): the association box becomes +-1) and `ekf_landmark_from_x_pred` (D-2: the landmark of an update read
+    from x_pred instead of x_t).  Switched ON - i.e. NOT the reference's behaviour - kernel and oracle still agree bit for bit, and the
+    trajectory differs from the default one (the switch is not vacuous); fast class and, for D-2, the HBM-streamed class (L_max 230)."""
+    g = load_golden(fixture)
+    res = {}
+    for on in (0, 1):
+        cfg = S.default_config(); cfg.landmark_id_is_known = idknown; cfg.w_r = 0.01; cfg.v_d = 0.002
+        setattr(cfg, switch, on)
+        f = S.BatchedEKF(2, L_max).readParams(cfg); f.init(0, 0, 0)
+        e = oracle.OracleEKF(cfg=cfg, L_max=L_max); e.init(0, 0, 0)
+        for t in range(T):
+            k = int(g["meas_count"][t])
+            f.update(g["cmds"][t], g["meas"][t, :k].ravel()); e.update(g["cmds"][t, 0], g["cmds"][t, 1], g["meas"][t, :k])
+            if t % 40 == 39:
+                _assert_state_equal(f.get_state(1), e.state())
+        res[on] = f.get_state(0)
+        f.close()
+    assert res[0]["M"] != res[1]["M"] or not np.array_equal(res[0]["x"], res[1]["x"])
+
+
 def test_call_order_errors(S):
     f = S.BatchedEKF(2, 20).readParams()
     with pytest.raises(S.SlamError):

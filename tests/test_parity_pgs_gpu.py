@@ -298,7 +298,7 @@ def test_fused_chain_syrk_and_slot_list_agree_with_the_oracle(monkeypatch, oracl
         assert np.array_equal(res[("2", "1")][b], res[("4", "1")][b]) and np.array_equal(res[("3", "1")][b], res[("4", "1")][b])
 
 
-@pytest.mark.parametrize("L,T,KP,B", [(20, 150, 8, 12), (8, 31, 8, 5), (8, 33, 8, 5), (8, 34, 8, 5), (8, 65, 8, 5), (100, 250, 24, 6),
+@pytest.mark.parametrize("L,T,KP,B", [(20, 150, 8, 12), (8, 31, 8, 5), (8, 32, 8, 5), (8, 33, 8, 5), (8, 34, 8, 5), (8, 65, 8, 5), (8, 16, 8, 3), (8, 7, 8, 3), (100, 250, 24, 6),
                                       (60, 400, 16, 9), (200, 999, 32, 5)])
 def test_segmented_elimination_agrees_with_the_oracle(monkeypatch, oracle, L, T, KP, B):
     """Round 5: the pose chain is eliminated segment by segment (pgs_seg_impl.h: interiors of the segments side by side, then the
@@ -390,4 +390,27 @@ def test_the_ill_conditioned_instance_of_the_round_4_soak(monkeypatch, oracle, s
         g1 = pg.get_graph(b, 1); M = r["M"][b]
         err = max(np.abs(g1["poses"] - r["pose_res"][b]).max(), np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max())
         assert err < max(POSE_TOL, 10.0 * spread[b]), (b, err, spread[b])
+    pg.close()
+
+
+@pytest.mark.parametrize("L,T,KP,B,seed,sc,seg,groups", [(200, 278, 4, 10, 898228925, 220903737, "32", 0), (200, 359, 8, 14, 41288564, 1035020105, "16", 0),
+                                                         (150, 274, 4, 8, 111986297, 1010396802, "5", 3)])
+def test_segmented_elimination_on_graphs_that_drop_detections(monkeypatch, oracle, L, T, KP, B, seed, sc, seg, groups):
+    """Found by tools/gpu_soak_pgs.py (round 5): with 4 - 8 factor slots per pose on a dense map most detections are dropped
+    (PGS_FLAG_MEAS_CAP) while their landmarks are still created, so a landmark's first FACTOR can come long after those of landmarks
+    numbered after it - the per-landmark first separator was not monotone in the landmark index, which the tile SYRK's k trimming assumes
+    (steps wrong by metres, LM paths of 50 - 100 iterations).  The plan now takes the suffix minimum."""
+    import live_ekf_slam_amd as S
+    lm, cmds = make_scenario(sc, L, T)
+    cfg = default_config()
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=seed, cfg=cfg, nthreads=8)
+    assert np.all(r["flags"] & 4)     # the premise: every instance dropped detections
+    monkeypatch.setenv("SLAM_PGS_SEG", seg)
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+    if groups:
+        pg.set_groups(groups)
+    pg.set_map(lm); pg.set_seed(seed); pg.init(0.0, 0.0, 0.0)
+    pg.run_sim(cmds); pg.solvePoseGraph()
+    assert pg.last_solve_paths()["segmented"]
+    _compare(pg, r, B)
     pg.close()

@@ -142,6 +142,30 @@ def test_ukf_many_detections_and_config_switches(S, oracle):
         f.close(); g.close()
 
 
+@pytest.mark.parametrize("switch,L", [("ukf_accumulate_zest1", 20), ("ukf_sensing_yaw_from_sigma", 20), ("ukf_accumulate_zest1", 60), ("ukf_sensing_yaw_from_sigma", 60)])
+def test_appendix_d_quirk_switches_ukf(S, oracle, switch, L):
+    """`ukf_accumulate_zest1` (D-8: z_est(1) accumulated instead of left at 0, ukf.cpp:310-314) and `ukf_sensing_yaw_from_sigma` (D-9: the
+    sensing model's yaw from its sigma-point argument instead of x_t, ukf.cpp:139).  Switched ON kernel and oracle agree bit for bit and the
+    result differs from the default; LDS class (L = 20) and HBM-streamed class (L = 60)."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    B, T = 4, 120 if L == 20 else 60
+    lm, cmds = make_scenario(1234, L, T)
+    res = {}
+    for on in (0, 1):
+        cfg = S.default_config(); cfg.w_r = 0.01; cfg.w_b = 0.003
+        setattr(cfg, switch, on)
+        f = S.BatchedUKF(B, L).readParams(cfg); f.set_map(lm); f.set_seed(9); f.init(0, 0, 0)
+        f.run_sim(cmds)
+        r = oracle.run_ukf_batch(lm, cmds, B, L, seed=9, cfg=cfg, nthreads=4)
+        assert r["M"].max() >= 2
+        for b in range(B):
+            n = 4 + 2 * r["M"][b]
+            _eq(f.get_state(b), dict(M=r["M"][b], ids=r["ids"][b, :r["M"][b]], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+        res[on] = f.get_state(0)["x"].copy()
+        f.close()
+    assert res[0].shape != res[1].shape or not np.array_equal(res[0], res[1])
+
+
 def test_ukf_loc_mode(S, oracle):
     """FilterChoice::UKF_LOC (ukf.cpp:146-154, localization_node.cpp:39-41,152-156): vehicle-only state, every
     detection updates against the known (float32) map; host-fed reference stream and device-generated streams."""

@@ -224,8 +224,9 @@ def explore(KG, pass_min, NS, steps, f32, SD=2, k_choices=None, clamp=True, max_
 @pytest.mark.parametrize("KG", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("f32", [0, 1])
 def test_decoupled_loop_protocol_has_no_deadlock_and_keeps_its_invariants(KG, f32):
-    # the kernel's thresholds: passes start at SLAM_PASS_MIN = 4 pending updates (fp32 storage: 3), clamped to the ring size
-    pass_min = 3 if f32 else 4
+    # the kernel's thresholds (ekf_kernel_impl.h, kPassMinCfg): fp64 passes start at SLAM_PASS_MIN = 4 pending updates, from six ring slots
+    # on at KG - 1; fp32 storage at 3, from five slots on at KG - 2 (round 5); clamped to the ring size
+    pass_min = (KG - 2 if KG > 4 else 3) if f32 else (KG - 1 if KG > 5 else 4)
     total = 0
     for NS, steps in ((1, 3), (2, 3), (3, 2)):          # W = 2, 3, 4 wavefronts per filter
         n, bad = explore(KG, pass_min, NS, steps, f32)
