@@ -48,8 +48,10 @@ enum slam_instance_flags {
                                     repeat of a mapped id is a second update - as the reference's loop does, detection by detection) */
     SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146), or a
                                     message held more detections than the landmark capacity of the handle's size class (20 / 50 /
-                                    100 / 200), which takes repeated ids; the surplus was dropped.  (The HBM-streamed EKF class,
-                                    L_max > 200, walks a message of any length where it lies, like ekf.cpp:73.)        */
+                                    100 / 200), which takes repeated ids; the surplus was dropped.  That limit holds for messages that
+                                    are already on the device (slam_step_dev, the simulator) and for fp32 storage / the UKF; fp64 EKF
+                                    handles walk a HOST message (slam_step) of any length like ekf.cpp:73 - one that exceeds the class
+                                    takes its timestep through the HBM-streamed kernel, as every message of an L_max > 200 handle does */
     SLAM_INST_SQRT_FAILED = 16,  /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
     SLAM_INST_WATCHDOG = 32      /* EKF: a polling loop of the step kernel's intra-workgroup protocol exceeded its budget (~0.1 s);
                                     the instance is frozen with an undefined state instead of hanging the GPU.  A defect if it ever
@@ -114,7 +116,12 @@ int slam_config_load(slam_config* cfg, const char* yaml_path);
  * state holds no landmarks - its map may have any size, one message up to 50 detections [20 while the map has <= 20 landmarks]; a
  * longer one raises SLAM_INST_CAPACITY and loses the surplus).  The reference grows the state without limit (ekf.cpp:144-146); here the limit of the
  * fast classes is what one workgroup keeps in the 160 KB of LDS of a CU, and of the streamed class 2 x n x n doubles per instance in HBM.
- * dtype SLAM_F32 (fp32 storage of x and P, fp64 arithmetic) is available for EKF_SLAM. */
+ * dtype SLAM_F32 (fp32 storage of x and P, fp64 arithmetic) is available for EKF_SLAM.
+ * UKF results depend on the capacity CLASS: the eigen-decomposition of nearestSPD / sqrt (ukf.cpp:106-123,208) is a cyclic
+ * Jacobi iteration whose pair schedule is this build's choice (the reference calls Eigen) - the LDS classes pad the state size to a multiple
+ * of four and walk the schedule over quadruples, the HBM-streamed class (L_max > 50) runs the circle method over the indices - so the same
+ * measurement stream gives factors that differ in the last bits between an L_max = 50 and an L_max = 51 handle (each bit-identical to the
+ * oracle configured with the same L_max, each within 1e-12 of LAPACK's eigh: tests/test_oracle_ukf.py, tests/test_jacobi_schedule.py). */
 int slam_create(const slam_config* cfg, int filter_kind, int batch, int L_max, int dtype, int device,
                 slam_handle** out);
 int slam_destroy(slam_handle* h);

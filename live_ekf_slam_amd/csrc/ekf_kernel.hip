@@ -87,6 +87,7 @@ int ekf_variant_available(int L_max, int f32_storage, int variant) {
 
 hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage, hipStream_t stream) {
     if (p.L_max > kEkfLdsMaxLandmarks) return f32_storage ? hipErrorInvalidConfiguration : launch_ekf_big_step(p, stream);
+    if (p.force_streamed && !f32_storage) return launch_ekf_big_step(p, stream);
     const EkfVariant* v = pick_variant(p.L_max, p.B, variant, f32_storage);
     if (!v) return hipErrorInvalidConfiguration;
     return v->launch(p, stream);

@@ -205,12 +205,13 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
 }
 
 // one timestep, either filter kind; `sim` = device-side measurement generator
-int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas, const int32_t* d_count, int k_stride) {
+int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas, const int32_t* d_count, int k_stride, bool over_long = false) {
     if (h->predicted) return fail(SLAM_ERR_STATE, "a prediction stage is pending: call slam_update_dev before the next step");
     if (h->kind == SLAM_EKF_SLAM) {
         slam::EkfStepParams p;
         fill_params(h, p, cmd);
         p.sim = sim;
+        p.force_streamed = over_long ? 1 : 0;
         p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
         if (sim && h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
         HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
@@ -663,7 +664,13 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
     HIP_TRY(hipMemcpyAsync(s.dmeas, s.hmeas, sizeof(float) * need, hipMemcpyHostToDevice, h->copy_stream));
     HIP_TRY(hipEventRecord(s.copied, h->copy_stream));
     HIP_TRY(hipStreamWaitEvent(h->stream, s.copied, 0));
-    int rc = launch_step(h, cmd, 0, s.dmeas, s.dcount, kmax);
+    // ekf.cpp:65,73 walk a message of any length.  The LDS size classes hold as many detections per message as they hold landmarks - every
+    // message without repeated ids fits - and drop the surplus with SLAM_INST_CAPACITY; a message beyond that (the host sees the counts here)
+    // takes this one timestep through the HBM-streamed kernel, which reads the message where it lies: same state layout, same arithmetic
+    // (both are bit-identical to the oracle), about a pass over P per detection slower.  fp64 EKF handles; the fp32-storage and the UKF
+    // classes keep the documented limit (the UKF's streamed class runs another Jacobi schedule: include/slam_batch.h).
+    const bool over_long = h->kind == SLAM_EKF_SLAM && h->esz == 8 && kmax > slam::ekf_class_message_capacity(h->L_max);
+    int rc = launch_step(h, cmd, 0, s.dmeas, s.dcount, kmax, over_long);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.used, h->stream));
     s.in_use = true;

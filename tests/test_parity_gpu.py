@@ -706,6 +706,52 @@ def test_streamed_class_walks_messages_of_any_length(S, oracle, idknown):
     f.close()
 
 
+@pytest.mark.parametrize("L,idknown", [(20, 1), (50, 1), (50, 0), (100, 1)])
+def test_over_long_host_messages_walk_every_detection_in_the_lds_classes(S, oracle, L, idknown):
+    """ekf.cpp:65,73 walk a message of any length; the LDS size classes hold L_class detections per message and drop
+    the surplus with SLAM_INST_CAPACITY.  Round 5: slam_step sees the counts, so a message beyond the class's capacity takes that one
+    timestep through the HBM-streamed kernel (same state layout, same arithmetic): fp64 EKF handles now follow the oracle WITHOUT its
+    per-message limit, interleaved with ordinary messages (fast kernel, queued and immediate), bit for bit and flag for flag.  The
+    fp32-storage class keeps the documented limit (the oracle restates it under set_message_capacity)."""
+    cap = 20 if L <= 20 else (50 if L <= 50 else 100)
+    for f32 in (False, True):
+        if f32 and L > 50:
+            continue
+        B, T = 4, 12
+        cfg = S.default_config(); cfg.landmark_id_is_known = idknown
+        f = S.BatchedEKF(B, L, dtype=S.F32 if f32 else S.F64).readParams(cfg); f.init(0.0, 0.0, 0.0)
+        es = []
+        for b in range(B):
+            e = oracle.OracleEKF(cfg, L_max=L, mode=oracle.MODE_FAST | (oracle.STORAGE_F32 if f32 else 0))
+            e.set_message_capacity(cap if f32 else 0)
+            e.init(0, 0, 0); es.append(e)
+        rng = np.random.default_rng(11 + L + idknown)
+        of = np.zeros(B, dtype=np.int64)
+        for t in range(T):
+            cmd = np.array([rng.uniform(0, 0.1), rng.uniform(-0.05, 0.05)], dtype=np.float32)
+            ks = rng.integers(0, 4, B)                        # ordinary messages ...
+            if t in (2, 5, 6, 9): ks[rng.integers(0, B)] = cap + int(rng.integers(1, 40))   # ... and over-long ones, for one instance at a time
+            if t == 7: ks[:] = cap + 5
+            K = max(1, int(ks.max()))
+            meas = np.zeros((B, K, 3), dtype=np.float32)
+            for b in range(B):
+                k = int(ks[b])
+                meas[b, :k, 0] = rng.integers(0, L + 10, k)   # repeated ids and ids beyond the capacity included
+                meas[b, :k, 1] = rng.uniform(0.5, 6.0, k)
+                meas[b, :k, 2] = rng.uniform(-3.1, 3.1, k)
+            f.update(cmd, meas, ks.astype(np.int32))
+            for b in range(B):
+                of[b] |= es[b].update(cmd[0], cmd[1], meas[b, :ks[b]])
+        assert np.array_equal(f.status().astype(np.int64), of), (f32, f.status(), of)
+        for b in range(B):
+            if of[b] & 4:
+                continue    # frozen in the pre-step state by a repeat of a freshly inserted id: compared through the flags
+            so, sg = es[b].state(), f.get_state(b)
+            assert sg["M"] == so["M"] and np.array_equal(sg["ids"], so["ids"])
+            assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"]), (f32, b)
+        f.close()
+
+
 @pytest.mark.parametrize("kind", ["ekf", "ekf_f32", "ukf"])
 def test_checkpoint_and_resume_are_bit_identical(S, tmp_path, kind):
     """slam_save_state / slam_load_state (the reference keeps the filter only in memory): a run continued from a checkpoint

@@ -26,7 +26,8 @@ while time.time() < t_end:
     kcap = int(rng.choice([2, 6, 20, 70] + ([300] if L > 200 else [])))
     # a message holds at most the size class's landmark count (include/slam_batch.h: the surplus is dropped, SLAM_INST_CAPACITY); the oracle
     # restates that limit under a switch (set_message_capacity), so over-long messages are drawn too and the flags compared exactly
-    class_cap = (20 if L <= 20 else 50) if ukf else (20 if L <= 20 else (50 if L <= 50 else (100 if L <= 100 else (200 if L <= 200 else 0))))
+    # (round 5: fp64 EKF handles route an over-long host message through the HBM-streamed kernel: no limit there any more)
+    class_cap = (20 if L <= 20 else 50) if ukf else ((20 if L <= 20 else 50) if f32 else 0)
     idmax = int(rng.choice([max(2, L // 2), L, 2 * L, 400]))
     idmin = int(rng.choice([0, 0, -3, -40]))   # any int is an id for the reference (ekf.cpp:99-108), negative ones included (-1 / -2 were sentinels once)
     seed = int(rng.integers(1, 1 << 30))
