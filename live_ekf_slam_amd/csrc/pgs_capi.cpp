@@ -420,7 +420,10 @@ int pgs_solve(pgs_handle* h) {
     }
     HIP_TRY(hipMemsetAsync(h->p.work, 0, 3 * sizeof(double), h->stream));
     h->path_ms[0] = h->path_ms[1] = h->path_ms[2] = 0.0;
-    int G = h->groups > 0 ? h->groups : (h->B >= 512 ? 2 : 1);
+    // (round 5: two groups from batch 128 on - with the segmented elimination a trial's kernels are short enough for two LM loops to fill
+    // each other's gaps: 5.20 -> 5.67 k solves/s at batch 256 (three groups 5.47 k, four 3.57 k), 3.49 -> 3.64 k at batch 128, 7.39 k at
+    // 1024 (three: 7.59 k); profiles/r05_pgs/groups_and_lanes.txt)
+    int G = h->groups > 0 ? h->groups : (h->B >= 128 ? 2 : 1);
     if (G > 16) G = 16;
     if (G > h->B) G = h->B;
     if (h->profiling) G = 1;   // per-kernel timing wants the kernels of one stream back to back
