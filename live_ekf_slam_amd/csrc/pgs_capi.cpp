@@ -472,7 +472,24 @@ int pgs_solve(pgs_handle* h) {
         return SLAM_OK;
     }
     // ---- G groups, each with its own stream and LM loop; the host serves them round-robin ----
-    while ((int)h->gstreams.size() < G) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); h->gstreams.push_back(st); }
+    // The groups' streams must not share a hardware queue: two LM loops whose launches sit in ONE in-order queue wait for each other's
+    // queued trials at every host synchronisation (measured inside bench.py's driver command, where the earlier legs' streams shift the
+    // runtime's stream -> queue assignment: 3.40 k solves/s with two groups against 5.21 k with one and 5.66 k with two on distinct
+    // queues; profiles/r05_pgs/hw_queues.txt).  The runtime keeps separate queues per stream PRIORITY, so the groups alternate between
+    // the priority levels the device offers (SLAM_PGS_GROUP_PRIO=0: all at the default priority, the behaviour before).
+    while ((int)h->gstreams.size() < G) {
+        hipStream_t st;
+        int lo = 0, hi = 0;
+        static const bool use_prio = !(getenv("SLAM_PGS_GROUP_PRIO") && atoi(getenv("SLAM_PGS_GROUP_PRIO")) == 0);
+        if (use_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+            const int nlev = lo - hi + 1, g = (int)h->gstreams.size();   // lo = least priority (numerically greatest), hi = greatest
+            HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi + (g % nlev)));
+        } else {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        }
+        h->gstreams.push_back(st);
+    }
     while ((int)h->gevents.size() < G + 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->gevents.push_back(e); }
     if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 64, hipHostMallocDefault));
     HIP_TRY(hipEventRecord(h->gevents[G], h->stream));   // everything queued on the handle's stream so far comes first
