@@ -1659,6 +1659,7 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
     constexpr int CTPB = 1024, NB = 16, NBL = 4, NW = CTPB / 64;
     extern __shared__ double s_dyn[];
     __shared__ double s_diag[NB], s_rdiag[NB];
+    __shared__ double s_xi[NB][NB + 1];   // inverse of the current diagonal block
     __shared__ int s_fail;
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
@@ -1793,6 +1794,37 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
                     if (c <= r) { SD(r, c) = v; grow[c] = v; }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the block's rows are in LDS
+            // X = L_block^-1 (lower triangular), column `lane` per lane by forward substitution  x_r = -(sum_{k<r} l(r, k) x_k) / l(r, r)
+            // through LDS (l(r, k): one broadcast read; x_k: the lane's own column of s_xi, written by itself).  The panel solve below is then
+            // rows * X^T  on the matrix pipe and the backward substitution a product with X^T: round 4 measured both (panel solve 105 -> 18 us,
+            // backward 67 -> 44 us per factorisation) and dropped them for the 5 us per block the inverse cost wavefront 0, then the long pole
+            // of this phase; behind the register-resident factorisation it fits in the shadow of the other wavefronts' tiles.  (With the
+            // column in 16 registers next to dg[] the kernel spilled: 12 us per block.)
+            if (lane < NB) {
+                const int cx = lane;
+                s_xi[0][cx] = cx == 0 && nb > 0 ? s_rdiag[0] : 0.0;
+#pragma unroll 1
+                for (int r = 1; r < NB; ++r) {
+                    double v = 0.0;
+                    if (r < nb && cx < nb) {
+                        double a = 0.0;
+#pragma unroll 4
+                        for (int k = 0; k < r; ++k) a += SD(r, k) * s_xi[k][cx];   // (x_k = 0 above the diagonal of X: rows k < cx hold zeros)
+                        const double rdr = s_rdiag[r];
+                        v = r == cx ? rdr : (r > cx ? -(a * rdr) : 0.0);
+                    }
+                    s_xi[r][cx] = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // s_xi is complete
+            if (lane < NB && lane < nb) {   // the strictly lower part of X goes into the (unused) strictly UPPER part of the block in S:
+                const int k = lane;         // row j0 + k holds X(c, k), c > k - column k of X, what the backward substitution's lane k needs
+                double* grow = Sb + (size_t)(j0 + k) * LD + j0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (c > k && c < nb) grow[c] = s_xi[c][k];
+            }
         } else if (has_next) {
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
@@ -1824,28 +1856,21 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         }
         __syncthreads();
         PGS_STAMP(1);   // diagonal block (+ the next panel's tiles beside it)
-        // (Measured and dropped: the panel solve as 4 MFMAs per tile against the INVERSE of the diagonal block, and the backward substitution
-        // as a product with it - panel solve 105 -> 18 us, backward 67 -> 44 us per factorisation, but forming the inverse costs wavefront 0,
-        // already the long pole of the diagonal phase, 5 us per block: 414 -> 457 us in all.)
-        for (int rr = nb + tid; rr < R; rr += CTPB) {   // panel solve: row <- row * L_block^-T, written to memory as L
-            double x[NB];
+        // (Round 4 measured the panel solve against the INVERSE of the diagonal block and dropped it: forming the inverse through LDS cost
+        // wavefront 0, then the long pole of the diagonal phase, 5 us per block - 414 -> 457 us in all.  Round 5 forms it in registers.)
+        // panel solve: rows * L_block^-T = rows * X^T, 16 x 16 tiles of the rows below the block as four MFMAs each (A = the rows of the
+        // panel in LDS, B = X), written to memory as L.  (A thread per row walked a 16-step forward substitution out of LDS: 105 us per
+        // factorisation.)
+        for (int t = (nb == NB ? 1 : 0) + w; t < nt; t += NW) {   // (tile 0 = the block itself, unless the block is short: then it also holds rows below it)
+            dbl4_t acc = dbl4_t{0.0, 0.0, 0.0, 0.0};
+            const int ar = 16 * t + cl < R ? 16 * t + cl : R - 1;   // (rows past the panel: clamped, never stored)
 #pragma unroll
-            for (int c = 0; c < NB; ++c) x[c] = c < nb ? SD(rr, c) : 0.0;
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(SD(ar, 4 * q + kq), s_xi[cl][4 * q + kq], acc, 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < NB; ++c) {
-                if (c < nb) {
-                    double v = x[c];
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        if (k < c) v -= x[k] * SD(c, k);
-                    x[c] = v * s_rdiag[c];
-                }
-                asm volatile("" ::: "memory");   // keep the LDS reads of later columns from being hoisted (register pressure)
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rl = 16 * t + kq + 4 * r4;
+                if (rl >= nb && rl < R && cl < nb) Sb[(size_t)(j0 + rl) * LD + j0 + cl] = acc[r4];
             }
-            double* row = Sb + (size_t)(j0 + rr) * LD + j0;
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                if (c < nb) row[c] = x[c];
         }
         __syncthreads();   // L of this panel is in memory before the next panel's tiles read its columns; s_c is free again
         PGS_STAMP(2);
@@ -1862,7 +1887,7 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
     {
         const int j0 = (nblk - 1) * NB, nb = m2 - j0;
         const int r = tid >> NBL, c = tid & (NB - 1);
-        if (tid < NB * NB && r < nb && c <= r) dreg = Sb[(size_t)(j0 + r) * LD + j0 + c];
+        if (tid < NB * NB && r < nb && c < nb) dreg = Sb[(size_t)(j0 + r) * LD + j0 + c];   // the whole block: L below / on the diagonal, X above it
     }
     __syncthreads();
     for (int bi = nblk - 1; bi >= 0; --bi) {
@@ -1870,25 +1895,26 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
         {
             const int r = tid >> NBL, c = tid & (NB - 1);
-            if (tid < NB * NB && r < nb && c <= r) s_d[r][c] = dreg;
+            if (tid < NB * NB && r < nb && c < nb) s_d[r][c] = dreg;
         }
         double lrow[NB];                       // L[j0 + k][c] for this thread's column c < j0 (m2 <= CTPB: one column per thread)
 #pragma unroll
         for (int k = 0; k < NB; ++k) lrow[k] = (tid < j0 && k < nb) ? Sb[(size_t)(j0 + k) * LD + tid] : 0.0;
         if (bi > 0) {                          // the next block's diagonal block
             const int r = tid >> NBL, c = tid & (NB - 1);
-            dreg = (tid < NB * NB && c <= r) ? Sb[(size_t)(j0 - NB + r) * LD + j0 - NB + c] : 0.0;
+            dreg = (tid < NB * NB) ? Sb[(size_t)(j0 - NB + r) * LD + j0 - NB + c] : 0.0;
         }
         __syncthreads();
-        if (tid < 64) {   // lane k owns y[j0 + k]; x_c is broadcast from lane c
-            double yk = tid < nb ? s_y[j0 + tid] : 0.0;
-            const double rd = tid < nb ? 1.0 / s_d[tid][tid] : 0.0;
-            for (int c = nb - 1; c >= 0; --c) {
-                const double xc = __shfl(yk, c, 64) * __shfl(rd, c, 64);
-                if (tid == c) yk = xc;
-                if (tid < c) yk -= s_d[c][tid] * xc;
+        if (tid < 64) {   // x_block = X^T y_block: lane k sums column k of X (the block's strictly upper part in S holds it, row k) against y
+            double xk = 0.0;
+            if (tid < nb) {
+                xk = (1.0 / s_d[tid][tid]) * s_y[j0 + tid];   // X(k, k) = 1 / l(k, k)
+#pragma unroll
+                for (int c = 1; c < NB; ++c)
+                    if (c > tid && c < nb) xk += s_d[tid][c] * s_y[j0 + c];   // X(c, k), staged from S[j0 + k][j0 + c]
             }
-            if (tid < nb) s_y[j0 + tid] = yk;
+            __builtin_amdgcn_wave_barrier();   // every lane has read y before any lane overwrites it
+            if (tid < nb) s_y[j0 + tid] = xk;
         }
         __syncthreads();
         if (tid < j0) {   // y[c] -= sum_k L[j0+k][c] x[j0+k]
