@@ -1744,8 +1744,7 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         if (((ldb >> 2) & 1) == 0) ldb += 4;
         // The diagonal block in wavefront 0's REGISTERS (round 5): lane r (mod 16; the four lane groups hold replicas) keeps row r, the
         // pivot and the column entries l(c2, c) another row needs arrive by v_readlane.  Through LDS - lane = (row, column group), two
-        // fenced round trips per column - a column cost ~1 300 cycles, 8.6 us per block, 190 of the 400 us of a factorisation.  Per
-        // element the same sqrt, the same division and the same  a - l * l  in the same order: the factor is bit-identical.
+        // fenced round trips per column - a column cost ~1 300 cycles, 8.6 us per block, 190 of the 400 us of a factorisation.
         auto diag_cols = [&](auto lo_tag, auto hi_tag) {
             constexpr int c_lo = decltype(lo_tag)::value, c_hi = decltype(hi_tag)::value;
             const int r = lane & 15;
@@ -1753,12 +1752,14 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
             for (int c = c_lo; c < c_hi; ++c) {
                 if (c >= nb) break;   // wave-uniform
                 const double d = dgl_rd(dg[c], c);   // the pivot: entry c of row c
-                const double sd = sqrt(d > 0.0 ? d : 1.0);
+                // 1 / sqrt(d) by v_rsq_f64 + two Newton steps (~1 ulp, like the pose chain's pivots): the column is scaled by a product, the
+                // diagonal entry is d * rs - a square root and a division per column were 280 of its ~500 dependent cycles
+                const double rs = rsqrt_nr(d > 0.0 ? d : 1.0);
                 if (lane == c) {
                     if (!(d > 0.0)) s_fail = 1;
-                    s_diag[c] = sd; s_rdiag[c] = 1.0 / sd;
+                    s_diag[c] = d * rs; s_rdiag[c] = rs;
                 }
-                const double lrc = dg[c] / sd;      // meaningful in the rows below c
+                const double lrc = dg[c] * rs;      // meaningful in the rows below c
                 if (r > c) dg[c] = lrc;
 #pragma unroll
                 for (int c2 = c + 1; c2 < NB; ++c2) {
@@ -1771,7 +1772,7 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
             const int r = lane & 15;
 #pragma unroll
             for (int c = 0; c < NB; ++c) dg[c] = (r < nb && c <= r) ? SD(r, c) : 0.0;
-            diag_cols(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+            diag_cols(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});   // all sixteen columns here, the inverse in the second half
         } else if (has_next) {
             for (int e = tid - 64; e < 16 * j0; e += CTPB - 64) {
                 const int r = e / j0, k = e - r * j0;
@@ -1783,7 +1784,6 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         }
         __syncthreads();
         if (w == 0) {
-            diag_cols(std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // s_diag of every column is written
             if (lane < NB && lane < nb) {   // row `lane` of the factored block: to LDS for the panel solve, to memory as L
                 const int r = lane;
@@ -1801,20 +1801,21 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
             // backward 67 -> 44 us per factorisation) and dropped them for the 5 us per block the inverse cost wavefront 0, then the long pole
             // of this phase; behind the register-resident factorisation it fits in the shadow of the other wavefronts' tiles.  (With the
             // column in 16 registers next to dg[] the kernel spilled: 12 us per block.)
-            if (lane < NB) {
-                const int cx = lane;
-                s_xi[0][cx] = cx == 0 && nb > 0 ? s_rdiag[0] : 0.0;
-#pragma unroll 1
-                for (int r = 1; r < NB; ++r) {
-                    double v = 0.0;
-                    if (r < nb && cx < nb) {
-                        double a = 0.0;
-#pragma unroll 4
-                        for (int k = 0; k < r; ++k) a += SD(r, k) * s_xi[k][cx];   // (x_k = 0 above the diagonal of X: rows k < cx hold zeros)
-                        const double rdr = s_rdiag[r];
-                        v = r == cx ? rdr : (r > cx ? -(a * rdr) : 0.0);
-                    }
-                    s_xi[r][cx] = v;
+            {   // (the column in registers - dg[] is dead by now, so they are free - and l(r, k) as broadcast LDS reads the compiler can issue
+                // ahead of the dependent chain; through s_xi in LDS the chain paid a round trip per term: 4 us per block, the long pole)
+                const int cx = lane & 15;
+                double xv[NB];
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int k = 0; k < r; ++k) a += SD(r < nb ? r : 0, k) * xv[k];   // (x_k = 0 above the diagonal of X)
+                    const double rdr = s_rdiag[r];
+                    xv[r] = (r < nb && cx < nb) ? (r == cx ? rdr : (r > cx ? -(a * rdr) : 0.0)) : 0.0;
+                }
+                if (lane < NB) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) s_xi[r][cx] = xv[r];   // X(r, c): row r, column c = lane
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // s_xi is complete
