@@ -2379,7 +2379,8 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     case 1: {
         if (p.seg_on) {   // segmented elimination: the interiors of all segments side by side, then the separator chain
             const int nseg = seg_ns(p.N, p.seg_len) + 1;
-            hipLaunchKernelGGL(pgs_seg_kernel, dim3(nslot * nseg), dim3(SG_TPB), 0, s, p);
+            hipLaunchKernelGGL(pgs_seg_chain_kernel, dim3(nslot), dim3(64 * ((nseg + 63) / 64)), 0, s, p);   // the segments' 3x3 chains: a lane each
+            hipLaunchKernelGGL(pgs_seg_kernel, dim3(nslot * nseg), dim3(SG_TPB), 0, s, p);                     // their column recurrences: a workgroup each
             if (nseg > 1) hipLaunchKernelGGL(pgs_sep_kernel, dim3(nslot), dim3(64 + p.LD), 0, s, p);
             break;
         }

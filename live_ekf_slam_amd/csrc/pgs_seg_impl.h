@@ -158,53 +158,47 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
     if (tid == 0) p.seg_umax[b] = umax;
 }
 
-// ---- interiors of one segment: the 3x3 chain with its spike (one lane), then the column recurrence on the segment's columns ----
-constexpr int SG_TPB = 192;   // >= 2 * kPgsSegMaxLm + 1 columns, one per thread
-__global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
-    // (a segment holds at most SL poses - except the ONLY segment of a graph of exactly SL + 1 poses, which has no separator yet: SL + 1;
-    // found by tools/gpu_soak_pgs.py on 33-pose graphs)
-    __shared__ double s_in[kPgsSegMaxLen + 1][18];    // A (00 10 11 20 21 22), C = H[i][i-1] (the segment's first pose: C_a = H[a+1][a]), g_p
-    __shared__ double s_fac[kPgsSegMaxLen + 1][24];   // Linv (6), Ginn (9), Gs (9)
-    __shared__ double s_ce[9], s_gr[9];
+// ---- interiors of the segments, part 1: the 3x3 chains with their spikes.  ONE workgroup per slot, one LANE per segment: the chains of a
+//      slot's segments are independent and run the same instruction stream, so a wavefront carries 64 of them in lockstep for the price of
+//      one (a workgroup per segment with one busy lane each: 8 192 workgroups at a full batch, 310 us against 36 for the chain itself).  Every
+//      lane fetches its next pose's blocks a step ahead, leaves the factor (Linv, Ginn, Gs) of its poses in global memory for part 2 and the
+//      pose step, and the segment's contributions to its two separators in segout. ----
+__global__ __launch_bounds__(64 * ((kPgsSegMaxSep + 1 + 63) / 64)) void pgs_seg_chain_kernel(const PgsParams p) {
     __shared__ int s_fail;
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
-    const int bl = blockIdx.x / nseg, ps = blockIdx.x - bl * nseg;
-    const int b = pgs_slot(p, bl), tid = threadIdx.x;
+    const int b = pgs_slot(p, blockIdx.x), ps = threadIdx.x;
     if (p.state[b]) return;
-    const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N), len = hi - lo, LD = p.LD;
-    const double lambda = p.lambda[b];
-    const double* Ab = p.A + (size_t)b * p.N_max * 9;
-    const double* Cb = p.C + (size_t)b * p.N_max * 9;
-    const double* gpb = p.gp + (size_t)b * p.N_max * 3;
-    if (tid < len) {
-        const int i = lo + tid;
-        const double* A = Ab + 9 * i;
-        s_in[tid][0] = A[0]; s_in[tid][1] = A[3]; s_in[tid][2] = A[4]; s_in[tid][3] = A[6]; s_in[tid][4] = A[7]; s_in[tid][5] = A[8];
-        if (i > 0) {   // H[i][i-1]; for i = lo and ps >= 1 that is C_a, the coupling to the left separator
-            const double* C = Cb + 9 * (i - 1);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) s_in[tid][6 + k] = C[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) s_in[tid][6 + k] = 0.0;
-        }
-        s_in[tid][15] = gpb[3 * i]; s_in[tid][16] = gpb[3 * i + 1]; s_in[tid][17] = gpb[3 * i + 2];
-    }
-    if (tid >= 64 && tid < 73) s_ce[tid - 64] = ps < NS ? Cb[9 * (size_t)(hi - 1) + (tid - 64)] : 0.0;   // H[b][hi-1]
-    if (tid == 0) s_fail = 0;
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
+    if (ps == 0) s_fail = 0;
     __syncthreads();
-    if (tid == 0) {
+    if (ps < nseg) {
+        const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N), len = hi - lo;
+        const double lambda = p.lambda[b];
+        const double* Ab = p.A + (size_t)b * p.N_max * 9;
+        const double* Cb = p.C + (size_t)b * p.N_max * 9;
+        double* Lb = p.Linv + (size_t)b * p.N_max * 6;
+        double* Gb = p.G + (size_t)b * p.N_max * 9;
+        double* Gsb = p.Gs + (size_t)b * p.N_max * 9;
+        auto fetch = [&](int i, double (&in)[15]) {   // A (00 10 11 20 21 22), H[i][i-1] (zero block before pose 0)
+            const double* A = Ab + 9 * (size_t)i;
+            in[0] = A[0]; in[1] = A[3]; in[2] = A[4]; in[3] = A[6]; in[4] = A[7]; in[5] = A[8];
+            const double* C = Cb + 9 * (size_t)(i > 0 ? i - 1 : 0);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) in[6 + k] = i > 0 ? C[k] : 0.0;
+        };
+        double in[15], nx[15];
+        fetch(lo, in);
         double I[6] = {0, 0, 0, 0, 0, 0}, Gsp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Bc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aL[6] = {0, 0, 0, 0, 0, 0};
-        if (ps >= 1) {   // H[a][lo] = C_a^T
+        if (ps >= 1) {   // H[a][lo] = C_a^T (for the segment's first pose in[6..14] is C_a, the coupling to the left separator)
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Bc[3 * r + c] = s_in[0][6 + 3 * c + r];
+                for (int c = 0; c < 3; ++c) Bc[3 * r + c] = in[6 + 3 * c + r];
         }
         bool ok = true;
 #pragma unroll 1
         for (int l = 0; l < len; ++l) {
-            const double* in = s_in[l];
+            const int i = lo + l;
+            fetch(l + 1 < len ? i + 1 : i, nx);   // the next pose's blocks travel under this pose's chain
             double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (l > 0) mul_linvT(in + 6, I, G);
             const double T0 = (in[0] + lambda) - ((G[0] * G[0] + G[1] * G[1]) + G[2] * G[2]);
@@ -220,11 +214,6 @@ __global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
                 for (int k = 0; k < 9; ++k) Bc[k] = -P[k];
             }
             if (!chol_inv3(T0, T3, T4, T6, T7, T8, I)) { ok = false; break; }
-            double* o = s_fac[l];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = I[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) o[6 + k] = G[k];
             if (ps >= 1) {
                 mul_linvT(Bc, I, Gsp);
                 double q[6];
@@ -232,43 +221,62 @@ __global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) aL[k] += q[k];
             }
+            double* L = Lb + 6 * (size_t)i;
+            double* Go = Gb + 9 * (size_t)i;
+            double* Gso = Gsb + 9 * (size_t)i;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) o[15 + k] = Gsp[k];
+            for (int k = 0; k < 6; ++k) L[k] = I[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { Go[k] = G[k]; Gso[k] = Gsp[k]; }
+#pragma unroll
+            for (int k = 0; k < 15; ++k) in[k] = nx[k];
         }
         double* so = p.segout + ((size_t)b * p.nseg_max + ps) * 32;
         if (ok) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) so[k] = aL[k];
             double Gr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aR[6] = {0, 0, 0, 0, 0, 0}, Hba[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (ps < NS) {
-                mul_linvT(s_ce, I, Gr);
+            if (ps < NS) {   // the right separator couples to the last interior pose through H[hi][hi-1]
+                double ce[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) ce[k] = Cb[9 * (size_t)(hi - 1) + k];
+                mul_linvT(ce, I, Gr);
                 sym_ggT(Gr, aR);
                 if (ps >= 1) mul_abT(Gr, Gsp, Hba);
             }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) so[6 + k] = aR[k];
+            for (int k = 0; k < 6; ++k) { so[k] = aL[k]; so[6 + k] = aR[k]; }
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { so[12 + k] = Gr[k]; so[21 + k] = Hba[k]; s_gr[k] = Gr[k]; }
+            for (int k = 0; k < 9; ++k) { so[12 + k] = Gr[k]; so[21 + k] = Hba[k]; }
         } else {
-            s_fail = 1;
+            s_fail = 1;   // (every failing lane stores the same value)
         }
     }
     __syncthreads();
-    if (s_fail) {
-        if (tid == 0) p.solve_ok[b] = 0;   // (every failing segment stores the same value)
-        return;
+    if (ps == 0 && s_fail) p.solve_ok[b] = 0;
+}
+
+// ---- interiors of the segments, part 2: the column recurrence, one workgroup per (slot, segment), one thread per local column ----
+constexpr int SG_TPB = 128;   // >= 2 * kPgsSegMaxLm + 1 columns, one per thread
+__global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
+    // (a segment holds at most SL poses - except the ONLY segment of a graph of exactly SL + 1 poses, which has no separator yet: SL + 1;
+    // found by tools/gpu_soak_pgs.py on 33-pose graphs)
+    __shared__ double s_fac[kPgsSegMaxLen + 1][28];   // Linv (6), Ginn (9), Gs (9), g_p (3)
+    __shared__ double s_gr[9];
+    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
+    const int bl = blockIdx.x / nseg, ps = blockIdx.x - bl * nseg;
+    const int b = pgs_slot(p, bl), tid = threadIdx.x;
+    if (p.state[b] || !p.solve_ok[b]) return;
+    const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N), len = hi - lo, LD = p.LD;
+    {   // the segment's factor (written by pgs_seg_chain_kernel: L2) and gradient blocks into LDS, coalesced
+        const double* Lb = p.Linv + (size_t)b * p.N_max * 6 + 6 * (size_t)lo;
+        const double* Gb = p.G + (size_t)b * p.N_max * 9 + 9 * (size_t)lo;
+        const double* Gsb = p.Gs + (size_t)b * p.N_max * 9 + 9 * (size_t)lo;
+        const double* gpb = p.gp + (size_t)b * p.N_max * 3 + 3 * (size_t)lo;
+        for (int e = tid; e < 6 * len; e += SG_TPB) s_fac[e / 6][e % 6] = Lb[e];
+        for (int e = tid; e < 9 * len; e += SG_TPB) { s_fac[e / 9][6 + e % 9] = Gb[e]; s_fac[e / 9][15 + e % 9] = Gsb[e]; }
+        for (int e = tid; e < 3 * len; e += SG_TPB) s_fac[e / 3][24 + e % 3] = gpb[e];
+        if (tid < 9) s_gr[tid] = p.segout[((size_t)b * p.nseg_max + ps) * 32 + 12 + tid];
     }
-    if (tid < len) {   // the factor for the pose back-substitution
-        const int i = lo + tid;
-        const double* o = s_fac[tid];
-        double* L = p.Linv + (size_t)b * p.N_max * 6 + 6 * i;
-        double* Go = p.G + (size_t)b * p.N_max * 9 + 9 * i;
-        double* Gso = p.Gs + (size_t)b * p.N_max * 9 + 9 * i;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) L[k] = o[k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { Go[k] = o[6 + k]; Gso[k] = o[15 + k]; }
-    }
+    __syncthreads();
     // ---- columns: local column lc = tid; 2 ncol landmark columns, then the gradient column ----
     const int ncol = p.seg_ncol[(size_t)b * p.nseg_max + ps], nc = 2 * ncol + 1;
     if (tid >= nc) return;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
         const int i = lo + l;
         const double* o = s_fac[l];
         double u0 = 0.0, u1 = 0.0, u2 = 0.0;
-        if (grad) { u0 = s_in[l][15]; u1 = s_in[l][16]; u2 = s_in[l][17]; }
+        if (grad) { u0 = o[24]; u1 = o[25]; u2 = o[26]; }
         SEG_SUB_GV(o + 6, y0, y1, y2, u0, u1, u2);   // Ginn is zero at the segment's first pose
         while (i == next_i) {   // (a message may hold the same landmark twice: two factors at one pose)
             u0 += e0; u1 += e1; u2 += e2;
