@@ -445,8 +445,10 @@ def secondary_lines(args, torch, dist, rank, local_rank, world, dev):
         keep["leg_seconds"] = round(time.perf_counter() - t0, 1)
         out.append(keep)
 
+    # (60 timed steps = 46 ms: a 20-step window is 15 ms on the wall clock, and one run in ten of round 5 read 1.94 M instead of 5.3 M there while the
+    # device-event time - the leg's roofline - had not moved)
     leg("configs[2] UKF-SLAM L=20 batch 4096", lambda a: bench_ukf(a, torch, dist, rank, local_rank, world, dev, cpu_budget_s=4.0),
-        landmarks=20, batch=4096, steps=20, warmup=5, preroll=20)
+        landmarks=20, batch=4096, steps=60, warmup=5, preroll=20)
     leg("configs[4] pose-graph SLAM 1000 x 200 batch 256", lambda a: bench_pgs(a, torch, dist, rank, local_rank, world, dev, cpu_budget_s=5.0),
         landmarks=200, batch=256, steps=2, warmup=1)
     leg("configs[3] storage: EKF-SLAM L=50 batch 65536 fp32", lambda a: bench_ekf(a, torch, dist, rank, local_rank, world, dev, compact=True),
