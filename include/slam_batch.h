@@ -46,12 +46,14 @@ enum slam_instance_flags {
     SLAM_INST_INDEX_OOR = 4,     /* landmark index outside x_t (ekf.cpp:115 under the duplicate/unknown-id quirk): a message repeats a
                                     NEW id that it has itself just inserted (a repeat of an id that found no room is skipped again, a
                                     repeat of a mapped id is a second update - as the reference's loop does, detection by detection) */
-    SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146), or a
-                                    message held more detections than the landmark capacity of the handle's size class (20 / 50 /
-                                    100 / 200), which takes repeated ids; the surplus was dropped.  That limit holds for messages that
-                                    are already on the device (slam_step_dev, the simulator) and for fp32 storage / the UKF; fp64 EKF
-                                    handles walk a HOST message (slam_step) of any length like ekf.cpp:73 - one that exceeds the class
-                                    takes its timestep through the HBM-streamed kernel, as every message of an L_max > 200 handle does */
+    SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146).  fp32-storage EKF
+                                    handles only: also a message that held more detections than the landmark capacity of the handle's size
+                                    class (20 / 50), which takes repeated ids; the surplus was dropped.  fp64 EKF, UKF and UKF_LOC handles
+                                    walk a message of ANY length like ekf.cpp:73 / ukf.cpp:249-287, from every entry point: the instances
+                                    whose message exceeds what the LDS size class holds take that timestep through the HBM-streamed
+                                    kernel (slam_step knows the counts; slam_step_dev / slam_update_dev take the caller's k_stride as the
+                                    bound, so a stride within the class's capacity keeps the launch on the fast kernel alone; the
+                                    simulator when the map is larger than the capacity) - bit-identical, slower for those instances */
     SLAM_INST_SQRT_FAILED = 16,  /* UKF: eigen-iteration did not converge; stale sqtP reused (ukf.cpp:207-211)  */
     SLAM_INST_WATCHDOG = 32      /* EKF: a polling loop of the step kernel's intra-workgroup protocol exceeded its budget (~0.1 s);
                                     the instance is frozen with an undefined state instead of hanging the GPU.  A defect if it ever
@@ -113,8 +115,8 @@ int slam_config_load(slam_config* cfg, const char* yaml_path);
  * (EKF_SLAM: <= 1000 in fp64 [LDS size classes 20 / 50 / 100 / 200; beyond 200 the HBM-streamed class: the same EKF::update with
  * the covariance streamed through HBM in every phase, one launch per timestep, bit-identical but slow - the state of the reference
  * grows without a limit, ekf.cpp:144-146]; <= 50 in fp32 storage; UKF_SLAM: <= 200 [LDS size classes 20 / 50, beyond 50 its HBM-streamed class]; UKF_LOC: ignored, the
- * state holds no landmarks - its map may have any size, one message up to 50 detections [20 while the map has <= 20 landmarks]; a
- * longer one raises SLAM_INST_CAPACITY and loses the surplus).  The reference grows the state without limit (ekf.cpp:144-146); here the limit of the
+ * state holds no landmarks - its map may have any size and a message any length [beyond 50 detections - 20 while the map has <= 20
+ * landmarks - the instance takes the HBM-streamed step kernel]).  The reference grows the state without limit (ekf.cpp:144-146); here the limit of the
  * fast classes is what one workgroup keeps in the 160 KB of LDS of a CU, and of the streamed class 2 x n x n doubles per instance in HBM.
  * dtype SLAM_F32 (fp32 storage of x and P, fp64 arithmetic) is available for EKF_SLAM.
  * UKF results depend on the capacity CLASS: the eigen-decomposition of nearestSPD / sqrt (ukf.cpp:106-123,208) is a cyclic

@@ -68,6 +68,10 @@ __global__ __launch_bounds__(kBigTpb) void ekf_big_step_kernel(const EkfStepPara
     int* const s_newid = s_i + 16;                        // ids of the landmarks inserted by this message
     float* const s_meas = reinterpret_cast<float*>(s_newid + ((Lcap + 1) & ~1));
 
+    if (p.long_mode == 2) {   // paired with the LDS kernel's launch: only the instances whose message that kernel cannot hold (ekf_kernel.h)
+        const int kk = p.meas_count_in[b];
+        if ((kk < p.k_stride_in ? kk : p.k_stride_in) <= p.long_cap) return;
+    }
     int flags = p.flags[b];
     if (flags & SLAM_INST_INDEX_OOR) return;   // frozen instance: the state stays as it is
     const int M0 = p.M[b], n0 = 3 + 2 * M0;

@@ -41,7 +41,11 @@ struct EkfStepParams {
     double V00, V11, W00, W11;
     int32_t id_known;
     float min_sep;
-    int32_t force_streamed;   // this launch runs the HBM-streamed kernel whatever the size class: a message longer than the class holds (slam_step)
+    // Messages longer than the size class holds (ekf_class_message_capacity).  0: none can occur (the LDS kernel alone).  Set by the host when
+    // one can: launch_ekf_step then pairs two launches on external measurements - the LDS kernel with long_mode = 1 leaves every instance
+    // whose message exceeds long_cap untouched, the HBM-streamed kernel with long_mode = 2 takes exactly those and walks their message where
+    // it lies - and gives the whole launch to the streamed kernel in SIM mode, where the count is not known before the generator has run.
+    int32_t long_mode, long_cap;
     int32_t abs_is_int, lm_from_pred;   // quirk switches ekf_abs_is_int / ekf_landmark_from_x_pred (include/slam_batch.h), 0 = reference
     // ---- simulator config (raw YAML values, used as half-widths: sim_node.py:216-217,247-248) ----
     double sV00, sV11, sW00, sW11, d_max, th_max, range_max, fov_min, fov_max;
@@ -77,7 +81,8 @@ static constexpr int kEkfTrafficSlot = 10;  // khist[10..13]: bytes moved by the
 // (6 n doubles) and the 2 x n^2 doubles of an instance in HBM.  fp32 storage is instantiated up to 50 landmarks.
 static constexpr int kEkfLdsMaxLandmarks = 200;
 // detections ONE message may hold in the LDS size class a handle of capacity L_max runs (the class's landmark capacity; the surplus is
-// dropped with SLAM_INST_CAPACITY).  The HBM-streamed kernel walks messages of any length: slam_step routes a longer message there.
+// dropped with SLAM_INST_CAPACITY by the fp32-storage classes).  The HBM-streamed kernel walks messages of any length: fp64 handles give the
+// instances with a longer message to it (EkfStepParams::long_mode).
 inline int ekf_class_message_capacity(int L_max) { return L_max <= 20 ? 20 : (L_max <= 50 ? 50 : (L_max <= 100 ? 100 : 200)); }
 static constexpr int kEkfMaxLandmarks = 1000;
 static constexpr int kEkfMaxLandmarksF32 = 50;

@@ -87,9 +87,16 @@ int ekf_variant_available(int L_max, int f32_storage, int variant) {
 
 hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage, hipStream_t stream) {
     if (p.L_max > kEkfLdsMaxLandmarks) return f32_storage ? hipErrorInvalidConfiguration : launch_ekf_big_step(p, stream);
-    if (p.force_streamed && !f32_storage) return launch_ekf_big_step(p, stream);
     const EkfVariant* v = pick_variant(p.L_max, p.B, variant, f32_storage);
     if (!v) return hipErrorInvalidConfiguration;
+    if (p.long_mode && !f32_storage) {   // a message may exceed what the size class holds (ekf_kernel.h)
+        if (p.sim || p.cmds != nullptr) return launch_ekf_big_step(p, stream);
+        EkfStepParams q = p;
+        q.long_mode = 1;                 // the LDS kernel: every instance whose message fits ...
+        if (const hipError_t e = v->launch(q, stream); e != hipSuccess) return e;
+        q.long_mode = 2;                 // ... and the streamed kernel: the others
+        return launch_ekf_big_step(q, stream);
+    }
     return v->launch(p, stream);
 }
 

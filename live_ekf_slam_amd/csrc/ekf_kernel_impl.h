@@ -226,6 +226,10 @@ __global__ __launch_bounds__(64 * W, (W >= 2 ? 4 : SLAM_W1_WAVES)) void ekf_step
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    if (p.long_mode == 1) {   // (workgroup-uniform) a message this size class cannot hold: the streamed kernel's launch takes the instance (ekf_kernel.h)
+        const int kk = p.meas_count_in[b];
+        if ((kk < p.k_stride_in ? kk : p.k_stride_in) > p.long_cap) return;
+    }
 
     const bool prof_on = (p.dbg & 4) && p.prof != nullptr;
     unsigned long long tprev = prof_on ? __builtin_readcyclecounter() : 0ull;

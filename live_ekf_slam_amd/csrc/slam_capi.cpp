@@ -204,14 +204,40 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
     p.prof = (h->dbg & 4) ? h->dprof : nullptr;
 }
 
+// ekf.cpp:65,73 and ukf.cpp:249-287 walk a message of any length.  The LDS size classes hold as many detections of one message as the class
+// holds landmarks (every message without repeated ids about a map the state can hold fits); a launch whose messages MAY be longer - external
+// measurements: the caller's bound k_stride is (slam_step passes the largest count it saw); SIM mode: the map is - runs the long-message path
+// of launch_ekf_step / launch_ukf_step: the instances concerned go through the HBM-streamed kernels, which read a message where it lies
+// (same state layout, same arithmetic: both are bit-identical to the oracle; about a pass over P per detection slower).  Returns the class
+// capacity if that path is needed, 0 if not (or if the handle has none: fp32 storage keeps the limit and drops the surplus with
+// SLAM_INST_CAPACITY; the streamed classes have no limit in the first place).
+int long_message_cap(slam_handle* h, int sim, int k_stride, int* cap_out) {
+    *cap_out = 0;
+    int cap;
+    if (h->kind == SLAM_EKF_SLAM) {
+        if (h->esz != 8 || h->L_max > slam::kEkfLdsMaxLandmarks) return SLAM_OK;
+        cap = slam::ekf_class_message_capacity(h->L_max);
+    } else {
+        if (h->kind == SLAM_UKF_SLAM && h->L_max > slam::kUkfLdsMaxLandmarks) return SLAM_OK;
+        cap = slam::ukf_class_message_capacity(h->L_max, h->kind == SLAM_UKF_LOC, h->L);
+    }
+    if (!(sim ? h->L > cap : k_stride > cap)) return SLAM_OK;
+    if (h->kind != SLAM_EKF_SLAM && !h->dbigws)   // scratch of the streamed step kernel (P_pred), on first use
+        HIP_TRY(hipMalloc(&h->dbigws, sizeof(double) * (size_t)h->B * 2 * h->pstride));
+    *cap_out = cap;
+    return SLAM_OK;
+}
+
 // one timestep, either filter kind; `sim` = device-side measurement generator
-int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas, const int32_t* d_count, int k_stride, bool over_long = false) {
+int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas, const int32_t* d_count, int k_stride) {
     if (h->predicted) return fail(SLAM_ERR_STATE, "a prediction stage is pending: call slam_update_dev before the next step");
+    int long_cap = 0;
+    if (const int rc = long_message_cap(h, sim, k_stride, &long_cap)) return rc;
     if (h->kind == SLAM_EKF_SLAM) {
         slam::EkfStepParams p;
         fill_params(h, p, cmd);
         p.sim = sim;
-        p.force_streamed = over_long ? 1 : 0;
+        p.long_mode = long_cap > 0 ? 1 : 0; p.long_cap = long_cap;
         p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
         if (sim && h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
         HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
@@ -219,6 +245,7 @@ int launch_step(slam_handle* h, const float cmd[2], int sim, const float* d_meas
         slam::UkfStepParams p;
         fill_ukf_params(h, p, cmd);
         p.sim = sim;
+        p.long_mode = long_cap > 0 ? 1 : 0; p.long_cap = long_cap;
         p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
         if (sim && h->dump_meas) { p.meas_out = h->dmeas; p.meas_count_out = h->dcount; p.k_stride_out = h->k_stride; }
         HIP_TRY(slam::launch_ukf_sqrt(p, h->stream));   // nearestSPD + sqrt (ukf.cpp:106-123,208)
@@ -528,7 +555,8 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
     }
     // Device buffers on the caller's stream: queueing is OPT-IN here (slam_set_lazy_steps / SLAM_LAZY_STEPS), because a queued
     // call enqueues only its device-to-device copy on the stream, not the step itself
-    if (h->kind == SLAM_EKF_SLAM && h->lazy_explicit && h->lazy_max > 1 && h->run_chunk != 1 && !h->dump_meas) {
+    if (h->kind == SLAM_EKF_SLAM && h->lazy_explicit && h->lazy_max > 1 && h->run_chunk != 1 && !h->dump_meas &&
+        (h->esz != 8 || k_stride <= slam::ekf_class_message_capacity(h->L_max))) {   // (messages that may be longer: one launch pair per step, launch_step)
         slam_handle::DevQueue& q = h->devq;
         if (!h->lazy_cmds.empty() || h->extq[h->extq_cur].n > 0 || (q.n > 0 && q.ks != k_stride)) FLUSH(h);   // earlier steps first
         const size_t B = (size_t)h->B;
@@ -664,13 +692,8 @@ int slam_step(slam_handle* h, const float cmd[2], const float* meas, const int32
     HIP_TRY(hipMemcpyAsync(s.dmeas, s.hmeas, sizeof(float) * need, hipMemcpyHostToDevice, h->copy_stream));
     HIP_TRY(hipEventRecord(s.copied, h->copy_stream));
     HIP_TRY(hipStreamWaitEvent(h->stream, s.copied, 0));
-    // ekf.cpp:65,73 walk a message of any length.  The LDS size classes hold as many detections per message as they hold landmarks - every
-    // message without repeated ids fits - and drop the surplus with SLAM_INST_CAPACITY; a message beyond that (the host sees the counts here)
-    // takes this one timestep through the HBM-streamed kernel, which reads the message where it lies: same state layout, same arithmetic
-    // (both are bit-identical to the oracle), about a pass over P per detection slower.  fp64 EKF handles; the fp32-storage and the UKF
-    // classes keep the documented limit (the UKF's streamed class runs another Jacobi schedule: include/slam_batch.h).
-    const bool over_long = h->kind == SLAM_EKF_SLAM && h->esz == 8 && kmax > slam::ekf_class_message_capacity(h->L_max);
-    int rc = launch_step(h, cmd, 0, s.dmeas, s.dcount, kmax, over_long);
+    // (kmax = the longest message of this call: beyond the size class's capacity the instances concerned take the streamed kernel, launch_step)
+    int rc = launch_step(h, cmd, 0, s.dmeas, s.dcount, kmax);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.used, h->stream));
     s.in_use = true;
@@ -733,10 +756,13 @@ static int run_sim_now(slam_handle* h, const float* cmds, int T) {
         HIP_TRY(hipEventRecord(h->aux_ev[0], h->stream));
         for (int a = 0; a < NP - 1; ++a) HIP_TRY(hipStreamWaitEvent(h->aux_stream[a], h->aux_ev[0], 0));
         const int per = (h->B + NP - 1) / NP;
+        int long_cap = 0;
+        if (const int rc = long_message_cap(h, 1, 0, &long_cap)) return rc;
         for (int t = 0; t < T; ++t) {
             slam::UkfStepParams p;
             fill_ukf_params(h, p, cmds + 2 * (size_t)t);
             p.sim = 1;
+            p.long_mode = long_cap > 0 ? 1 : 0; p.long_cap = long_cap;
             for (int part = 0; part < NP; ++part) {
                 p.b_off = part * per;
                 p.b_cnt = h->B - p.b_off < per ? h->B - p.b_off : per;
@@ -773,11 +799,14 @@ static int run_sim_now(slam_handle* h, const float* cmds, int T) {
     }
     HIP_TRY(hipMemcpyAsync(h->dcmds, cmds, sizeof(float) * 2 * (size_t)T, hipMemcpyHostToDevice, h->stream));
     const int chunk = h->run_chunk > 0 ? h->run_chunk : T;
+    int long_cap = 0;   // a map with more landmarks than a message of this size class holds: the streamed kernel, a launch per timestep
+    if (const int rc = long_message_cap(h, 1, 0, &long_cap)) return rc;
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int tc = T - t0 < chunk ? T - t0 : chunk;
         slam::EkfStepParams p;
         fill_params(h, p, cmds + 2 * (size_t)t0);
         p.sim = 1;
+        p.long_mode = long_cap > 0 ? 1 : 0; p.long_cap = long_cap;
         p.cmds = h->dcmds + 2 * (size_t)t0;
         p.T = tc;
         HIP_TRY(slam::launch_ekf_step(p, h->waves_per_filter, h->esz == 4, h->stream));
@@ -892,9 +921,12 @@ int slam_update_dev(slam_handle* h, const float* d_meas, const int32_t* d_count,
         HIP_TRY(hipMemsetAsync(h->dcount, 0, sizeof(int32_t) * (size_t)h->B, h->stream));
         d_meas = h->dmeas; d_count = h->dcount; k_stride = 1;
     }
+    int long_cap = 0;
+    if (const int rc = long_message_cap(h, 0, k_stride, &long_cap)) return rc;
     slam::UkfStepParams p;
     fill_ukf_params(h, p, h->pred_cmd);
     p.sim = 0;
+    p.long_mode = long_cap > 0 ? 1 : 0; p.long_cap = long_cap;
     p.meas_in = d_meas; p.meas_count_in = d_count; p.k_stride_in = k_stride;
     HIP_TRY(slam::launch_ukf_step(p, h->stream));
     std::swap(h->dP, h->dP2);

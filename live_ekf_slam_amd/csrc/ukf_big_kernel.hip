@@ -7,7 +7,8 @@
 // parallel-order Jacobi with its warm start, fused products, tau-free parameters; the weighted covariance as a chain of fused
 // multiply-adds in ascending sigma index; updates before insertions, detection by detection - so the results are bit-identical to the
 // oracle (and a message may hold any number of detections: it is walked where it lies).  Slow by design: thousands of barrier-separated
-// rounds over global memory per eigen-decomposition.
+// rounds over global memory per eigen-decomposition.  The STEP kernel also serves the LDS classes (UKF_SLAM up to 50 landmarks, UKF_LOC) for
+// the instances whose message is longer than their step kernel holds (UkfStepParams::long_mode; the sqrt kernel stays the class's own).
 #include "ukf_kernel.h"
 
 #include "../../include/slam_batch.h"
@@ -220,6 +221,10 @@ __global__ __launch_bounds__(kTpb) void ukf_big_step_kernel(const UkfStepParams 
     int* const s_ids = s_i + 16;                          // [L_max]
     float* const s_meas = reinterpret_cast<float*>(s_ids + ((p.L_max + 1) & ~1));   // SIM mode: [3 L]
 
+    if (p.long_mode == 2) {   // paired with the LDS kernel's launch: only the instances whose message that kernel cannot hold (ukf_kernel.h)
+        const int kk = p.meas_count_in[b];
+        if ((kk < p.k_stride_in ? kk : p.k_stride_in) <= p.long_cap) return;
+    }
     int flags = p.flags[b];
     const int M_old = p.M[b];
     const int n = 4 + 2 * M_old, ns = 2 * n + 1;
@@ -340,12 +345,16 @@ __global__ __launch_bounds__(kTpb) void ukf_big_step_kernel(const UkfStepParams 
     // ---- pass 1: landmark updates in message order (ukf.cpp:293-349) ----
 #pragma unroll 1
     for (int l = 0; l < k; ++l) {
-        const int j = associate((int)meas[3 * l]);
+        const int id_l = (int)meas[3 * l];
+        // UKF_LOC (ukf.cpp:146-154,272-276): every detection is an update against the known map, there is no landmark in the state
+        const int j = p.loc ? ((id_l >= 0 && id_l < p.L) ? id_l : -2) : associate(id_l);
+        if (j == -2 && tid == 0) s_i[2] |= SLAM_INST_INDEX_OOR;   // an id outside the map
         if (j < 0) continue;
         const float r_m = meas[3 * l + 1], b_m = meas[3 * l + 2];
-        const int li = 2 * j + 4;
+        const int li = p.loc ? 0 : 2 * j + 4;
+        const double mx = p.loc ? (double)p.mapf[3 * j + 1] : 0.0, my = p.loc ? (double)p.mapf[3 * j + 2] : 0.0;
         for (int i = tid; i < ns; i += kTpb) {   // sensing model of every sigma point (yaw from x_t)
-            const double dx = xel(li, i) - xel(0, i), dy = xel(li + 1, i) - xel(1, i);
+            const double dx = (p.loc ? mx : xel(li, i)) - xel(0, i), dy = (p.loc ? my : xel(li + 1, i)) - xel(1, i);
             s_Z0[i] = sqrt(dx * dx + dy * dy) + (double)p.w_r;
             const double yaw_i = p.yaw_sigma ? (double)yawf(xel(2, i), xel(3, i)) : (double)yaw_t;   // quirk D-9: from x_t
             s_Z1[i] = remainder((det_atan2(dy, dx) - yaw_i) + (double)p.w_b, kTwoPi);
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(kTpb) void ukf_big_step_kernel(const UkfStepParams 
     // ---- pass 2: insertions in message order (ukf.cpp:351-372): x_pred grows, P = blkdiag(P_pred, W) ----
     int M = M_old;
 #pragma unroll 1
-    for (int l = 0; l < k; ++l) {
+    for (int l = 0; l < (p.loc ? 0 : k); ++l) {
         const int id = (int)meas[3 * l];
         const int j = associate(id);
         if (j >= 0) continue;

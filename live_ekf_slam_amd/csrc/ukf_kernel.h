@@ -58,7 +58,14 @@ struct UkfStepParams {
     // the size class beyond LDS (ukf_big_kernel.hip, n = 4 + 2 L_max > 104): [B][2 * pstride] doubles of scratch per instance (the scaled
     // symmetrised matrix and the warm-start product of the sqrt kernel, then P_pred of the step kernel); NULL for the LDS classes
     double* big_ws;
+    // Messages longer than the size class holds (ukf_class_message_capacity).  0: none can occur.  1 (set by the host when one can, with
+    // long_cap = that capacity and big_ws allocated): launch_ukf_step pairs the LDS step kernel, which then leaves every instance whose
+    // message exceeds long_cap untouched, with ukf_big_step_kernel for exactly those (long_mode = 2 inside that launch); in SIM mode, where the
+    // count is not known before the generator has run, the streamed kernel takes the whole launch.  The sqrt kernel is the class's own either way.
+    int32_t long_mode, long_cap;
 };
+// detections ONE message may hold in the LDS size class of the step kernel (launch_ukf_step picks the class the same way)
+inline int ukf_class_message_capacity(int L_max, bool loc, int L_map) { return ((loc && L_map > 20) ? 104 : 4 + 2 * L_max) <= 44 ? 20 : 50; }
 
 static constexpr int kUkfRotThreads = 256;   // threads of the variant with the pass table
 // Pass table for ukf_sqrt_kernel<44, 256> at the padded sizes nj = 4, 8, ..., 44: kUkfQuadTabEntries uint4 entries (2 MB), built on the host

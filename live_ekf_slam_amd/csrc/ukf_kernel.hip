@@ -902,6 +902,10 @@ __global__ __launch_bounds__(TPB, (NMAX == 44 && TPB == 128 && !PROF) ? SLAM_UKF
     __shared__ int s_misc[8];                 // k, n_upd, n_ins, capacity, singular
 
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x, lane = tid & 63;
+    if (p.long_mode == 3) {   // (workgroup-uniform) a message this size class cannot hold: the streamed kernel's launch takes the instance (ukf_kernel.h)
+        const int kk = p.meas_count_in[b];
+        if ((kk < p.k_stride_in ? kk : p.k_stride_in) > p.long_cap) return;
+    }
     unsigned long long tacc[PROF ? 10 : 1] = {0}, tprev = 0ull;
     if constexpr (PROF) tprev = wall_clock64();
 #define UKF_STAMP(i) do { if constexpr (PROF) { if (tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } } while (0)
@@ -1393,6 +1397,14 @@ hipError_t launch_ukf_step(const UkfStepParams& p, hipStream_t stream) {
     // sees a map of any size: with more than 20 landmarks it takes the large class (found by tools/gpu_soak_ekf.py: SLAM_INST_CAPACITY
     // and dropped detections on a 35-landmark map where the reference - ukf.cpp:146-154 - uses every one).
     const int nmax = (p.loc && p.L > 20) ? 104 : 4 + 2 * p.L_max;
+    if (p.long_mode == 1 && nmax <= 104) {   // a message may exceed what the class holds (ukf_kernel.h)
+        if (p.sim) return launch_ukf_big_step(p, stream);
+        UkfStepParams q = p;
+        q.long_mode = 3;                     // the LDS kernel below: every instance whose message fits ...
+        if (const hipError_t e = launch_ukf_step(q, stream); e != hipSuccess) return e;
+        q.long_mode = 2;                     // ... and the streamed kernel: the others
+        return launch_ukf_big_step(q, stream);
+    }
     if (nmax <= 44) {
         switch (env_tpb(1, 128)) {
             case 64: hipLaunchKernelGGL((ukf_step_kernel<44, 64, 8>), dim3(p.b_cnt), dim3(64), 0, stream, p); break;

@@ -709,10 +709,11 @@ def test_streamed_class_walks_messages_of_any_length(S, oracle, idknown):
 @pytest.mark.parametrize("L,idknown", [(20, 1), (50, 1), (50, 0), (100, 1)])
 def test_over_long_host_messages_walk_every_detection_in_the_lds_classes(S, oracle, L, idknown):
     """ekf.cpp:65,73 walk a message of any length; the LDS size classes hold L_class detections per message and drop
-    the surplus with SLAM_INST_CAPACITY.  Round 5: slam_step sees the counts, so a message beyond the class's capacity takes that one
-    timestep through the HBM-streamed kernel (same state layout, same arithmetic): fp64 EKF handles now follow the oracle WITHOUT its
-    per-message limit, interleaved with ordinary messages (fast kernel, queued and immediate), bit for bit and flag for flag.  The
-    fp32-storage class keeps the documented limit (the oracle restates it under set_message_capacity)."""
+    the surplus with SLAM_INST_CAPACITY.  Round 5: slam_step sees the counts, so the instances whose message is beyond the class's capacity
+    take that one timestep through the HBM-streamed kernel (same state layout, same arithmetic; the LDS kernel of the same launch pair skips
+    them, EkfStepParams::long_mode): fp64 EKF handles now follow the oracle WITHOUT its per-message limit, interleaved with ordinary messages
+    (fast kernel, queued and immediate) in the same batch and from step to step, bit for bit and flag for flag.  The fp32-storage class keeps
+    the documented limit (the oracle restates it under set_message_capacity)."""
     cap = 20 if L <= 20 else (50 if L <= 50 else 100)
     for f32 in (False, True):
         if f32 and L > 50:
@@ -749,6 +750,74 @@ def test_over_long_host_messages_walk_every_detection_in_the_lds_classes(S, orac
             so, sg = es[b].state(), f.get_state(b)
             assert sg["M"] == so["M"] and np.array_equal(sg["ids"], so["ids"])
             assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"]), (f32, b)
+        f.close()
+
+
+def test_long_messages_from_device_buffers_and_from_the_generator(S, oracle):
+    """The other two entry points of the same limit.  slam_step_dev: the counts are on the device, so the caller's stride is the bound - a
+    stride beyond the class's capacity runs the launch pair (LDS kernel for the instances whose message fits, streamed kernel for the others,
+    EkfStepParams::long_mode), a stride within it the LDS kernel alone.  SIM mode: a map with more landmarks than a message of the class
+    holds (30 on a 20-landmark handle: the state fills up and says so, but every detection of a KNOWN landmark is still an update,
+    ekf.cpp:73) takes the streamed kernel.  Bit for bit and flag for flag against the oracle without a per-message limit."""
+    import ctypes as C
+    from live_ekf_slam_amd.scenario import make_scenario
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L, B, T, KS = 20, 5, 10, 48
+    d_meas, d_cnt = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_meas), B * KS * 3 * 4) == 0 and hip.hipMalloc(C.byref(d_cnt), B * 4) == 0
+    for lazy in (0, 8):
+        f = S.BatchedEKF(B, L).readParams(); f.init(0.0, 0.0, 0.0)
+        if lazy: f.set_lazy_steps(lazy)
+        es = []
+        for b in range(B):
+            e = oracle.OracleEKF(S.default_config(), L_max=L); e.init(0, 0, 0); es.append(e)
+        rng = np.random.default_rng(77)
+        of = np.zeros(B, dtype=np.int64)
+        for t in range(T):
+            cmd = np.array([rng.uniform(0, 0.1), rng.uniform(-0.05, 0.05)], dtype=np.float32)
+            ks = rng.integers(0, 4, B)
+            if t in (1, 4, 5, 8): ks[rng.integers(0, B)] = 21 + int(rng.integers(0, 27))
+            K = KS if t % 3 else 16                       # strides beyond and within the capacity alternate
+            ks = np.minimum(ks, K)
+            meas = np.zeros((B, K, 3), dtype=np.float32)
+            for b in range(B):
+                k = int(ks[b])
+                meas[b, :k, 0] = rng.integers(0, L + 6, k)
+                meas[b, :k, 1] = rng.uniform(0.5, 6.0, k)
+                meas[b, :k, 2] = rng.uniform(-3.1, 3.1, k)
+            cnt = ks.astype(np.int32)
+            f.sync()                                       # (the buffers are re-used: the previous step has read them)
+            assert hip.hipMemcpy(d_meas, meas.ctypes.data_as(C.c_void_p), meas.nbytes, 1) == 0
+            assert hip.hipMemcpy(d_cnt, cnt.ctypes.data_as(C.c_void_p), cnt.nbytes, 1) == 0
+            f.update_dev(cmd, d_meas.value, d_cnt.value, K)
+            for b in range(B):
+                of[b] |= es[b].update(cmd[0], cmd[1], meas[b, :ks[b]])
+        assert np.array_equal(f.status().astype(np.int64), of), (lazy, f.status(), of)
+        for b in range(B):
+            if of[b] & 4:
+                continue
+            so, sg = es[b].state(), f.get_state(b)
+            assert sg["M"] == so["M"] and np.array_equal(sg["ids"], so["ids"])
+            assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"]), (lazy, b)
+        f.close()
+    Lm, T = 30, 40
+    lm, cmds = make_scenario(9, Lm, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]; vis[7] = [1e9, -4.0, 4.0]; vis[8] = [1e9, -4.0, 4.0]
+    for chunked in (False, True):
+        f = S.BatchedEKF(6, L).readParams(); f.set_map(lm); f.set_seed(4); f.init(0, 0, 0)
+        if chunked:
+            for t in range(T):
+                f.set_vision(*vis[t]); f.update_sim(cmds[t])
+        else:
+            f.set_vision(1e9, -4.0, 4.0); f.run_sim(cmds)
+        r = oracle.run_ekf_batch(lm, cmds, 6, L, seed=4, nthreads=3, vision=vis if chunked else np.tile([1e9, -4.0, 4.0], (T, 1)))
+        assert np.all(r["M"] == L) and np.all(r["flags"] & 8) and np.array_equal(f.status(), r["flags"])
+        assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
+        n = 3 + 2 * L
+        for b in range(6):
+            _assert_state_equal(f.get_state(b), dict(M=L, ids=r["ids"][b, :L], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
         f.close()
 
 

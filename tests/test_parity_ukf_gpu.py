@@ -312,6 +312,95 @@ def test_ukf_loc_on_a_map_larger_than_the_small_size_class(S, oracle):
     f.close()
 
 
+def _hip_buffers(nbytes_meas, nbytes_cnt):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")   # the runtime libslam_hip.so itself links (device buffers without torch)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    d_meas, d_cnt = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_meas), nbytes_meas) == 0 and hip.hipMalloc(C.byref(d_cnt), nbytes_cnt) == 0
+    def put(meas, cnt):
+        assert hip.hipMemcpy(d_meas, meas.ctypes.data_as(C.c_void_p), meas.nbytes, 1) == 0   # hipMemcpyHostToDevice
+        assert hip.hipMemcpy(d_cnt, cnt.ctypes.data_as(C.c_void_p), cnt.nbytes, 1) == 0
+    return d_meas, d_cnt, put
+
+
+@pytest.mark.parametrize("L,entry", [(20, "host"), (20, "stages"), (50, "host")])
+def test_ukf_over_long_messages_walk_every_detection_in_the_lds_classes(S, oracle, L, entry):
+    """VERDICT r04 item 5 for the UKF: ukf.cpp:249-287 walk a message of any length; the LDS size classes of the step kernel hold 20 / 50
+    detections of one message.  A launch whose messages may be longer is now a PAIR of launches: the LDS kernel leaves the instances whose
+    message it cannot hold untouched and the HBM-streamed step kernel takes exactly those (UkfStepParams::long_mode) - the sqrt kernel, and
+    with it the Jacobi schedule, stays the class's own.  Ordinary and over-long messages side by side in one batch and from step to step,
+    repeated ids and ids beyond the capacity, through slam_step (host buffers) and slam_predict + slam_update_dev (device buffers, the
+    caller's stride as the bound): the oracle WITHOUT a per-message limit, bit for bit and flag for flag."""
+    cap = 20 if L <= 20 else 50
+    B, T = 4, 9 if L <= 20 else 6
+    KS = cap + 45
+    f = S.BatchedUKF(B, L).readParams(); f.init(0.0, 0.0, 0.0)
+    es = [oracle.OracleUKF(L_max=L) for _ in range(B)]
+    for e in es: e.init(0, 0, 0)
+    if entry == "stages":
+        d_meas, d_cnt, put = _hip_buffers(B * KS * 3 * 4, B * 4)
+    rng = np.random.default_rng(3 + L)
+    of = np.zeros(B, dtype=np.int64)
+    for t in range(T):
+        cmd = np.array([rng.uniform(0, 0.1), rng.uniform(-0.05, 0.05)], dtype=np.float32)
+        ks = rng.integers(0, 4, B)                                                        # ordinary messages ...
+        if t in (1, 3, 4, 7): ks[rng.integers(0, B)] = cap + int(rng.integers(1, 40))   # ... and over-long ones, for one instance at a time
+        if t == 5: ks[:] = cap + 5
+        K = KS if entry == "stages" else max(1, int(ks.max()))
+        meas = np.zeros((B, K, 3), dtype=np.float32)
+        for b in range(B):
+            k = int(ks[b])
+            meas[b, :k, 0] = rng.integers(0, L + 10, k)
+            meas[b, :k, 1] = rng.uniform(0.5, 6.0, k)
+            meas[b, :k, 2] = rng.uniform(-3.1, 3.1, k)
+        if entry == "stages":
+            put(meas, ks.astype(np.int32))
+            f.predictionStage(S.Command(cmd[0], cmd[1])); f.updateStage(d_meas.value, d_cnt.value, K); f.sync()
+        else:
+            f.update(cmd, meas, ks.astype(np.int32))
+        for b in range(B):
+            of[b] |= es[b].update(cmd[0], cmd[1], meas[b, :ks[b]])
+    assert np.array_equal(f.status().astype(np.int64), of), (f.status(), of)
+    for b in range(B):
+        so = es[b].state()
+        _eq(f.get_state(b), dict(M=so["M"], ids=so["ids"], x=so["x"], P=so["P"]))
+    f.close()
+
+
+def test_ukf_loc_messages_longer_than_the_size_class(S, oracle):
+    """UKF_LOC sees a map of any size (ukf.cpp:146-154): 80 landmarks, all of them in view - 80 detections per message, the large size class
+    holds 50.  Device-generated messages (the map is larger than a message of the class: the streamed step kernel takes the launch) and
+    host-fed ones with an id outside the map; every detection is used, nothing is flagged but the foreign id."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, T, B = 80, 24, 5
+    lm, cmds = make_scenario(41, L, T)
+    cfg = S.default_config(); cfg.range_max = 1e9; cfg.fov_min = -4.0; cfg.fov_max = 4.0
+    f = S.BatchedUKFLoc(B).readParams(cfg); f.set_map(lm); f.set_seed(5); f.init(0, 0, 0)
+    f.run_sim(cmds[:10]); f.run_sim(cmds[10:])
+    r = oracle.run_ukf_batch(lm, cmds, B, 1, seed=5, nthreads=4, cfg=cfg, loc=True)
+    assert not f.status().any() and not r["flags"].any()
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
+    for b in range(B):
+        _eq(f.get_state(b), dict(M=0, ids=r["ids"][b, :0], x=r["x"][b, :4], P=r["P"][b, :16].reshape(4, 4)))
+    f.close()
+    f = S.BatchedUKFLoc(2).readParams(); f.set_map(lm); f.init(0.0, 0.0, 0.0)
+    u = oracle.OracleUKF(L_max=1); u.set_loc_map(lm); u.init(0, 0, 0)
+    rng = np.random.default_rng(6)
+    fl = 0
+    for t in range(8):
+        k = 70 if t in (2, 5) else int(rng.integers(0, 6))
+        meas = np.zeros((k, 3), dtype=np.float32)
+        meas[:, 0] = rng.integers(0, L, k); meas[:, 1] = rng.uniform(0.5, 6.0, k); meas[:, 2] = rng.uniform(-3.1, 3.1, k)
+        if t == 5: meas[60, 0] = L + 3
+        f.update((0.05, 0.01), meas.ravel())
+        fl |= u.update(0.05, 0.01, meas)
+    assert fl != 0 and np.all(f.status() == fl)
+    _eq(f.get_state(1), u.state())
+    f.close()
+
+
 def test_ukf_state_of_100_landmarks(S, oracle):
     """n = 204: beyond the LDS size classes of the UKF kernels (up to round 3: SLAM_ERR_UNSUPPORTED above 50 landmarks; the reference's
     state grows without a limit, ukf.cpp:357,371).  The HBM-streamed class (ukf_big_kernel.hip): a first look at all 100 landmarks
