@@ -46,11 +46,10 @@ enum slam_instance_flags {
     SLAM_INST_INDEX_OOR = 4,     /* landmark index outside x_t (ekf.cpp:115 under the duplicate/unknown-id quirk): a message repeats a
                                     NEW id that it has itself just inserted (a repeat of an id that found no room is skipped again, a
                                     repeat of a mapped id is a second update - as the reference's loop does, detection by detection) */
-    SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146).  fp32-storage EKF
-                                    handles only: also a message that held more detections than the landmark capacity of the handle's size
-                                    class (20 / 50), which takes repeated ids; the surplus was dropped.  fp64 EKF, UKF and UKF_LOC handles
-                                    walk a message of ANY length like ekf.cpp:73 / ukf.cpp:249-287, from every entry point: the instances
-                                    whose message exceeds what the LDS size class holds take that timestep through the HBM-streamed
+    SLAM_INST_CAPACITY = 8,      /* a new landmark did not fit L_max (the reference grows without limit, ekf.cpp:144-146).  NOT raised by
+                                    long messages (it was, until round 5): every handle walks a message of ANY length like ekf.cpp:73 /
+                                    ukf.cpp:249-287, from every entry point - the instances whose message exceeds what the LDS size class
+                                    holds (EKF 20 / 50 / 100 / 200, UKF 20 / 50 detections) take that timestep through the HBM-streamed
                                     kernel (slam_step knows the counts; slam_step_dev / slam_update_dev take the caller's k_stride as the
                                     bound, so a stride within the class's capacity keeps the launch on the fast kernel alone; the
                                     simulator when the map is larger than the capacity) - bit-identical, slower for those instances */

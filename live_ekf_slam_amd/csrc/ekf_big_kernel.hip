@@ -55,7 +55,13 @@ __device__ __forceinline__ bool big_inv2x2_lu(const double S[4], double Si[4]) {
 
 // LDS layout (dynamic): x_t [np], x_pred [np], K / P H^T [2 np] (interleaved per state index), H P [2 np] (row 0, row 1), scalars [32],
 // ints [16], new ids [L_max], message [3 L] floats (SIM mode)
+// ST = storage type of x_t and P_t.  double: the streamed size class (L_max > 200) and the long messages of the fp64 LDS classes.  float
+// (round 5): the long messages of the fp32-storage classes - x_t / P_t are read as floats, the timestep runs in fp64 in the working matrix
+// (the handle's fp64 slab `scratch`, [B][pstride] doubles: n x ld8(n) fits since ld4(n) >= ld8(n)) and the result is rounded to float where it
+// is stored: the oracle's STORAGE_F32 (slam_oracle.cpp round_storage: once per timestep), which is what the fp32 LDS kernel computes too.
+template <class ST>
 __global__ __launch_bounds__(kBigTpb) void ekf_big_step_kernel(const EkfStepParams p, const int t_off, const int multi) {
+    constexpr int ESZ = (int)sizeof(ST);
     extern __shared__ double sm[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int Lcap = p.L_max, nmax = 3 + 2 * Lcap, np = (nmax + 1) & ~1;
@@ -76,14 +82,14 @@ __global__ __launch_bounds__(kBigTpb) void ekf_big_step_kernel(const EkfStepPara
     if (flags & SLAM_INST_INDEX_OOR) return;   // frozen instance: the state stays as it is
     const int M0 = p.M[b], n0 = 3 + 2 * M0;
     const int ldw = ekf_ld(nmax, 8);           // leading dimension of the working matrix
-    const int ld0 = ekf_ld(n0, 8);
-    const double* PA = static_cast<const double*>(p.P) + (size_t)b * p.pstride;
-    double* __restrict__ PB = static_cast<double*>(p.P_out) + (size_t)b * p.pstride;
-    double* __restrict__ xb = static_cast<double*>(p.x) + (size_t)b * p.xstride;
+    const int ld0 = ekf_ld(n0, ESZ);
+    const ST* PA = static_cast<const ST*>(p.P) + (size_t)b * p.pstride;
+    double* __restrict__ PB = (ESZ == 8 ? static_cast<double*>(p.P_out) : p.scratch) + (size_t)b * p.pstride;
+    ST* __restrict__ xb = static_cast<ST*>(p.x) + (size_t)b * p.xstride;
     const int* __restrict__ idsb = p.ids + (size_t)b * p.L_max;
 
     for (int i = tid; i < np; i += kBigTpb) {
-        const double v = i < n0 ? xb[i] : 0.0;
+        const double v = i < n0 ? (double)xb[i] : 0.0;
         s_xt[i] = v; s_xp[i] = v;
     }
     if (tid < 16) s_i[tid] = 0;
@@ -130,14 +136,14 @@ __global__ __launch_bounds__(kBigTpb) void ekf_big_step_kernel(const EkfStepPara
             s_xp[1] = s_xt[1] + (double)dd * sn;
             s_xp[2] = rem2pi((th + (double)ang) + (double)p.v_th);
         }
-        const double p22 = PA[(size_t)2 * ld0 + 2];
+        const double p22 = (double)PA[(size_t)2 * ld0 + 2];
         for (int e = tid; e < n0 * n0; e += kBigTpb) {
             const int r = e / n0, c = e - r * n0;
-            double t = PA[(size_t)r * ld0 + c];
+            double t = (double)PA[(size_t)r * ld0 + c];
             const double f_r = r == 0 ? fa : fb;
-            if (r < 2) t = t + f_r * PA[(size_t)2 * ld0 + c];          // rows 0, 1 of F_x P
+            if (r < 2) t = t + f_r * (double)PA[(size_t)2 * ld0 + c];   // rows 0, 1 of F_x P
             if (c < 2) {                                               // cols 0, 1 of (F_x P) F_x^T
-                double a2 = PA[(size_t)r * ld0 + 2];
+                double a2 = (double)PA[(size_t)r * ld0 + 2];
                 if (r < 2) a2 = a2 + f_r * p22;
                 t = t + a2 * (c == 0 ? fa : fb);
             }
@@ -306,17 +312,17 @@ __global__ __launch_bounds__(kBigTpb) void ekf_big_step_kernel(const EkfStepPara
         return;
     }
     // ---- x_t = x_pred, P_t = P_pred (ekf.cpp:176-177): compact the working matrix into the layout of the new state size ----
-    const int ldn = ekf_ld(n, 8);
-    double* PAw = const_cast<double*>(PA);
+    const int ldn = ekf_ld(n, ESZ);
+    ST* PAw = const_cast<ST*>(PA);
     int bad = 0;
     for (int e = tid; e < n * ldn; e += kBigTpb) {
         const int r = e / ldn, c = e - r * ldn;
-        const double v = c < n ? PB[(size_t)r * ldw + c] : 0.0;   // pad columns stay zero
+        const ST v = (ST)(c < n ? PB[(size_t)r * ldw + c] : 0.0);   // pad columns stay zero
         bad |= !isfinite(v);
         PAw[e] = v;
     }
     for (int i = tid; i < n; i += kBigTpb) {
-        const double v = s_xp[i];
+        const ST v = (ST)s_xp[i];
         bad |= !isfinite(v);
         xb[i] = v;
     }
@@ -343,17 +349,20 @@ size_t big_lds_bytes(int L_max, int L_map) {
 
 }  // namespace
 
-hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream) {
+hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream, int f32_storage) {
     const size_t lds = big_lds_bytes(p.L_max, p.sim ? p.L : 1);
     if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
+    if (f32_storage && p.scratch == nullptr) return hipErrorInvalidValue;   // the fp64 working matrix of an fp32-storage handle
+    const void* fn = f32_storage ? reinterpret_cast<const void*>(&ekf_big_step_kernel<float>) : reinterpret_cast<const void*>(&ekf_big_step_kernel<double>);
     if (lds > 64 * 1024) {   // once per device, to the kernel's maximum (lds_attr.h)
-        const hipError_t e = slam_allow_full_lds(reinterpret_cast<const void*>(&ekf_big_step_kernel));
+        const hipError_t e = slam_allow_full_lds(fn);
         if (e != hipSuccess) return e;
     }
     const int multi = (p.cmds != nullptr && p.T > 1) ? 1 : 0;
     const int T = multi ? p.T : 1;
     for (int t = 0; t < T; ++t) {   // one launch per timestep: the kernel keeps nothing on chip between steps
-        hipLaunchKernelGGL(ekf_big_step_kernel, dim3(p.B), dim3(kBigTpb), lds, stream, p, t, multi);
+        if (f32_storage) hipLaunchKernelGGL(ekf_big_step_kernel<float>, dim3(p.B), dim3(kBigTpb), lds, stream, p, t, multi);
+        else hipLaunchKernelGGL(ekf_big_step_kernel<double>, dim3(p.B), dim3(kBigTpb), lds, stream, p, t, multi);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -362,7 +371,7 @@ hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream) {
 
 hipError_t ekf_big_kernel_info(EkfKernelInfo* out) {
     hipFuncAttributes a;
-    const hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&ekf_big_step_kernel));
+    const hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&ekf_big_step_kernel<double>));
     if (e != hipSuccess) return e;
     snprintf(out->name, sizeof(out->name), "ekf_big_step_kernel");
     out->lds_bytes = (int)a.sharedSizeBytes;

@@ -81,8 +81,8 @@ static constexpr int kEkfTrafficSlot = 10;  // khist[10..13]: bytes moved by the
 // (6 n doubles) and the 2 x n^2 doubles of an instance in HBM.  fp32 storage is instantiated up to 50 landmarks.
 static constexpr int kEkfLdsMaxLandmarks = 200;
 // detections ONE message may hold in the LDS size class a handle of capacity L_max runs (the class's landmark capacity; the surplus is
-// dropped with SLAM_INST_CAPACITY by the fp32-storage classes).  The HBM-streamed kernel walks messages of any length: fp64 handles give the
-// instances with a longer message to it (EkfStepParams::long_mode).
+// not dropped any more).  The HBM-streamed kernel walks messages of any length: the instances with a longer message go to it
+// (EkfStepParams::long_mode), in either storage type.
 inline int ekf_class_message_capacity(int L_max) { return L_max <= 20 ? 20 : (L_max <= 50 ? 50 : (L_max <= 100 ? 100 : 200)); }
 static constexpr int kEkfMaxLandmarks = 1000;
 static constexpr int kEkfMaxLandmarksF32 = 50;
@@ -118,7 +118,7 @@ hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage,
 hipError_t ekf_kernel_info(int L_max, int B, int variant, int f32_storage, int multi, EkfKernelInfo* out);
 
 // the size class beyond the LDS classes (ekf_big_kernel.hip): p.T timesteps as p.T launches
-hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream);
+hipError_t launch_ekf_big_step(const EkfStepParams& p, hipStream_t stream, int f32_storage = 0);   // f32: long messages of the fp32 LDS classes only
 hipError_t ekf_big_kernel_info(EkfKernelInfo* out);
 
 // sum over instances of 2*(n^2+n)*8 bytes into *out (device double, must be zeroed)

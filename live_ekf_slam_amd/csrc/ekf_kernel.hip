@@ -89,13 +89,13 @@ hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage,
     if (p.L_max > kEkfLdsMaxLandmarks) return f32_storage ? hipErrorInvalidConfiguration : launch_ekf_big_step(p, stream);
     const EkfVariant* v = pick_variant(p.L_max, p.B, variant, f32_storage);
     if (!v) return hipErrorInvalidConfiguration;
-    if (p.long_mode && !f32_storage) {   // a message may exceed what the size class holds (ekf_kernel.h)
-        if (p.sim || p.cmds != nullptr) return launch_ekf_big_step(p, stream);
+    if (p.long_mode) {   // a message may exceed what the size class holds (ekf_kernel.h)
+        if (p.sim || p.cmds != nullptr) return launch_ekf_big_step(p, stream, f32_storage);
         EkfStepParams q = p;
         q.long_mode = 1;                 // the LDS kernel: every instance whose message fits ...
         if (const hipError_t e = v->launch(q, stream); e != hipSuccess) return e;
         q.long_mode = 2;                 // ... and the streamed kernel: the others
-        return launch_ekf_big_step(q, stream);
+        return launch_ekf_big_step(q, stream, f32_storage);
     }
     return v->launch(p, stream);
 }

@@ -209,13 +209,13 @@ void fill_ukf_params(slam_handle* h, slam::UkfStepParams& p, const float cmd[2])
 // measurements: the caller's bound k_stride is (slam_step passes the largest count it saw); SIM mode: the map is - runs the long-message path
 // of launch_ekf_step / launch_ukf_step: the instances concerned go through the HBM-streamed kernels, which read a message where it lies
 // (same state layout, same arithmetic: both are bit-identical to the oracle; about a pass over P per detection slower).  Returns the class
-// capacity if that path is needed, 0 if not (or if the handle has none: fp32 storage keeps the limit and drops the surplus with
-// SLAM_INST_CAPACITY; the streamed classes have no limit in the first place).
+// capacity if that path is needed, 0 if not (the streamed classes have no limit in the first place).  fp32-storage EKF handles too: the
+// streamed kernel reads and writes floats there and runs the timestep in the handle's fp64 slab.
 int long_message_cap(slam_handle* h, int sim, int k_stride, int* cap_out) {
     *cap_out = 0;
     int cap;
     if (h->kind == SLAM_EKF_SLAM) {
-        if (h->esz != 8 || h->L_max > slam::kEkfLdsMaxLandmarks) return SLAM_OK;
+        if (h->L_max > slam::kEkfLdsMaxLandmarks) return SLAM_OK;
         cap = slam::ekf_class_message_capacity(h->L_max);
     } else {
         if (h->kind == SLAM_UKF_SLAM && h->L_max > slam::kUkfLdsMaxLandmarks) return SLAM_OK;
@@ -556,7 +556,7 @@ int slam_step_dev(slam_handle* h, const float cmd[2], const float* d_meas, const
     // Device buffers on the caller's stream: queueing is OPT-IN here (slam_set_lazy_steps / SLAM_LAZY_STEPS), because a queued
     // call enqueues only its device-to-device copy on the stream, not the step itself
     if (h->kind == SLAM_EKF_SLAM && h->lazy_explicit && h->lazy_max > 1 && h->run_chunk != 1 && !h->dump_meas &&
-        (h->esz != 8 || k_stride <= slam::ekf_class_message_capacity(h->L_max))) {   // (messages that may be longer: one launch pair per step, launch_step)
+        k_stride <= slam::ekf_class_message_capacity(h->L_max)) {   // (messages that may be longer: one launch pair per step, launch_step)
         slam_handle::DevQueue& q = h->devq;
         if (!h->lazy_cmds.empty() || h->extq[h->extq_cur].n > 0 || (q.n > 0 && q.ks != k_stride)) FLUSH(h);   // earlier steps first
         const size_t B = (size_t)h->B;

@@ -36,8 +36,6 @@ def lib():
         L.orc_ekf_destroy.argtypes = [C.c_void_p]
         L.orc_ekf_init.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.orc_ekf_update.argtypes = [C.c_void_p, C.c_float, C.c_float, _fp, C.c_int]
-        L.orc_ekf_set_message_capacity.argtypes = [C.c_void_p, C.c_int]
-        L.orc_ukf_set_message_capacity.argtypes = [C.c_void_p, C.c_int]
         L.orc_ekf_get.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, _ip]
         L.orc_ekf_set.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _ip, C.c_int]
         L.orc_sim_create.restype = C.c_void_p
@@ -122,11 +120,6 @@ class OracleEKF:
 
     def init(self, x0=0.0, y0=0.0, yaw0=0.0):
         lib().orc_ekf_init(self.h, x0, y0, yaw0)
-
-    def set_message_capacity(self, cap):
-        """Restate the PRODUCT's per-message limit (detections beyond `cap` dropped, SLAM_INST_CAPACITY raised); 0 = the reference's
-        unbounded loop (default).  For the soaks, so that flags can be compared exactly on over-long messages."""
-        lib().orc_ekf_set_message_capacity(self.h, int(cap))
 
     def update(self, fwd, ang, meas):
         """meas: array-like [k][3] float32 (id, r, b)."""
@@ -215,10 +208,6 @@ class OracleUKF:
 
     def init(self, x0=0.0, y0=0.0, yaw0=0.0):
         lib().orc_ukf_init(self.h, x0, y0, yaw0)
-
-    def set_message_capacity(self, cap):
-        """See OracleEKF.set_message_capacity."""
-        lib().orc_ukf_set_message_capacity(self.h, int(cap))
 
     def update(self, fwd, ang, meas):
         m = np.ascontiguousarray(np.asarray(meas, dtype=np.float32).reshape(-1, 3))

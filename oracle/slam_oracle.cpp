@@ -89,13 +89,9 @@ struct Ekf {
     void insert_fast(double rd, double sphi, double cphi);
     void insert_dense(double rd, double sphi, double cphi);
 
-    // The PRODUCT holds a message in LDS: at most `msg_cap` detections of one message are used (the landmark capacity of the handle's size
-    // class; only a message with repeated ids can be longer), the surplus is dropped and SLAM_INST_CAPACITY raised (include/slam_batch.h).
-    // The reference walks on over any number of detections (ekf.cpp:73); 0 (default) = that.  A positive value makes the oracle
-    // restate the product's documented limit so that the soaks can compare FLAGS exactly on over-long messages as well.
-    int msg_cap = 0;
+    // (a message is walked whatever its length, ekf.cpp:65,73; the product's LDS size classes had a per-message limit until round 5 and this
+    // oracle a switch that restated it for the soaks: both are gone)
     int update(float fwd, float ang, const float* meas, int k) {
-        if (!frozen && msg_cap > 0 && k > msg_cap) { flags |= SLAM_INST_CAPACITY; k = msg_cap; }
         return math == MATH_DET ? update_t<DetMath>(fwd, ang, meas, k) : update_t<LibmMath>(fwd, ang, meas, k);
     }
 };
@@ -374,7 +370,6 @@ void* orc_ekf_create(const slam_config* cfg, int L_max, int math, int mode) { re
 void orc_ekf_destroy(void* h) { delete (Ekf*)h; }
 void orc_ekf_init(void* h, float x0, float y0, float yaw0) { ((Ekf*)h)->init(x0, y0, yaw0); }
 int orc_ekf_update(void* h, float fwd, float ang, const float* meas, int k) { return ((Ekf*)h)->update(fwd, ang, meas, k); }
-void orc_ekf_set_message_capacity(void* h, int cap) { ((Ekf*)h)->msg_cap = cap; }
 // x: n doubles; P: n*n row-major; ids: M ints
 void orc_ekf_get(void* h, double* x, double* P, int* M, int* ids, int* timestep) {
     Ekf* e = (Ekf*)h;

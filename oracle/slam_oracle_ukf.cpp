@@ -447,9 +447,7 @@ struct Ukf {
         if (!fin) flags |= SLAM_INST_NONFINITE;
         return flags;
     }
-    int msg_cap = 0;   // see Ekf::msg_cap (slam_oracle.cpp): the product's per-message limit, restated for the soaks; 0 = the reference
     int update(float fwd, float ang, const float* meas, int k) {
-        if (msg_cap > 0 && k > msg_cap) { flags |= SLAM_INST_CAPACITY; k = msg_cap; }
         return math == MATH_DET ? update_t<DetMath>(fwd, ang, meas, k) : update_t<LibmMath>(fwd, ang, meas, k);
     }
     double yaw_est() const { return remainder(math == MATH_DET ? DetMath::atan2(x_t[3], x_t[2]) : LibmMath::atan2(x_t[3], x_t[2]), slam::kTwoPi); }
@@ -470,7 +468,6 @@ void orc_ukf_set_loc_map(void* h, const double* map_xy, int L) {
 void orc_ukf_destroy(void* h) { delete (Ukf*)h; }
 void orc_ukf_init(void* h, float x0, float y0, float yaw0) { ((Ukf*)h)->init(x0, y0, yaw0); }
 int orc_ukf_update(void* h, float fwd, float ang, const float* meas, int k) { return ((Ukf*)h)->update(fwd, ang, meas, k); }
-void orc_ukf_set_message_capacity(void* h, int cap) { ((Ukf*)h)->msg_cap = cap; }
 void orc_ukf_get(void* h, double* x, double* P, int* M, int* ids, int* timestep, int* sweeps) {
     Ukf* u = (Ukf*)h;
     const int n = u->n();

@@ -712,8 +712,9 @@ def test_over_long_host_messages_walk_every_detection_in_the_lds_classes(S, orac
     the surplus with SLAM_INST_CAPACITY.  Round 5: slam_step sees the counts, so the instances whose message is beyond the class's capacity
     take that one timestep through the HBM-streamed kernel (same state layout, same arithmetic; the LDS kernel of the same launch pair skips
     them, EkfStepParams::long_mode): fp64 EKF handles now follow the oracle WITHOUT its per-message limit, interleaved with ordinary messages
-    (fast kernel, queued and immediate) in the same batch and from step to step, bit for bit and flag for flag.  The fp32-storage class keeps
-    the documented limit (the oracle restates it under set_message_capacity)."""
+    (fast kernel, queued and immediate) in the same batch and from step to step, bit for bit and flag for flag.  fp32 storage too: the
+    streamed kernel reads and writes floats and runs the timestep in the handle's fp64 slab, which is the oracle's STORAGE_F32 (x_t and
+    P_t rounded once per timestep).  The oracle has no per-message limit any more."""
     cap = 20 if L <= 20 else (50 if L <= 50 else 100)
     for f32 in (False, True):
         if f32 and L > 50:
@@ -724,7 +725,6 @@ def test_over_long_host_messages_walk_every_detection_in_the_lds_classes(S, orac
         es = []
         for b in range(B):
             e = oracle.OracleEKF(cfg, L_max=L, mode=oracle.MODE_FAST | (oracle.STORAGE_F32 if f32 else 0))
-            e.set_message_capacity(cap if f32 else 0)
             e.init(0, 0, 0); es.append(e)
         rng = np.random.default_rng(11 + L + idknown)
         of = np.zeros(B, dtype=np.int64)
@@ -753,7 +753,8 @@ def test_over_long_host_messages_walk_every_detection_in_the_lds_classes(S, orac
         f.close()
 
 
-def test_long_messages_from_device_buffers_and_from_the_generator(S, oracle):
+@pytest.mark.parametrize("f32", [False, True])
+def test_long_messages_from_device_buffers_and_from_the_generator(S, oracle, f32):
     """The other two entry points of the same limit.  slam_step_dev: the counts are on the device, so the caller's stride is the bound - a
     stride beyond the class's capacity runs the launch pair (LDS kernel for the instances whose message fits, streamed kernel for the others,
     EkfStepParams::long_mode), a stride within it the LDS kernel alone.  SIM mode: a map with more landmarks than a message of the class
@@ -767,12 +768,13 @@ def test_long_messages_from_device_buffers_and_from_the_generator(S, oracle):
     L, B, T, KS = 20, 5, 10, 48
     d_meas, d_cnt = C.c_void_p(), C.c_void_p()
     assert hip.hipMalloc(C.byref(d_meas), B * KS * 3 * 4) == 0 and hip.hipMalloc(C.byref(d_cnt), B * 4) == 0
+    dt, omode = (S.F32, oracle.MODE_FAST | oracle.STORAGE_F32) if f32 else (S.F64, oracle.MODE_FAST)
     for lazy in (0, 8):
-        f = S.BatchedEKF(B, L).readParams(); f.init(0.0, 0.0, 0.0)
+        f = S.BatchedEKF(B, L, dtype=dt).readParams(); f.init(0.0, 0.0, 0.0)
         if lazy: f.set_lazy_steps(lazy)
         es = []
         for b in range(B):
-            e = oracle.OracleEKF(S.default_config(), L_max=L); e.init(0, 0, 0); es.append(e)
+            e = oracle.OracleEKF(S.default_config(), L_max=L, mode=omode); e.init(0, 0, 0); es.append(e)
         rng = np.random.default_rng(77)
         of = np.zeros(B, dtype=np.int64)
         for t in range(T):
@@ -806,13 +808,13 @@ def test_long_messages_from_device_buffers_and_from_the_generator(S, oracle):
     lm, cmds = make_scenario(9, Lm, T)
     vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]; vis[7] = [1e9, -4.0, 4.0]; vis[8] = [1e9, -4.0, 4.0]
     for chunked in (False, True):
-        f = S.BatchedEKF(6, L).readParams(); f.set_map(lm); f.set_seed(4); f.init(0, 0, 0)
+        f = S.BatchedEKF(6, L, dtype=dt).readParams(); f.set_map(lm); f.set_seed(4); f.init(0, 0, 0)
         if chunked:
             for t in range(T):
                 f.set_vision(*vis[t]); f.update_sim(cmds[t])
         else:
             f.set_vision(1e9, -4.0, 4.0); f.run_sim(cmds)
-        r = oracle.run_ekf_batch(lm, cmds, 6, L, seed=4, nthreads=3, vision=vis if chunked else np.tile([1e9, -4.0, 4.0], (T, 1)))
+        r = oracle.run_ekf_batch(lm, cmds, 6, L, seed=4, nthreads=3, mode=omode, vision=vis if chunked else np.tile([1e9, -4.0, 4.0], (T, 1)))
         assert np.all(r["M"] == L) and np.all(r["flags"] & 8) and np.array_equal(f.status(), r["flags"])
         assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
         n = 3 + 2 * L

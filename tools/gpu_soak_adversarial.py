@@ -24,11 +24,8 @@ while time.time() < t_end:
     B = int(rng.integers(1, 10))
     idknown = int(rng.random() < 0.75)
     kcap = int(rng.choice([2, 6, 20, 70] + ([300] if L > 200 else [])))
-    # Round 5: no per-message limit on fp64 EKF and on UKF handles any more - the instances whose message is longer than the size class
-    # holds go through the HBM-streamed kernels (EkfStepParams / UkfStepParams::long_mode), so the oracle runs as the reference does
-    # (capacity 0).  Only the fp32-storage EKF classes still drop the surplus with SLAM_INST_CAPACITY (include/slam_batch.h); the oracle
-    # restates that limit under a switch (set_message_capacity), so over-long messages are drawn there too and the flags compared exactly.
-    class_cap = (20 if L <= 20 else 50) if f32 else 0
+    # Round 5: no per-message limit any more - the instances whose message is longer than the size class holds go through the HBM-streamed
+    # kernels (EkfStepParams / UkfStepParams::long_mode; fp32 storage included), so the oracle runs exactly as the reference does.
     idmax = int(rng.choice([max(2, L // 2), L, 2 * L, 400]))
     idmin = int(rng.choice([0, 0, -3, -40]))   # any int is an id for the reference (ekf.cpp:99-108), negative ones included (-1 / -2 were sentinels once)
     seed = int(rng.integers(1, 1 << 30))
@@ -46,7 +43,6 @@ while time.time() < t_end:
     es = []
     for b in range(B):
         e = O.OracleUKF(cfg, L_max=L) if ukf else O.OracleEKF(cfg, L_max=L, mode=O.MODE_FAST | (O.STORAGE_F32 if f32 else 0))
-        e.set_message_capacity(class_cap)
         e.init(0, 0, 0); es.append(e)
     oflags = np.zeros(B, dtype=np.int64)
     for t in range(T):
