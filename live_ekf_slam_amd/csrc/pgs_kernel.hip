@@ -874,12 +874,12 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
                         for (int r4 = 0; r4 < 4; ++r4)
                             if (rowbase + 16 * i + kq + 4 * r4 == m2 && colbase + 16 * j + cl < m2) acc[i][j][r4] = rh[16 * j + cl];
             }
-#pragma unroll 1
-            for (int ps = 0; ps < nseg; ++ps) {
-                const int32_t* bk = blk + (size_t)ps * nb1;
-                if (!(bk[rb + 1] > bk[rb] && bk[cb + 1] > bk[cb])) continue;   // wave-uniform
+            // Which segments touch the tile: one LANE per segment tests its seg_blk row, a ballot gives the list - one round trip for all of
+            // them (segment after segment with scalar loads it was one per segment, ~30 of them for the handful that are relevant).  The
+            // relevant ones are then subtracted in ascending order, the index loads of the next one in flight beside the T entries of the
+            // current one: about one dependent round trip per relevant segment instead of two.
+            auto load_idx = [&](const int ps, int (&lr)[NI][4], int (&lc)[NI]) {
                 const int32_t* iv = sinv + (size_t)ps * p.L_max;
-                int lr[NI][4], lc[NI];
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -896,14 +896,46 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
                     if (c < m2) { const int q = iv[c >> 1]; l = q >= 0 ? 2 * q + (c & 1) : -1; }
                     lc[j] = l;
                 }
-                const double* Tp = Tb + (size_t)ps * (128 * 128);
+            };
+#pragma unroll 1
+            for (int ps0 = 0; ps0 < nseg; ps0 += 64) {
+                bool rel = false;
+                if (ps0 + lane < nseg) {
+                    const int32_t* bk = blk + (size_t)(ps0 + lane) * nb1;
+                    rel = bk[rb + 1] > bk[rb] && bk[cb + 1] > bk[cb];
+                }
+                unsigned long long mask = __ballot(rel);   // wave-uniform from here on
+                int lr[NI][4], lc[NI];
+                int ps = mask ? ps0 + (__ffsll((long long)mask) - 1) : -1;
+                if (ps >= 0) load_idx(ps, lr, lc);
+#pragma unroll 1
+                while (ps >= 0) {
+                    mask &= mask - 1ull;
+                    const int psn = mask ? ps0 + (__ffsll((long long)mask) - 1) : -1;
+                    int lrn[NI][4], lcn[NI];
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
+                    for (int i = 0; i < NI; ++i) {
+                        lcn[i] = -1;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
+                        for (int r4 = 0; r4 < 4; ++r4) lrn[i][r4] = -1;
+                    }
+                    if (psn >= 0) load_idx(psn, lrn, lcn);
+                    const double* Tp = Tb + (size_t)ps * (128 * 128);
 #pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4)
-                            if (lr[i][r4] >= 0 && lc[j] >= 0 && lc[j] <= lr[i][r4]) acc[i][j][r4] = acc[i][j][r4] - Tp[(size_t)lr[i][r4] * 128 + lc[j]];
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4)
+                                if (lr[i][r4] >= 0 && lc[j] >= 0 && lc[j] <= lr[i][r4]) acc[i][j][r4] = acc[i][j][r4] - Tp[(size_t)lr[i][r4] * 128 + lc[j]];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        lc[i] = lcn[i];
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) lr[i][r4] = lrn[i][r4];
+                    }
+                    ps = psn;
+                }
             }
         }
     }
