@@ -1698,11 +1698,13 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
     const int LD = p.LD, m2 = 2 * p.M[b];
     if (m2 == 0) return;
     double* Sb = p.S + (size_t)b * LD * LD;
-    // dynamic LDS: the panel C [rows j0 .. m2][NB + 1] (its first 16 rows are the diagonal block), then the block rows of L [16][ldb]
-    double* const s_c = s_dyn;
-    double* const s_b = s_dyn + (size_t)(LD + 16) * (NB + 1);
+    // Dynamic LDS, T = 2 (LD + 1) (NB + 1) doubles.  The panel C [rows j0 .. m2][NB + 1] (its first 16 rows are the diagonal block) of an even
+    // panel sits at the bottom of it, of an odd panel at the top end: the panel solve leaves L in its panel's buffer, so the NEXT panel completes
+    // its tiles (phase F: the last 16 k) out of LDS instead of reading back from memory what has just been written there (a round trip through
+    // L2 per panel, 4 of the 14 us of a panel step).  The staged block rows of L [16][ldb] take the opposite end, over the panel before, which is
+    // dead once phase F is through: R (NB + 1) + 16 ldb <= (m2 + 1) (NB + 1) + 112 and two consecutive panels need (2 R + 16) (NB + 1) <= T.
+    const int T_dbl = 2 * (LD + 1) * (NB + 1);
     double* const s_y = s_dyn;           // backward phase: y / x [m2]
-    auto SD = [&](int r, int c) -> double& { return s_c[r * (NB + 1) + c]; };
     if (tid == 0) s_fail = 0;
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = p.prof ? wall_clock64() : 0ull;
 #define PGS_STAMP(i) do { if (p.prof && tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tprev; tprev = now_; } } while (0)
@@ -1744,6 +1746,13 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         const int nb = (m2 - j0) < NB ? (m2 - j0) : NB;
         const int R = m2 + 1 - j0;                 // rows of the panel: the block rows, the rows below, the rhs row
         const int nt = (R + 15) >> 4;
+        int ldb = (j0 + 3) & ~3;                   // row length of the staged block rows: a multiple of 4 with an odd quotient (bank spread)
+        if (((ldb >> 2) & 1) == 0) ldb += 4;
+        const bool odd = (j0 >> 4) & 1;
+        double* const s_c = odd ? s_dyn + (T_dbl - R * (NB + 1)) : s_dyn;                            // this panel
+        const double* const s_p = odd ? s_dyn : s_dyn + (T_dbl - (R + NB) * (NB + 1));              // the panel before (R + 16 rows), holding L
+        double* const s_b = odd ? s_dyn : s_dyn + (T_dbl - 16 * ldb);                               // block rows staged for the next panel's tiles
+        auto SD = [&](int r, int c) -> double& { return s_c[r * (NB + 1) + c]; };
         // ---- phase F: the tiles of this panel get the last 16 k (columns j0-16 .. j0-1, written by the previous panel's solve) ----
         if (w >= 1) {
 #pragma unroll
@@ -1751,12 +1760,12 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
                 const int t = (w - 1) + NTW * q;
                 if (t >= nt) continue;
                 dbl4_t acc = accn[q];
-                if (j0 > 0) {
-                    const int ar = j0 + 16 * t + cl <= m2 ? j0 + 16 * t + cl : m2, br = j0 + cl <= m2 ? j0 + cl : m2;
-                    const dbl4v_t a1 = *reinterpret_cast<const dbl4v_t*>(Sb + (size_t)ar * LD + j0 - 16 + 4 * kq);
-                    const dbl4v_t b1 = *reinterpret_cast<const dbl4v_t*>(Sb + (size_t)br * LD + j0 - 16 + 4 * kq);
+                if (j0 > 0) {   // rows j0 + 16 t + cl and j0 + cl (clamped to m2) of the previous panel's columns: its buffer's rows 16 + ..
+                    const int la = 16 + 16 * t + cl < R + NB ? 16 + 16 * t + cl : R + NB - 1, lb = 16 + cl < R + NB ? 16 + cl : R + NB - 1;
+                    const double* __restrict__ pa = s_p + la * (NB + 1) + 4 * kq;
+                    const double* __restrict__ pb = s_p + lb * (NB + 1) + 4 * kq;
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[qq], b1[qq], acc, 0, 0, 0);
+                    for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[qq], pb[qq], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
@@ -1772,8 +1781,6 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
         const int jn = j0 + NB;                    // next panel
         const bool has_next = jn < m2;
         const int ntn = has_next ? (m2 + 1 - jn + 15) >> 4 : 0;
-        int ldb = (j0 + 3) & ~3;                   // row length of the staged block rows: a multiple of 4 with an odd quotient (bank spread)
-        if (((ldb >> 2) & 1) == 0) ldb += 4;
         // The diagonal block in wavefront 0's REGISTERS (round 5): lane r (mod 16; the four lane groups hold replicas) keeps row r, the
         // pivot and the column entries l(c2, c) another row needs arrive by v_readlane.  Through LDS - lane = (row, column group), two
         // fenced round trips per column - a column cost ~1 300 cycles, 8.6 us per block, 190 of the 400 us of a factorisation.
@@ -1902,7 +1909,10 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int rl = 16 * t + kq + 4 * r4;
-                if (rl >= nb && rl < R && cl < nb) Sb[(size_t)(j0 + rl) * LD + j0 + cl] = acc[r4];
+                if (rl >= nb && rl < R && cl < nb) {
+                    Sb[(size_t)(j0 + rl) * LD + j0 + cl] = acc[r4];
+                    SD(rl, cl) = acc[r4];   // L stays in the panel's buffer for the next panel's phase F (this wavefront has read the tile's rows above)
+                }
             }
         }
         __syncthreads();   // L of this panel is in memory before the next panel's tiles read its columns; s_c is free again
@@ -2462,8 +2472,8 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
         const void* ck = p.chol_threads == 256 ? (const void*)pgs_chol_kernel<256> : (p.chol_ll && p.LD <= 448) ? (const void*)pgs_chol_ll_kernel : (const void*)pgs_chol_kernel<1024>;
         if (const hipError_t e = slam_allow_full_lds(ck); e != hipSuccess) return e;
         if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(nslot), dim3(256), lds, s, p); break; }
-        if (p.chol_ll && p.LD <= 448) {   // left-looking: the panel [LD + 16][17] and the staged block rows [16][<= LD + 8] (its staging registers are sized for LD <= 448)
-            const size_t lds_ll = lds + sizeof(double) * 16 * (size_t)(p.LD + 8);
+        if (p.chol_ll && p.LD <= 448) {   // left-looking: two consecutive panels [<= LD + 1][17] each, the staged block rows over the older one (its staging registers are sized for LD <= 448)
+            const size_t lds_ll = sizeof(double) * 2 * (size_t)(p.LD + 1) * 17;
             hipLaunchKernelGGL(pgs_chol_ll_kernel, dim3(nslot), dim3(1024), lds_ll, s, p);
             break;
         }
