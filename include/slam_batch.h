@@ -113,7 +113,7 @@ int slam_config_load(slam_config* cfg, const char* yaml_path);
  * (localization_node.cpp:33-47).  batch = number of instances on THIS device, L_max = landmark capacity
  * (EKF_SLAM: <= 1000 in fp64 [LDS size classes 20 / 50 / 100 / 200; beyond 200 the HBM-streamed class: the same EKF::update with
  * the covariance streamed through HBM in every phase, one launch per timestep, bit-identical but slow - the state of the reference
- * grows without a limit, ekf.cpp:144-146]; <= 50 in fp32 storage; UKF_SLAM: <= 200 [LDS size classes 20 / 50, beyond 50 its HBM-streamed class]; UKF_LOC: ignored, the
+ * grows without a limit, ekf.cpp:144-146]; fp32 storage: LDS size classes 20 / 50, the streamed class beyond; UKF_SLAM: <= 200 [LDS size classes 20 / 50, beyond 50 its HBM-streamed class]; UKF_LOC: ignored, the
  * state holds no landmarks - its map may have any size and a message any length [beyond 50 detections - 20 while the map has <= 20
  * landmarks - the instance takes the HBM-streamed step kernel]).  The reference grows the state without limit (ekf.cpp:144-146); here the limit of the
  * fast classes is what one workgroup keeps in the 160 KB of LDS of a CU, and of the streamed class 2 x n x n doubles per instance in HBM.

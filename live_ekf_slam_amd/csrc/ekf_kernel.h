@@ -78,14 +78,15 @@ static constexpr int kEkfTrafficSlot = 10;  // khist[10..13]: bytes moved by the
 // per CU; n <= 203: 72 KB, two per CU; the limit is LDS, not registers).  Beyond it ekf_big_kernel.hip takes over (round 4): the same
 // EKF::update with the covariance streamed through HBM / L2 in every phase, one launch per timestep, fp64 storage only - slow, but the
 // reference's state grows without a limit (ekf.cpp:144-146) and 200 landmarks was one.  Its own limit is the LDS for x, K and H P
-// (6 n doubles) and the 2 x n^2 doubles of an instance in HBM.  fp32 storage is instantiated up to 50 landmarks.
+// (6 n doubles) and the 2 x n^2 doubles of an instance in HBM.  fp32 storage: LDS classes up to 50 landmarks, the streamed kernel beyond (round 5: it reads and
+// writes floats and runs the timestep in the handle's fp64 slab).
 static constexpr int kEkfLdsMaxLandmarks = 200;
 // detections ONE message may hold in the LDS size class a handle of capacity L_max runs (the class's landmark capacity; the surplus is
 // not dropped any more).  The HBM-streamed kernel walks messages of any length: the instances with a longer message go to it
 // (EkfStepParams::long_mode), in either storage type.
 inline int ekf_class_message_capacity(int L_max) { return L_max <= 20 ? 20 : (L_max <= 50 ? 50 : (L_max <= 100 ? 100 : 200)); }
 static constexpr int kEkfMaxLandmarks = 1000;
-static constexpr int kEkfMaxLandmarksF32 = 50;
+static constexpr int kEkfLdsMaxLandmarksF32 = 50;   // fp32 storage: the LDS size classes instantiated (20, 50); beyond them the streamed kernel, like fp64 beyond 200
 
 // Tuning variants of the step kernel.  Every instantiation unit (ekf_inst.hip compiled with -DV_NMAX=.. -DV_W=.. -DV_KG=..
 // -DV_UNR=.. -DV_F32=.. -DV_PIPE=.., see build.py) registers its launcher at load time; launch_ekf_step picks one by size

@@ -81,12 +81,12 @@ static const EkfVariant* pick_variant(int L_max, int B, int variant, int f32_sto
 }
 
 int ekf_variant_available(int L_max, int f32_storage, int variant) {
-    if (L_max > kEkfLdsMaxLandmarks) return !f32_storage && variant <= 0 && L_max <= kEkfMaxLandmarks;   // the HBM-streamed class has one kernel
+    if (L_max > (f32_storage ? kEkfLdsMaxLandmarksF32 : kEkfLdsMaxLandmarks)) return variant <= 0 && L_max <= kEkfMaxLandmarks;   // the HBM-streamed class has one kernel
     return pick_variant(L_max, 1, variant, f32_storage) != nullptr;
 }
 
 hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage, hipStream_t stream) {
-    if (p.L_max > kEkfLdsMaxLandmarks) return f32_storage ? hipErrorInvalidConfiguration : launch_ekf_big_step(p, stream);
+    if (p.L_max > (f32_storage ? kEkfLdsMaxLandmarksF32 : kEkfLdsMaxLandmarks)) return launch_ekf_big_step(p, stream, f32_storage);
     const EkfVariant* v = pick_variant(p.L_max, p.B, variant, f32_storage);
     if (!v) return hipErrorInvalidConfiguration;
     if (p.long_mode) {   // a message may exceed what the size class holds (ekf_kernel.h)
@@ -101,7 +101,7 @@ hipError_t launch_ekf_step(const EkfStepParams& p, int variant, int f32_storage,
 }
 
 hipError_t ekf_kernel_info(int L_max, int B, int variant, int f32_storage, int multi, EkfKernelInfo* out) {
-    if (L_max > kEkfLdsMaxLandmarks) return f32_storage ? hipErrorInvalidConfiguration : ekf_big_kernel_info(out);
+    if (L_max > (f32_storage ? kEkfLdsMaxLandmarksF32 : kEkfLdsMaxLandmarks)) return ekf_big_kernel_info(out);
     const EkfVariant* v = pick_variant(L_max, B, variant, f32_storage);
     if (!v) return hipErrorInvalidConfiguration;
     return v->info(multi, out);

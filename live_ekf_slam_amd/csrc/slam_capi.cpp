@@ -215,7 +215,7 @@ int long_message_cap(slam_handle* h, int sim, int k_stride, int* cap_out) {
     *cap_out = 0;
     int cap;
     if (h->kind == SLAM_EKF_SLAM) {
-        if (h->L_max > slam::kEkfLdsMaxLandmarks) return SLAM_OK;
+        if (h->L_max > (h->esz == 4 ? slam::kEkfLdsMaxLandmarksF32 : slam::kEkfLdsMaxLandmarks)) return SLAM_OK;   // a streamed class: no limit
         cap = slam::ekf_class_message_capacity(h->L_max);
     } else {
         if (h->kind == SLAM_UKF_SLAM && h->L_max > slam::kUkfLdsMaxLandmarks) return SLAM_OK;
@@ -341,8 +341,8 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (kind == SLAM_UKF_LOC) L_max = 1;   // localisation only: the state never holds landmarks
     if (dtype != SLAM_F64 && !(dtype == SLAM_F32 && kind == SLAM_EKF_SLAM))
         return fail(SLAM_ERR_UNSUPPORTED, "fp32 state storage is implemented for EKF_SLAM only");
-    if (L_max > (kind != SLAM_EKF_SLAM ? slam::kUkfMaxLandmarks : (dtype == SLAM_F32 ? slam::kEkfMaxLandmarksF32 : slam::kEkfMaxLandmarks)))
-        return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the limit of this filter kind / storage type (EKF fp64 %d, EKF fp32 %d, UKF %d): EKF fp64 beyond %d landmarks and the UKF beyond 50 run the HBM-streamed size classes; fp32 storage keeps the per-instance working set in the 160 KB of LDS of one CU", L_max, slam::kEkfMaxLandmarks, slam::kEkfMaxLandmarksF32, slam::kUkfMaxLandmarks, slam::kEkfLdsMaxLandmarks);
+    if (L_max > (kind != SLAM_EKF_SLAM ? slam::kUkfMaxLandmarks : slam::kEkfMaxLandmarks))
+        return fail(SLAM_ERR_UNSUPPORTED, "L_max %d exceeds the limit of this filter kind (EKF %d, UKF %d): the EKF beyond %d landmarks (fp32 storage: beyond %d) and the UKF beyond 50 run the HBM-streamed size classes, whose working set is 2 x n x n doubles per instance in HBM", L_max, slam::kEkfMaxLandmarks, slam::kUkfMaxLandmarks, slam::kEkfLdsMaxLandmarks, slam::kEkfLdsMaxLandmarksF32);
     HIP_TRY(hipSetDevice(device));
     slam_handle* h = new slam_handle();
     h->cfg = *cfg; h->kind = kind; h->B = batch; h->L_max = L_max; h->dtype = dtype; h->device = device;

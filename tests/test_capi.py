@@ -94,7 +94,7 @@ def test_bad_arguments_return_error_codes():
     c = default_config()
     assert L.slam_create(C.byref(c), 1, 0, 20, 0, 0, C.byref(h)) == -1          # batch 0
     assert L.slam_create(C.byref(c), 1, 4, 1001, 0, 0, C.byref(h)) == -3        # above kernel capacity (EKF fp64: 1000 landmarks, the HBM-streamed class)
-    assert L.slam_create(C.byref(c), 1, 4, 51, 1, 0, C.byref(h)) == -3          # fp32 storage: 50
+    assert L.slam_create(C.byref(c), 1, 4, 1001, 1, 0, C.byref(h)) == -3        # fp32 storage: the same limit (beyond 50 landmarks the streamed class, since round 5)
     assert b"limit" in L.slam_last_error()
     assert L.slam_create(C.byref(c), 3, 4, 20, 1, 0, C.byref(h)) == -3          # f32 storage: EKF only
     assert L.slam_create(C.byref(c), 9, 4, 20, 0, 0, C.byref(h)) == -1          # unknown filter kind

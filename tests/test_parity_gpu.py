@@ -753,6 +753,55 @@ def test_over_long_host_messages_walk_every_detection_in_the_lds_classes(S, orac
         f.close()
 
 
+@pytest.mark.parametrize("L", [60, 210])
+def test_fp32_storage_beyond_the_lds_classes(S, oracle, L):
+    """fp32 storage of x and P ended at 50 landmarks (the LDS classes instantiated for it; SLAM_ERR_UNSUPPORTED beyond).  Round 5: the HBM-streamed
+    kernel reads and writes floats and runs the timestep in the handle's fp64 slab - the oracle's STORAGE_F32 (x_t, P_t rounded once per
+    timestep) - so an fp32 handle takes any capacity the fp64 one does.  Device-generated messages with a first look at the whole map, and
+    external messages with repeated ids and ids beyond the capacity; bit-identical to the oracle."""
+    from live_ekf_slam_amd.scenario import make_scenario
+    B, T = 3, 12
+    lm, cmds = make_scenario(17, L, T)
+    vis = np.tile([3.0, -1.57, 1.57], (T, 1)); vis[0] = [1e9, -4.0, 4.0]; vis[5] = [1e9, -4.0, 4.0]
+    omode = oracle.MODE_FAST | oracle.STORAGE_F32
+    f = S.BatchedEKF(B, L, dtype=S.F32).readParams(); f.set_map(lm); f.set_seed(6); f.init(0, 0, 0)
+    for t in range(T):
+        f.set_vision(*vis[t]); f.update_sim(cmds[t])
+    r = oracle.run_ekf_batch(lm, cmds, B, L, seed=6, nthreads=3, mode=omode, vision=vis)
+    assert np.all(r["M"] == L) and np.array_equal(f.landmark_counts(), r["M"]) and np.array_equal(f.status(), r["flags"])
+    assert np.array_equal(f.error_stats(), r["avg_err"]) and np.array_equal(f.truth(), r["truth"])
+    n = 3 + 2 * L
+    for b in range(B):
+        _assert_state_equal(f.get_state(b), dict(M=L, ids=r["ids"][b, :L], x=r["x"][b, :n], P=r["P"][b, :n * n].reshape(n, n)))
+    f.close()
+    f = S.BatchedEKF(2, L, dtype=S.F32).readParams(); f.init(0.0, 0.0, 0.0)
+    es = []
+    for b in range(2):
+        e = oracle.OracleEKF(S.default_config(), L_max=L, mode=omode); e.init(0, 0, 0); es.append(e)
+    rng = np.random.default_rng(L)
+    of = np.zeros(2, dtype=np.int64)
+    for t in range(6):
+        cmd = np.array([rng.uniform(0, 0.1), rng.uniform(-0.05, 0.05)], dtype=np.float32)
+        ks = np.array([L + 20 if t == 0 else int(rng.integers(0, 30)) for _ in range(2)])
+        K = max(1, int(ks.max()))
+        meas = np.zeros((2, K, 3), dtype=np.float32)
+        for b in range(2):
+            k = int(ks[b])
+            meas[b, :k, 0] = rng.permutation(L + 30)[:k] if t == 0 else rng.integers(0, L + 30, k)
+            meas[b, :k, 1] = rng.uniform(0.5, 6.0, k); meas[b, :k, 2] = rng.uniform(-3.1, 3.1, k)
+        f.update(cmd, meas, ks.astype(np.int32))
+        for b in range(2):
+            of[b] |= es[b].update(cmd[0], cmd[1], meas[b, :ks[b]])
+    assert np.array_equal(f.status().astype(np.int64), of)
+    for b in range(2):
+        if of[b] & 4:
+            continue
+        so, sg = es[b].state(), f.get_state(b)
+        assert sg["M"] == so["M"] and np.array_equal(sg["ids"], so["ids"])
+        assert np.array_equal(sg["x"], so["x"]) and np.array_equal(sg["P"], so["P"]), b
+    f.close()
+
+
 @pytest.mark.parametrize("f32", [False, True])
 def test_long_messages_from_device_buffers_and_from_the_generator(S, oracle, f32):
     """The other two entry points of the same limit.  slam_step_dev: the counts are on the device, so the caller's stride is the bound - a

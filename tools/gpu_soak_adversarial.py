@@ -26,7 +26,7 @@ cat = {}
 while time.time() < t_end:
     ukf = which == "ukf" or (which == "both" and rng.random() < 0.35)
     L = int(rng.choice([3, 8, 20, 50] if ukf else [3, 8, 20, 50, 100, 230]))   # 230: the HBM-streamed EKF class (no per-message limit)
-    f32 = (not ukf) and L <= 50 and rng.random() < 0.3
+    f32 = (not ukf) and rng.random() < 0.3     # (fp32 storage beyond 50 landmarks: the streamed kernel, round 5)
     T = int(rng.integers(3, 50 if L <= 200 else 12))
     B = int(rng.integers(1, 10))
     idknown = int(rng.random() < 0.75)
