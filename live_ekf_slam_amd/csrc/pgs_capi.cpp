@@ -53,7 +53,7 @@ struct pgs_handle {
     std::vector<hipEvent_t> gevents;
     int32_t* h_active = nullptr;               // pinned host: per-group active counts
     int p_notrim = 0;
-    int chol_ll = 1;                           // SLAM_PGS_CHOL_LL=0: the right-looking Cholesky of rounds 1-3
+    int chol_ll = 2;                           // SLAM_PGS_CHOL_LL=0: the right-looking Cholesky of rounds 1-3; 1: the left-looking kernel on 1024 threads; 2 (default): on 768
     int chol_threads = 0, chol_switch = 256;   // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces; else 256 while > chol_switch instances are active
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
     double path_ms[3] = {0.0, 0.0, 0.0};      // profiled solve: ms in the separate SYRK launches / in the fused chain + SYRK launches / in the segmented path's SYRK launches
@@ -138,7 +138,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_GROUPS")) h->groups = atoi(e);
     if (const char* e = getenv("SLAM_PGS_CHOL_THREADS")) h->chol_threads = atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0);
     if (const char* e = getenv("SLAM_PGS_CHOL_SWITCH")) h->chol_switch = atoi(e);
-    if (const char* e = getenv("SLAM_PGS_CHOL_LL")) h->chol_ll = atoi(e) != 0;
+    if (const char* e = getenv("SLAM_PGS_CHOL_LL")) h->chol_ll = atoi(e);
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;

@@ -1687,8 +1687,12 @@ __global__ __launch_bounds__(CTPB) void pgs_chol_kernel(const PgsParams p) {
 #ifndef SLAM_PGS_LL_KU
 #define SLAM_PGS_LL_KU 4
 #endif
-__global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
-    constexpr int CTPB = 1024, NB = 16, NBL = 4, NW = CTPB / 64;
+// CTPB_ threads: 768 by default since the end of round 5 - three wavefronts per SIMD have 168 registers per lane and the kernel no longer spills (at 1024 threads =
+// 128 registers it kept 56 bytes per lane in scratch, most of it around the completion step): 13.4 -> 11.5 ms per solve on one box (docs/dev/sessions/gpu_r5aq.sh), the
+// same factor bit for bit.  SLAM_PGS_CHOL_LL=1 keeps the 1024-thread instantiation.
+template <int CTPB_>
+__global__ __launch_bounds__(CTPB_) void pgs_chol_ll_kernel(const PgsParams p) {
+    constexpr int CTPB = CTPB_, NB = 16, NBL = 4, NW = CTPB / 64;
     extern __shared__ double s_dyn[];
     __shared__ double s_diag[NB], s_rdiag[NB];
     __shared__ double s_xi[NB][NB + 1];   // inverse of the current diagonal block
@@ -1711,7 +1715,7 @@ __global__ __launch_bounds__(1024) void pgs_chol_ll_kernel(const PgsParams p) {
     const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
     typedef double dbl4v_t __attribute__((ext_vector_type(4)));
     constexpr int KU = SLAM_PGS_LL_KU;                      // 16-k blocks in flight per lane
-    constexpr int NTW = NW - 1, TPW = 2;                    // wavefronts that own tiles (1 .. 15), tiles per wavefront (nt <= 30: LD <= 448)
+    constexpr int NTW = NW - 1, TPW = (28 + NTW - 1) / NTW; // wavefronts that own tiles (1 .. NW - 1), tiles per wavefront (nt <= 28: LD <= 448)
     // PIPELINE over the panels.  A panel step is: complete the tiles (the last 16 k), factor the 16 x 16 diagonal block, solve the rows
     // below, write L.  The factorisation of the diagonal block is a 16-step dependent chain - one wavefront's work (wave-synchronous on LDS,
     // no workgroup barrier inside; it had thirty-two of them with sixteen wavefronts waiting at each) - and meanwhile wavefronts 1 .. 15 form
@@ -2469,12 +2473,14 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
         const size_t lds = sizeof(double) * (size_t)(p.LD + 16) * 17;   // panel rows x (NB + 1)
         // panels of L_max > 235 need more than the default 64 KiB of dynamic LDS (gfx950: 160 KiB); solve groups launch from several
         // host threads and a single-process host may hold several devices: per (kernel, device), checked (lds_attr.h)
-        const void* ck = p.chol_threads == 256 ? (const void*)pgs_chol_kernel<256> : (p.chol_ll && p.LD <= 448) ? (const void*)pgs_chol_ll_kernel : (const void*)pgs_chol_kernel<1024>;
+        const void* ck = p.chol_threads == 256 ? (const void*)pgs_chol_kernel<256> : (p.chol_ll == 1 && p.LD <= 448) ? (const void*)pgs_chol_ll_kernel<1024>
+                       : (p.chol_ll && p.LD <= 448) ? (const void*)pgs_chol_ll_kernel<768> : (const void*)pgs_chol_kernel<1024>;
         if (const hipError_t e = slam_allow_full_lds(ck); e != hipSuccess) return e;
         if (p.chol_threads == 256) { hipLaunchKernelGGL(pgs_chol_kernel<256>, dim3(nslot), dim3(256), lds, s, p); break; }
         if (p.chol_ll && p.LD <= 448) {   // left-looking: two consecutive panels [<= LD + 1][17] each, the staged block rows over the older one (its staging registers are sized for LD <= 448)
             const size_t lds_ll = sizeof(double) * 2 * (size_t)(p.LD + 1) * 17;
-            hipLaunchKernelGGL(pgs_chol_ll_kernel, dim3(nslot), dim3(1024), lds_ll, s, p);
+            if (p.chol_ll == 1) hipLaunchKernelGGL(pgs_chol_ll_kernel<1024>, dim3(nslot), dim3(1024), lds_ll, s, p);
+            else hipLaunchKernelGGL(pgs_chol_ll_kernel<768>, dim3(nslot), dim3(768), lds_ll, s, p);
             break;
         }
         hipLaunchKernelGGL(pgs_chol_kernel<1024>, dim3(nslot), dim3(1024), lds, s, p);
