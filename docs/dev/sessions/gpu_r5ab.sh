@@ -10,12 +10,12 @@ python3 bench.py --filter ukf --landmarks 50 --batch 4096 --steps 40 --warmup 5 
 python3 bench.py --dtype f32 --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_f32_default_window.json
 timeout 2400 python3 -m pytest tests -q -m gpu -rs > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
-timeout 400 python3 tools/gpu_soak_ekf.py 200 6201 both > $OUT/soak_ekf.txt 2>&1
-timeout 300 python3 tools/gpu_soak_api.py 120 6202 > $OUT/soak_api.txt 2>&1
-timeout 400 python3 tools/gpu_soak_pgs.py 240 6203 > $OUT/soak_pgs.txt 2>&1
-timeout 300 python3 tools/gpu_soak_pgs.py 150 6204 big > $OUT/soak_pgs_big.txt 2>&1
-timeout 300 python3 tools/gpu_soak_pgs_api.py 100 6205 > $OUT/soak_pgs_api.txt 2>&1
-timeout 300 python3 tools/gpu_soak_adversarial.py 120 6206 both > $OUT/soak_adversarial.txt 2>&1
+timeout 400 python3 tools/gpu_soak_ekf.py 200 8201 both > $OUT/soak_ekf.txt 2>&1
+timeout 300 python3 tools/gpu_soak_api.py 120 8202 > $OUT/soak_api.txt 2>&1
+timeout 400 python3 tools/gpu_soak_pgs.py 240 8203 > $OUT/soak_pgs.txt 2>&1
+timeout 300 python3 tools/gpu_soak_pgs.py 150 8204 big > $OUT/soak_pgs_big.txt 2>&1
+timeout 300 python3 tools/gpu_soak_pgs_api.py 100 8205 > $OUT/soak_pgs_api.txt 2>&1
+timeout 300 python3 tools/gpu_soak_adversarial.py 120 8206 both > $OUT/soak_adversarial.txt 2>&1
 bash tools/profile_pgs.sh r05_pgs > $OUT/profile_pgs.log 2>&1
 python3 tools/summarize_pgs_profile.py gpurun_out/prof_r05_pgs gpurun_out/r05_pgs > /dev/null 2>&1
 cp $(find gpurun_out/prof_r05_pgs/stats -name "*kernel_trace.csv" | head -1) gpurun_out/r05_pgs/kernel_trace.csv 2>/dev/null
