@@ -295,6 +295,105 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
     return line
 
 
+def bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0):
+    """Pose graph in the reference's DEFAULT mode, solve_graph_every_iteration: true (params.yaml:64; pose_graph.cpp:258-264): after every
+    timer tick the graph - one pose and its detections longer - is solved again from the previous result, which then becomes the initial
+    estimate.  One run = N - 1 ticks of {simulator + NaiveFilter + append, solvePoseGraph, initial_estimate = result} for every graph of
+    the batch, all on the device (pgs_run_sim_every_iteration).  value = graph-ticks per second.  Every tick is a full re-linearisation
+    at the adopted result (what GTSAM's LM does), so nothing is carried across ticks but the estimate."""
+    import live_ekf_slam_amd as S
+    from live_ekf_slam_amd.scenario import make_scenario
+    L, B, W = args.landmarks, args.batch, args.warmup
+    N = args.poses
+    T = N - 1
+    lm, cmds = make_scenario(1234, L, T)
+
+    def make():
+        pg = S.BatchedPoseGraph(B, num_iterations=N, L_max=L, k_per_pose=args.k_per_pose, device=local_rank).readParams(solve_graph_every_iteration=True)
+        pg.set_stream(stream.cuda_stream)
+        pg.set_map(lm); pg.set_seed(2025); pg.set_instance_offset(rank * B); pg.init(0.0, 0.0, 0.0)
+        return pg
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        if W > 0:   # warm-up: the first W ticks on a handle of their own (kernels loaded, streams and events created)
+            w = make(); w.run_sim_every_iteration(cmds[:min(W, T)]); w.close()
+        pg = make()
+        sync_all()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        counts = pg.run_sim_every_iteration(cmds)
+        ev1.record(stream)
+        sync_all()
+        wall = time.perf_counter() - t0
+        dev_s = ev0.elapsed_time(ev1) * 1e-3
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    if getattr(args, "event_value", False):
+        wall = dev_s
+    ph = pg.last_iter_phases()
+    st = pg.stats()
+    e1 = pg.error_stats(1)
+    parity = None
+    if not args.no_parity_check:
+        from oracle import oracle as O
+        mx, bad, same = 0.0, None, True
+        for b in sorted(set([0, B - 1])):
+            g = pg.get_graph(b, 1)
+            r = O.run_pgs_batch(lm, cmds, 1, L, KP=args.k_per_pose, seed=2025, inst0=rank * B + b, nthreads=1, every_iteration=True, lin_mode=O.LIN_SEG)
+            Mo = int(r["M"][0])
+            if int(g["M"]) != Mo:
+                bad = f"instance {rank * B + b}: {int(g['M'])} landmarks on the GPU, {Mo} in the oracle"
+                break
+            dp = np.abs(np.asarray(g["poses"])[:, :2] - r["pose_res"][0][:, :2]).max()
+            dl = np.abs(np.asarray(g["landmarks"])[:Mo] - r["lm_res"][0][:Mo]).max() if Mo else 0.0
+            mx = max(mx, float(dp), float(dl))
+            same = same and int(counts[b, 0]) == int(r["iterations"][0]) and int(counts[b, 1]) == int(r["trials"][0])
+        parity = {"max_abs_diff_m": None if bad else mx, "mismatch": bad, "lm_iteration_and_trial_counts_equal": bool(same) and not bad,
+                  "what": f"final result after {T} ticks and the LM iteration / lambda-trial counts SUMMED over the ticks, vs the oracle run in the same mode",
+                  "instances": [int(rank * B), int(rank * B + B - 1)]}
+    line = None
+    if rank == 0:
+        flop = ph["syrk_flop"] + ph["chol_flop"]
+        tf = flop / dev_s / 1e12
+        line = {"metric": "pose-graph SLAM graph-ticks/sec, solve_graph_every_iteration (the reference's default mode; BASELINE configs[4] shape)",
+                "value": round(B * world * T / wall, 1), "unit": "graph-ticks/s", "n_gpus": world, "steps": T, "warmup": W,
+                "ms_per_step": round(wall / T * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"pose-graph SLAM, solve after every tick + adopt (params.yaml:64), {T} ticks to {N} poses x {L} landmarks, "
+                                       f"batch={B} graphs per GPU, device-built graphs (simulator + NaiveFilter secondary)",
+                           "batch_per_gpu": B, "poses": N, "landmarks": L, "seconds_per_run": round(wall, 3),
+                           "lm_iterations_per_tick": round(float(counts[:, 0].mean()) / T, 3), "lm_trials_per_tick": round(float(counts[:, 1].mean()) / T, 3),
+                           "lm_trials_launched_per_tick": round(ph["trials_launched"] / T, 3),
+                           "instances_flagged": int((st["flags"] != 0).sum()), "avg_position_error_m": round(float(e1.mean()), 4),
+                           "parity_check": parity,
+                           "parity": "the one-shot solve's bar (tests/test_parity_pgs_gpu.py) at every tick: test_solve_every_iteration_*"},
+                "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": 78.6, "unit": "TFLOP/s", "frac": round(tf / 78.6, 5), "traffic": None,
+                             "kernel": "whole run: algorithmic FLOP of every consumed trial's Schur-complement SYRK + dense Cholesky (v_mfma_f64_16x16x4_f64) over the run's HIP-event time",
+                             "algorithmic_flop": flop, "syrk_flop": ph["syrk_flop"], "chol_flop": ph["chol_flop"], "run_ms": round(dev_s * 1e3, 2),
+                             "limiter": "launch latency: a tick is one solve of a graph that is on average half the final size - plan, begin, 2-3 trials of "
+                                        "twelve dependent launches, end, adopt - and the batch waits for the tick's slowest instance"}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            r = O.run_pgs_batch(lm, cmds, 1, L, KP=args.k_per_pose, seed=2025, nthreads=1, every_iteration=True, lin_mode=O.LIN_SEG)
+            Bc = int(max(1, min(64, cpu_budget_s / max(r["seconds"], 1e-3))))
+            if Bc > 1:
+                r = O.run_pgs_batch(lm, cmds, Bc, L, KP=args.k_per_pose, seed=2025, nthreads=1, every_iteration=True, lin_mode=O.LIN_SEG)
+            line["cpu_baseline"] = {"value": round(Bc * T / r["seconds"], 1), "unit": "graph-ticks/s", "cores": 1, "kind": "port",
+                                    "sample": f"oracle pose-graph LM in the same mode (solve + adopt after every tick), {Bc} graph(s) x {T} ticks of the same workload, 1 thread, {r['seconds']:.1f} s in the solves"}
+    pg.close()
+    return line
+
+
 def finish(line, dist, rank, world):
     if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
@@ -330,6 +429,8 @@ def main():
                     help="ekf = the headline metric (default); ukf / pgs = BASELINE configs[2] / configs[4]-style secondary lines")
     ap.add_argument("--poses", type=int, default=1000, help="pgs: poses per graph (num_iterations)")
     ap.add_argument("--k-per-pose", type=int, default=32, help="pgs: detections stored per timestep")
+    ap.add_argument("--iterative", action="store_true",
+                    help="pgs: the reference's default mode solve_graph_every_iteration (params.yaml:64): one run of poses - 1 ticks, each solved and adopted")
     args = ap.parse_args()
     if args.filter == "pgs":   # configs[4] defaults unless given explicitly
         argv = " ".join(sys.argv[1:])
@@ -372,6 +473,8 @@ def main():
 
     if args.filter == "ukf":
         return finish(bench_ukf(args, torch, dist, rank, local_rank, world, dev), dist, rank, world)
+    if args.filter == "pgs" and args.iterative:
+        return finish(bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev), dist, rank, world)
     if args.filter == "pgs":
         return finish(bench_pgs(args, torch, dist, rank, local_rank, world, dev), dist, rank, world)
     line = bench_ekf(args, torch, dist, rank, local_rank, world, dev)

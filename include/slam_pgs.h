@@ -80,8 +80,29 @@ int pgs_solve(pgs_handle* h);
  * latency-bound phases of one group overlap the bandwidth-bound phases of another); results do not depend on it.
  * 0 = automatic (2 from 512 instances, else 1; 4 groups measured best in a process without other HIP streams). */
 int pgs_set_groups(pgs_handle* h, int groups);
+/* Streaming solve (round 6): the handle holds `batch` graphs but at most `slots` of them are IN FLIGHT (0 = lockstep, all of them from
+ * the first trial on; SLAM_PGS_SLOTS sets the default).  The others wait; when a graph converges the device-side decide step hands
+ * its running slot to the next waiting graph, so every LM trial runs a full list of slots instead of a list that decays to the
+ * batch's slowest instances, and the host - which no longer decides anything per trial - enqueues trials ahead
+ * (SLAM_PGS_STREAM_DEPTH, default 3) and reads the counters of the trial that far back.  Once nothing waits and at most
+ * SLAM_PGS_LANES_SWITCH graphs are left the lockstep loop with its lambda lanes finishes them.  Results, iteration and trial counts
+ * do not depend on `slots`: a graph's LM sequence depends on nothing but the graph (the reference solves ONE graph per call,
+ * pose_graph.cpp:269-300; the batch and its schedule are this library's). */
+int pgs_set_slots(pgs_handle* h, int slots);
+/* The last solve's schedule: slots[i] = running slots of trial i of solve group `group` (at most cap entries written), *n = trials of
+ * that group, *groups = solve groups of the solve.  Mean occupancy = sum(slots) / (trials x slots per group). */
+int pgs_last_solve_timeline(pgs_handle* h, int group, int32_t* slots, int cap, int32_t* n, int32_t* groups);
 /* `this->initial_estimate = this->result` (pose_graph.cpp:263, solve_graph_every_iteration). */
 int pgs_adopt_result(pgs_handle* h);
+/* The reference's DEFAULT mode, solve_graph_every_iteration: true (params.yaml:64; pose_graph.cpp:258-264), with the simulator on the
+ * device: T x { one tick of pgs_run_sim, pgs_solve, pgs_adopt_result }.  counts [batch][2] (may be NULL) = the LM iterations and
+ * lambda trials of every instance summed over the T ticks. */
+int pgs_run_sim_every_iteration(pgs_handle* h, const float* cmds, int T, int32_t* counts);
+/* Phase table of the last such call when SLAM_PGS_ITER_PROF=1 was set (a stream synchronisation after every phase; timing runs leave it
+ * unset): out = {host-clock ms in simulator + append, in solve, in adopt, LM trials launched, algorithmic FLOP of the call's consumed
+ * trials summed over the batch: Schur-complement SYRK, dense Cholesky + substitutions (n^3/3 + 2 n^2 at n = 2 M)}; the last three are
+ * always filled. */
+int pgs_last_iter_phases(pgs_handle* h, double out[6]);
 
 /* PoseGraphState payload (pose_graph.cpp:302-387, PoseGraphState.msg): which = 0 initial_estimate, 1 result.
  * poses [timestep+1][3] (x, y, yaw), landmarks [M][2], ids [M]; any pointer may be NULL. */
@@ -110,7 +131,9 @@ int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]);
  * SLAM_PGS_SEG-th pose, default 32; segments' interiors side by side, then the separators - the reference's solve,
  * pose_graph.cpp:273-300, in another exact elimination order), ms in its SYRK launches, 1 if the solve ran that order (0: a
  * segment of some instance sees more than 63 landmarks, or SLAM_PGS_SEG=0: the sequential chain of rounds 1-4), the segment length}. */
-int pgs_last_solve_paths(pgs_handle* h, double out[8]);
+int pgs_last_solve_paths_v2(pgs_handle* h, double* out, int n /* entries of out, <= 8 */);
+/* The first four entries only (the ABI of rounds 1-4; ADVICE r05: a caller with `double out[4]` must stay valid). */
+int pgs_last_solve_paths(pgs_handle* h, double out[4]);
 int pgs_sync(pgs_handle* h);
 int pgs_timestep(const pgs_handle* h);
 

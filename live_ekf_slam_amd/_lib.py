@@ -89,6 +89,11 @@ SIGNATURES = {
     "pgs_set_profiling": (C.c_int, [_H, C.c_int]),
     "pgs_last_solve_kernel_ms": (C.c_int, [_H, _dp]),
     "pgs_last_solve_paths": (C.c_int, [_H, _dp]),
+    "pgs_last_solve_paths_v2": (C.c_int, [_H, _dp, C.c_int]),
+    "pgs_set_slots": (C.c_int, [_H, C.c_int]),
+    "pgs_run_sim_every_iteration": (C.c_int, [_H, _fp, C.c_int, _ip]),
+    "pgs_last_iter_phases": (C.c_int, [_H, _dp]),
+    "pgs_last_solve_timeline": (C.c_int, [_H, C.c_int, _ip, C.c_int, _ip, _ip]),
     "pgs_sync": (C.c_int, [_H]),
     "pgs_timestep": (C.c_int, [_H]),
     # include/slam_multi.h

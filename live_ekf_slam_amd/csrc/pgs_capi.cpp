@@ -52,9 +52,25 @@ struct pgs_handle {
     std::vector<hipStream_t> gstreams;
     std::vector<hipEvent_t> gevents;
     int32_t* h_active = nullptr;               // pinned host: per-group active counts
+    // streaming (round 6, pgs_kernel.h "streaming"): at most `slots` graphs of the batch are in flight (0 = lockstep: all of them), split over
+    // the solve groups; trials are enqueued `stream_depth` ahead of the host's reading of their counters
+    int slots = 0, stream_depth = 3;
+    static constexpr int kRing = 8, kMaxGroups = 16;
+    int32_t* d_cnt = nullptr;                  // device [kMaxGroups][2][8]: the counter blocks, ping-pong by trial parity
+    int32_t* d_wait = nullptr;                 // device [kMaxGroups]: the groups' wait cursors
+    int32_t* h_ring = nullptr;                 // pinned host [kMaxGroups][kRing][8]
+    std::vector<hipEvent_t> ring_events;       // [kMaxGroups][kRing]
+    std::vector<std::vector<int32_t>> timeline;   // per group: slots that ran in every trial of the last solve
+    double* d_tick_flop = nullptr;             // [B][2] algorithmic FLOP (SYRK | Cholesky) of the same
+    int32_t* d_tick = nullptr;                 // [B][2] LM iterations / trials summed over the ticks of pgs_run_sim_every_iteration
+    double iter_ms[4] = {0, 0, 0, 0};
+    long long iter_trials = 0;
     int p_notrim = 0;
     int chol_ll = 2;                           // SLAM_PGS_CHOL_LL=0: the right-looking Cholesky of rounds 1-3; 1: the left-looking kernel on 1024 threads; 2 (default): on 768
-    int chol_threads = 0, chol_switch = 256;   // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces; else 256 while > chol_switch instances are active
+    // SLAM_PGS_CHOL_THREADS = 256 | 1024 forces a Cholesky build; else the 256-thread right-looking one while > chol_switch slots run.  Round 6:
+    // never by default - since round 5's work on the left-looking kernel it wins at every count (batch 1024: 7.99 k -> 9.45 k solves/s,
+    // profiles/r06_pgs/stream_table.txt), and with ONE Cholesky build a graph's result no longer depends on how many others run beside it
+    int chol_threads = 0, chol_switch = 1 << 30;
     bool trace = false;                       // SLAM_PGS_TRACE: print the active-instance count after every trial
     double path_ms[3] = {0.0, 0.0, 0.0};      // profiled solve: ms in the separate SYRK launches / in the fused chain + SYRK launches / in the segmented path's SYRK launches
     int seg_len = 32;                         // SLAM_PGS_SEG: poses per segment of the segmented elimination (pgs_seg_impl.h), 0 = the sequential chain of rounds 1-4
@@ -139,6 +155,8 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_CHOL_THREADS")) h->chol_threads = atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0);
     if (const char* e = getenv("SLAM_PGS_CHOL_SWITCH")) h->chol_switch = atoi(e);
     if (const char* e = getenv("SLAM_PGS_CHOL_LL")) h->chol_ll = atoi(e);
+    if (const char* e = getenv("SLAM_PGS_SLOTS")) h->slots = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("SLAM_PGS_STREAM_DEPTH")) h->stream_depth = atoi(e) >= 1 && atoi(e) < pgs_handle::kRing ? atoi(e) : h->stream_depth;
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     h->own_stream = true;
@@ -194,12 +212,15 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     A(&p.Y, S * (size_t)p.y_stride); A(&p.S, S * (size_t)h->LD * h->LD);
     A(&p.dl, S * L * 2); A(&p.dp, S * N * 3);
     A(&p.lambda, S); A(&p.error, B); A(&p.cur_error, B); A(&p.err_init, B);
-    A(&p.iters, B); A(&p.trials, B); A(&p.state, S); AC(&p.solve_ok, 1); A(&p.n_active, 64); A(&p.alist, S); A(&p.inst_flop, B); A(&p.work, 3);
+    A(&p.iters, B); A(&p.trials, B); A(&p.state, S + 1); AC(&p.solve_ok, 1); A(&p.n_active, 64); A(&p.alist, S); A(&p.inst_flop, B); A(&p.work, 3);
     A(&p.nl, B); A(&p.nlin, S); A(&p.nerr, S); A(&p.nok, S);
     A(&h->dcount, B); A(&h->dsec, B * 3); A(&h->dout, B);
+    A(&h->d_cnt, (size_t)pgs_handle::kMaxGroups * 16); A(&h->d_wait, (size_t)pgs_handle::kMaxGroups);
     if (getenv("SLAM_PGS_PROF")) { A(&p.prof, S * 24); }   // [S][8] chol phase timers, then [S][2][8] per-workgroup stamps of the fused chain
     if (rc != SLAM_OK) { pgs_destroy(h); return rc; }
     hipMemsetAsync(p.truth_hist, 0, sizeof(double) * B * N * 2, h->stream);
+    p.dead_slot = (int32_t)S; p.slots_cap = 0; p.n_list_dev = nullptr; p.wait_next = h->d_wait;
+    hipMemsetD32Async((hipDeviceptr_t)(p.state + S), 1, 1, h->stream);   // the slot every kernel returns for at entry (pgs_slot)
     hipMemsetAsync(p.cnt, 0, sizeof(int32_t) * B * N, h->stream);
     // effective noise after Filter::readCommonParams (filter.h:105-121)
     double V00, V11, W00, W11;
@@ -224,6 +245,8 @@ int pgs_destroy(pgs_handle* h) {
     for (void* ptr : h->allocs) hipFree(ptr);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
     for (hipEvent_t e : h->gevents) hipEventDestroy(e);
+    for (hipEvent_t e : h->ring_events) hipEventDestroy(e);
+    if (h->h_ring) hipHostFree(h->h_ring);
     for (hipStream_t st : h->gstreams) hipStreamDestroy(st);
     if (h->h_active) hipHostFree(h->h_active);
     if (h->dmeas) hipFree(h->dmeas);
@@ -338,7 +361,7 @@ int prelaunch_trial(pgs_handle* h, slam::PgsParams& p, hipStream_t stream) {
 }
 
 int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lanes, int32_t nslots, hipStream_t stream, int trial_index,
-                 bool profile, bool prelaunched = false) {
+                 bool profile, bool prelaunched = false, int force_lanes_next = 0) {
     p.lanes = lanes < 1 ? 1 : (lanes > h->lanes ? h->lanes : lanes);
     p.use_list = h->use_list ? 1 : 0; p.n_list = nslots;   // the slots pgs_decide_kernel (or lm_begin) listed for this trial
     {   // Chain + SYRK fused: NB workgroups per slot, each alone on a CU.  With idle CUs to spare the chain is replicated on up to
@@ -357,6 +380,7 @@ int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lan
     // Few instances left: the per-trial latency counts and spare slots cost little.  Two lanes from `lanes_switch` active
     // instances down (the common streak is one failure, then a success at 10 lambda), all of them from `lanes_switch_all` down.
     p.lanes_next = active_hint <= h->lanes_switch_all ? h->lanes : (active_hint <= h->lanes_switch ? (h->lanes < 2 ? h->lanes : 2) : 1);
+    if (force_lanes_next > 0) p.lanes_next = force_lanes_next;
     active_hint *= p.lanes;   // the kernel variants below are chosen by the number of slots that run (an upper bound), not of instances
     p.syrk_notrim = h->p_notrim;
     p.chol_threads = h->chol_threads ? h->chol_threads : (active_hint > h->chol_switch ? 256 : 1024);
@@ -424,60 +448,16 @@ int pgs_solve(pgs_handle* h) {
     // each other's gaps: 5.20 -> 5.67 k solves/s at batch 256 (three groups 5.47 k, four 3.57 k), 3.49 -> 3.64 k at batch 128, 7.39 k at
     // 1024 (three: 7.59 k); profiles/r05_pgs/groups_and_lanes.txt)
     int G = h->groups > 0 ? h->groups : (h->B >= 128 ? 2 : 1);
-    if (G > 16) G = 16;
+    if (G > pgs_handle::kMaxGroups) G = pgs_handle::kMaxGroups;
     if (G > h->B) G = h->B;
     if (h->profiling) G = 1;   // per-kernel timing wants the kernels of one stream back to back
-    if (G <= 1) {
-        HIP_TRY(slam::pgs_launch_lm_begin(h->p, h->stream));
-        TRY(clone_instances(h, h->p, h->stream));
-        int trials = 0;
-        int32_t act[3] = {h->B, 1, h->B};   // active instances, lanes and active slots of the next trial
-        if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 64, hipHostMallocDefault));
-        while ((int)h->gevents.size() < 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->gevents.push_back(e); }
-        const bool pipe = !h->profiling;   // per-kernel timing wants every kernel of a trial between its own events
-        if (pipe) TRY(prelaunch_trial(h, h->p, h->stream));
-        for (; trials < h->max_trials; ++trials) {
-            TRY(launch_trial(h, h->p, act[0], act[1], act[2], h->stream, trials, h->profiling, pipe));
-            HIP_TRY(hipMemcpyAsync(h->h_active, h->p.n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipEventRecord(h->gevents[0], h->stream));
-            if (pipe) TRY(prelaunch_trial(h, h->p, h->stream));   // the next trial's linearisation runs while the host waits below
-            HIP_TRY(hipEventSynchronize(h->gevents[0]));
-            act[0] = h->h_active[0]; act[1] = h->h_active[1]; act[2] = h->h_active[2];
-            if (h->trace) {
-                static thread_local double t_prev = 0.0;
-                timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
-                const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-                fprintf(stderr, "pgs trial %d: %.2f ms, lanes %d -> active %d, lanes next %d\n", trials, trials ? now - t_prev : 0.0, (int)h->p.lanes, (int)act[0], (int)act[1]);
-                t_prev = now;
-            }
-            if (act[0] == 0) { trials += 1; break; }
-        }
-        h->last_trials = trials;
-        HIP_TRY(slam::pgs_launch_lm_end(h->p, h->stream));
-        if (h->profiling) {
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            for (int k = 0; k < slam::kPgsTrialKernels; ++k) h->kernel_ms[k] = 0.0;
-            for (int t = 0; t < trials; ++t)
-                for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
-                    float ms = 0.f;
-                    const size_t e0 = (size_t)t * (slam::kPgsTrialKernels + 1) + k;
-                    HIP_TRY(hipEventElapsedTime(&ms, h->events[e0], h->events[e0 + 1]));
-                    h->kernel_ms[k] += ms;
-                    const int tf = t < (int)h->trial_fused.size() ? h->trial_fused[t] : 0;
-                    if (k == 1 && tf) h->path_ms[1] += ms;      // chain + SYRK in one launch
-                    if (k == 2 && !tf) h->path_ms[h->seg_ok ? 2 : 0] += ms;     // the SYRK launch(es) of the two-launch path / of the segmented path
-                    if (h->trace) fprintf(stderr, "%s%.3f%s", k == 0 ? "pgs trial kernels (ms): " : " ", ms, k + 1 == slam::kPgsTrialKernels ? "\n" : "");
-                }
-        }
-        return SLAM_OK;
-    }
-    // ---- G groups, each with its own stream and LM loop; the host serves them round-robin ----
+    const bool profile = h->profiling;
     // The groups' streams must not share a hardware queue: two LM loops whose launches sit in ONE in-order queue wait for each other's
     // queued trials at every host synchronisation (measured inside bench.py's driver command, where the earlier legs' streams shift the
     // runtime's stream -> queue assignment: 3.40 k solves/s with two groups against 5.21 k with one and 5.66 k with two on distinct
     // queues; profiles/r05_pgs/hw_queues.txt).  The runtime keeps separate queues per stream PRIORITY, so the groups alternate between
     // the priority levels the device offers (SLAM_PGS_GROUP_PRIO=0: all at the default priority, the behaviour before).
-    while ((int)h->gstreams.size() < G) {
+    while (G > 1 && (int)h->gstreams.size() < G) {
         hipStream_t st;
         int lo = 0, hi = 0;
         static const bool use_prio = !(getenv("SLAM_PGS_GROUP_PRIO") && atoi(getenv("SLAM_PGS_GROUP_PRIO")) == 0);
@@ -492,45 +472,115 @@ int pgs_solve(pgs_handle* h) {
     }
     while ((int)h->gevents.size() < G + 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->gevents.push_back(e); }
     if (!h->h_active) HIP_TRY(hipHostMalloc((void**)&h->h_active, sizeof(int32_t) * 64, hipHostMallocDefault));
-    HIP_TRY(hipEventRecord(h->gevents[G], h->stream));   // everything queued on the handle's stream so far comes first
-    std::vector<slam::PgsParams> gp(G, h->p);
-    std::vector<int> gtrials(G, 0);
-    std::vector<char> gdone(G, 0);
+    // streaming: `slots` graphs in flight over all groups; a group whose share of the slots covers its graphs runs lockstep as before
     const int per = (h->B + G - 1) / G;
-    for (int g = 0; g < G; ++g) {
-        gp[g].b_off = g * per;
-        gp[g].b_cnt = (h->B - g * per) < per ? (h->B - g * per) : per;
-        gp[g].n_active = h->p.n_active + 4 * g;
-        gp[g].alist = h->p.alist + (size_t)g * per * h->lanes;
-        if (gp[g].b_cnt <= 0) { gdone[g] = 1; continue; }
-        HIP_TRY(hipStreamWaitEvent(h->gstreams[g], h->gevents[G], 0));
-        HIP_TRY(slam::pgs_launch_lm_begin(gp[g], h->gstreams[g]));
-        TRY(clone_instances(h, gp[g], h->gstreams[g]));
-        TRY(launch_trial(h, gp[g], h->B, 1, gp[g].b_cnt, h->gstreams[g], 0, false));
-        HIP_TRY(hipMemcpyAsync(h->h_active + 4 * g, gp[g].n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
-        HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
-        TRY(prelaunch_trial(h, gp[g], h->gstreams[g]));
+    const int cap_g = (h->slots > 0 && !profile) ? (h->slots + G - 1) / G : 0;
+    if (cap_g > 0) {
+        if (!h->h_ring) HIP_TRY(hipHostMalloc((void**)&h->h_ring, sizeof(int32_t) * 8 * pgs_handle::kRing * pgs_handle::kMaxGroups, hipHostMallocDefault));
+        while ((int)h->ring_events.size() < pgs_handle::kRing * pgs_handle::kMaxGroups) {
+            hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ring_events.push_back(e);
+        }
     }
-    // one host thread per group drives its LM loop (launch a trial, wait for its active count, decide); the HIP runtime
-    // is thread-safe and the groups touch disjoint instance ranges
-    std::vector<int> grc(G, SLAM_OK);
+    h->timeline.assign(G, {});
+    if (G > 1) HIP_TRY(hipEventRecord(h->gevents[G], h->stream));   // everything queued on the handle's stream so far comes first
+    std::vector<slam::PgsParams> gp(G, h->p);
+    std::vector<int> gtrials(G, 0), grc(G, SLAM_OK);
+    std::vector<char> gdone(G, 0);
+    auto gstream = [&](int g) { return G > 1 ? h->gstreams[g] : h->stream; };
+    for (int g = 0; g < G; ++g) {
+        slam::PgsParams& q = gp[g];
+        q.b_off = g * per;
+        q.b_cnt = (h->B - g * per) < per ? (h->B - g * per) : per;
+        q.n_active = h->p.n_active + 4 * g;
+        q.alist = h->p.alist + (size_t)g * per * h->lanes;
+        q.wait_next = h->d_wait + g;
+        q.slots_cap = (cap_g > 0 && cap_g < q.b_cnt) ? cap_g : 0;
+        q.n_list_dev = nullptr;
+        if (q.b_cnt <= 0) { gdone[g] = 1; continue; }
+        if (G > 1) HIP_TRY(hipStreamWaitEvent(gstream(g), h->gevents[G], 0));
+        HIP_TRY(slam::pgs_launch_lm_begin(q, gstream(g)));
+        TRY(clone_instances(h, q, gstream(g)));
+    }
+    // One host thread per group drives its LM loop; the HIP runtime is thread-safe and the groups touch disjoint instance ranges.
+    //  * streaming phase (slots_cap > 0): the list of every trial is refilled on the device, its length read on the device, so the host
+    //    enqueues trials `stream_depth` ahead and only looks at the counters of the trial that far back - to learn that the queue of
+    //    waiting graphs is empty and few are left (then the lockstep loop below takes over, with its lambda lanes), or none at all.
+    //  * lockstep phase: launch a trial, wait for its active count, choose the next trial's kernel variants and lanes from it.  The first
+    //    two operations of a trial (counters, linearisation) are enqueued before that wait (prelaunch_trial).
     auto drive = [&](int g) -> int {
         HIP_TRY(hipSetDevice(h->device));
-        for (;;) {
-            HIP_TRY(hipEventSynchronize(h->gevents[g]));
-            const int32_t active = h->h_active[4 * g], lanes_next = h->h_active[4 * g + 1], nslots = h->h_active[4 * g + 2];
-            gtrials[g] += 1;
-            if (h->trace) fprintf(stderr, "pgs group %d trial %d: active %d\n", g, gtrials[g] - 1, (int)active);
-            if (active == 0 || gtrials[g] >= h->max_trials) {
-                HIP_TRY(slam::pgs_launch_lm_end(gp[g], h->gstreams[g]));
-                HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
+        slam::PgsParams& q = gp[g];
+        hipStream_t st = gstream(g);
+        std::vector<int32_t>& tl = h->timeline[g];
+        int32_t act[3] = {q.b_cnt * G, 1, q.b_cnt};   // active instances (scaled to the batch), lanes and active slots of the next trial
+        int trials = 0;
+        if (q.slots_cap > 0) {
+            constexpr int R = pgs_handle::kRing;
+            const int cap = q.slots_cap, D = h->stream_depth, wend = q.b_off + q.b_cnt;
+            int32_t* dcnt = h->d_cnt + (size_t)g * 16;
+            int32_t* ring = h->h_ring + (size_t)g * R * 8;
+            hipEvent_t* ev = &h->ring_events[(size_t)g * R];
+            int32_t* const n_active0 = q.n_active;
+            // "the counters trial -1 left": the first `cap` graphs run (pgs_lm_begin_kernel listed them), the cursor stands behind them
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(dcnt + 2), cap, 1, st));
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)q.wait_next, q.b_off + cap, 1, st));
+            int t = 0, seen = 0;   // trials enqueued / trials whose counters the host has read
+            bool leave = false;
+            int32_t last[8] = {cap * G, 1, cap, 0, q.b_off + cap, 0, 0, 0};
+            tl.push_back(cap);
+            auto read_one = [&]() -> int {
+                HIP_TRY(hipEventSynchronize(ev[seen % R]));
+                memcpy(last, ring + 8 * (seen % R), sizeof(last));
+                seen += 1;
+                if (h->trace) fprintf(stderr, "pgs group %d trial %d (streaming): active %d, slots %d, next waiting %d of %d\n", g, seen - 1, last[0], last[2], last[4], wend);
+                tl.push_back(last[2]);
+                // nothing left, or nothing waiting and few enough running that the lanes pay: the lockstep loop finishes the group
+                if (last[0] == 0 || (last[4] >= wend && last[0] * G <= h->lanes_switch)) leave = true;
                 return SLAM_OK;
+            };
+            while (!leave && t < h->max_trials) {
+                q.n_list_dev = dcnt + 8 * (t & 1) + 2;
+                q.n_active = dcnt + 8 * ((t + 1) & 1);
+                TRY(launch_trial(h, q, cap * G, 1, cap, st, t, false, false, 1));
+                HIP_TRY(hipMemcpyAsync(ring + 8 * (t % R), q.n_active, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(ev[t % R], st));
+                t += 1;
+                while (!leave && t - seen >= D) TRY(read_one());
             }
-            TRY(launch_trial(h, gp[g], active * G, lanes_next, nslots, h->gstreams[g], gtrials[g], false, true));
-            HIP_TRY(hipMemcpyAsync(h->h_active + 4 * g, gp[g].n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->gstreams[g]));
-            HIP_TRY(hipEventRecord(h->gevents[g], h->gstreams[g]));
-            TRY(prelaunch_trial(h, gp[g], h->gstreams[g]));
+            while (seen < t) TRY(read_one());   // the trials already enqueued are real ones (or return at entry): their counters are the state to go on from
+            tl.pop_back();                      // (the last entry is the list of a trial the lockstep loop launches and records itself)
+            trials = t;
+            q.slots_cap = 0; q.n_list_dev = nullptr; q.n_active = n_active0;
+            act[0] = last[0] * G; act[1] = last[1] > 0 ? last[1] : 1; act[2] = last[2];
+            // (graphs still waiting at the trial cap keep state 2: pgs_lm_end_kernel flags them NOT_CONVERGED)
         }
+        const bool pipe = !profile;   // per-kernel timing wants every kernel of a trial between its own events
+        int32_t* hact = h->h_active + 4 * g;
+        if (act[0] > 0 && trials < h->max_trials) {
+            bool pre = false;   // the phase's first trial runs over the list it was handed; later ones have their first kernels enqueued ahead
+            for (;;) {
+                tl.push_back(act[2]);
+                TRY(launch_trial(h, q, act[0], act[1], act[2], st, trials, profile, pre));
+                HIP_TRY(hipMemcpyAsync(hact, q.n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(h->gevents[g], st));
+                if (pipe) { TRY(prelaunch_trial(h, q, st)); pre = true; }   // the next trial's linearisation runs while the host waits below
+                HIP_TRY(hipEventSynchronize(h->gevents[g]));
+                act[0] = hact[0] * G; act[1] = hact[1]; act[2] = hact[2];
+                trials += 1;
+                if (h->trace) {
+                    static thread_local double t_prev = 0.0;
+                    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+                    const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+                    fprintf(stderr, "pgs group %d trial %d: %.2f ms, lanes %d -> active %d, lanes next %d\n", g, trials - 1, trials > 1 ? now - t_prev : 0.0, (int)q.lanes, (int)hact[0], (int)act[1]);
+                    t_prev = now;
+                }
+                if (hact[0] == 0 || trials >= h->max_trials) break;
+            }
+        }
+        gtrials[g] = trials;
+        HIP_TRY(slam::pgs_launch_lm_end(q, st));
+        if (G > 1) HIP_TRY(hipEventRecord(h->gevents[g], st));
+        return SLAM_OK;
     };
     std::vector<std::thread> workers;
     for (int g = 1; g < G; ++g)
@@ -540,10 +590,38 @@ int pgs_solve(pgs_handle* h) {
     int max_trials = 0;
     for (int g = 0; g < G; ++g) {
         if (grc[g] != SLAM_OK) return grc[g];
-        if (gp[g].b_cnt > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->gevents[g], 0));   // the handle's stream continues after every group
+        if (G > 1 && gp[g].b_cnt > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->gevents[g], 0));   // the handle's stream continues after every group
         max_trials = gtrials[g] > max_trials ? gtrials[g] : max_trials;
     }
     h->last_trials = max_trials;
+    if (profile) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int k = 0; k < slam::kPgsTrialKernels; ++k) h->kernel_ms[k] = 0.0;
+        for (int t = 0; t < max_trials; ++t)
+            for (int k = 0; k < slam::kPgsTrialKernels; ++k) {
+                float ms = 0.f;
+                const size_t e0 = (size_t)t * (slam::kPgsTrialKernels + 1) + k;
+                HIP_TRY(hipEventElapsedTime(&ms, h->events[e0], h->events[e0 + 1]));
+                h->kernel_ms[k] += ms;
+                const int tf = t < (int)h->trial_fused.size() ? h->trial_fused[t] : 0;
+                if (k == 1 && tf) h->path_ms[1] += ms;      // chain + SYRK in one launch
+                if (k == 2 && !tf) h->path_ms[h->seg_ok ? 2 : 0] += ms;     // the SYRK launch(es) of the two-launch path / of the segmented path
+                if (h->trace) fprintf(stderr, "%s%.3f%s", k == 0 ? "pgs trial kernels (ms): " : " ", ms, k + 1 == slam::kPgsTrialKernels ? "\n" : "");
+            }
+    }
+    return SLAM_OK;
+}
+
+// Streaming: at most `slots` graphs of the batch in flight (0 = lockstep, every graph from the first trial on).  Results do not depend on it.
+int pgs_set_slots(pgs_handle* h, int slots) { TRY(check(h)); h->slots = slots < 0 ? 0 : slots; return SLAM_OK; }
+// The last solve's running slots per trial of solve group `group`: slots[0 .. *n) (at most cap entries written); *groups = number of groups.
+int pgs_last_solve_timeline(pgs_handle* h, int group, int32_t* slots, int cap, int32_t* n, int32_t* groups) {
+    TRY(check(h));
+    if (groups) *groups = (int32_t)h->timeline.size();
+    if (group < 0 || group >= (int)h->timeline.size()) { if (n) *n = 0; return SLAM_OK; }
+    const std::vector<int32_t>& tl = h->timeline[group];
+    if (n) *n = (int32_t)tl.size();
+    if (slots) for (int i = 0; i < (int)tl.size() && i < cap; ++i) slots[i] = tl[i];
     return SLAM_OK;
 }
 
@@ -553,6 +631,62 @@ int pgs_set_groups(pgs_handle* h, int groups) { TRY(check(h)); h->groups = group
 int pgs_adopt_result(pgs_handle* h) {
     TRY(check(h));
     HIP_TRY(slam::pgs_launch_adopt(h->p, h->stream));
+    return SLAM_OK;
+}
+
+// solve_graph_every_iteration with the simulator on the device: T x { get_cmd + NaiveFilter + graph append (one tick of pgs_run_sim),
+// pgs_solve, pgs_adopt_result }.  SLAM_PGS_ITER_PROF=1: the host clock per phase with a stream synchronisation after each (phase table only).
+int pgs_run_sim_every_iteration(pgs_handle* h, const float* cmds, int T, int32_t* counts) {
+    TRY(check(h));
+    if (!h->inited) return fail(SLAM_ERR_STATE, "pgs_init must be called before pgs_run_sim_every_iteration");
+    if (!h->p.map) return fail(SLAM_ERR_STATE, "pgs_set_map must be called before pgs_run_sim_every_iteration");
+    if (!cmds || T <= 0) return fail(SLAM_ERR_ARG, "bad command sequence");
+    if (h->timestep + T >= h->N_max) return fail(SLAM_ERR_STATE, "timestep %d + %d commands exceed the pose capacity N_max = %d", h->timestep, T, h->N_max);
+    HIP_TRY(hipMemcpyAsync(h->dcmds + 2 * (size_t)h->timestep, cmds, sizeof(float) * 2 * (size_t)T, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // cmds is a pageable host array
+    if (!h->d_tick) TRY(dalloc(h, &h->d_tick, (size_t)h->B * 2));
+    if (!h->d_tick_flop) TRY(dalloc(h, &h->d_tick_flop, (size_t)h->B * 2));
+    HIP_TRY(hipMemsetAsync(h->d_tick, 0, sizeof(int32_t) * 2 * (size_t)h->B, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_tick_flop, 0, sizeof(double) * 2 * (size_t)h->B, h->stream));
+    const bool prof = getenv("SLAM_PGS_ITER_PROF") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    for (int k = 0; k < 4; ++k) h->iter_ms[k] = 0.0;
+    h->iter_trials = 0;
+    for (int t = 0; t < T; ++t) {
+        double t0 = prof ? now_ms() : 0.0;
+        h->p.N = h->timestep + 1;
+        HIP_TRY(slam::pgs_launch_run_sim(h->p, 1, (uint32_t)h->timestep, h->stream));
+        h->timestep += 1;
+        h->p.N = h->timestep + 1;
+        if (prof) { HIP_TRY(hipStreamSynchronize(h->stream)); const double t1 = now_ms(); h->iter_ms[0] += t1 - t0; t0 = t1; }
+        TRY(pgs_solve(h));
+        h->iter_trials += h->last_trials;
+        if (prof) { HIP_TRY(hipStreamSynchronize(h->stream)); const double t1 = now_ms(); h->iter_ms[1] += t1 - t0; t0 = t1; }
+        h->p.tick_acc = h->d_tick; h->p.tick_flop = h->d_tick_flop;
+        const hipError_t e = slam::pgs_launch_adopt(h->p, h->stream);
+        h->p.tick_acc = nullptr; h->p.tick_flop = nullptr;
+        if (e != hipSuccess) return fail(SLAM_ERR_HIP, "pgs_launch_adopt -> %s", hipGetErrorString(e));
+        if (prof) { HIP_TRY(hipStreamSynchronize(h->stream)); const double t1 = now_ms(); h->iter_ms[2] += t1 - t0; }
+    }
+    if (counts) {
+        HIP_TRY(hipMemcpyAsync(counts, h->d_tick, sizeof(int32_t) * 2 * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return SLAM_OK;
+}
+// Host-clock phase times of the last pgs_run_sim_every_iteration under SLAM_PGS_ITER_PROF=1: ms in {simulator + append, solve, adopt}, and the
+// LM trials launched over all ticks.
+int pgs_last_iter_phases(pgs_handle* h, double ms[6]) {
+    TRY(check(h));
+    if (!ms) return fail(SLAM_ERR_ARG, "NULL output");
+    ms[0] = h->iter_ms[0]; ms[1] = h->iter_ms[1]; ms[2] = h->iter_ms[2]; ms[3] = (double)h->iter_trials;
+    ms[4] = ms[5] = 0.0;
+    if (h->d_tick_flop) {   // algorithmic FLOP of the call's trials, summed over the batch: SYRK | Cholesky
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::vector<double> f((size_t)h->B * 2);
+        HIP_TRY(hipMemcpy(f.data(), h->d_tick_flop, sizeof(double) * f.size(), hipMemcpyDeviceToHost));
+        for (int b = 0; b < h->B; ++b) { ms[4] += f[2 * (size_t)b]; ms[5] += f[2 * (size_t)b + 1]; }
+    }
     return SLAM_OK;
 }
 
@@ -635,16 +769,17 @@ int pgs_last_solve_work(pgs_handle* h, double* syrk_flop, int32_t* trials_launch
 // The last PROFILED solve by path: out = {algorithmic SYRK FLOP of the trials that ran pgs_syrk_*_kernel, of the trials that ran
 // pgs_chain_syrk_kernel, ms in those SYRK launches, ms in those fused launches, FLOP of the trials of the segmented elimination, ms in
 // its SYRK launches (tile kernel on the separator rows + pgs_seg_syrk_kernel), 1 if the solve ran the segmented elimination, segment length}
-int pgs_last_solve_paths(pgs_handle* h, double out[8]) {
+int pgs_last_solve_paths_v2(pgs_handle* h, double* out, int n) {
     TRY(check(h));
-    if (!out) return fail(SLAM_ERR_ARG, "NULL output");
+    if (!out || n < 0 || n > 8) return fail(SLAM_ERR_ARG, "bad output (n = %d, at most 8 entries)", n);
     HIP_TRY(hipStreamSynchronize(h->stream));
     double w[3];
     HIP_TRY(hipMemcpy(w, h->p.work, 3 * sizeof(double), hipMemcpyDeviceToHost));
-    out[0] = w[0]; out[1] = w[1]; out[2] = h->path_ms[0]; out[3] = h->path_ms[1];
-    out[4] = w[2]; out[5] = h->path_ms[2]; out[6] = h->seg_ok ? 1.0 : 0.0; out[7] = (double)h->seg_len;
+    const double v[8] = {w[0], w[1], h->path_ms[0], h->path_ms[1], w[2], h->path_ms[2], h->seg_ok ? 1.0 : 0.0, (double)h->seg_len};
+    for (int i = 0; i < n; ++i) out[i] = v[i];
     return SLAM_OK;
 }
+int pgs_last_solve_paths(pgs_handle* h, double out[4]) { return pgs_last_solve_paths_v2(h, out, 4); }
 int pgs_set_profiling(pgs_handle* h, int on) { TRY(check(h)); h->profiling = on != 0; return SLAM_OK; }
 int pgs_last_solve_kernel_ms(pgs_handle* h, double ms[6]) {
     TRY(check(h));

@@ -65,14 +65,25 @@ struct PgsParams {
     double* S;                         // [B][LD*LD]
     double* dl; double* dp;            // [B][L_max*2], [B][N_max*3]
     double* lambda; double* error; double* cur_error; double* err_init;
-    int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done
-    int32_t* n_active;                 // [4] per solve group: active instances after the trial, lanes the next trial needs, active SLOTS
+    int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done, 2 = waiting for a running slot (streaming)
+    int32_t* n_active;                 // [4] per solve group: active instances after the trial, lanes the next trial needs, active SLOTS,
+                                       //     (streaming) workgroups of the decide kernel that finished; [4]: copy of the wait cursor for the host
     // The slots that run in the next trial, compacted by pgs_decide_kernel (order = arrival order of its atomics; the mapping of
     // workgroups to instances does not touch any result).  A launch over the list has exactly one workgroup (or FC_NB / SI_NB) per
     // running slot with consecutive ids - the dispatcher deals ids round-robin over XCDs and shader engines, so a sparse set of
     // live ids in a full-size grid left engines idle while others queued (158 live workgroups of 512 took two rounds).
     int32_t* alist;                    // [b_cnt * lanes_max] of this solve group
     int32_t use_list, n_list;          // the launch's block index -> slot through alist[0 .. n_list) (else: lane * B + instance)
+    // ---- streaming (round 6): graphs of a solve group wait for one of `slots_cap` RUNNING SLOTS ----
+    // A group holds b_cnt graphs but only slots_cap of them are in flight; the rest wait in state 2.  The last workgroup of
+    // pgs_decide_kernel to finish admits waiting graphs (in index order, cursor *wait_next) into the list of the next trial until it holds
+    // slots_cap slots again, so every trial runs a full list while graphs wait.  The host then no longer decides anything per trial:
+    // launches cover slots_cap slots, the LIST LENGTH is read on the device (n_list_dev = the counter block the previous trial's decide
+    // kernel wrote; block ids beyond it map to `dead_slot`, whose state is 1 = every kernel returns at entry), and trials are enqueued ahead.
+    int32_t slots_cap;                 // 0: lockstep (every instance of the group runs from the first trial on)
+    int32_t dead_slot;                 // index of a slot that is never active
+    int32_t* wait_next;                // [1] of this group: next waiting instance (b_off + b_cnt = none left)
+    const int32_t* n_list_dev;         // NULL: the list length is n_list (host-known)
     // ---- speculative lambda lanes ----
     // Every instance b owns `lanes_max` slots of every per-instance array: slot b (the instance itself) and the clones
     // j * B + b, j = 1 .. lanes_max - 1.  After a failed tryLambda GTSAM multiplies lambda by 10 and tries again on the same
@@ -114,6 +125,8 @@ struct PgsParams {
                                        // sides ([nseg][6]: left 3, right 3, local columns) and the separators' rows of Y ([NS][3], global columns) live
     // the tile SYRK over an arbitrary block of Y rows: row offset, rows (-1: 3 N), per-landmark first non-zero row / 3 (NULL: lm_first)
     int64_t syrk_row0; int32_t syrk_rows; const int32_t* syrk_first;
+    int32_t* tick_acc;                 // optional [B][2]: pgs_adopt_kernel adds the solve's LM iterations / lambda trials (solve_graph_every_iteration: sums over the ticks)
+    double* tick_flop;                 // optional [B][2]: ... and the algorithmic FLOP of its trials: Schur-complement SYRK (inst_flop) | dense Cholesky + substitutions (n^3/3 + 2 n^2, n = 2 M)
     unsigned long long* prof;          // optional [B][8] phase timers of the chol kernel (100 MHz wall clock), debug only
     // ---- factor constants ----
     double prior[3];

@@ -262,7 +262,10 @@ constexpr int TPB = 512;   // threads of the per-pose kernels (two poses per thr
 
 // logical block `bl` of a trial-kernel launch -> slot: lane = bl / b_cnt, instance = b_off + bl % b_cnt (PgsParams::lanes)
 __device__ __forceinline__ int pgs_slot(const PgsParams& p, int bl) {
-    if (p.use_list) return p.alist[bl];
+    if (p.use_list) {
+        if (p.n_list_dev && bl >= *p.n_list_dev) return p.dead_slot;   // enqueued-ahead launch: the list is shorter than the grid
+        return p.alist[bl];
+    }
     const int lane = bl / p.b_cnt;
     return lane * p.B + p.b_off + (bl - lane * p.b_cnt);
 }
@@ -369,8 +372,11 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     if (tid == 0) {
         p.error[b] = err; p.err_init[b] = err; p.cur_error[b] = err;
         p.lambda[b] = 1e-5;                    // LevenbergMarquardtParams::lambdaInitial
-        p.iters[b] = 0; p.trials[b] = 0; p.state[b] = 0; p.solve_ok[b] = 1; p.nl[b] = 1;
-        p.alist[blockIdx.x] = b;               // first trial: every instance of the group, one lane
+        p.iters[b] = 0; p.trials[b] = 0; p.solve_ok[b] = 1; p.nl[b] = 1;
+        // first trial: every instance of the group, one lane - or, streaming, the first slots_cap of them; the others wait
+        const bool runs = p.slots_cap <= 0 || (int)blockIdx.x < p.slots_cap;
+        p.state[b] = runs ? 0 : 2;
+        if (runs) p.alist[blockIdx.x] = b;
         for (int j = 0; j < p.lanes_max; ++j) p.lin_ok[(size_t)j * p.B + b] = 0;   // (the clones copy nothing of this: plain per-slot state)
         p.flags[b] &= ~(PGS_FLAG_NOT_CONVERGED | PGS_FLAG_NONFINITE);
     }
@@ -2256,8 +2262,10 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
 __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
     __shared__ int s_win, s_next;
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
-    if (p.state[b]) return;
+    const bool running = p.state[b] == 0;
+    if (!running && p.slots_cap <= 0) return;
     const int N = p.N, M = p.M[b], B = p.B;
+    if (running) {
     if (tid == 0) {
         const double lambdaFactor = 10.0, lambdaUpper = 1e5, minFidelity = 1e-3, relTol = 1e-5, absTol = 1e-5;
         const int maxIter = 100;
@@ -2342,6 +2350,31 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
         for (int i = tid; i < 3 * N; i += TPB) cp[i] = pose[i];
         for (int a = tid; a < 2 * M; a += TPB) cl[a] = lm[a];
     }
+    }   // running
+    if (p.slots_cap > 0) {
+        // Streaming: the LAST workgroup of the launch to arrive here (every workgroup counts, also those of finished and waiting
+        // graphs) refills the list: waiting graphs take the running slots this trial freed, in index order.  Which graph runs when
+        // touches no result - a graph's LM sequence depends on nothing but the graph.
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            const int arrived = atomicAdd(p.n_active + 3, 1);
+            if (arrived == (int)gridDim.x - 1) {
+                __threadfence();
+                int nslots = atomicAdd(p.n_active + 2, 0), nact = atomicAdd(p.n_active, 0);
+                int w = *p.wait_next;
+                const int wend = p.b_off + p.b_cnt;
+                while (nslots < p.slots_cap && w < wend) {
+                    p.state[w] = 0;
+                    p.alist[nslots] = w;
+                    nslots += 1; nact += 1; w += 1;
+                }
+                *p.wait_next = w;
+                p.n_active[0] = nact; p.n_active[2] = nslots; p.n_active[4] = w;
+                if (nact > 0) atomicMax(p.n_active + 1, 1);
+            }
+        }
+    }
 }
 
 // result <- current values (also for instances cut off by the trial cap)
@@ -2354,7 +2387,7 @@ __global__ __launch_bounds__(TPB) void pgs_lm_end_kernel(const PgsParams p) {
     double* l1 = p.lm1 + (size_t)b * p.L_max * 2;
     for (int i = tid; i < 3 * N; i += TPB) p1[i] = pw[i];
     for (int i = tid; i < 2 * M; i += TPB) l1[i] = lw[i];
-    if (tid == 0 && p.state[b] == 0) { p.state[b] = 1; p.flags[b] |= PGS_FLAG_NOT_CONVERGED; }
+    if (tid == 0 && p.state[b] != 1) { p.state[b] = 1; p.flags[b] |= PGS_FLAG_NOT_CONVERGED; }   // still running or still waiting at the trial cap
 }
 
 __global__ __launch_bounds__(TPB) void pgs_adopt_kernel(const PgsParams p) {
@@ -2366,6 +2399,12 @@ __global__ __launch_bounds__(TPB) void pgs_adopt_kernel(const PgsParams p) {
     const double* l1 = p.lm1 + (size_t)b * p.L_max * 2;
     for (int i = tid; i < 3 * N; i += TPB) p0[i] = p1[i];
     for (int i = tid; i < 2 * M; i += TPB) l0[i] = l1[i];
+    if (tid == 0 && p.tick_acc) { p.tick_acc[2 * b] += p.iters[b]; p.tick_acc[2 * b + 1] += p.trials[b]; }
+    if (tid == 0 && p.tick_flop) {
+        const double n = 2.0 * M, tr = (double)p.trials[b];
+        p.tick_flop[2 * b] += tr * p.inst_flop[b];
+        p.tick_flop[2 * b + 1] += tr * (n * n * n / 3.0 + 2.0 * n * n);
+    }
 }
 
 // compute_average_error as the pose-graph plot calls it (plotting_node.py:203-213,432-434): pose i of the message

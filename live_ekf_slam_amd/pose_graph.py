@@ -171,6 +171,21 @@ class BatchedPoseGraph:
         _lib.check(_lib.lib().pgs_run_sim(self.h, _f(c), c.shape[0]))
         self.timestep += c.shape[0]
 
+    def run_sim_every_iteration(self, cmds):
+        """solve_graph_every_iteration (params.yaml:64; pose_graph.cpp:258-264) with the simulator on the device: per command one tick of
+        run_sim, solvePoseGraph, initial_estimate = result.  Returns [batch][2]: LM iterations / lambda trials summed over the ticks."""
+        self._need()
+        c = np.ascontiguousarray(cmds, dtype=np.float32).reshape(-1, 2)
+        counts = np.zeros((self.batch, 2), dtype=np.int32)
+        _lib.check(_lib.lib().pgs_run_sim_every_iteration(self.h, _f(c), c.shape[0], _i(counts)))
+        self.timestep += c.shape[0]
+        self.solved_pose_graph = True
+        return counts
+
+    def last_iter_phases(self):
+        self._need(); o = np.zeros(6); _lib.check(_lib.lib().pgs_last_iter_phases(self.h, _d(o)))
+        return dict(sim_append_ms=o[0], solve_ms=o[1], adopt_ms=o[2], trials_launched=int(o[3]), syrk_flop=o[4], chol_flop=o[5])
+
     # -- PoseGraph::solvePoseGraph (pose_graph.cpp:269-300) --
     def solvePoseGraph(self):
         self._need()
@@ -180,6 +195,23 @@ class BatchedPoseGraph:
     def set_groups(self, groups):
         """Number of concurrently solved sub-batches (separate HIP streams); 0 = automatic."""
         self._need(); _lib.check(_lib.lib().pgs_set_groups(self.h, int(groups)))
+
+    def set_slots(self, slots):
+        """Streaming solve: at most `slots` graphs of the batch in flight, the others wait for a running slot (0 = lockstep)."""
+        self._need(); _lib.check(_lib.lib().pgs_set_slots(self.h, int(slots)))
+
+    def last_solve_timeline(self):
+        """Running slots per trial of the last solve, one array per solve group."""
+        self._need()
+        out, g, ng = [], 0, C.c_int32(1)
+        while g < ng.value:
+            n = C.c_int32(0)
+            _lib.check(_lib.lib().pgs_last_solve_timeline(self.h, g, None, 0, C.byref(n), C.byref(ng)))
+            a = np.zeros(max(n.value, 1), dtype=np.int32)
+            _lib.check(_lib.lib().pgs_last_solve_timeline(self.h, g, _i(a), n.value, C.byref(n), C.byref(ng)))
+            out.append(a[:n.value].copy())
+            g += 1
+        return out
 
     def adopt_result(self):
         self._need(); _lib.check(_lib.lib().pgs_adopt_result(self.h))
@@ -236,7 +268,7 @@ class BatchedPoseGraph:
 
     def last_solve_paths(self):
         """The last profiled solve by path: algorithmic SYRK FLOP and ms of the separate SYRK launches / of the fused chain + SYRK launches."""
-        self._need(); o = np.zeros(8); _lib.check(_lib.lib().pgs_last_solve_paths(self.h, _d(o)))
+        self._need(); o = np.zeros(8); _lib.check(_lib.lib().pgs_last_solve_paths_v2(self.h, _d(o), 8))
         return dict(flop_separate=o[0], flop_fused=o[1], ms_separate_syrk=o[2], ms_fused=o[3], flop_segmented=o[4], ms_segmented_syrk=o[5],
                     segmented=bool(o[6]), segment_length=int(o[7]))
 

@@ -82,6 +82,8 @@ def lib():
         L.orc_run_pgs_batch.argtypes = [C.POINTER(SlamConfig), C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _fp, C.c_int,
                                         C.c_uint64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp, _ip, _ip, _ip, _dp, _dp, _dp,
                                         _fp, _ip]
+        L.orc_run_pgs_batch_ex.restype = C.c_double
+        L.orc_run_pgs_batch_ex.argtypes = L.orc_run_pgs_batch.argtypes + [C.c_int, _ip]
         L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
         L.orc_noise_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
         for name in ("orc_det_sincos", "orc_libm_sincos"):
@@ -330,8 +332,10 @@ class OraclePoseGraph:
 
 
 def run_pgs_batch(map_xy, cmds, B, L_max, KP=8, seed=2025, inst0=0, cfg=None, math=MATH_DET, lin_mode=LIN_SCHUR, nthreads=1,
-                  want_streams=False):
-    """Simulator + NaiveFilter secondary + graph building + one LM solve per instance (T commands -> T+1 poses)."""
+                  want_streams=False, every_iteration=False):
+    """Simulator + NaiveFilter secondary + graph building + one LM solve per instance (T commands -> T+1 poses).
+    every_iteration: solve_graph_every_iteration (params.yaml:64) - solve + `initial_estimate = result` after every update; `iterations` /
+    `trials` are then the sums over the T ticks, `tick_counts` [B][T][2] those of every tick, `seconds` covers all T solves."""
     cfg = cfg or default_config()
     map_xy = np.ascontiguousarray(map_xy, dtype=np.float64); cmds = np.ascontiguousarray(cmds, dtype=np.float32)
     L, T = map_xy.shape[0], cmds.shape[0]
@@ -341,9 +345,11 @@ def run_pgs_batch(map_xy, cmds, B, L_max, KP=8, seed=2025, inst0=0, cfg=None, ma
     istats = np.zeros((B, 3), dtype=np.int32); dstats = np.zeros((B, 3)); avg_err = np.zeros((B, 2)); truth = np.zeros((B, T, 2))
     meas = np.zeros((B, T, KP, 3), dtype=np.float32) if want_streams else None
     cnt = np.zeros((B, T), dtype=np.int32) if want_streams else None
-    secs = lib().orc_run_pgs_batch(C.byref(cfg), L_max, KP, math, lin_mode, _d(map_xy), L, _f(cmds), T, seed, inst0, B, nthreads,
-                                   _d(pose_init), _d(pose_res), _d(lm_res), _i(M), _i(ids), _i(istats), _d(dstats), _d(avg_err),
-                                   _d(truth), _f(meas) if want_streams else None, _i(cnt) if want_streams else None)
-    return dict(pose_init=pose_init, pose_res=pose_res, lm_res=lm_res, M=M, ids=ids, iterations=istats[:, 0], trials=istats[:, 1],
+    tick = np.zeros((B, T, 2), dtype=np.int32) if every_iteration else None
+    secs = lib().orc_run_pgs_batch_ex(C.byref(cfg), L_max, KP, math, lin_mode, _d(map_xy), L, _f(cmds), T, seed, inst0, B, nthreads,
+                                      _d(pose_init), _d(pose_res), _d(lm_res), _i(M), _i(ids), _i(istats), _d(dstats), _d(avg_err),
+                                      _d(truth), _f(meas) if want_streams else None, _i(cnt) if want_streams else None,
+                                      1 if every_iteration else 0, _i(tick) if every_iteration else None)
+    return dict(tick_counts=tick, pose_init=pose_init, pose_res=pose_res, lm_res=lm_res, M=M, ids=ids, iterations=istats[:, 0], trials=istats[:, 1],
                 flags=istats[:, 2], err_init=dstats[:, 0], err_final=dstats[:, 1], lam=dstats[:, 2], avg_err_init=avg_err[:, 0],
                 avg_err_result=avg_err[:, 1], truth_xy=truth, meas=meas, cnt=cnt, seconds=secs)

@@ -937,10 +937,14 @@ void orc_pgs_retract(void* h, const double* poses, const double* lms, const doub
 // istats [B][3] (iterations, trials, flags), dstats [B][3] (err_init, err_final, lambda), avg_err [B][2] (initial,
 // result; plotting_node.py alignment), truth_xy [B][T][2], meas_out [B][T][KP][3] + cnt_out [B][T] (the streams, so a
 // test can feed the identical input to the GPU path).  Returns seconds spent in solve() only.
-double orc_run_pgs_batch(const slam_config* cfg, int L_max, int KP, int math, int lin_mode, const double* map_xy, int L,
-                         const float* cmds, int T, uint64_t seed, int64_t inst0, int B, int nthreads,
-                         double* pose_init, double* pose_res, double* lm_res, int* M_out, int* ids_out, int* istats,
-                         double* dstats, double* avg_err, double* truth_xy, float* meas_out, int* cnt_out) {
+// every_iteration != 0: solve_graph_every_iteration (params.yaml:64; pose_graph.cpp:258-264) - after every update the graph is solved
+// and `initial_estimate = result`; istats then holds the LM iterations / lambda trials SUMMED over the T ticks, tick_counts (optional,
+// [B][T][2]) those of every tick, pose_init the last adopted estimate, and the returned seconds cover all T solves.
+double orc_run_pgs_batch_ex(const slam_config* cfg, int L_max, int KP, int math, int lin_mode, const double* map_xy, int L,
+                            const float* cmds, int T, uint64_t seed, int64_t inst0, int B, int nthreads,
+                            double* pose_init, double* pose_res, double* lm_res, int* M_out, int* ids_out, int* istats,
+                            double* dstats, double* avg_err, double* truth_xy, float* meas_out, int* cnt_out,
+                            int every_iteration, int* tick_counts) {
     std::atomic<int> next(0);
     std::atomic<long long> solve_ns(0);
     const int N = T + 1;
@@ -956,6 +960,8 @@ double orc_run_pgs_batch(const slam_config* cfg, int L_max, int KP, int math, in
             sim.cfg = *cfg; sim.L = L; sim.math = math; sim.map.assign(map_xy, map_xy + 2 * L);
             sim.xv[0] = cfg->init_x; sim.xv[1] = cfg->init_y; sim.xv[2] = cfg->init_yaw;
             double nv[3] = {(double)(float)cfg->init_x, (double)(float)cfg->init_y, (double)(float)cfg->init_yaw};
+            int it_sum = 0, tr_sum = 0;
+            LmStats last{};
             for (int t = 0; t < T; ++t) {
                 int k = 0;
                 auto draw = [&](int pair, int which) { double u0, u1; slam::noise_pair(seed, (uint64_t)(inst0 + b), (uint32_t)t, (uint32_t)pair, &u0, &u1); return which ? u1 : u0; };
@@ -974,10 +980,22 @@ double orc_run_pgs_batch(const slam_config* cfg, int L_max, int KP, int math, in
                     for (int i = 0; i < 3 * std::min(k, KP); ++i) mo[i] = meas[i];
                 }
                 if (cnt_out) cnt_out[(size_t)b * T + t] = k;
+                if (every_iteration) {   // pose_graph.cpp:258-264
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const LmStats si = g.solve(lin_mode);
+                    g.adopt();
+                    solve_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                    it_sum += si.iterations; tr_sum += si.trials;
+                    if (tick_counts) { tick_counts[((size_t)b * T + t) * 2] = si.iterations; tick_counts[((size_t)b * T + t) * 2 + 1] = si.trials; }
+                    last = si;
+                }
             }
-            const auto t0 = std::chrono::steady_clock::now();
-            LmStats st = g.solve(lin_mode);
-            solve_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            LmStats st = last;
+            if (!every_iteration) {
+                const auto t0 = std::chrono::steady_clock::now();
+                st = g.solve(lin_mode);
+                solve_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            } else { st.iterations = it_sum; st.trials = tr_sum; }
             if (pose_init) memcpy(pose_init + (size_t)b * N * 3, g.pose0.data(), sizeof(double) * 3 * N);
             if (pose_res) memcpy(pose_res + (size_t)b * N * 3, g.pose1.data(), sizeof(double) * 3 * N);
             if (lm_res) memcpy(lm_res + (size_t)b * L_max * 2, g.lm1.data(), sizeof(double) * 2 * g.M);
@@ -997,6 +1015,14 @@ double orc_run_pgs_batch(const slam_config* cfg, int L_max, int KP, int math, in
     worker();
     for (auto& t : th) t.join();
     return (double)solve_ns.load() * 1e-9;
+}
+
+double orc_run_pgs_batch(const slam_config* cfg, int L_max, int KP, int math, int lin_mode, const double* map_xy, int L,
+                         const float* cmds, int T, uint64_t seed, int64_t inst0, int B, int nthreads,
+                         double* pose_init, double* pose_res, double* lm_res, int* M_out, int* ids_out, int* istats,
+                         double* dstats, double* avg_err, double* truth_xy, float* meas_out, int* cnt_out) {
+    return orc_run_pgs_batch_ex(cfg, L_max, KP, math, lin_mode, map_xy, L, cmds, T, seed, inst0, B, nthreads, pose_init, pose_res, lm_res, M_out,
+                                ids_out, istats, dstats, avg_err, truth_xy, meas_out, cnt_out, 0, nullptr);
 }
 
 }  // extern "C"

@@ -113,6 +113,41 @@ def test_solve_every_iteration_mode(oracle):
         assert st["flags"][b] == 0
 
 
+@pytest.mark.parametrize("L,T,B,KP", [(10, 60, 6, 6), (20, 300, 5, 8), (60, 200, 3, 16)])
+def test_solve_every_iteration_on_the_device_matches_oracle(oracle, L, T, B, KP):
+    """pgs_run_sim_every_iteration: the reference's default mode (params.yaml:64; pose_graph.cpp:258-264) with the simulator on the device -
+    per tick one step of the simulator + NaiveFilter + append, the solve, `initial_estimate = result`.  Against the oracle run in the same
+    mode: the LM iteration and lambda-trial counts SUMMED over all ticks are equal, the final result within the one-shot bar."""
+    import live_ekf_slam_amd as S
+    lm, cmds = make_scenario(61 + L, L, T)
+    cfg = default_config()
+    for lin in (oracle.LIN_SCHUR, oracle.LIN_SEG):
+        r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=9, cfg=cfg, every_iteration=True, lin_mode=lin, nthreads=8)
+        if lin == oracle.LIN_SCHUR:
+            r0 = r
+    assert np.array_equal(r0["iterations"], r["iterations"]) and np.array_equal(r0["trials"], r["trials"])   # the oracle's two orders agree
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg, solve_graph_every_iteration=True)
+    pg.set_map(lm); pg.set_seed(9); pg.init(0.0, 0.0, 0.0)
+    counts = pg.run_sim_every_iteration(cmds)
+    assert pg.timestep == T and pg.solved_pose_graph
+    assert np.array_equal(counts[:, 0], r["iterations"]), (counts[:, 0], r["iterations"])
+    assert np.array_equal(counts[:, 1], r["trials"]), (counts[:, 1], r["trials"])
+    assert np.all(counts[:, 1] >= T)          # at least one lambda trial per tick
+    st = pg.stats()
+    assert np.all(st["flags"] == 0)
+    for b in range(B):
+        g1 = pg.get_graph(b, 1)
+        M = r["M"][b]
+        assert g1["M"] == M and np.array_equal(g1["ids"], r["ids"][b, :M])
+        assert np.abs(g1["poses"] - r["pose_res"][b]).max() < POSE_TOL
+        assert np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max() < POSE_TOL
+        assert np.abs(pg.get_graph(b, 0)["poses"] - r["pose_res"][b]).max() < POSE_TOL     # adopted: initial_estimate = result
+    assert np.allclose(pg.error_stats(1), r["avg_err_result"], rtol=1e-6)
+    ph = pg.last_iter_phases()
+    assert ph["trials_launched"] >= T and ph["chol_flop"] > 0 and ph["syrk_flop"] > 0
+    pg.close()
+
+
 def test_capacity_flags_and_errors():
     import live_ekf_slam_amd as S
     pg = S.BatchedPoseGraph(2, num_iterations=4, L_max=2, k_per_pose=2).readParams()
@@ -244,6 +279,50 @@ def test_solve_groups_do_not_change_results():
             assert np.array_equal(graphs[b]["landmarks"], out[0][0][b]["landmarks"])
         for key in ("iterations", "trials", "flags", "err_final", "lam"):
             assert np.array_equal(st[key], out[0][1][key])
+
+
+@pytest.mark.parametrize("G", [1, 2])
+def test_streaming_slots_do_not_change_results(oracle, G):
+    """pgs_set_slots (round 6): only `slots` graphs are in flight, the others wait and take over the running slots of converged ones
+    on the device; trials are enqueued ahead of the host.  A graph's LM sequence depends on nothing but the graph: poses, landmarks,
+    iteration / trial counts, objective and lambda are BIT-identical to the lockstep solve for every slot count and pipeline depth,
+    and equal to the oracle's within the usual bar.  The timeline shows the refill: full lists while graphs wait."""
+    import live_ekf_slam_amd as S
+    L, T, KP, B = 20, 150, 8, 45
+    lm, cmds = make_scenario(9, L, T)
+    cfg = default_config()
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=4, cfg=cfg, nthreads=8)
+    out = []
+    for slots in (0, 8, 7, 44, 64):
+        pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+        pg.set_groups(G); pg.set_slots(slots)
+        pg.set_map(lm); pg.set_seed(4); pg.init(0.0, 0.0, 0.0)
+        pg.run_sim(cmds); pg.solvePoseGraph()
+        if slots == 0:
+            _compare(pg, r, B)
+        out.append(([pg.get_graph(b, 1) for b in range(B)], pg.stats(), pg.last_solve_timeline()))
+        # a second solve of the same handle re-uses the counters and cursors
+        pg.solvePoseGraph()
+        st2 = pg.stats()
+        for key in ("iterations", "trials", "flags", "err_final", "lam"):
+            assert np.array_equal(st2[key], out[-1][1][key]), (slots, key)
+        pg.close()
+    for (graphs, st, tl), slots in zip(out[1:], (8, 7, 44, 64)):
+        for b in range(B):
+            assert np.array_equal(graphs[b]["poses"], out[0][0][b]["poses"]), (slots, b)
+            assert np.array_equal(graphs[b]["landmarks"], out[0][0][b]["landmarks"]), (slots, b)
+        for key in ("iterations", "trials", "flags", "err_final", "lam"):
+            assert np.array_equal(st[key], out[0][1][key]), (slots, key)
+        assert len(tl) == G
+        cap = -(-slots // G)
+        per = -(-B // G)
+        if cap < per:      # streaming: never more than the group's share in flight, and the list stays full while graphs wait
+            for g, a in enumerate(tl):
+                assert a.max() <= max(cap, 1) * 4 and a[0] == cap, (slots, g, a)   # (x lanes once the lockstep tail runs its lambda lanes)
+                total = int(st["trials"][g * per:(g + 1) * per].sum())
+                assert int(a.sum()) >= total, (slots, g)          # every consumed trial ran in some slot (speculative lanes add more)
+                full = int((a[:max(1, len(a) // 3)] == cap).sum())
+                assert full >= max(1, len(a) // 3) - 1, (slots, g, a)
 
 
 @pytest.mark.parametrize("L,T", [(20, 150), (60, 400)])
