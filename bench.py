@@ -341,6 +341,8 @@ def bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s
     if getattr(args, "event_value", False):
         wall = dev_s
     ph = pg.last_iter_phases()
+    if os.environ.get("SLAM_PGS_ITER_PROF"):
+        print(f"# every-iteration phases (host clock, a stream sync after each): {ph}", file=sys.stderr)
     st = pg.stats()
     e1 = pg.error_stats(1)
     parity = None

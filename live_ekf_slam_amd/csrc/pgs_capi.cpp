@@ -61,6 +61,16 @@ struct pgs_handle {
     int32_t* h_ring = nullptr;                 // pinned host [kMaxGroups][kRing][8]
     std::vector<hipEvent_t> ring_events;       // [kMaxGroups][kRing]
     std::vector<std::vector<int32_t>> timeline;   // per group: slots that ran in every trial of the last solve
+    // asynchronous ticks (pgs_run_sim_every_iteration; pgs_kernel.h "asynchronous ticks")
+    // SLAM_PGS_ITER_ASYNC=1: every graph walks through its ticks at its own pace.  Off by default: measured slower on BASELINE configs[4] (9.0 k
+    // against 15.0 k graph-ticks/s) - a run lasts as long as its HARDEST graph's dependent chain of lambda trials (42 per tick for the slowest of
+    // 256 graphs, median 3: profiles/r06_pgs/iterative_mode.txt), which the lockstep loop shortens with its speculative lambda lanes
+    int iter_async = 0;
+    int32_t* d_Nv = nullptr;                   // [slots + 1] poses per graph
+    int32_t* d_mono = nullptr;                 // [2]
+    hipStream_t tick_stream = nullptr;
+    std::vector<hipEvent_t> async_events;      // [2 * kRing + 1]: decide done, tick step done (rings), start
+    long long async_trials = 0;
     double* d_tick_flop = nullptr;             // [B][2] algorithmic FLOP (SYRK | Cholesky) of the same
     int32_t* d_tick = nullptr;                 // [B][2] LM iterations / trials summed over the ticks of pgs_run_sim_every_iteration
     double iter_ms[4] = {0, 0, 0, 0};
@@ -156,6 +166,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_CHOL_SWITCH")) h->chol_switch = atoi(e);
     if (const char* e = getenv("SLAM_PGS_CHOL_LL")) h->chol_ll = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SLOTS")) h->slots = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("SLAM_PGS_ITER_ASYNC")) h->iter_async = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PGS_STREAM_DEPTH")) h->stream_depth = atoi(e) >= 1 && atoi(e) < pgs_handle::kRing ? atoi(e) : h->stream_depth;
     hipError_t e = hipStreamCreate(&h->stream);
     if (e != hipSuccess) { delete h; return fail(SLAM_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorString(e)); }
@@ -246,6 +257,8 @@ int pgs_destroy(pgs_handle* h) {
     for (hipEvent_t e : h->events) hipEventDestroy(e);
     for (hipEvent_t e : h->gevents) hipEventDestroy(e);
     for (hipEvent_t e : h->ring_events) hipEventDestroy(e);
+    for (hipEvent_t e : h->async_events) hipEventDestroy(e);
+    if (h->tick_stream) hipStreamDestroy(h->tick_stream);
     if (h->h_ring) hipHostFree(h->h_ring);
     for (hipStream_t st : h->gstreams) hipStreamDestroy(st);
     if (h->h_active) hipHostFree(h->h_active);
@@ -634,6 +647,92 @@ int pgs_adopt_result(pgs_handle* h) {
     return SLAM_OK;
 }
 
+namespace {
+// solve_graph_every_iteration WITHOUT a batch-wide barrier per tick (pgs_kernel.h "asynchronous ticks"): a graph's tick t + 1 depends on
+// nothing but its own tick t, so every graph walks through its ticks at its own pace - one LM trial of ALL unfinished graphs per round of
+// launches, whatever tick each is at; the graphs whose solve converged in a round are advanced (result, adopt, simulator tick, append, plan,
+// begin) on a second stream beside the next round and rejoin the one after.  The lockstep tick loop launches, per tick, as many trials as
+// the tick's slowest graph needs (27.5 at BASELINE configs[4] against a mean of 7.5 consumed); here a graph pays its own trials + 1 per tick.
+// The host only sizes grids (from the monotone counters the decide kernel forwards) and enqueues rounds `stream_depth` ahead.
+int run_every_iteration_async(pgs_handle* h, int T) {
+    constexpr int R = pgs_handle::kRing;
+    const int D = h->stream_depth, B = h->B;
+    const size_t S = (size_t)B * h->lanes;
+    if (!h->d_Nv) TRY(dalloc(h, &h->d_Nv, S + 1));
+    if (!h->d_mono) TRY(dalloc(h, &h->d_mono, 2));
+    if (!h->h_ring) HIP_TRY(hipHostMalloc((void**)&h->h_ring, sizeof(int32_t) * 8 * pgs_handle::kRing * pgs_handle::kMaxGroups, hipHostMallocDefault));
+    while ((int)h->ring_events.size() < pgs_handle::kRing * pgs_handle::kMaxGroups) {
+        hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ring_events.push_back(e);
+    }
+    while ((int)h->async_events.size() < 2 * R + 1) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->async_events.push_back(e); }
+    if (!h->tick_stream) HIP_TRY(hipStreamCreateWithFlags(&h->tick_stream, hipStreamNonBlocking));
+    hipStream_t sa = h->stream, sb = h->tick_stream;
+    hipEvent_t* evDec = &h->async_events[0];
+    hipEvent_t* evAdv = &h->async_events[R];
+    hipEvent_t evStart = h->async_events[2 * R];
+    const int N0 = h->timestep + 1;
+    slam::PgsParams q = h->p;
+    q.async_ticks = 1; q.seg_on = 1; q.Nv = h->d_Nv; q.T_end = h->timestep + T; q.split_decide = 1; q.max_trials = h->max_trials;
+    q.mono = h->d_mono; q.tick_acc = h->d_tick; q.tick_flop = h->d_tick_flop;
+    q.b_off = 0; q.b_cnt = B; q.slots_cap = 0; q.N = N0;
+    h->seg_ok = true; h->fused_ok = false;
+    int32_t* dcnt = h->d_cnt;                        // group 0's counter blocks
+    int32_t* ring = h->h_ring;
+    hipEvent_t* ev = &h->ring_events[0];
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_Nv, N0, S + 1, sa));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)q.state, 5, (size_t)B, sa));                      // first tick: nothing to adopt
+    if (S > (size_t)B) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(q.state + B), 1, S - (size_t)B, sa));   // the lambda lanes are off
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_mono, 0, 1, sa));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(h->d_mono + 1), N0, 1, sa));
+    HIP_TRY(hipMemsetAsync(dcnt, 0, 16 * sizeof(int32_t), sa));
+    HIP_TRY(hipMemsetAsync(h->p.work, 0, 3 * sizeof(double), sa));
+    HIP_TRY(hipEventRecord(evStart, sa));
+    HIP_TRY(hipStreamWaitEvent(sb, evStart, 0));
+    HIP_TRY(slam::pgs_launch_tick(q, sb));                                                       // every graph's first tick
+    HIP_TRY(hipEventRecord(evAdv[R - 1], sb));
+    int k = 0, seen = 0;
+    bool leave = false;
+    int32_t last[8] = {B, 1, 0, 0, 0, 0, N0 + 1, 0};
+    int n_known = N0 + 1, f_known = 0;
+    const long long cap = (long long)T * h->max_trials + 16;
+    auto read_one = [&]() -> int {
+        HIP_TRY(hipEventSynchronize(ev[seen % R]));
+        memcpy(last, ring + 8 * (seen % R), sizeof(last));
+        seen += 1;
+        if (last[5] > f_known) f_known = last[5];
+        if (last[6] > n_known) n_known = last[6];
+        if (h->trace) fprintf(stderr, "pgs async round %d: unfinished %d, listed %d, most factors %d, most poses %d\n", seen - 1, last[0], last[2], last[5], last[6]);
+        if (last[0] == 0) leave = true;
+        return SLAM_OK;
+    };
+    std::vector<int32_t>& tl = (h->timeline.assign(1, {}), h->timeline[0]);
+    while (!leave && k < cap) {
+        q.n_list_dev = dcnt + 8 * (k & 1) + 2;
+        q.n_active = dcnt + 8 * ((k + 1) & 1);
+        // grids: the most poses / factors a graph can have when this round runs - every round ahead of the host's knowledge may have advanced it by a tick
+        q.N = n_known + D + 2 < h->N_max ? n_known + D + 2 : h->N_max;
+        q.nfact_max = f_known + h->KP * (D + 2);
+        TRY(launch_trial(h, q, B, 1, B, sa, k, false, false, 1));
+        HIP_TRY(hipStreamWaitEvent(sa, evAdv[(k + R - 1) % R], 0));      // the graphs advanced beside this round are ready to be listed
+        HIP_TRY(slam::pgs_launch_trial_kernel(q, 6, sa));                // decide
+        HIP_TRY(hipEventRecord(evDec[k % R], sa));
+        HIP_TRY(hipStreamWaitEvent(sb, evDec[k % R], 0));
+        HIP_TRY(slam::pgs_launch_tick(q, sb));                           // ... and those that converged in it advance beside the next one
+        HIP_TRY(hipEventRecord(evAdv[k % R], sb));
+        HIP_TRY(hipMemcpyAsync(ring + 8 * (k % R), q.n_active, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, sa));
+        HIP_TRY(hipEventRecord(ev[k % R], sa));
+        k += 1;
+        while (!leave && k - seen >= D) { TRY(read_one()); tl.push_back(last[2]); }
+    }
+    while (seen < k) { TRY(read_one()); tl.push_back(last[2]); }
+    HIP_TRY(hipStreamWaitEvent(sa, evAdv[(k + R - 1) % R], 0));          // the handle's stream continues after the last tick step
+    h->async_trials = k;
+    h->last_trials = k;
+    if (last[0] != 0) return fail(SLAM_ERR_STATE, "asynchronous ticks: %d graphs unfinished after %d rounds of launches", last[0], k);
+    return SLAM_OK;
+}
+}  // namespace
+
 // solve_graph_every_iteration with the simulator on the device: T x { get_cmd + NaiveFilter + graph append (one tick of pgs_run_sim),
 // pgs_solve, pgs_adopt_result }.  SLAM_PGS_ITER_PROF=1: the host clock per phase with a stream synchronisation after each (phase table only).
 int pgs_run_sim_every_iteration(pgs_handle* h, const float* cmds, int T, int32_t* counts) {
@@ -652,6 +751,23 @@ int pgs_run_sim_every_iteration(pgs_handle* h, const float* cmds, int T, int32_t
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     for (int k = 0; k < 4; ++k) h->iter_ms[k] = 0.0;
     h->iter_trials = 0;
+    // asynchronous ticks need the segmented elimination (its plan is checked on the device) and its separators within the staging of
+    // pgs_sep_kernel for the whole run; per-kernel profiling and the phase table want the lockstep loop
+    if (h->iter_async && !prof && !h->profiling && h->seg_len > 0 && (h->timestep + T - 1) / h->seg_len <= slam::kPgsSegMaxSep && h->use_list) {
+        TRY(run_every_iteration_async(h, T));
+        h->iter_trials = h->async_trials;
+        h->timestep += T;
+        h->p.N = h->timestep + 1;
+        if (counts) HIP_TRY(hipMemcpyAsync(counts, h->d_tick, sizeof(int32_t) * 2 * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::vector<int32_t> fl((size_t)h->B);
+        HIP_TRY(hipMemcpy(fl.data(), h->p.flags, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost));
+        int nlim = 0;
+        for (int32_t f : fl) nlim += (f & slam::PGS_FLAG_SEG_LIMIT) ? 1 : 0;
+        if (nlim) return fail(SLAM_ERR_UNSUPPORTED, "%d graphs have a segment that sees more than %d landmarks (PGS_FLAG_SEG_LIMIT): they stopped at their last "
+                              "adopted result; re-run with SLAM_PGS_ITER_ASYNC=0 (the lockstep tick loop falls back to the sequential chain)", nlim, slam::kPgsSegMaxLm);
+        return SLAM_OK;
+    }
     for (int t = 0; t < T; ++t) {
         double t0 = prof ? now_ms() : 0.0;
         h->p.N = h->timestep + 1;

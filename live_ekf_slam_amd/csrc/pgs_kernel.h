@@ -7,7 +7,8 @@
 
 namespace slam {
 
-enum { PGS_FLAG_POSE_CAP = 1, PGS_FLAG_LM_CAP = 2, PGS_FLAG_MEAS_CAP = 4, PGS_FLAG_NOT_CONVERGED = 8, PGS_FLAG_NONFINITE = 16 };
+enum { PGS_FLAG_POSE_CAP = 1, PGS_FLAG_LM_CAP = 2, PGS_FLAG_MEAS_CAP = 4, PGS_FLAG_NOT_CONVERGED = 8, PGS_FLAG_NONFINITE = 16,
+       PGS_FLAG_SEG_LIMIT = 32 /* asynchronous ticks: a segment of the graph sees more landmarks than the segmented elimination holds */ };
 static constexpr int kPgsFirstBit = 1 << 30;   // mlm: this factor is the first detection of its landmark
 
 // One workgroup per instance in every kernel; instance b owns slab b of every array (strides in elements).
@@ -65,7 +66,8 @@ struct PgsParams {
     double* S;                         // [B][LD*LD]
     double* dl; double* dp;            // [B][L_max*2], [B][N_max*3]
     double* lambda; double* error; double* cur_error; double* err_init;
-    int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done, 2 = waiting for a running slot (streaming)
+    int32_t* iters; int32_t* trials; int32_t* state; int32_t* solve_ok;   // state: 0 = active, 1 = done, 2 = waiting for a running slot (streaming);
+                                       // asynchronous ticks: 3 = solve converged, 5 = first tick (nothing to adopt), 6 = tick appended, 4 = next solve prepared
     int32_t* n_active;                 // [4] per solve group: active instances after the trial, lanes the next trial needs, active SLOTS,
                                        //     (streaming) workgroups of the decide kernel that finished; [4]: copy of the wait cursor for the host
     // The slots that run in the next trial, compacted by pgs_decide_kernel (order = arrival order of its atomics; the mapping of
@@ -125,6 +127,17 @@ struct PgsParams {
                                        // sides ([nseg][6]: left 3, right 3, local columns) and the separators' rows of Y ([NS][3], global columns) live
     // the tile SYRK over an arbitrary block of Y rows: row offset, rows (-1: 3 N), per-landmark first non-zero row / 3 (NULL: lm_first)
     int64_t syrk_row0; int32_t syrk_rows; const int32_t* syrk_first;
+    // ---- asynchronous ticks (round 6): solve_graph_every_iteration without a batch-wide barrier per tick ----
+    // Graph b is at its OWN tick: Nv[b] poses.  When its solve converges pgs_decide_kernel parks it (state 3); pgs_tick_kernel - on a
+    // second stream, beside the next trial of the others - stores the result, adopts it, runs the graph's next simulator tick and appends
+    // it; pgs_seg_plan_kernel and pgs_lm_begin_kernel (same stream, only for graphs in state 6) prepare the next solve (state 4), and the
+    // next decide kernel lists the graph again.  A graph is finished (state 1) at timestep T_end.  Kernels take a graph's pose count from
+    // pgs_N(p, slot); p.N is then only the launch's upper bound (grid sizes, block-index decomposition, dynamic LDS).
+    int32_t* Nv;                       // NULL: every graph has N poses (lockstep).  Else [slots + 1]
+    int32_t async_ticks, T_end;        // T_end: the timestep at which a graph is finished
+    int32_t split_decide;              // trial kernel 5 ends before pgs_decide_kernel (launched on its own as kernel 6)
+    int32_t max_trials;                // async: lambda trials after which a graph's solve is cut off (NOT_CONVERGED); lockstep: the host's cap
+    int32_t* mono;                     // [2] never reset during a run: most factors of a graph, most poses of a graph (the host sizes grids from them)
     int32_t* tick_acc;                 // optional [B][2]: pgs_adopt_kernel adds the solve's LM iterations / lambda trials (solve_graph_every_iteration: sums over the ticks)
     double* tick_flop;                 // optional [B][2]: ... and the algorithmic FLOP of its trials: Schur-complement SYRK (inst_flop) | dense Cholesky + substitutions (n^3/3 + 2 n^2, n = 2 M)
     unsigned long long* prof;          // optional [B][8] phase timers of the chol kernel (100 MHz wall clock), debug only
@@ -152,8 +165,11 @@ hipError_t pgs_launch_seg_plan(const PgsParams& p, hipStream_t s);
 static constexpr int kPgsSegMaxLen = 32;      // poses a segment holds at most (seg_len <= this)
 static constexpr int kPgsSegMaxLm = 63;       // landmarks a segment's column set may hold for the segmented path (2 * 63 + 1 = 127 columns)
 static constexpr int kPgsSegMaxSep = 128;     // separators the separator kernel stages in LDS
-// one tryLambda for every active instance = kernels 0..5 in order: linearize, chain, syrk, chol, backsolve, evaluate
+// one tryLambda for every active instance = kernels 0..5 in order: linearize, chain, syrk, chol, backsolve, evaluate (+ decide; with
+// p.split_decide the decide kernel is launch 6 of its own)
 static constexpr int kPgsTrialKernels = 6;
+// asynchronous ticks: store + adopt the converged graphs' results, their next simulator tick + append, plan and begin of the next solve
+hipError_t pgs_launch_tick(const PgsParams& p, hipStream_t s);
 hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s);
 hipError_t pgs_launch_lm_end(const PgsParams& p, hipStream_t s);     // result = current values, flags
 hipError_t pgs_launch_adopt(const PgsParams& p, hipStream_t s);      // initial_estimate = result

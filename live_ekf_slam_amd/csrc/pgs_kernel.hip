@@ -139,10 +139,10 @@ __device__ __forceinline__ double pose_cost(const PgsParams& p, const Inst& g, c
 }
 
 template <int TPB>
-__device__ __forceinline__ double block_cost(const PgsParams& p, int b, const double* pose, const double* lm, double* s_buf) {
+__device__ __forceinline__ double block_cost(const PgsParams& p, int b, int N, const double* pose, const double* lm, double* s_buf) {
     const Inst g = inst_view(p, b);
     double acc = 0.0;
-    for (int i = threadIdx.x; i < p.N; i += TPB) acc = acc + pose_cost(p, g, pose, lm, i, p.N);
+    for (int i = threadIdx.x; i < N; i += TPB) acc = acc + pose_cost(p, g, pose, lm, i, N);
     return block_sum<TPB>(acc, s_buf);
 }
 
@@ -269,13 +269,16 @@ __device__ __forceinline__ int pgs_slot(const PgsParams& p, int bl) {
     const int lane = bl / p.b_cnt;
     return lane * p.B + p.b_off + (bl - lane * p.b_cnt);
 }
+// poses of the graph behind slot b: the handle's (lockstep) or the graph's own (asynchronous ticks: lanes are off, slot == instance)
+__device__ __forceinline__ int pgs_N(const PgsParams& p, int b) { return p.Nv ? p.Nv[b] : p.N; }
 // slots a trial-kernel launch covers
 __host__ __device__ __forceinline__ int pgs_nslot(const PgsParams& p) { return p.use_list ? p.n_list : p.b_cnt * (p.lanes > 0 ? p.lanes : 1); }
 
 __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
-    const int N = p.N, M = p.M[b];
+    if (p.async_ticks && p.state[b] != 6) return;   // asynchronous ticks: only the graphs whose next tick was just appended
+    const int N = pgs_N(p, b), M = p.M[b];
     double* pw = p.pw + (size_t)b * p.N_max * 3;
     double* lw = p.lw + (size_t)b * p.L_max * 2;
     const double* p0 = p.pose0 + (size_t)b * p.N_max * 3;
@@ -368,15 +371,18 @@ __global__ __launch_bounds__(TPB) void pgs_lm_begin_kernel(const PgsParams p) {
         f = block_sum<TPB>(f, s_buf);
         if (tid == 0) p.inst_flop[b] = f + extra;
     }
-    const double err = block_cost<TPB>(p, b, pw, lw, s_buf);
+    const double err = block_cost<TPB>(p, b, N, pw, lw, s_buf);
     if (tid == 0) {
         p.error[b] = err; p.err_init[b] = err; p.cur_error[b] = err;
         p.lambda[b] = 1e-5;                    // LevenbergMarquardtParams::lambdaInitial
         p.iters[b] = 0; p.trials[b] = 0; p.solve_ok[b] = 1; p.nl[b] = 1;
         // first trial: every instance of the group, one lane - or, streaming, the first slots_cap of them; the others wait
         const bool runs = p.slots_cap <= 0 || (int)blockIdx.x < p.slots_cap;
-        p.state[b] = runs ? 0 : 2;
-        if (runs) p.alist[blockIdx.x] = b;
+        if (p.async_ticks) p.state[b] = 4;         // the next decide kernel lists it
+        else {
+            p.state[b] = runs ? 0 : 2;
+            if (runs) p.alist[blockIdx.x] = b;
+        }
         for (int j = 0; j < p.lanes_max; ++j) p.lin_ok[(size_t)j * p.B + b] = 0;   // (the clones copy nothing of this: plain per-slot state)
         p.flags[b] &= ~(PGS_FLAG_NOT_CONVERGED | PGS_FLAG_NONFINITE);
     }
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(LF_TPB) void pgs_lin_factor_kernel(const PgsParams 
 __global__ __launch_bounds__(TPB) void pgs_linearize_kernel(const PgsParams p) {
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
-    const int N = p.N, KP = p.KP, M = p.M[b];
+    const int N = pgs_N(p, b), KP = p.KP, M = p.M[b];
     if (p.seg_on && tid == 0) p.solve_ok[b] = 1;   // segmented elimination: a failing segment / separator clears it (the sequential chain kernel sets it itself)
     if (p.lin_ok[b]) return;                       // the previous trial of this slot failed: same values, same linearisation
     const Inst g = inst_view(p, b);
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(1024) void pgs_chain_kernel(const PgsParams p) {
     __shared__ int s_fail;
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
-    const int N = p.N, LD = p.LD, m2 = 2 * p.M[b];
+    const int N = pgs_N(p, b), LD = p.LD, m2 = 2 * p.M[b];
     const double lambda = p.lambda[b];
     const double* Ab = p.A + (size_t)b * p.N_max * 9;
     const double* Cb = p.C + (size_t)b * p.N_max * 9;
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
     const int rowbase = ti * SY_T + wr * WT, colbase = tj * SY_T + wc * WT;
     if (rowbase > m2 || colbase > m2) return;
     // (segmented elimination: the block of Y rows is the separators' - syrk_row0 / syrk_rows / syrk_first, pgs_kernel.h)
-    const int K3 = p.syrk_rows >= 0 ? p.syrk_rows : 3 * p.N;
+    const int K3 = p.syrk_rows >= 0 ? (p.Nv ? 3 * seg_ns(pgs_N(p, b), p.seg_len) : p.syrk_rows) : 3 * pgs_N(p, b);
     int k0 = 0;
     // Y[k][c] == 0 before the first detection of column c's landmark, and landmarks are numbered in order of first
     // detection: this wavefront's 64 rows are all zero before pose lm_first[rowbase / 2] (unless it holds the z row)
@@ -824,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void pgs_syrk_kernel(const PgsParams p) {
             // segment touches this wavefront's 32 x 32 tile only if it sees a landmark of the tile's row block AND one of its column block
             // (seg_blk: the local ranges of the 16-landmark blocks): a handful of the segments for a tile near the diagonal, none far from
             // it; the right-hand-side row (the gradient column of every segment) meets them all.
-            const int nb1 = seg_nb1(p.L_max), nseg = seg_ns(p.N, p.seg_len) + 1;
+            const int nb1 = seg_nb1(p.L_max), nseg = seg_ns(pgs_N(p, b), p.seg_len) + 1;
             const int32_t* blk = p.seg_blk + (size_t)b * p.nseg_max * nb1;
             const int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * p.L_max;
             const int32_t* ncolb = p.seg_ncol + (size_t)b * p.nseg_max;
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(SI_TPB) void pgs_syrk_inst_kernel(const PgsParams p
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int kq = lane >> 4, cl = lane & 15;
     const int gw = w * SI_NB + hb;                // wavefront number within the instance
-    const int K3 = 3 * p.N;
+    const int K3 = 3 * pgs_N(p, b);
     const int nchunk = (K3 + SI_ROWS - 1) / SI_ROWS;
     const double* Yb = p.Y + (size_t)b * p.y_stride;
 
@@ -1161,7 +1167,7 @@ __global__ __launch_bounds__(FC_TPB) void pgs_chain_syrk_kernel(const PgsParams 
         if (p.prof && tid == 0) p.prof[(size_t)p.B * p.lanes_max * 8 + (size_t)b * 16 + 8 * hb + 1] = 0;   // debug: no stamp from this launch
         return;
     }
-    const int N = p.N, LD = p.LD, m2 = 2 * p.M[b];
+    const int N = pgs_N(p, b), LD = p.LD, m2 = 2 * p.M[b];
     const int nch = (N + FC_P - 1) / FC_P;
     const int ncol = (m2 + 1 + 31) & ~31, ldl = ncol + 16;
     if (tid == 0) s_fail = 0;
@@ -2067,7 +2073,7 @@ constexpr int BTPB = 256;
 __global__ __launch_bounds__(BTPB) void pgs_backsolve_kernel(const PgsParams p) {
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
-    const int N = p.N, KP = p.KP;
+    const int N = pgs_N(p, b), KP = p.KP;
     const Inst g = inst_view(p, b);
     const double* gpb = p.gp + (size_t)b * p.N_max * 3;
     const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
@@ -2177,7 +2183,7 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
     __shared__ double s_buf[TPB];
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b]) return;
-    const int N = p.N, KP = p.KP, M = p.M[b];
+    const int N = pgs_N(p, b), KP = p.KP, M = p.M[b];
     const Inst g = inst_view(p, b);
     double* pose = p.pw + (size_t)b * p.N_max * 3;
     double* lm = p.lw + (size_t)b * p.L_max * 2;
@@ -2263,8 +2269,22 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
     __shared__ int s_win, s_next;
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
     const bool running = p.state[b] == 0;
+    if (p.async_ticks) {
+        // asynchronous ticks: a graph whose next solve is prepared (state 4: pgs_lm_begin_kernel on the tick stream, complete before this
+        // launch) joins the next trial's list; the counters the host sizes the coming grids from ride along
+        if (tid == 0) {
+            if (blockIdx.x == 0) { p.n_active[5] = p.mono[0]; p.n_active[6] = p.mono[1]; }
+            const int stt = p.state[b];
+            if (stt == 4) {
+                p.state[b] = 0;
+                atomicAdd(p.n_active, 1); atomicMax(p.n_active + 1, 1);
+                p.alist[atomicAdd(p.n_active + 2, 1)] = b;
+            } else if (stt == 3 || stt == 5 || stt == 6) atomicAdd(p.n_active, 1);   // between two solves: still counts as unfinished
+        }
+        if (!running) return;
+    }
     if (!running && p.slots_cap <= 0) return;
-    const int N = p.N, M = p.M[b], B = p.B;
+    const int N = pgs_N(p, b), M = p.M[b], B = p.B;
     if (running) {
     if (tid == 0) {
         const double lambdaFactor = 10.0, lambdaUpper = 1e5, minFidelity = 1e-3, relTol = 1e-5, absTol = 1e-5;
@@ -2306,6 +2326,7 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
             else if (error <= 0.0 || relDec <= relTol || absDec <= absTol) done = 1;
             else p.cur_error[b] = error;
         }
+        if (p.async_ticks && !done && trials >= p.max_trials) { done = 1; fl = PGS_FLAG_NOT_CONVERGED; }   // (lockstep: the host's trial cap + pgs_lm_end_kernel)
         atomicAdd(p.work + (p.seg_on ? 2 : (p.fused ? 1 : 0)), (double)(trials - p.trials[b]) * p.inst_flop[b]);   // reporting only
         p.lambda[b] = lambda; p.error[b] = error; p.iters[b] = iters; p.trials[b] = trials;
         // the next trial runs the next `lanes_next` lambdas of the sequence GTSAM would walk if every one of them failed:
@@ -2323,7 +2344,11 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
         }
         for (int j = 1; j < p.lanes_max; ++j) p.state[j * B + b] = (!done && j < nnext) ? 0 : 1;
         p.nl[b] = nnext;
-        if (done) { p.state[b] = 1; p.flags[b] |= fl; }
+        if (done) {
+            p.flags[b] |= fl;
+            if (p.async_ticks) { p.state[b] = 3; atomicAdd(p.n_active, 1); }   // parked until pgs_tick_kernel has advanced it (or finished it)
+            else p.state[b] = 1;
+        }
         else {
             atomicAdd(p.n_active, 1); atomicMax(p.n_active + 1, nnext);
             const int at = atomicAdd(p.n_active + 2, nnext);
@@ -2380,7 +2405,7 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
 // result <- current values (also for instances cut off by the trial cap)
 __global__ __launch_bounds__(TPB) void pgs_lm_end_kernel(const PgsParams p) {
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
-    const int N = p.N, M = p.M[b];
+    const int N = pgs_N(p, b), M = p.M[b];
     const double* pw = p.pw + (size_t)b * p.N_max * 3;
     const double* lw = p.lw + (size_t)b * p.L_max * 2;
     double* p1 = p.pose1 + (size_t)b * p.N_max * 3;
@@ -2392,7 +2417,7 @@ __global__ __launch_bounds__(TPB) void pgs_lm_end_kernel(const PgsParams p) {
 
 __global__ __launch_bounds__(TPB) void pgs_adopt_kernel(const PgsParams p) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int N = p.N, M = p.M[b];
+    const int N = pgs_N(p, b), M = p.M[b];
     double* p0 = p.pose0 + (size_t)b * p.N_max * 3;
     double* l0 = p.lm0 + (size_t)b * p.L_max * 2;
     const double* p1 = p.pose1 + (size_t)b * p.N_max * 3;
@@ -2407,12 +2432,69 @@ __global__ __launch_bounds__(TPB) void pgs_adopt_kernel(const PgsParams p) {
     }
 }
 
+// Asynchronous ticks: the step between two solves of ONE graph (pose_graph.cpp:258-264, then the next timer tick's :216-256).  result <-
+// current values (pgs_lm_end_kernel), initial_estimate <- result (pgs_adopt_kernel), the sums over the ticks; then - unless the graph has
+// reached T_end - the graph's next simulator tick, NaiveFilter::update and the append (pgs_run_sim_kernel's body for one timestep, with the
+// graph's own timestep as the noise stream's step index).  State 3 (solve converged) / 5 (first tick: nothing to adopt) -> 6, or 1 = finished.
+__global__ __launch_bounds__(256) void pgs_tick_kernel(const PgsParams p) {
+    constexpr int KCAP = 64;
+    __shared__ float s_meas[3 * KCAP];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int st = p.state[b];
+    if (st != 3 && st != 5) return;
+    const int N = p.Nv[b], M = p.M[b];
+    if (st == 3) {
+        const double* pw = p.pw + (size_t)b * p.N_max * 3;
+        const double* lw = p.lw + (size_t)b * p.L_max * 2;
+        double* p0 = p.pose0 + (size_t)b * p.N_max * 3;
+        double* l0 = p.lm0 + (size_t)b * p.L_max * 2;
+        double* p1 = p.pose1 + (size_t)b * p.N_max * 3;
+        double* l1 = p.lm1 + (size_t)b * p.L_max * 2;
+        for (int i = tid; i < 3 * N; i += 256) { const double v = pw[i]; p1[i] = v; p0[i] = v; }
+        for (int i = tid; i < 2 * M; i += 256) { const double v = lw[i]; l1[i] = v; l0[i] = v; }
+        if (tid == 0 && p.tick_acc) { p.tick_acc[2 * b] += p.iters[b]; p.tick_acc[2 * b + 1] += p.trials[b]; }
+        if (tid == 0 && p.tick_flop) {
+            const double n = 2.0 * M, tr = (double)p.trials[b];
+            p.tick_flop[2 * b] += tr * p.inst_flop[b];
+            p.tick_flop[2 * b + 1] += tr * (n * n * n / 3.0 + 2.0 * n * n);
+        }
+    }
+    const int i = N - 1, t1 = N;   // the graph's timestep, the pose the tick adds
+    if (i >= p.T_end || t1 >= p.N_max) {
+        if (tid == 0) { p.state[b] = 1; if (i < p.T_end) p.flags[b] |= PGS_FLAG_POSE_CAP; }
+        return;
+    }
+    if (tid >= 64) return;
+    const int lane = tid;
+    double tx = p.truth[3 * b], ty = p.truth[3 * b + 1], tth = p.truth[3 * b + 2];
+    double lmx = 0.0, lmy = 0.0;
+    if (lane < p.L) { lmx = p.map[2 * lane]; lmy = p.map[2 * lane + 1]; }
+    const float fwd = p.cmds[2 * i], ang = p.cmds[2 * i + 1];
+    int k = sim_wave<KCAP>(p, b, lane, fwd, ang, (uint32_t)i, tx, ty, tth, lmx, lmy, s_meas);
+    if (k > KCAP) { k = KCAP; if (lane == 0) p.flags[b] |= PGS_FLAG_MEAS_CAP; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane == 0) {
+        double s, c;
+        const double th = p.cur[3 * b + 2];
+        det_sincos(th, &s, &c);
+        p.cur[3 * b] = p.cur[3 * b] + (double)fwd * c;
+        p.cur[3 * b + 1] = p.cur[3 * b + 1] + (double)fwd * s;
+        p.cur[3 * b + 2] = remainder(th + (double)ang, kTwoPi);
+        double* th_hist = p.truth_hist + ((size_t)b * p.N_max + (t1 - 1)) * 2;
+        th_hist[0] = tx; th_hist[1] = ty;
+        append_step(p, b, t1, s_meas, k);
+        p.Nv[b] = N + 1;
+        atomicMax(p.mono + 1, N + 1);
+        p.state[b] = 6;
+    }
+}
+
 // compute_average_error as the pose-graph plot calls it (plotting_node.py:203-213,432-434): pose i of the message
 // (i < timestep, float32 on the wire) against true_poses[i] = the true pose after step i+1.
 __global__ __launch_bounds__(TPB) void pgs_avg_error_kernel(const PgsParams p, int which, double* out) {
     __shared__ double s_buf[TPB];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int ts = p.N - 1;
+    const int ts = pgs_N(p, b) - 1;
     const double* pose = (which ? p.pose1 : p.pose0) + (size_t)b * p.N_max * 3;
     const double* th = p.truth_hist + (size_t)b * p.N_max * 2;
     double acc = 0.0;
@@ -2455,6 +2537,10 @@ hipError_t pgs_launch_lm_begin(const PgsParams& p, hipStream_t s) {
 
 hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s) {
     const int nslot = pgs_nslot(p);   // slots covered: the instances of the group and their active lambda lanes, or the compacted list
+    if (which == 6) {   // the decide kernel alone (split_decide): one workgroup per graph of the group, whatever the list holds
+        hipLaunchKernelGGL(pgs_decide_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
+        return hipGetLastError();
+    }
     if (nslot <= 0) return hipSuccess;
     switch (which) {
     case 0:
@@ -2535,9 +2621,16 @@ hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s)
     default:   // the candidates of every slot, then GTSAM's accept / lambda / convergence logic per instance
         if (p.nfact_max > 0) hipLaunchKernelGGL(pgs_eval_factor_kernel, dim3(nslot * ((p.nfact_max + LF_TPB - 1) / LF_TPB)), dim3(LF_TPB), 0, s, p);
         hipLaunchKernelGGL(pgs_evaluate_kernel, dim3(nslot), dim3(TPB), 0, s, p);
-        hipLaunchKernelGGL(pgs_decide_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
+        if (!p.split_decide) hipLaunchKernelGGL(pgs_decide_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
         break;
     }
+    return hipGetLastError();
+}
+
+hipError_t pgs_launch_tick(const PgsParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(pgs_tick_kernel, dim3(p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pgs_seg_plan_kernel, dim3(p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pgs_lm_begin_kernel, dim3(p.B), dim3(TPB), 0, s, p);
     return hipGetLastError();
 }
 

