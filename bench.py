@@ -107,10 +107,12 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=10.0
         sync_all()
         wall = time.perf_counter() - t0
     if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall], dtype=torch.float64, device=args.coll_device if args.coll_device is not None else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     M = f.landmark_counts(); n = 4 + 2 * int(round(M.mean()))
+    from live_ekf_slam_amd.parallel import gather_error_stats
+    allerr = gather_error_stats(f.error_stats(), dist if world > 1 else None, args.coll_device)   # the one collective: after timing (RCCL)
     parity = None
     if not args.no_parity_check:
         # the oracle on two instances over the whole trajectory up to the end of the timed window (untimed, after it)
@@ -140,7 +142,8 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=10.0
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"UKF-SLAM fused sim+update step, L={L} (n={n}, {2 * n + 1} sigma points), batch={B}, steady state",
                        "mean_detections_per_step": round(k_mean, 3), "mean_jacobi_sweeps": round(sweeps_mean, 3),
-                       "instances_flagged": int((f.status() != 0).sum()), "avg_position_error_m": round(float(f.error_stats().mean()), 5),
+                       "instances_flagged": int((f.status() != 0).sum()), "avg_position_error_m": round(float(allerr.mean()), 5),
+                       "instances_global": int(allerr.size), "first_instance_of_rank0": int(rank * B),
                        "parity_check": parity,
                        "parity": "bit-exact vs the CPU oracle (tests/test_parity_ukf_gpu.py); the oracle's eigen-decomposition is pinned to LAPACK at 1e-12 and to a numpy transliteration of ukf.cpp, not to the reference binary (Eigen/ROS absent)"},
             "roofline": {"bound": "fp64-valu", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
@@ -205,11 +208,13 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
         pg.set_profiling(False)
         sync_all()
     if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall], dtype=torch.float64, device=args.coll_device if args.coll_device is not None else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     st = pg.stats()
     e0, e1 = pg.error_stats(0), pg.error_stats(1)
+    from live_ekf_slam_amd.parallel import gather_error_stats
+    e1_all = gather_error_stats(e1, dist if world > 1 else None, args.coll_device)   # the one collective: after timing (RCCL)
     parity = None
     if not args.no_parity_check:
         # the oracle builds and solves the graphs of two instances (same simulator draws: global instance ids)
@@ -271,7 +276,8 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
                            "batch_per_gpu": B, "poses": N, "landmarks": L, "lm_trials_launched_per_solve": trials_launched / K,
                            "lm_iterations_mean": float(st["iterations"].mean()), "lm_trials_mean": float(st["trials"].mean()),
                            "instances_flagged": int((st["flags"] != 0).sum()),
-                           "avg_position_error_m": {"initial": round(float(e0.mean()), 4), "result": round(float(e1.mean()), 4)},
+                           "avg_position_error_m": {"initial": round(float(e0.mean()), 4), "result": round(float(e1_all.mean()), 4)},
+                           "instances_global": int(e1_all.size),
                            "parity_check": parity,
                            "parity": "identical LM iteration / trial counts and max(1e-7 m, 10 x the instance's rounding spread among the oracle's own elimination orders) vs the CPU oracle (tests/test_parity_pgs_gpu.py)",
                            "elimination": ("segmented: %d poses per segment, interiors side by side, then the separators (pgs_seg_impl.h)" % paths["segment_length"]) if paths.get("segmented") else "sequential chain (rounds 1-4)",
@@ -335,7 +341,7 @@ def bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s
         wall = time.perf_counter() - t0
         dev_s = ev0.elapsed_time(ev1) * 1e-3
     if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall], dtype=torch.float64, device=args.coll_device if args.coll_device is not None else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     if getattr(args, "event_value", False):
@@ -344,7 +350,8 @@ def bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s
     if os.environ.get("SLAM_PGS_ITER_PROF"):
         print(f"# every-iteration phases (host clock, a stream sync after each): {ph}", file=sys.stderr)
     st = pg.stats()
-    e1 = pg.error_stats(1)
+    from live_ekf_slam_amd.parallel import gather_error_stats
+    e1 = gather_error_stats(pg.error_stats(1), dist if world > 1 else None, args.coll_device)   # the one collective: after timing (RCCL)
     parity = None
     if not args.no_parity_check:
         from oracle import oracle as O
@@ -377,6 +384,7 @@ def bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s
                            "lm_iterations_per_tick": round(float(counts[:, 0].mean()) / T, 3), "lm_trials_per_tick": round(float(counts[:, 1].mean()) / T, 3),
                            "lm_trials_launched_per_tick": round(ph["trials_launched"] / T, 3),
                            "instances_flagged": int((st["flags"] != 0).sum()), "avg_position_error_m": round(float(e1.mean()), 4),
+                           "instances_global": int(e1.size),
                            "parity_check": parity,
                            "parity": "the one-shot solve's bar (tests/test_parity_pgs_gpu.py) at every tick: test_solve_every_iteration_*"},
                 "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": 78.6, "unit": "TFLOP/s", "frac": round(tf / 78.6, 5), "traffic": None,

@@ -84,6 +84,31 @@ def test_two_ranks_short_window_keeps_the_k_step_definition():
     assert d["config"]["state_rmse_vs_oracle"] == 0.0
 
 
+@pytest.mark.parametrize("flt,extra,metric", [
+    ("ukf", ["--landmarks", "20", "--batch", "256", "--steps", "6", "--warmup", "2", "--preroll", "10"], "UKF"),
+    ("pgs", ["--landmarks", "20", "--poses", "120", "--batch", "24", "--k-per-pose", "8", "--steps", "1", "--warmup", "1"], "pose-graph SLAM solves"),
+    ("pgs", ["--iterative", "--landmarks", "20", "--poses", "60", "--batch", "12", "--k-per-pose", "8", "--warmup", "3"], "graph-ticks")])
+def test_two_ranks_of_the_secondary_filters_on_one_gpu(flt, extra, metric):
+    """`--filter ukf | pgs` under torch.distributed - weak scaling (per-GPU batch), rank r owns the global
+    instances [r B, (r + 1) B) (slam / pgs_set_instance_offset), barrier-bracketed timing, the end-of-run gather of the error statistics;
+    the in-run oracle check of rank 0's first and last instance is part of the line (global ids)."""
+    env = dict(os.environ, BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--filter", flt, "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    d = _last_json(out.stdout)
+    B = int(extra[extra.index("--batch") + 1])
+    assert d["n_gpus"] == 2 and metric in d["metric"] and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["instances_global"] == 2 * B and d["config"]["instances_flagged"] == 0
+    pc = d["config"]["parity_check"]
+    assert pc["mismatch"] is None
+    if flt == "ukf":
+        assert pc["max_abs_diff"] == 0.0
+    else:
+        assert pc["lm_iteration_and_trial_counts_equal"] and pc["max_abs_diff_m"] < 1e-7
+
+
 def test_two_ranks_over_rccl_on_one_gpu_or_the_reason_why_not():
     """the RCCL branch of bench.py (init_process_group("nccl"), the barrier-bracketed timing, the end-of-run
     all-gather / all-reduce of the error statistics) has only ever run with one rank.  Two ranks on GPU 0 over the nccl backend

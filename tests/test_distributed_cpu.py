@@ -102,3 +102,38 @@ def test_two_rank_weak_scaling_covers_disjoint_global_instances():
     ref = O.run_ekf_batch(lm, cmds, 2 * B, 20, seed=9, inst0=0, nthreads=2, want_P=False)
     assert total == 2 * B and summ[2] == 2 * B
     assert np.array_equal(allerr, ref["avg_err"])
+
+
+def test_strong_scaling_plan_at_eight_gpus_of_the_baseline_batch():
+    """BASELINE configs[3]: 65 536 instances over 8 GPUs.  The plan ShardedRun makes for every rank gives eight contiguous 8 192-shards;
+    an engine that runs a shard with that plan's first global instance produces, at both ends of every shard, exactly the errors of those
+    GLOBAL instances in a single-process run (the noise streams are keyed by global id) - checked with the oracle on the two first and two
+    last instances of each shard (the full 65 536 x 120 steps would be minutes of CPU)."""
+    from live_ekf_slam_amd.parallel import ShardedRun
+    from oracle import oracle as O
+
+    class FakeDist:   # what ShardedRun reads of torch.distributed
+        def __init__(self, rank, world): self.rank, self.world = rank, world
+        def is_initialized(self): return True
+        def get_world_size(self): return self.world
+        def get_rank(self): return self.rank
+
+    B, G = 65536, 8
+    lm, cmds = make_scenario(1234, 20, 120)
+    ends = []
+    for r in range(G):
+        first, n, total = ShardedRun(FakeDist(r, G)).plan(B, "strong")
+        assert (first, n, total) == (r * 8192, 8192, B)
+        for lo in (first, first + n - 2):          # the two first and the two last instances of the shard, run AS a shard at that offset
+            eng = OracleEngine(lm, 20, lo, 2, seed=9)
+            eng.run_sim(cmds)
+            ends.append((lo, eng.error_stats()))
+    # single process: the same global instances from ONE run whose first instance is 0 (ids 0, 1) or any other offset
+    for lo, err in ends:
+        ref = O.run_ekf_batch(lm, cmds, 4, 20, seed=9, inst0=lo - 1 if lo > 0 else 0, nthreads=1, want_P=False)["avg_err"]
+        sel = ref[1:3] if lo > 0 else ref[0:2]
+        assert np.array_equal(err, sel), lo
+    assert len({lo for lo, _ in ends}) == 2 * G and np.unique(np.concatenate([e for _, e in ends])).size == 4 * G   # distinct streams
+    # weak scaling at N = 8: 65 536 per rank, disjoint ranges
+    for r in range(G):
+        assert ShardedRun(FakeDist(r, G)).plan(B, "weak") == (r * B, B, G * B)
