@@ -96,10 +96,10 @@ def bench_ukf(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=10.0
 
     with torch.cuda.stream(stream):
         f.set_vision(1e9, -4.0, 4.0); f.update_sim(cmds[0]); f.set_vision(3.0, -1.57, 1.57)
-        f.run_sim(cmds[1:1 + PRE + W])
-        sync_all()
-        f.k_histogram(reset=True); f.sweep_stats(reset=True)   # workload counters of the timed window only
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f.run_sim(cmds[1:1 + PRE + W])
+        f.reset_counters_async()                                # workload counters of the timed window only, zeroed in stream order:
+        sync_all()                                              # nothing but the barrier between the warm-up and the timed steps
         t0 = time.perf_counter()
         ev0.record(stream)
         f.run_sim(cmds[1 + PRE + W:])
@@ -642,12 +642,17 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
         f.set_vision(*vis[0]); f.update_sim(cmds[0]); f.set_vision(*vis[1])   # step 0: every instance maps all L landmarks
         f.run_sim(cmds[1:T0 - W])                    # pre-roll to the window (untimed)
         f.set_run_chunk(spl)                         # timesteps per launch of the timed entry point (default: all K in one)
-        f.run_sim(cmds[T0 - W:T0])                   # W untimed warm-up steps through the timed entry point
+        # Everything the host asks of the device about the window's start is asked BEFORE the warm-up (every landmark is mapped since step
+        # 0: the state size does not change any more), and the counters are zeroed in stream order behind it: between the warm-up steps and
+        # the timed region there is nothing but the contract's barrier + synchronize.  An idle device before the timed launch costs a 20-step
+        # launch 9 % (profiles/r06a/launch_edges.txt: 18.3 ms right behind a launch, 20.1 ms after 50 ms of idling; rounds 3-5 ran four
+        # synchronous queries and resets in that gap).
         f.sync()
         alg_bytes = f.algorithmic_bytes()           # sum_b 2(n_b^2+n_b)*s at the start of the timed window
         M = f.landmark_counts()
-        f.k_histogram(reset=True); f.traffic_counters(reset=True)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f.run_sim(cmds[T0 - W:T0])                   # W untimed warm-up steps through the timed entry point
+        f.reset_counters_async()                     # detection-count histogram, traffic counters: the timed launches only
 
         def timed_region():
             ev0.record(stream)
@@ -659,6 +664,7 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
         dev_ms = run.max_over_ranks(ev0.elapsed_time(ev1))   # the K timed steps on the device, MAX over ranks (no host / barrier latency in it)
         khist = f.k_histogram().astype(np.int64)
         tc = f.traffic_counters().astype(np.float64)     # counted ON THE DEVICE during the timed launches
+        steady = bool(np.array_equal(M, f.landmark_counts()))   # (alg_bytes / M were read before the warm-up)
         kinfo = f.kernel_info(multi_step=spl > 1 and K > 1)
 
         # ---- after the timed region: parity of the timed trajectory, once-per-step leg, per-k table, long runs ----
@@ -677,7 +683,7 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
             g1.set_vision(*vis[0]); g1.update_sim(cmds[0]); g1.set_vision(*vis[1])
             g1.run_sim(cmds[1:T0])
             g1.set_run_chunk(1)
-            g1.sync(); g1.traffic_counters(reset=True); g1.k_histogram(reset=True)
+            g1.reset_counters_async()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
             def once_region():
@@ -777,7 +783,7 @@ def bench_ekf(args, torch, dist, rank, local_rank, world, dev, compact=False):
                "secondary_digest": None,
                "batch_per_gpu": B, "global_batch": B_global, "landmarks": L, "state_dim": n_state, "min_M": int(M.min()),
                "parallelism": f"instance-sharded x{world} ({args.scaling} scaling), no per-step collective",
-               "window_start": T0, "mean_detections_per_step": round(kbar, 3),
+               "window_start": T0, "mean_detections_per_step": round(kbar, 3), "state_size_constant_over_warmup_and_window": steady,
                "k_histogram": {str(k): int(v) for k, v in enumerate(khist) if v},
                "storage": args.dtype,
                "state_rmse_vs_oracle": None if parity is None else parity["state_rmse_vs_oracle"],

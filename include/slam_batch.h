@@ -262,6 +262,9 @@ int slam_ukf_sweep_stats(slam_handle* h, uint64_t out[2], int reset);
  * start and end), out[2] = passes, out[3] = rank-2 updates those passes applied.  bench.py's roofline.traffic is
  * out[0] + out[1] of the timed launches; profiles/r03* hold the rocprofv3 PMC cross-check.  Synchronises. */
 int slam_traffic_counters(slam_handle* h, uint64_t out[4], int reset);
+/* Zero the counters of slam_k_histogram and slam_traffic_counters in stream order (no host synchronisation): for measurements that
+ * must not leave the device idle between their warm-up and their timed launches (bench.py). */
+int slam_reset_counters_async(slam_handle* h);
 /* The step-kernel instantiation this handle launches (multi_step != 0: the multi-step launch of slam_run_sim / the queues,
  * else the one-step launch): name as rocprofv3 prints it (e.g. "ekf_step_kernel<103,4,4,4,double,1,true>"), and
  * out = {static LDS bytes per workgroup, VGPRs, threads per workgroup, workgroups one CU holds at once, CUs of the device}.

@@ -65,6 +65,7 @@ SIGNATURES = {
     "slam_k_histogram": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
     "slam_ukf_sweep_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
     "slam_traffic_counters": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int]),
+    "slam_reset_counters_async": (C.c_int, [_H]),
     "slam_kernel_info": (C.c_int, [_H, C.c_int, C.c_char_p, C.c_int, _ip]),
     "slam_math_probe": (C.c_int, [_dp, _dp, _dp, C.c_int, C.c_int]),
     # include/slam_pgs.h

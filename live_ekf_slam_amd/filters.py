@@ -239,6 +239,10 @@ class BatchedFilter:
         _lib.check(_lib.lib().slam_ukf_sweep_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(bool(reset))))
         return out
 
+    def reset_counters_async(self):
+        """Zero the detection-count histogram and the traffic counters in stream order (no host synchronisation)."""
+        _lib.check(_lib.lib().slam_reset_counters_async(self.h))
+
     def traffic_counters(self, reset=False):
         """EKF: device-counted (P-stream bytes read + written by passes, other global bytes, passes, updates applied by passes)
         since creation / the last reset (slam_traffic_counters)."""
