@@ -124,6 +124,14 @@ int check(pgs_handle* h) {
     return SLAM_OK;
 }
 
+// the segments' Gram matrices: [slots][nseg_max][seg_tld^2] doubles, only when a solve runs the segmented order (128 x 128 per
+// segment whatever L_max, allocated also for handles whose every solve takes the sequential chain)
+int ensure_segT(pgs_handle* h) {
+    if (h->p.segT || h->seg_len <= 0) return SLAM_OK;
+    const size_t S = (size_t)h->B * h->lanes;
+    return dalloc(h, &h->p.segT, S * (size_t)h->p.nseg_max * (size_t)h->p.seg_tld * h->p.seg_tld);
+}
+
 int ensure_staging(pgs_handle* h, int k_stride) {
     if (h->dmeas && h->k_stride >= k_stride) return SLAM_OK;
     if (h->dmeas) { hipFree(h->dmeas); h->dmeas = nullptr; }
@@ -180,7 +188,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     // clone that pgs_solve fills from the instance; PgsParams::lanes_max).  Arrays only the instance itself uses keep B slots.
     {   // the lanes multiply the LM work space (Y alone is 3 N_max x LD doubles per slot): keep them within half of the free memory
         const double nsegx = h->seg_len > 0 ? (double)((N_max - 2) / h->seg_len + 1) : 0.0;
-        const double per_slot = 8.0 * (((double)round_up(3 * N_max, 4) + 10.0 * nsegx) * h->LD + (double)h->LD * h->LD + (double)K * 29 + (double)N * 51 + (double)L * 12 + nsegx * (48 + 128.0 * 128.0)) +
+        const double per_slot = 8.0 * (((double)round_up(3 * N_max, 4) + 10.0 * nsegx) * h->LD + (double)h->LD * h->LD + (double)K * 29 + (double)N * 51 + (double)L * 12 + nsegx * (48 + (double)round_up(2 * (L_max < slam::kPgsSegMaxLm ? L_max : slam::kPgsSegMaxLm) + 1, 16) * round_up(2 * (L_max < slam::kPgsSegMaxLm ? L_max : slam::kPgsSegMaxLm) + 1, 16))) +
                                 4.0 * ((double)K * 5 + (double)N + (double)L * 6 + nsegx * (4.0 * L + 16));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -218,7 +226,9 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
         const size_t G = (size_t)p.nseg_max;
         AC(&p.seg_ncol, G); AC(&p.seg_lm, G * L); AC(&p.seg_inv, G * L); AC(&p.seg_evt, G * L); AC(&p.sep_first, L);
         AC(&p.seg_blk, G * (size_t)slam::seg_nb1(L_max)); AC(&p.sep_evt, G * L);
-        A(&p.Gs, S * N * 9); A(&p.segout, S * G * 32); A(&p.sepfac, S * G * 16); A(&p.segT, S * G * 128 * 128);
+        A(&p.Gs, S * N * 9); A(&p.segout, S * G * 32); A(&p.sepfac, S * G * 16);
+        // (segT, the segments' Gram matrices - the largest of these arrays - is allocated by the first solve that runs the segmented order: ensure_segT)
+        p.seg_tld = round_up(2 * (L_max < slam::kPgsSegMaxLm ? L_max : slam::kPgsSegMaxLm) + 1, 16);
     }
     A(&p.Y, S * (size_t)p.y_stride); A(&p.S, S * (size_t)h->LD * h->LD);
     A(&p.dl, S * L * 2); A(&p.dp, S * N * 3);
@@ -440,6 +450,7 @@ int pgs_solve(pgs_handle* h) {
             for (int32_t u : U) mx = u > mx ? u : mx;
             h->seg_ok = mx <= slam::kPgsSegMaxLm;
             h->p.seg_on = h->seg_ok ? 1 : 0;
+            if (h->seg_ok) TRY(ensure_segT(h));
         }
     }
     {   // chain + SYRK in one launch (Y stays in LDS) is possible while the lower triangle of every instance fits the 72 wavefront
@@ -671,6 +682,7 @@ int run_every_iteration_async(pgs_handle* h, int T) {
     hipEvent_t* evAdv = &h->async_events[R];
     hipEvent_t evStart = h->async_events[2 * R];
     const int N0 = h->timestep + 1;
+    TRY(ensure_segT(h));
     slam::PgsParams q = h->p;
     q.async_ticks = 1; q.seg_on = 1; q.Nv = h->d_Nv; q.T_end = h->timestep + T; q.split_decide = 1; q.max_trials = h->max_trials;
     q.mono = h->d_mono; q.tick_acc = h->d_tick; q.tick_flop = h->d_tick_flop;

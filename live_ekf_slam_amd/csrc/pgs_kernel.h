@@ -117,7 +117,8 @@ struct PgsParams {
     int32_t* seg_blk;                  // [S][nseg_max * nb1]    local landmarks of the segment below landmark 16 * block (nb1 = seg_nb1(L_max) entries):
                                        //                        the local range of a 32-row block of S_ext without a search
     int32_t* sep_evt;                  // [S][nseg_max * L_max]  separator k, landmark j -> the landmark's first event AT the separator's pose, -1: none
-    double* segT;                      // [S][nseg_max * 128 * 128]  Gram matrix Y_p^T Y_p of the segment's columns (lower 16x16 tiles), leading dimension 128
+    double* segT;                      // [S][nseg_max * seg_tld^2]  Gram matrix Y_p^T Y_p of the segment's columns (lower 16x16 tiles); allocated by the first solve that runs this order
+    int32_t seg_tld;                   // its leading dimension: roundup(2 min(L_max, kPgsSegMaxLm) + 1, 16) <= 128
     int32_t* sep_first;                // [S][L_max]             first separator (0-based) whose row of Y can be non-zero in the landmark's columns
     int32_t* seg_umax;                 // [B]                    largest seg_ncol of the instance (the host picks the path from it)
     double* Gs;                        // [S][N_max * 9]         spike blocks: coupling of interior pose i to its segment's LEFT separator

@@ -544,12 +544,13 @@ __global__ __launch_bounds__(GR_TPB) void pgs_seg_gram_kernel(const PgsParams p)
         }
         __syncthreads();
     }
-    double* Tp = p.segT + ((size_t)b * p.nseg_max + ps) * (128 * 128);
+    const int TLD = p.seg_tld;   // leading dimension of a segment's Gram matrix (>= its columns, a multiple of 16)
+    double* Tp = p.segT + ((size_t)b * p.nseg_max + ps) * ((size_t)TLD * TLD);
 #pragma unroll
     for (int q = 0; q < GR_TW; ++q) {
         if (w + 4 * q >= ntile) break;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) Tp[(size_t)(16 * ti[q] + kq + 4 * r4) * 128 + 16 * tj[q] + cl] = acc[q][r4];   // C/D layout: row = (lane >> 4) + 4 reg
+        for (int r4 = 0; r4 < 4; ++r4) Tp[(size_t)(16 * ti[q] + kq + 4 * r4) * TLD + 16 * tj[q] + cl] = acc[q][r4];   // C/D layout: row = (lane >> 4) + 4 reg
     }
 }
 

@@ -338,6 +338,11 @@ int slam_create(const slam_config* cfg, int kind, int batch, int L_max, int dtyp
     if (batch <= 0 || L_max <= 0) return fail(SLAM_ERR_ARG, "batch and L_max must be positive");
     if (kind != SLAM_EKF_SLAM && kind != SLAM_UKF_SLAM && kind != SLAM_UKF_LOC)
         return fail(SLAM_ERR_ARG, "unknown filter kind %d", kind);
+    // The four quirk switches took over fields that were `reserved` until round 4: a caller compiled against that header may
+    // have left anything there, and any non-zero value would silently switch a reference quirk off.  Only 0 and 1 are configurations.
+    for (const int q : {cfg->ekf_abs_is_int, cfg->ekf_landmark_from_x_pred, cfg->ukf_accumulate_zest1, cfg->ukf_sensing_yaw_from_sigma})
+        if (q != 0 && q != 1) return fail(SLAM_ERR_ARG, "slam_config quirk switch = %d: the switches (ekf_abs_is_int, ekf_landmark_from_x_pred, ukf_accumulate_zest1, "
+                                          "ukf_sensing_yaw_from_sigma) are 0 or 1 - zero-initialise the struct (slam_config_default)", q);
     if (kind == SLAM_UKF_LOC) L_max = 1;   // localisation only: the state never holds landmarks
     if (dtype != SLAM_F64 && !(dtype == SLAM_F32 && kind == SLAM_EKF_SLAM))
         return fail(SLAM_ERR_UNSUPPORTED, "fp32 state storage is implemented for EKF_SLAM only");

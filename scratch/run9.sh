@@ -1,0 +1,1 @@
+python -m pytest tests -x -q -m gpu 2>&1 | tail -8

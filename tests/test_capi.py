@@ -100,6 +100,14 @@ def test_bad_arguments_return_error_codes():
     assert L.slam_create(C.byref(c), 9, 4, 20, 0, 0, C.byref(h)) == -1          # unknown filter kind
     assert L.slam_step_sim(None, None) == -1
     assert L.slam_destroy(None) == 0
+    # the quirk switches live where `reserved` fields were until round 4: anything but 0 / 1 is refused, not read as "switch the quirk off"
+    for name in ("ekf_abs_is_int", "ekf_landmark_from_x_pred", "ukf_accumulate_zest1", "ukf_sensing_yaw_from_sigma"):
+        c2 = default_config()
+        setattr(c2, name, 7)
+        assert L.slam_create(C.byref(c2), 1, 4, 20, 0, 0, C.byref(h)) == -1, name
+        assert b"quirk switch" in L.slam_last_error()
+    # pgs_last_solve_paths keeps its four-double ABI (the eight-entry form is _v2 with an explicit length)
+    assert L.pgs_last_solve_paths_v2(None, None, 8) == -1 and L.pgs_last_solve_paths(None, None) == -1
 
 
 def test_multi_handle_rejects_a_device_listed_twice():
