@@ -85,6 +85,11 @@ struct pgs_handle {
     double path_ms[3] = {0.0, 0.0, 0.0};      // profiled solve: ms in the separate SYRK launches / in the fused chain + SYRK launches / in the segmented path's SYRK launches
     int seg_len = 32;                         // SLAM_PGS_SEG: poses per segment of the segmented elimination (pgs_seg_impl.h), 0 = the sequential chain of rounds 1-4
     bool seg_ok = false;                      // this solve runs the segmented elimination (decided in pgs_solve from the plan)
+    // Round 6: the segment length is chosen PER SOLVE from {seg_len, seg_len / 2, ... >= 8}: the longest whose every segment sees at most
+    // kPgsSegMaxLm landmarks (a wide sensor on a dense map overflowed 32-pose segments and the whole solve fell back to the sequential chain,
+    // 2.3 x slower).  seg_cur: where the next solve's search starts (only goes down while the graph grows; pgs_init resets it); seg_alloc: the
+    // length the segment-count-dependent arrays are sized for (re-made on demand, resize_segments); seg_used: the last solve's.
+    int seg_cur = 32, seg_alloc = 32, seg_used = 0;
     bool fused_ok = false;                    // this solve's graphs fit the fused kernel (decided in pgs_solve from max M)
     int cus = 256;                            // compute units of the device
     bool use_list = true;                     // SLAM_PGS_LIST=0: full-size grids, inactive workgroups return (the round-2 launch shape)
@@ -132,6 +137,45 @@ int ensure_segT(pgs_handle* h) {
     return dalloc(h, &h->p.segT, S * (size_t)h->p.nseg_max * (size_t)h->p.seg_tld * h->p.seg_tld);
 }
 
+template <class T>
+void dfree(pgs_handle* h, T*& ptr) {
+    if (!ptr) return;
+    for (size_t i = 0; i < h->allocs.size(); ++i)
+        if (h->allocs[i] == (void*)ptr) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
+    hipFree((void*)ptr);
+    ptr = nullptr;
+}
+
+// The arrays whose size follows the number of segments (the plan, the segments' outputs, their Gram matrices, and Y - whose separator rows
+// live behind the pose rows) re-made for segments of SL poses, if they were sized for longer ones.  Nothing in them outlives a solve.
+int resize_segments(pgs_handle* h, int SL) {
+    if (SL >= h->seg_alloc) return SLAM_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    slam::PgsParams& p = h->p;
+    const size_t S = (size_t)h->B * h->lanes, L = (size_t)h->L_max;
+    void* old[6] = {p.seg_ncol, p.seg_lm, p.seg_inv, p.seg_evt, p.seg_blk, p.sep_evt};
+    dfree(h, p.seg_ncol); dfree(h, p.seg_lm); dfree(h, p.seg_inv); dfree(h, p.seg_evt); dfree(h, p.seg_blk); dfree(h, p.sep_evt);
+    dfree(h, p.segout); dfree(h, p.sepfac); dfree(h, p.segT); dfree(h, p.Y);
+    p.nseg_max = (h->N_max - 2) / SL + 1;
+    p.yr_sep = p.yr_rc + 6 * (int64_t)p.nseg_max;
+    p.y_stride = (int64_t)(p.yr_sep + round_up(3 * p.nseg_max, 4)) * h->LD;
+    const size_t G = (size_t)p.nseg_max;
+    const size_t per[6] = {G, G * L, G * L, G * L, G * (size_t)slam::seg_nb1(h->L_max), G * L};
+    TRY(dalloc(h, &p.seg_ncol, S * per[0])); TRY(dalloc(h, &p.seg_lm, S * per[1])); TRY(dalloc(h, &p.seg_inv, S * per[2]));
+    TRY(dalloc(h, &p.seg_evt, S * per[3])); TRY(dalloc(h, &p.seg_blk, S * per[4])); TRY(dalloc(h, &p.sep_evt, S * per[5]));
+    void* now[6] = {p.seg_ncol, p.seg_lm, p.seg_inv, p.seg_evt, p.seg_blk, p.sep_evt};
+    for (pgs_handle::Slab& sl : h->clone_slabs)     // the lambda lanes get copies of the plan (clone_instances)
+        for (int k = 0; k < 6; ++k)
+            if (sl.ptr == old[k]) {   // (once per slab: the allocator may hand a new array the address another old one had)
+                sl.ptr = now[k]; sl.bytes = per[k] * sizeof(int32_t);
+                break;
+            }
+    TRY(dalloc(h, &p.segout, S * G * 32)); TRY(dalloc(h, &p.sepfac, S * G * 16));
+    TRY(dalloc(h, &p.Y, S * (size_t)p.y_stride));
+    h->seg_alloc = SL;
+    return SLAM_OK;   // (segT: ensure_segT, by the solve that runs the order)
+}
+
 int ensure_staging(pgs_handle* h, int k_stride) {
     if (h->dmeas && h->k_stride >= k_stride) return SLAM_OK;
     if (h->dmeas) { hipFree(h->dmeas); h->dmeas = nullptr; }
@@ -167,6 +211,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
     if (const char* e = getenv("SLAM_PGS_FUSED")) h->fused_mode = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SEG")) { const int v = atoi(e); h->seg_len = v <= 0 ? 0 : (v < 2 ? 2 : (v > slam::kPgsSegMaxLen ? slam::kPgsSegMaxLen : v)); }
+    h->seg_cur = h->seg_alloc = h->seg_len;
     if (const char* e = getenv("SLAM_PGS_LIST")) h->use_list = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PGS_NOTRIM")) h->p_notrim = atoi(e) ? atoi(e) : 1;
     if (const char* e = getenv("SLAM_PGS_GROUPS")) h->groups = atoi(e);
@@ -303,6 +348,7 @@ int pgs_set_map(pgs_handle* h, const double* map_xy, int L) {
 int pgs_init(pgs_handle* h, float x0, float y0, float yaw0) {
     TRY(check(h));
     h->timestep = 0; h->p.N = 1;
+    h->seg_cur = h->seg_len;
     h->p.prior[0] = x0; h->p.prior[1] = y0; h->p.prior[2] = yaw0;
     HIP_TRY(slam::pgs_launch_init(h->p, x0, y0, yaw0, h->stream));
     h->inited = true;
@@ -438,20 +484,33 @@ int pgs_solve(pgs_handle* h) {
         // see; the path runs when no segment of any instance sees more than kPgsSegMaxLm of them (its columns fit the segment kernels)
         // and the separators fit the separator kernel's staging.  Otherwise - dense visibility on a big map - the sequential chain.
         h->seg_ok = false; h->p.seg_on = 0;
-        HIP_TRY(slam::pgs_launch_seg_plan(h->p, h->stream));   // (also counts the factors: the grid of the per-factor kernels)
-        std::vector<int32_t> U((size_t)h->B), F((size_t)h->B);
-        if (h->seg_len > 0) HIP_TRY(hipMemcpyAsync(U.data(), h->p.seg_umax, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(F.data(), h->p.fact_cnt, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        int mx = 0, fx = 0;
-        for (int32_t f : F) fx = f > fx ? f : fx;
-        h->p.nfact_max = fx;
-        if (h->seg_len > 0) {
+        int SL = h->seg_len > 0 ? h->seg_cur : 0;
+        for (;;) {
+            // The segment length of this solve: the longest of seg_cur, seg_cur / 2, ... (>= 8 poses) whose every segment sees at most
+            // kPgsSegMaxLm landmarks and whose separators fit the separator kernel's staging.
+            h->p.seg_len = SL;
+            HIP_TRY(slam::pgs_launch_seg_plan(h->p, h->stream));   // (also counts the factors: the grid of the per-factor kernels)
+            std::vector<int32_t> U((size_t)h->B), F((size_t)h->B);
+            if (SL > 0) HIP_TRY(hipMemcpyAsync(U.data(), h->p.seg_umax, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(F.data(), h->p.fact_cnt, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            int mx = 0, fx = 0;
+            for (int32_t f : F) fx = f > fx ? f : fx;
+            h->p.nfact_max = fx;
+            if (SL <= 0) break;
             for (int32_t u : U) mx = u > mx ? u : mx;
-            h->seg_ok = mx <= slam::kPgsSegMaxLm;
-            h->p.seg_on = h->seg_ok ? 1 : 0;
-            if (h->seg_ok) TRY(ensure_segT(h));
+            if (mx <= slam::kPgsSegMaxLm) { h->seg_ok = true; break; }
+            const int next = SL / 2;
+            // (0x7fffffff: more separators than pgs_sep_kernel stages - shorter segments only add separators)
+            if (mx == 0x7fffffff || next < 8 || (h->p.N - 2) / next > slam::kPgsSegMaxSep) break;
+            TRY(resize_segments(h, next));
+            SL = next;
         }
+        if (h->seg_ok) { h->seg_cur = SL; h->seg_used = SL; TRY(ensure_segT(h)); }
+        else {   // (a graph only grows: what no segment length holds now, none will hold later - the next solves go straight to the sequential chain)
+            h->p.seg_len = h->seg_len > 0 ? h->seg_alloc : 0; h->seg_used = 0; h->seg_cur = 0;
+        }
+        h->p.seg_on = h->seg_ok ? 1 : 0;
     }
     {   // chain + SYRK in one launch (Y stays in LDS) is possible while the lower triangle of every instance fits the 72 wavefront
         // tiles of pgs_chain_syrk_kernel, a column of Y per lane (2M + 1 <= 448) and its event staging (32 factor slots per pose)
@@ -684,6 +743,7 @@ int run_every_iteration_async(pgs_handle* h, int T) {
     const int N0 = h->timestep + 1;
     TRY(ensure_segT(h));
     slam::PgsParams q = h->p;
+    q.seg_len = h->seg_cur;
     q.async_ticks = 1; q.seg_on = 1; q.Nv = h->d_Nv; q.T_end = h->timestep + T; q.split_decide = 1; q.max_trials = h->max_trials;
     q.mono = h->d_mono; q.tick_acc = h->d_tick; q.tick_flop = h->d_tick_flop;
     q.b_off = 0; q.b_cnt = B; q.slots_cap = 0; q.N = N0;
@@ -903,7 +963,7 @@ int pgs_last_solve_paths_v2(pgs_handle* h, double* out, int n) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     double w[3];
     HIP_TRY(hipMemcpy(w, h->p.work, 3 * sizeof(double), hipMemcpyDeviceToHost));
-    const double v[8] = {w[0], w[1], h->path_ms[0], h->path_ms[1], w[2], h->path_ms[2], h->seg_ok ? 1.0 : 0.0, (double)h->seg_len};
+    const double v[8] = {w[0], w[1], h->path_ms[0], h->path_ms[1], w[2], h->path_ms[2], h->seg_ok ? 1.0 : 0.0, (double)(h->seg_ok ? h->seg_used : h->seg_len)};
     for (int i = 0; i < n; ++i) out[i] = v[i];
     return SLAM_OK;
 }

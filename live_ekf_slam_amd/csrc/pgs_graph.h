@@ -82,7 +82,10 @@ __global__ void pgs_append_kernel(const PgsParams p, const float* meas, const in
 // T x { get_cmd (sim_node.py:209-250), NaiveFilter::update (filter.h:342-348), updateNaiveVehPoseEstimate, update }
 // for one instance per wavefront.  The secondary filter's state IS `cur` (the naive filter keeps nothing else).
 __global__ __launch_bounds__(64) void pgs_run_sim_kernel(const PgsParams p, int T, uint32_t step0) {
-    constexpr int KCAP = 64;
+    // Every detection of the message reaches append_step (a map has at most 255 landmarks): a detection beyond the k_per_pose factor slots of its
+    // pose is dropped THERE, after its landmark was created - like the reference's loop (pose_graph.cpp:249-256) and the oracle.  Until round 6 the
+    // message was cut at 64 detections before that (tools/gpu_soak_pgs.py wide: landmarks created at another pose, metres apart).
+    constexpr int KCAP = 256;
     __shared__ float s_meas[3 * KCAP];
     const int b = blockIdx.x, lane = threadIdx.x;
     double tx = p.truth[3 * b], ty = p.truth[3 * b + 1], tth = p.truth[3 * b + 2];

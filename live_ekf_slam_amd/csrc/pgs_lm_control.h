@@ -307,7 +307,7 @@ __global__ __launch_bounds__(TPB) void pgs_adopt_kernel(const PgsParams p) {
 // reached T_end - the graph's next simulator tick, NaiveFilter::update and the append (pgs_run_sim_kernel's body for one timestep, with the
 // graph's own timestep as the noise stream's step index).  State 3 (solve converged) / 5 (first tick: nothing to adopt) -> 6, or 1 = finished.
 __global__ __launch_bounds__(256) void pgs_tick_kernel(const PgsParams p) {
-    constexpr int KCAP = 64;
+    constexpr int KCAP = 256;   // (every detection reaches append_step: pgs_run_sim_kernel)
     __shared__ float s_meas[3 * KCAP];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int st = p.state[b];

@@ -285,6 +285,55 @@ def test_solve_groups_do_not_change_results():
             assert np.array_equal(st[key], out[0][1][key])
 
 
+@pytest.mark.parametrize("range_max,expect_sl", [(3.0, 32), (5.4, 16), (5.8, 8), (6.1, 0)])
+def test_segment_length_is_chosen_per_solve(oracle, range_max, expect_sl):
+    """a wide sensor on a dense map (200 landmarks, field of view +-3 rad) makes the interior poses of a 32-pose segment see
+    more than the 63 landmarks the segment kernels hold - until round 5 the whole solve then fell back to the sequential chain.  Now the solve
+    takes the longest segment length of 32 / 16 / 8 that fits (the segment-count-dependent arrays are re-made on demand); only a sensor that
+    sees more than 63 landmarks from 8 poses still takes the sequential chain.  Whatever the order, the LM path equals the oracle's, the result
+    agrees with the SAME-order oracle (LIN_SEG with that segment length) to 1e-9 m and with the sequential oracle within the usual bar."""
+    import live_ekf_slam_amd as S
+    L, T, B, KP = 200, 300, 3, 64
+    lm, cmds = make_scenario(700, L, T)
+    cfg = default_config(); cfg.range_max = range_max; cfg.fov_min = -3.0; cfg.fov_max = 3.0
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=3, cfg=cfg, nthreads=8)
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+    pg.set_map(lm); pg.set_seed(3); pg.init(0.0, 0.0, 0.0)
+    pg.run_sim(cmds)
+    pg.set_profiling(True)      # (last_solve_paths reports the order the solve ran)
+    pg.solvePoseGraph()
+    paths = pg.last_solve_paths()
+    assert paths["segmented"] == (expect_sl > 0) and (expect_sl == 0 or paths["segment_length"] == expect_sl), paths
+    _compare(pg, r, B)
+    if expect_sl:
+        rs = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=3, cfg=cfg, nthreads=8, lin_mode=oracle.LIN_SEG | (expect_sl << 8))
+        for b in range(B):
+            assert np.abs(pg.get_graph(b, 1)["poses"] - rs["pose_res"][b]).max() < 1e-9
+    # a second solve of the same handle starts from the length the first one found
+    pg.set_profiling(False)
+    pg.solvePoseGraph()
+    _compare(pg, r, B)
+    pg.close()
+
+
+@pytest.mark.parametrize("KP", [64, 100])
+def test_messages_of_more_than_64_detections_on_the_device_simulator(oracle, KP):
+    """Found by tools/gpu_soak_pgs.py `wide` (round 6): the device simulator cut a message at 64 detections BEFORE the graph append, so the
+    landmarks of the detections beyond were not created at that pose (the reference's loop creates the landmark, then drops the factor that
+    does not fit: pose_graph.cpp:249-256) - same counts, same flags, landmarks metres apart.  Now every detection reaches the append."""
+    import live_ekf_slam_amd as S
+    L, T, B = 200, 196, 2
+    lm, cmds = make_scenario(1050712621, L, T)
+    cfg = default_config(); cfg.range_max = 6.413; cfg.fov_min = -3.068; cfg.fov_max = 3.068
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=602889364, cfg=cfg, nthreads=4, want_streams=True)
+    assert r["cnt"].max() > 64 and (KP == 100 or np.all(r["flags"] & 4))
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+    pg.set_map(lm); pg.set_seed(602889364); pg.init(0.0, 0.0, 0.0)
+    pg.run_sim(cmds); pg.solvePoseGraph()
+    _compare(pg, r, B)
+    pg.close()
+
+
 @pytest.mark.parametrize("G", [1, 2])
 def test_streaming_slots_do_not_change_results(oracle, G):
     """pgs_set_slots (round 6): only `slots` graphs are in flight, the others wait and take over the running slots of converged ones
