@@ -213,6 +213,19 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
         wall = float(tw.item())
     st = pg.stats()
     e0, e1 = pg.error_stats(0), pg.error_stats(1)
+    small = None
+    if B > 256 and rank == 0 and world == 1:
+        # the batch-256 figure of rounds 1-5 beside the headline batch (same graphs: the first 256 instances), one warm-up + two timed solves
+        ps = S.BatchedPoseGraph(256, num_iterations=N, L_max=L, k_per_pose=args.k_per_pose, device=local_rank).readParams()
+        ps.set_stream(stream.cuda_stream)
+        ps.set_map(lm); ps.set_seed(2025); ps.set_instance_offset(rank * B); ps.init(0.0, 0.0, 0.0)
+        with torch.cuda.stream(stream):
+            ps.run_sim(cmds); ps.solvePoseGraph(); torch.cuda.synchronize(dev)
+            es0, es1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            es0.record(stream); ps.solvePoseGraph(); ps.solvePoseGraph(); es1.record(stream)
+            torch.cuda.synchronize(dev)
+        small = round(256 * 2 / (es0.elapsed_time(es1) * 1e-3), 1)
+        ps.close()
     from live_ekf_slam_amd.parallel import gather_error_stats
     e1_all = gather_error_stats(e1, dist if world > 1 else None, args.coll_device)   # the one collective: after timing (RCCL)
     parity = None
@@ -273,7 +286,7 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"pose-graph SLAM one-time LM solve, {N} poses x {L} landmarks (mapped: {int(M.min())}-{int(M.max())}), "
                                        f"batch={B} graphs per GPU, device-built graphs (simulator + NaiveFilter secondary)",
-                           "batch_per_gpu": B, "poses": N, "landmarks": L, "lm_trials_launched_per_solve": trials_launched / K,
+                           "batch_per_gpu": B, "batch_256_value": small, "poses": N, "landmarks": L, "lm_trials_launched_per_solve": trials_launched / K,
                            "lm_iterations_mean": float(st["iterations"].mean()), "lm_trials_mean": float(st["trials"].mean()),
                            "instances_flagged": int((st["flags"] != 0).sum()),
                            "avg_position_error_m": {"initial": round(float(e0.mean()), 4), "result": round(float(e1_all.mean()), 4)},
@@ -356,9 +369,11 @@ def bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s
     if not args.no_parity_check:
         from oracle import oracle as O
         mx, bad, same = 0.0, None, True
-        for b in sorted(set([0, B - 1])):
+        oracle_s, oracle_n = 0.0, 0
+        for b in (sorted(set([0, B - 1])) if not getattr(args, "lean", False) else [0]):
             g = pg.get_graph(b, 1)
             r = O.run_pgs_batch(lm, cmds, 1, L, KP=args.k_per_pose, seed=2025, inst0=rank * B + b, nthreads=1, every_iteration=True, lin_mode=O.LIN_SEG)
+            oracle_s += r["seconds"]; oracle_n += 1
             Mo = int(r["M"][0])
             if int(g["M"]) != Mo:
                 bad = f"instance {rank * B + b}: {int(g['M'])} landmarks on the GPU, {Mo} in the oracle"
@@ -392,7 +407,11 @@ def bench_pgs_iter(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s
                              "algorithmic_flop": flop, "syrk_flop": ph["syrk_flop"], "chol_flop": ph["chol_flop"], "run_ms": round(dev_s * 1e3, 2),
                              "limiter": "launch latency: a tick is one solve of a graph that is on average half the final size - plan, begin, 2-3 trials of "
                                         "twelve dependent launches, end, adopt - and the batch waits for the tick's slowest instance"}}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and getattr(args, "lean", False) and parity is not None and oracle_n:
+            # (secondary leg of the headline run: the in-run oracle check above IS a single-thread run of the same workload - its time is the baseline)
+            line["cpu_baseline"] = {"value": round(oracle_n * T / oracle_s, 1), "unit": "graph-ticks/s", "cores": 1, "kind": "port",
+                                    "sample": f"oracle pose-graph LM in the same mode, {oracle_n} graph(s) x {T} ticks of the same workload (the run of the parity check), 1 thread, {oracle_s:.1f} s in the solves"}
+        elif world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             r = O.run_pgs_batch(lm, cmds, 1, L, KP=args.k_per_pose, seed=2025, nthreads=1, every_iteration=True, lin_mode=O.LIN_SEG)
             Bc = int(max(1, min(64, cpu_budget_s / max(r["seconds"], 1e-3))))
@@ -445,7 +464,7 @@ def main():
     if args.filter == "pgs":   # configs[4] defaults unless given explicitly
         argv = " ".join(sys.argv[1:])
         if "--landmarks" not in argv: args.landmarks = 200
-        if "--batch" not in argv: args.batch = 256
+        if "--batch" not in argv: args.batch = 256 if args.iterative else 2048   # one-time solve: 10 k solves/s from batch 2048 on (profiles/r06_pgs/stream_table*.txt)
         if "--steps" not in argv: args.steps = 5
         if "--warmup" not in argv: args.warmup = 1
 
@@ -520,9 +539,9 @@ def _pstr(pc, key):
 
 def secondary_digest(line):
     """One string <= 110 characters with value, roofline fraction and in-run parity of every secondary leg and of the once-per-step
-    leg, e.g. `ukf 5.32M f.196 p0|pgs 2849 f.185 p4e-11|f32 70.9M f.535 p0|L20 241M f.11 p0|1step 27.2M f.63` (the
-    driver's record keeps scalars and short strings of the headline line only)."""
-    tags = {"configs[2]": "ukf", "configs[4]": "pgs", "configs[3]": "f32", "configs[1]": "L20"}
+    leg, e.g. `ukf 5.07M f.19 p0|pgs 10.1k f.07 p6e-11|pgsit 15.2k p4e-11|f32 73.3M f.40 p0|L20 206M f.20 p0|1step 27M f.62` (VERDICT r04
+    item 3: the driver's record keeps scalars and short strings of the headline line only; pgsit = the every-iteration mode, graph-ticks/s)."""
+    tags = {"configs[2]": "ukf", "configs[4] every": "pgsit", "configs[4]": "pgs", "configs[3]": "f32", "configs[1]": "L20"}
     parts = []
     for leg in line.get("secondary", []):
         tag = next((t for k, t in tags.items() if leg.get("name", "").startswith(k)), "?")
@@ -530,9 +549,9 @@ def secondary_digest(line):
             parts.append(f"{tag} ERR")
             continue
         pc = leg.get("config", {}).get("parity_check")
-        key = "max_abs_diff_m" if tag == "pgs" else "max_abs_diff"
-        fr = f"{leg['roofline']['frac']:.3f}".lstrip("0")[:4]
-        parts.append(f"{tag} {_short(leg['value'])} f{fr} {_pstr(pc, key)}")
+        key = "max_abs_diff_m" if tag.startswith("pgs") else "max_abs_diff"
+        fr = f"{leg['roofline']['frac']:.2f}".lstrip("0")[:3]
+        parts.append(f"{tag} {_short(leg['value'])} f{fr} {_pstr(pc, key)}" if tag != "pgsit" else f"{tag} {_short(leg['value'])} {_pstr(pc, key)}")
     once = line["roofline"].get("once_per_step")
     if once:
         parts.append(f"1step {_short(once['value'])} f{once['frac']:.2f}".replace("f0.", "f."))
@@ -558,7 +577,8 @@ def secondary_lines(args, torch, dist, rank, local_rank, world, dev):
             keep = {k: ln[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline") if k in ln}
             c = ln.get("config", {})
             keep["config"] = {k: c[k] for k in ("workload", "mean_detections_per_step", "mean_jacobi_sweeps", "instances_flagged",
-                                                 "lm_trials_launched_per_solve", "lm_iterations_mean", "kernel_ms_per_solve", "elimination",
+                                                 "lm_trials_launched_per_solve", "lm_iterations_mean", "kernel_ms_per_solve", "elimination", "batch_256_value",
+                                                 "lm_trials_per_tick", "lm_trials_launched_per_tick", "seconds_per_run",
                                                  "parity_check", "avg_position_error_m") if k in c}
             keep["name"] = name
         except Exception as e:   # noqa: BLE001 - the headline must survive a failing secondary leg
@@ -570,8 +590,11 @@ def secondary_lines(args, torch, dist, rank, local_rank, world, dev):
     # device-event time - the leg's roofline - had not moved)
     leg("configs[2] UKF-SLAM L=20 batch 4096", lambda a: bench_ukf(a, torch, dist, rank, local_rank, world, dev, cpu_budget_s=4.0),
         landmarks=20, batch=4096, steps=60, warmup=5, preroll=20)
-    leg("configs[4] pose-graph SLAM 1000 x 200 batch 256", lambda a: bench_pgs(a, torch, dist, rank, local_rank, world, dev, cpu_budget_s=5.0),
-        landmarks=200, batch=256, steps=2, warmup=1)
+    leg("configs[4] pose-graph SLAM 1000 x 200 batch 2048", lambda a: bench_pgs(a, torch, dist, rank, local_rank, world, dev, cpu_budget_s=5.0),
+        landmarks=200, batch=2048, steps=2, warmup=1, iterative=False)
+    # the reference's DEFAULT pose-graph mode (params.yaml:64): solve + adopt after every tick, 999 ticks to 1000 x 200, batch 256
+    leg("configs[4] every-iteration mode: pose-graph SLAM 1000 x 200 batch 256, solve_graph_every_iteration",
+        lambda a: bench_pgs_iter(a, torch, dist, rank, local_rank, world, dev), landmarks=200, batch=256, warmup=3, iterative=True, lean=True)
     leg("configs[3] storage: EKF-SLAM L=50 batch 65536 fp32", lambda a: bench_ekf(a, torch, dist, rank, local_rank, world, dev, compact=True),
         dtype="f32", steps=20, warmup=5)
     leg("configs[1] EKF-SLAM L=20 batch 4096", lambda a: bench_ekf(a, torch, dist, rank, local_rank, world, dev, compact=True),

@@ -840,6 +840,11 @@ int pgs_run_sim_every_iteration(pgs_handle* h, const float* cmds, int T, int32_t
                               "adopted result; re-run with SLAM_PGS_ITER_ASYNC=0 (the lockstep tick loop falls back to the sequential chain)", nlim, slam::kPgsSegMaxLm);
         return SLAM_OK;
     }
+    // One solve group per tick unless the caller chose a number: a tick's solve is a handful of latency-bound trials - two groups gain 2 % in
+    // a process of their own (15.2 k against 14.9 k graph-ticks/s) and lose 20 % when their streams land on one hardware queue behind other
+    // handles' streams (bench.py's secondary leg: 12.3 k; the stream -> queue assignment of the runtime, profiles/r05_pgs/hw_queues.txt).
+    struct GroupsGuard { pgs_handle* h; int saved; ~GroupsGuard() { h->groups = saved; } } guard{h, h->groups};
+    if (h->groups == 0) h->groups = 1;
     for (int t = 0; t < T; ++t) {
         double t0 = prof ? now_ms() : 0.0;
         h->p.N = h->timestep + 1;

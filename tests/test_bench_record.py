@@ -44,10 +44,12 @@ def test_digest_format_is_short_and_complete():
         {"name": "configs[2] UKF", "value": 5.32e6, "roofline": {"frac": 0.196}, "config": {"parity_check": {"max_abs_diff": 0.0}}},
         {"name": "configs[4] pgs", "value": 10400.0, "roofline": {"frac": 0.067},
          "config": {"parity_check": {"max_abs_diff_m": 4e-11, "lm_iteration_and_trial_counts_equal": True}}},
+        {"name": "configs[4] every-iteration mode: pose graph", "value": 15200.0, "roofline": {"frac": 0.016},
+         "config": {"parity_check": {"max_abs_diff_m": 4e-11, "lm_iteration_and_trial_counts_equal": True}}},
         {"name": "configs[3] f32", "value": 73.3e6, "roofline": {"frac": 0.40}, "config": {"parity_check": {"max_abs_diff": 0.0}}},
         {"name": "configs[1] L20", "value": 242e6, "roofline": {"frac": 0.11}, "config": {"parity_check": {"max_abs_diff": 0.0}}}],
         "roofline": {"once_per_step": {"value": 27.2e6, "frac": 0.63}}}
     d = bench.secondary_digest(line)
-    assert len(d) <= 110 and d.count("|") >= 4
-    for tag in ("ukf 5.32M", "pgs 10.4k", "f32 73.3M", "L20 242M", "1step 27.2M"):
+    assert len(d) <= 110 and d.count("|") >= 5, (len(d), d)
+    for tag in ("ukf 5.32M f.20 p0", "pgs 10.4k f.07 p4e-11", "pgsit 15.2k p4e-11", "f32 73.3M", "L20 242M", "1step 27.2M"):
         assert tag in d, (tag, d)
