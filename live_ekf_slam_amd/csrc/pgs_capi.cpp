@@ -621,7 +621,10 @@ int pgs_solve(pgs_handle* h) {
                 if (last[0] == 0 || (last[4] >= wend && last[0] * G <= h->lanes_switch)) leave = true;
                 return SLAM_OK;
             };
-            while (!leave && t < h->max_trials) {
+            // (the trial cap is per graph - pgs_decide_kernel applies it while graphs stream; the launches only need a bound that cannot bind first)
+            q.max_trials = h->max_trials;
+            const long long launch_cap = ((long long)q.b_cnt / cap + 2) * h->max_trials;
+            while (!leave && t < launch_cap) {
                 q.n_list_dev = dcnt + 8 * (t & 1) + 2;
                 q.n_active = dcnt + 8 * ((t + 1) & 1);
                 TRY(launch_trial(h, q, cap * G, 1, cap, st, t, false, false, 1));
@@ -639,7 +642,8 @@ int pgs_solve(pgs_handle* h) {
         }
         const bool pipe = !profile;   // per-kernel timing wants every kernel of a trial between its own events
         int32_t* hact = h->h_active + 4 * g;
-        if (act[0] > 0 && trials < h->max_trials) {
+        const int trials_end = trials + h->max_trials;   // (after a streaming phase: that many more launches for the graphs still running)
+        if (act[0] > 0 && trials < trials_end) {
             bool pre = false;   // the phase's first trial runs over the list it was handed; later ones have their first kernels enqueued ahead
             for (;;) {
                 tl.push_back(act[2]);
@@ -657,7 +661,7 @@ int pgs_solve(pgs_handle* h) {
                     fprintf(stderr, "pgs group %d trial %d: %.2f ms, lanes %d -> active %d, lanes next %d\n", g, trials - 1, trials > 1 ? now - t_prev : 0.0, (int)q.lanes, (int)hact[0], (int)act[1]);
                     t_prev = now;
                 }
-                if (hact[0] == 0 || trials >= h->max_trials) break;
+                if (hact[0] == 0 || trials >= trials_end) break;
             }
         }
         gtrials[g] = trials;

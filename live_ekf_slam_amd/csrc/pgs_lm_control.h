@@ -196,7 +196,9 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
             else if (error <= 0.0 || relDec <= relTol || absDec <= absTol) done = 1;
             else p.cur_error[b] = error;
         }
-        if (p.async_ticks && !done && trials >= p.max_trials) { done = 1; fl = PGS_FLAG_NOT_CONVERGED; }   // (lockstep: the host's trial cap + pgs_lm_end_kernel)
+        // the trial cap is per GRAPH: where the host's count of launches is not a graph's count of trials (asynchronous ticks, streaming) the decide
+        // step applies it (lockstep: the host stops launching + pgs_lm_end_kernel)
+        if ((p.async_ticks || p.slots_cap > 0) && !done && trials >= p.max_trials) { done = 1; fl = PGS_FLAG_NOT_CONVERGED; }
         atomicAdd(p.work + (p.seg_on ? 2 : (p.fused ? 1 : 0)), (double)(trials - p.trials[b]) * p.inst_flop[b]);   // reporting only
         p.lambda[b] = lambda; p.error[b] = error; p.iters[b] = iters; p.trials[b] = trials;
         // the next trial runs the next `lanes_next` lambdas of the sequence GTSAM would walk if every one of them failed:

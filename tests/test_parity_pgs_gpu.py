@@ -378,6 +378,26 @@ def test_streaming_slots_do_not_change_results(oracle, G):
                 assert full >= max(1, len(a) // 3) - 1, (slots, g, a)
 
 
+def test_streaming_trial_cap_is_per_graph(monkeypatch, oracle):
+    """Found by tools/gpu_soak_pgs.py big (round 6): with few running slots a batch needs many more LAUNCHES than any graph needs trials;
+    the host's cap on launches (SLAM_PGS_MAX_TRIALS, default 400) cut the queue off and left the graphs at its end unsolved.  The cap is a
+    graph's own trial count now (pgs_decide_kernel applies it while graphs stream)."""
+    import live_ekf_slam_amd as S
+    monkeypatch.setenv("SLAM_PGS_MAX_TRIALS", "8")
+    L, T, KP, B = 20, 150, 8, 45
+    lm, cmds = make_scenario(9, L, T)
+    cfg = default_config()
+    r = oracle.run_pgs_batch(lm, cmds, B, L, KP=KP, seed=4, cfg=cfg, nthreads=8)
+    assert r["trials"].max() < 8 and r["trials"].sum() > 2 * 6 * 8    # no graph at the cap, the batch through 2 slots far beyond it
+    pg = S.BatchedPoseGraph(B, num_iterations=T + 1, L_max=L, k_per_pose=KP).readParams(cfg)
+    pg.set_groups(1); pg.set_slots(2)
+    pg.set_map(lm); pg.set_seed(4); pg.init(0.0, 0.0, 0.0)
+    pg.run_sim(cmds); pg.solvePoseGraph()
+    _compare(pg, r, B)
+    assert len(pg.last_solve_timeline()[0]) > 6 * 8
+    pg.close()
+
+
 @pytest.mark.parametrize("L,T", [(20, 150), (60, 400)])
 def test_syrk_variants_agree_with_the_oracle(monkeypatch, oracle, L, T):
     """The Schur complement has tile kernels (few active instances) and one with instance-resident accumulators and Y
