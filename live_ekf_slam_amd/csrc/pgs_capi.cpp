@@ -74,6 +74,8 @@ struct pgs_handle {
     double* d_tick_flop = nullptr;             // [B][2] algorithmic FLOP (SYRK | Cholesky) of the same
     int32_t* d_tick = nullptr;                 // [B][2] LM iterations / trials summed over the ticks of pgs_run_sim_every_iteration
     double iter_ms[4] = {0, 0, 0, 0};
+    bool host_prof = false;                    // SLAM_PGS_HOST_PROF: host clock spent enqueuing trials / waiting for their counters (stderr, every-iteration runs)
+    double host_launch_ms = 0.0, host_wait_ms = 0.0;
     long long iter_trials = 0;
     int p_notrim = 0;
     int chol_ll = 2;                           // SLAM_PGS_CHOL_LL=0: the right-looking Cholesky of rounds 1-3; 1: the left-looking kernel on 1024 threads; 2 (default): on 768
@@ -209,6 +211,7 @@ int pgs_create(const slam_config* cfg, int batch, int N_max, int L_max, int k_pe
     if (const char* e = getenv("SLAM_PGS_SYRK_INST_SWITCH")) h->syrk_inst_switch = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SYRK_SWITCH")) h->syrk_switch = atoi(e);
     h->trace = getenv("SLAM_PGS_TRACE") != nullptr;
+    h->host_prof = getenv("SLAM_PGS_HOST_PROF") != nullptr;
     if (const char* e = getenv("SLAM_PGS_FUSED")) h->fused_mode = atoi(e);
     if (const char* e = getenv("SLAM_PGS_SEG")) { const int v = atoi(e); h->seg_len = v <= 0 ? 0 : (v < 2 ? 2 : (v > slam::kPgsSegMaxLen ? slam::kPgsSegMaxLen : v)); }
     h->seg_cur = h->seg_alloc = h->seg_len;
@@ -647,11 +650,19 @@ int pgs_solve(pgs_handle* h) {
             bool pre = false;   // the phase's first trial runs over the list it was handed; later ones have their first kernels enqueued ahead
             for (;;) {
                 tl.push_back(act[2]);
+                timespec ta, tb, tc;
+                if (h->host_prof) clock_gettime(CLOCK_MONOTONIC, &ta);
                 TRY(launch_trial(h, q, act[0], act[1], act[2], st, trials, profile, pre));
                 HIP_TRY(hipMemcpyAsync(hact, q.n_active, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipEventRecord(h->gevents[g], st));
                 if (pipe) { TRY(prelaunch_trial(h, q, st)); pre = true; }   // the next trial's linearisation runs while the host waits below
+                if (h->host_prof) clock_gettime(CLOCK_MONOTONIC, &tb);
                 HIP_TRY(hipEventSynchronize(h->gevents[g]));
+                if (h->host_prof) {
+                    clock_gettime(CLOCK_MONOTONIC, &tc);
+                    h->host_launch_ms += (tb.tv_sec - ta.tv_sec) * 1e3 + (tb.tv_nsec - ta.tv_nsec) * 1e-6;
+                    h->host_wait_ms += (tc.tv_sec - tb.tv_sec) * 1e3 + (tc.tv_nsec - tb.tv_nsec) * 1e-6;
+                }
                 act[0] = hact[0] * G; act[1] = hact[1]; act[2] = hact[2];
                 trials += 1;
                 if (h->trace) {
@@ -869,6 +880,7 @@ int pgs_run_sim_every_iteration(pgs_handle* h, const float* cmds, int T, int32_t
         HIP_TRY(hipMemcpyAsync(counts, h->d_tick, sizeof(int32_t) * 2 * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    if (h->host_prof) fprintf(stderr, "pgs host clock over the run's trials: %.0f ms enqueuing, %.0f ms waiting for the trials' counters\n", h->host_launch_ms, h->host_wait_ms);
     return SLAM_OK;
 }
 // Host-clock phase times of the last pgs_run_sim_every_iteration under SLAM_PGS_ITER_PROF=1: ms in {simulator + append, solve, adopt}, and the
