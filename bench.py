@@ -214,7 +214,7 @@ def bench_pgs(args, torch, dist, rank, local_rank, world, dev, cpu_budget_s=15.0
     st = pg.stats()
     e0, e1 = pg.error_stats(0), pg.error_stats(1)
     small = None
-    if B > 256 and rank == 0 and world == 1:
+    if B > 256 and rank == 0 and world == 1 and not args.no_batch_256:
         # the batch-256 figure of rounds 1-5 beside the headline batch (same graphs: the first 256 instances), one warm-up + two timed solves
         ps = S.BatchedPoseGraph(256, num_iterations=N, L_max=L, k_per_pose=args.k_per_pose, device=local_rank).readParams()
         ps.set_stream(stream.cuda_stream)
@@ -458,6 +458,7 @@ def main():
                     help="ekf = the headline metric (default); ukf / pgs = BASELINE configs[2] / configs[4]-style secondary lines")
     ap.add_argument("--poses", type=int, default=1000, help="pgs: poses per graph (num_iterations)")
     ap.add_argument("--k-per-pose", type=int, default=32, help="pgs: detections stored per timestep")
+    ap.add_argument("--no-batch-256", action="store_true", help="pgs: skip the batch-256 figure measured beside a larger batch (profiling runs)")
     ap.add_argument("--iterative", action="store_true",
                     help="pgs: the reference's default mode solve_graph_every_iteration (params.yaml:64): one run of poses - 1 ticks, each solved and adopted")
     args = ap.parse_args()
@@ -595,8 +596,10 @@ def secondary_lines(args, torch, dist, rank, local_rank, world, dev):
     # the reference's DEFAULT pose-graph mode (params.yaml:64): solve + adopt after every tick, 999 ticks to 1000 x 200, batch 256
     leg("configs[4] every-iteration mode: pose-graph SLAM 1000 x 200 batch 256, solve_graph_every_iteration",
         lambda a: bench_pgs_iter(a, torch, dist, rank, local_rank, world, dev), landmarks=200, batch=256, warmup=3, iterative=True, lean=True)
-    leg("configs[3] storage: EKF-SLAM L=50 batch 65536 fp32", lambda a: bench_ekf(a, torch, dist, rank, local_rank, world, dev, compact=True),
-        dtype="f32", steps=20, warmup=5)
+    # (100 timed steps in one launch = `bench.py --dtype f32`'s own default window: a launch costs 22 us per workgroup beyond its timesteps, which is
+    # 10 % of a 20-step fp32 launch - 73 M on 20 steps against 84 M on 100 is the launch shape, not the storage type)
+    leg("configs[3] storage: EKF-SLAM L=50 batch 65536 fp32, 100 steps", lambda a: bench_ekf(a, torch, dist, rank, local_rank, world, dev, compact=True),
+        dtype="f32", steps=100, warmup=10)
     leg("configs[1] EKF-SLAM L=20 batch 4096", lambda a: bench_ekf(a, torch, dist, rank, local_rank, world, dev, compact=True),
         landmarks=20, batch=4096, steps=400, warmup=5)   # 400 steps = 6-7 ms (20 steps were 0.31 ms: launch-scale noise)
     return out

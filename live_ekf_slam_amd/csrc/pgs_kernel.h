@@ -54,7 +54,7 @@ struct PgsParams {
     int32_t* evt_slot;                 // [B][N_max*KP]   factor slot of event e (the inverse of slot_pos)
     double* PF;                        // [S][N_max*KP*12] per factor slot: its share of the pose block (Jp^T Jp: 9, -Jp^T e: 3) between
                                        //                  pgs_lin_factor_kernel and pgs_linearize_kernel; later in the trial its cost terms
-                                       //                  (pgs_eval_factor_kernel -> pgs_evaluate_kernel)
+                                       //                  (pgs_eval_factor_kernel -> pgs_evaluate_kernel: three per factor slot, compact at the head of the slot's block)
     int32_t* lin_ok;                   // [S] the slot's linearisation (A, C, g_p, E, D, g_l) belongs to its current values: a trial after a
                                        //     FAILED one re-uses it, like GTSAM's inner lambda loop (pgs_decide_kernel clears it on an accept)
     int32_t* fact_cnt;                 // [B] factors of the instance (pgs_seg_plan_kernel), nfact_max: the largest (grid of the per-factor kernels)

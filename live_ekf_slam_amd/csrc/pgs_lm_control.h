@@ -13,7 +13,7 @@ __device__ __forceinline__ void retract_pose(const double* ps, const double* d, 
 
 // Evaluation, part 1: one thread per FACTOR (see pgs_lin_factor_kernel) - its two terms of the linearised cost 0.5 |J delta + e|^2 at the
 // current values and its term of the true cost at the candidate (the factor forms the candidate pose / landmark itself, with the
-// expressions part 2 stores them with).  PF[slot] = {0.5 v_0^2, 0.5 v_1^2, 0.5 |e(candidate)|^2}; part 2 adds them where the one-kernel
+// expressions part 2 stores them with).  PF[3 slot ..] = {0.5 v_0^2, 0.5 v_1^2, 0.5 |e(candidate)|^2}; part 2 adds them where the one-kernel
 // version added them (bit-identical sums).
 __global__ __launch_bounds__(LF_TPB) void pgs_eval_factor_kernel(const PgsParams p) {
     const int nfb = (p.nfact_max + LF_TPB - 1) / LF_TPB;
@@ -34,7 +34,10 @@ __global__ __launch_bounds__(LF_TPB) void pgs_eval_factor_kernel(const PgsParams
     const double bb = g.mb[k], rr = g.mr[k];
     double e2[2], Jp[6], Jl[4];
     bearing_range_factor<true>(p, pose, lm, bb, rr, e2, Jp, Jl);
-    double* PF = p.PF + ((size_t)b * p.N_max * KP + k) * 12;
+    // The three terms go COMPACT into the head of the slot's PF block, 24 bytes per factor slot (round 6; the linearisation's 96-byte records there are
+    // dead once pgs_linearize_kernel has run): written into the records they dirtied a 64-byte line per 24 bytes - 23 GB written and 27 GB fetched back
+    // per solve of 2048 graphs for 6 GB of terms (profiles/r06_pgs/summary.txt).
+    double* PF = p.PF + (size_t)b * p.N_max * KP * 12 + 3 * k;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const double v = (e2[r] + ((Jp[3 * r] * dp[0] + Jp[3 * r + 1] * dp[1]) + Jp[3 * r + 2] * dp[2])) + (Jl[2 * r] * dl[0] + Jl[2 * r + 1] * dl[1]);
@@ -82,18 +85,18 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
                 }
             }
             const int kc = g.cnt[i];
-            const double* PF = PFb + (size_t)i * KP * 12;
+            const double* PF = PFb + (size_t)i * KP * 3;   // (compact: three terms per factor slot, pgs_eval_factor_kernel)
             constexpr int UB = 8;   // the factors' terms (pgs_eval_factor_kernel) are fetched eight factors at a time, added in slot order
             int s = 0;
 #pragma unroll 1
             for (; s + UB <= kc; s += UB) {
                 double w[UB][2];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) { w[u][0] = PF[12 * (size_t)(s + u)]; w[u][1] = PF[12 * (size_t)(s + u) + 1]; }
+                for (int u = 0; u < UB; ++u) { w[u][0] = PF[3 * (size_t)(s + u)]; w[u][1] = PF[3 * (size_t)(s + u) + 1]; }
 #pragma unroll
                 for (int u = 0; u < UB; ++u) { acc = acc + w[u][0]; acc = acc + w[u][1]; }
             }
-            for (; s < kc; ++s) { acc = acc + PF[12 * (size_t)s]; acc = acc + PF[12 * (size_t)s + 1]; }
+            for (; s < kc; ++s) { acc = acc + PF[3 * (size_t)s]; acc = acc + PF[3 * (size_t)s + 1]; }
             double pn[3];
             retract_pose(pose + 3 * i, dp + 3 * i, pn);
             pose_n[3 * i] = pn[0]; pose_n[3 * i + 1] = pn[1]; pose_n[3 * i + 2] = pn[2];
@@ -113,18 +116,18 @@ __global__ __launch_bounds__(TPB) void pgs_evaluate_kernel(const PgsParams p) {
                 pc = pc + 0.5 * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
             }
             const int kc = g.cnt[i];
-            const double* PF = PFb + (size_t)i * KP * 12 + 2;
+            const double* PF = PFb + (size_t)i * KP * 3 + 2;
             constexpr int UB = 8;
             int s = 0;
 #pragma unroll 1
             for (; s + UB <= kc; s += UB) {
                 double w[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) w[u] = PF[12 * (size_t)(s + u)];
+                for (int u = 0; u < UB; ++u) w[u] = PF[3 * (size_t)(s + u)];
 #pragma unroll
                 for (int u = 0; u < UB; ++u) pc = pc + w[u];
             }
-            for (; s < kc; ++s) pc = pc + PF[12 * (size_t)s];
+            for (; s < kc; ++s) pc = pc + PF[3 * (size_t)s];
             acc2 = acc2 + pc;
         }
         newError = block_sum<TPB>(acc2, s_buf);

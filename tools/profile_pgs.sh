@@ -6,7 +6,7 @@ TAG=${1:-pgs}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="bench.py --filter pgs --no-cpu-baseline --steps 2 --warmup 1 $*"
+ARGS="bench.py --filter pgs --no-cpu-baseline --no-batch-256 --steps 2 --warmup 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ARGS > $OUT/bench_stats.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o pmc -- python3 $ARGS > $OUT/bench_pmc_mfma.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ARGS > $OUT/bench_pmc_fetch.log 2>&1
