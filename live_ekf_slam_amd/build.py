@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslam_hip.so")
 SOURCES = ["ekf_kernel.hip", "ekf_big_kernel.hip", "ukf_kernel.hip", "ukf_big_kernel.hip", "pgs_kernel.hip", "pgs_capi.cpp", "slam_capi.cpp", "scenario_capi.cpp", "multi_capi.cpp"]
-HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_inst.hip", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h", "pgs_seg_impl.h", "pgs_factors.h", "pgs_graph.h", "pgs_linearize.h", "pgs_chain.h", "pgs_syrk.h", "pgs_chol.h",
+HEADERS = ["ukf_kernel.h", "ekf_kernel.h", "ekf_kernel_impl.h", "ekf_step_prestep.h", "ekf_step_control.h", "ekf_step_stream.h", "ekf_step_decoupled.h", "ekf_step_lockstep.h", "ekf_inst.hip", "sim_device.h", "slam_math.h", "slam_rng.h", "pgs_kernel.h", "pgs_seg_impl.h", "pgs_factors.h", "pgs_graph.h", "pgs_linearize.h", "pgs_chain.h", "pgs_syrk.h", "pgs_chol.h",
            "pgs_backsolve.h", "pgs_lm_control.h",
            "capi_internal.h", "jacobi_schedule.h", "lds_attr.h", "../../include/slam_batch.h", "../../include/slam_pgs.h", "../../include/slam_scenario.hpp",
            "../../include/slam_filter.hpp", "../../include/slam_multi.h", "host/filter_driver.cpp", "host/config_parse.h", "host/stream_parse.h"]
