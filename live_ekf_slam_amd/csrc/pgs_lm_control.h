@@ -35,8 +35,9 @@ __global__ __launch_bounds__(LF_TPB) void pgs_eval_factor_kernel(const PgsParams
     double e2[2], Jp[6], Jl[4];
     bearing_range_factor<true>(p, pose, lm, bb, rr, e2, Jp, Jl);
     // The three terms go COMPACT into the head of the slot's PF block, 24 bytes per factor slot (round 6; the linearisation's 96-byte records there are
-    // dead once pgs_linearize_kernel has run): written into the records they dirtied a 64-byte line per 24 bytes - 23 GB written and 27 GB fetched back
-    // per solve of 2048 graphs for 6 GB of terms (profiles/r06_pgs/summary.txt).
+    // dead once pgs_linearize_kernel has run): pgs_evaluate_kernel then reads a pose's terms as one contiguous run instead of three doubles out of every
+    // 96-byte record - 27 -> 11 GB fetched per solve of 2048 graphs, that kernel 16.8 -> 10.5 ms (profiles/r06_pgs/summary.txt).  The writes here stay
+    // scattered (threads run in event order, slots are pose-major): 24 bytes per dirtied line, 23 GB per solve.
     double* PF = p.PF + (size_t)b * p.N_max * KP * 12 + 3 * k;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
