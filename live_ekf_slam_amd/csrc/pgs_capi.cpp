@@ -408,15 +408,35 @@ namespace {
 
 // after pgs_launch_lm_begin on the same stream: the clones (lambda lanes) of the group's instances get the instance's graph,
 // event lists, values and scalars - one contiguous copy per array and lane - and start inactive
-int clone_instances(pgs_handle* h, const slam::PgsParams& p, hipStream_t stream) {
+int clone_instances(pgs_handle* h, const slam::PgsParams& p, hipStream_t stream, bool slabs = true) {
     const size_t B = (size_t)h->B, off = (size_t)p.b_off, cnt = (size_t)p.b_cnt;
     for (int j = 1; j < h->lanes; ++j) {
-        for (const pgs_handle::Slab& sl : h->clone_slabs)
-            HIP_TRY(hipMemcpyAsync((char*)sl.ptr + ((size_t)j * B + off) * sl.bytes, (const char*)sl.ptr + off * sl.bytes, cnt * sl.bytes,
-                                   hipMemcpyDeviceToDevice, stream));
+        if (slabs)
+            for (const pgs_handle::Slab& sl : h->clone_slabs)
+                HIP_TRY(hipMemcpyAsync((char*)sl.ptr + ((size_t)j * B + off) * sl.bytes, (const char*)sl.ptr + off * sl.bytes, cnt * sl.bytes,
+                                       hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(p.state + (size_t)j * B + off), 1, cnt, stream));
     }
     return SLAM_OK;
+}
+
+// the slabs of the instances in the group's current list only, in one launch (pgs_clone_kernel): when the first trial with lanes is near
+int clone_listed(pgs_handle* h, const slam::PgsParams& p, int n_list, hipStream_t stream) {
+    slam::PgsCloneTable t;
+    t.n = 0;
+    for (const pgs_handle::Slab& sl : h->clone_slabs) {
+        if (t.n >= 28 || (sl.bytes & 3)) return fail(SLAM_ERR_STATE, "clone table: %d arrays, %zu bytes per slot", (int)h->clone_slabs.size(), sl.bytes);
+        t.ptr[t.n] = sl.ptr; t.words[t.n] = (uint32_t)(sl.bytes / 4); t.n += 1;
+    }
+    slam::PgsParams q = p;
+    q.n_list = n_list;
+    HIP_TRY(slam::pgs_launch_clone(q, t, h->lanes, stream));
+    return SLAM_OK;
+}
+
+// lanes the decide kernel of a trial may hand out, from the number of active instances (of the whole batch) before it
+int lanes_for(const pgs_handle* h, int32_t active_hint) {
+    return active_hint <= h->lanes_switch_all ? h->lanes : (active_hint <= h->lanes_switch ? (h->lanes < 2 ? h->lanes : 2) : 1);
 }
 
 // one tryLambda of the instances [p.b_off, p.b_off + p.b_cnt) on `stream`; `lanes` = the most slots any of them runs in this
@@ -451,7 +471,7 @@ int launch_trial(pgs_handle* h, slam::PgsParams& p, int32_t active_hint, int lan
     }
     // Few instances left: the per-trial latency counts and spare slots cost little.  Two lanes from `lanes_switch` active
     // instances down (the common streak is one failure, then a success at 10 lambda), all of them from `lanes_switch_all` down.
-    p.lanes_next = active_hint <= h->lanes_switch_all ? h->lanes : (active_hint <= h->lanes_switch ? (h->lanes < 2 ? h->lanes : 2) : 1);
+    p.lanes_next = lanes_for(h, active_hint);
     if (force_lanes_next > 0) p.lanes_next = force_lanes_next;
     active_hint *= p.lanes;   // the kernel variants below are chosen by the number of slots that run (an upper bound), not of instances
     p.syrk_notrim = h->p_notrim;
@@ -585,7 +605,7 @@ int pgs_solve(pgs_handle* h) {
         if (q.b_cnt <= 0) { gdone[g] = 1; continue; }
         if (G > 1) HIP_TRY(hipStreamWaitEvent(gstream(g), h->gevents[G], 0));
         HIP_TRY(slam::pgs_launch_lm_begin(q, gstream(g)));
-        TRY(clone_instances(h, q, gstream(g)));
+        TRY(clone_instances(h, q, gstream(g), /*slabs=*/!h->use_list || profile));   // (with the slot list: copied on demand, for the listed instances)
     }
     // One host thread per group drives its LM loop; the HIP runtime is thread-safe and the groups touch disjoint instance ranges.
     //  * streaming phase (slots_cap > 0): the list of every trial is refilled on the device, its length read on the device, so the host
@@ -648,7 +668,10 @@ int pgs_solve(pgs_handle* h) {
         const int trials_end = trials + h->max_trials;   // (after a streaming phase: that many more launches for the graphs still running)
         if (act[0] > 0 && trials < trials_end) {
             bool pre = false;   // the phase's first trial runs over the list it was handed; later ones have their first kernels enqueued ahead
+            bool cloned = !h->use_list || profile || h->lanes <= 1;
             for (;;) {
+                // the first trial whose decide step may hand out lanes: the instances it lists (every later list is a subset) get their clones now
+                if (!cloned && lanes_for(h, act[0]) > 1) { TRY(clone_listed(h, q, act[2], st)); cloned = true; }
                 tl.push_back(act[2]);
                 timespec ta, tb, tc;
                 if (h->host_prof) clock_gettime(CLOCK_MONOTONIC, &ta);

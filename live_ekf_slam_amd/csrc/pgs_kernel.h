@@ -172,6 +172,10 @@ static constexpr int kPgsTrialKernels = 6;
 // asynchronous ticks: store + adopt the converged graphs' results, their next simulator tick + append, plan and begin of the next solve
 hipError_t pgs_launch_tick(const PgsParams& p, hipStream_t s);
 hipError_t pgs_launch_trial_kernel(const PgsParams& p, int which, hipStream_t s);
+// The lambda lanes' copies of the graph / plan arrays of the instances in the CURRENT list (p.alist[0 .. p.n_list): instances, lanes off so far):
+// slot b's share of every listed array to the slots j B + b, j = 1 .. lanes - 1.  Per-slot sizes in 4-byte words.
+struct PgsCloneTable { void* ptr[28]; uint32_t words[28]; int32_t n; };
+hipError_t pgs_launch_clone(const PgsParams& p, const PgsCloneTable& t, int lanes, hipStream_t s);
 hipError_t pgs_launch_lm_end(const PgsParams& p, hipStream_t s);     // result = current values, flags
 hipError_t pgs_launch_adopt(const PgsParams& p, hipStream_t s);      // initial_estimate = result
 // avg position error (plotting_node.py:203-213 alignment) of initial (which = 0) / result (1) vs truth_hist: out [B]

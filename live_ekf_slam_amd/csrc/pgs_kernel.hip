@@ -167,6 +167,12 @@ hipError_t pgs_launch_tick(const PgsParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t pgs_launch_clone(const PgsParams& p, const PgsCloneTable& t, int lanes, hipStream_t s) {
+    if (p.n_list <= 0 || lanes <= 1) return hipSuccess;
+    hipLaunchKernelGGL(pgs_clone_kernel, dim3(p.n_list, lanes - 1), dim3(256), 0, s, p, t);
+    return hipGetLastError();
+}
+
 hipError_t pgs_launch_lm_end(const PgsParams& p, hipStream_t s) {
     hipLaunchKernelGGL(pgs_lm_end_kernel, dim3(p.b_cnt), dim3(TPB), 0, s, p);
     return hipGetLastError();

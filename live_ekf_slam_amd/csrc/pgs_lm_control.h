@@ -278,6 +278,20 @@ __global__ __launch_bounds__(TPB) void pgs_decide_kernel(const PgsParams p) {
     }
 }
 
+// The lambda lanes' graph copies, on demand (round 6): until a solve's first trial with lanes the clones hold nothing; then the instances still
+// listed get their arrays copied, one workgroup per (listed instance, lane).  Copying every instance's arrays for every lane when the solve began
+// was ~100 device copies and 1 GB per solve - 4 % of a run of the every-iteration mode, where most ticks' solves need lanes for a handful of graphs.
+__global__ __launch_bounds__(256) void pgs_clone_kernel(const PgsParams p, const PgsCloneTable t) {
+    const int b = p.alist[blockIdx.x], j = blockIdx.y + 1, tid = threadIdx.x;
+    if (b >= p.B) return;   // (a lane's slot in the list: lanes were on before - its instance is listed too)
+    for (int a = 0; a < t.n; ++a) {
+        const uint32_t w = t.words[a];
+        const uint32_t* src = (const uint32_t*)t.ptr[a] + (size_t)b * w;
+        uint32_t* dst = (uint32_t*)t.ptr[a] + ((size_t)j * p.B + b) * w;
+        for (uint32_t i = tid; i < w; i += 256) dst[i] = src[i];
+    }
+}
+
 // result <- current values (also for instances cut off by the trial cap)
 __global__ __launch_bounds__(TPB) void pgs_lm_end_kernel(const PgsParams p) {
     const int b = blockIdx.x + p.b_off, tid = threadIdx.x;
